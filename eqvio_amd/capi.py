@@ -1,0 +1,321 @@
+"""ctypes binding of the C-ABI in include/eqf_hip.h (libeqf_hip.so) and include/eqvio_filter.h
+(libeqvio_filter.so). Plumbing only: numpy arrays in, numpy arrays out, errors raised loudly.
+
+There is no CPU fallback anywhere in this package: if the HIP library is missing or no gfx950 device is
+present, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_TIMING = 1, 2, 100
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class Camera(C.Structure):
+    """eqvio_camera (include/eqvio_types.h)."""
+
+    _fields_ = [
+        ("model", C.c_int),
+        ("width", C.c_int),
+        ("height", C.c_int),
+        ("fx", C.c_double),
+        ("fy", C.c_double),
+        ("cx", C.c_double),
+        ("cy", C.c_double),
+        ("dist", C.c_double * 5),
+    ]
+
+    @staticmethod
+    def pinhole(fx, fy, cx, cy, width, height):
+        cam = Camera()
+        cam.model, cam.width, cam.height = 0, int(width), int(height)
+        cam.fx, cam.fy, cam.cx, cam.cy = fx, fy, cx, cy
+        return cam
+
+
+_SETTINGS_DOUBLES = [
+    "biasOmegaProcessVariance", "biasAccelProcessVariance", "attitudeProcessVariance", "positionProcessVariance",
+    "velocityProcessVariance", "cameraAttitudeProcessVariance", "cameraPositionProcessVariance", "pointProcessVariance",
+    "velGyrNoise", "velAccNoise", "velGyrBiasWalk", "velAccBiasWalk",
+    "measurementNoise", "outlierThresholdAbs", "outlierThresholdProb", "featureRetention",
+    "initialAttitudeVariance", "initialPositionVariance", "initialVelocityVariance", "initialCameraAttitudeVariance",
+    "initialCameraPositionVariance", "initialPointVariance", "initialPointDepthVariance", "initialBiasOmegaVariance",
+    "initialBiasAccelVariance", "initialSceneDepth",
+]
+_SETTINGS_INTS = [
+    "useDiscreteInnovationLift", "useDiscreteVelocityLift", "useDiscreteStateMatrix", "fastRiccati", "useMedianDepth",
+    "useFeaturePredictions", "useEquivariantOutput", "removeLostLandmarks", "coordinateChoice",
+]
+
+
+class Settings(C.Structure):
+    """eqvio_settings (include/eqvio_types.h) == VIOFilter::Settings (VIOFilterSettings.h:58-124)."""
+
+    _fields_ = [(n, C.c_double) for n in _SETTINGS_DOUBLES] + [(n, C.c_int) for n in _SETTINGS_INTS] + [("cameraOffset", C.c_double * 7)]
+
+    @staticmethod
+    def defaults():
+        """Defaults of VIOFilterSettings.h:59-99."""
+        s = Settings()
+        vals = dict(
+            biasOmegaProcessVariance=0.001, biasAccelProcessVariance=0.001, attitudeProcessVariance=0.001, positionProcessVariance=0.001,
+            velocityProcessVariance=0.001, cameraAttitudeProcessVariance=0.001, cameraPositionProcessVariance=0.001, pointProcessVariance=0.001,
+            velGyrNoise=1e-4, velAccNoise=1e-3, velGyrBiasWalk=1e-5, velAccBiasWalk=1e-3,
+            measurementNoise=2.0, outlierThresholdAbs=1e8, outlierThresholdProb=1e8, featureRetention=0.3,
+            initialAttitudeVariance=1e-4, initialPositionVariance=1e-4, initialVelocityVariance=1e-2, initialCameraAttitudeVariance=1e-5,
+            initialCameraPositionVariance=1e-4, initialPointVariance=1.0, initialPointDepthVariance=-1.0, initialBiasOmegaVariance=0.1,
+            initialBiasAccelVariance=0.1, initialSceneDepth=1.0,
+            useDiscreteInnovationLift=1, useDiscreteVelocityLift=1, useDiscreteStateMatrix=0, fastRiccati=0, useMedianDepth=1,
+            useFeaturePredictions=0, useEquivariantOutput=1, removeLostLandmarks=1, coordinateChoice=COORD_EUCLIDEAN,
+        )
+        for k, v in vals.items():
+            setattr(s, k, v)
+        s.cameraOffset[:] = [1, 0, 0, 0, 0, 0, 0]
+        return s
+
+    def state_gain_diag8(self):
+        """constructStateGainMatrix (VIOFilterSettings.h:176-190) as 7 sensor classes + point."""
+        return np.array([self.biasOmegaProcessVariance, self.biasAccelProcessVariance, self.attitudeProcessVariance, self.positionProcessVariance,
+                         self.velocityProcessVariance, self.cameraAttitudeProcessVariance, self.cameraPositionProcessVariance, self.pointProcessVariance])
+
+    def input_gain_diag12(self):
+        """constructInputGainMatrix (VIOFilterSettings.h:192-201)."""
+        v = [self.velGyrNoise**2, self.velAccNoise**2, self.velGyrBiasWalk**2, self.velAccBiasWalk**2]
+        return np.repeat(np.array(v), 3)
+
+    def initial_cov_diag(self, N):
+        """constructInitialStateCovariance (VIOFilterSettings.h:208-229)."""
+        v = [self.initialBiasOmegaVariance, self.initialBiasAccelVariance, self.initialAttitudeVariance, self.initialPositionVariance,
+             self.initialVelocityVariance, self.initialCameraAttitudeVariance, self.initialCameraPositionVariance]
+        d = np.concatenate([np.repeat(np.array(v), 3), np.full(3 * N, self.initialPointVariance)])
+        if self.initialPointDepthVariance > 0:
+            d[21 + 2::3] = self.initialPointDepthVariance
+        return d
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class EqfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"eqf_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_eqf_lib():
+    """Load libeqf_hip.so and declare every prototype of include/eqf_hip.h. Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(LIB_DIR, "libeqf_hip.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` — the EqF path has no CPU fallback")
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    P = C.POINTER
+    protos = {
+        "eqf_error_string": (C.c_char_p, [C.c_int]),
+        "eqf_kernel_name": (C.c_char_p, [C.c_int]),
+        "eqf_create": (C.c_int, [P(vp), C.c_int, C.c_int, C.c_int]),
+        "eqf_destroy": (None, [vp]),
+        "eqf_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
+        "eqf_synchronize": (C.c_int, [vp]),
+        "eqf_num_landmarks": (C.c_int, [vp]),
+        "eqf_stream": (vp, [vp]),
+        "eqf_set_state": (C.c_int, [vp, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p, C.c_int]),
+        "eqf_get_state": (C.c_int, [vp, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p, C.c_int]),
+        "eqf_set_sigma": (C.c_int, [vp, c_double_p, C.c_int]),
+        "eqf_set_sigma_diag": (C.c_int, [vp, c_double_p, C.c_int]),
+        "eqf_get_sigma": (C.c_int, [vp, c_double_p, C.c_int]),
+        "eqf_get_sigma_block": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p]),
+        "eqf_state_estimate": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int]),
+        "eqf_add_landmarks": (C.c_int, [vp, c_int_p, c_double_p, C.c_int, C.c_double]),
+        "eqf_remove_landmarks": (C.c_int, [vp, c_int_p, C.c_int]),
+        "eqf_remove_invalid_landmarks": (C.c_int, [vp]),
+        "eqf_integrate_riccati_fast": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p]),
+        "eqf_integrate_observer": (C.c_int, [vp, c_double_p, c_double_p, C.c_int, C.c_int]),
+        "eqf_outlier_stats": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+        "eqf_vision_update": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_int]),
+        "eqf_last_gamma": (C.c_int, [vp, c_double_p, C.c_int]),
+        "eqf_debug_matrices_AB": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
+        "eqf_debug_matrix_C": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p]),
+        "eqf_mfma_f64_peak": (C.c_int, [vp, c_double_p]),
+        "eqf_last_kernel_times": (C.c_int, [vp, c_int_p, P(C.c_float), C.c_int]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    lib._declared = sorted(protos)
+    _lib = lib
+    return lib
+
+
+class EqfCore:
+    """One eqf_ctx == one reference VIO_eqf (include/eqvio/mathematical/VIO_eqf.h:34-134) on a gfx950 device."""
+
+    def __init__(self, max_landmarks, coordinate_choice=COORD_EUCLIDEAN, device=0):
+        self.lib = load_eqf_lib()
+        self.h = C.c_void_p()
+        self._chk0(self.lib.eqf_create(C.byref(self.h), device, max_landmarks, coordinate_choice))
+        self.cap = max_landmarks + 16
+
+    def _chk0(self, rc):
+        if rc != 0:
+            raise EqfError(rc, self.lib.eqf_error_string(rc).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.eqf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def N(self):
+        return self.lib.eqf_num_landmarks(self.h)
+
+    @property
+    def n(self):
+        return 21 + 3 * self.N
+
+    def set_option(self, opt, val):
+        self._chk0(self.lib.eqf_set_option(self.h, opt, val))
+
+    def synchronize(self):
+        self._chk0(self.lib.eqf_synchronize(self.h))
+
+    def stream(self):
+        return self.lib.eqf_stream(self.h)
+
+    def set_state(self, xi0_sensor, X_sensor, ids, q0, Q):
+        xi0_sensor, X_sensor, ids, q0, Q = _f64(xi0_sensor), _f64(X_sensor), _i32(ids), _f64(q0), _f64(Q)
+        self._chk0(self.lib.eqf_set_state(self.h, _dp(xi0_sensor), _dp(X_sensor), _ip(ids), _dp(q0), _dp(Q), len(ids)))
+
+    def get_state(self):
+        xi0, Xs = np.zeros(23), np.zeros(23)
+        ids, q0, Q = np.zeros(self.cap, np.int32), np.zeros(3 * self.cap), np.zeros(5 * self.cap)
+        N = self.lib.eqf_get_state(self.h, _dp(xi0), _dp(Xs), _ip(ids), _dp(q0), _dp(Q), self.cap)
+        if N < 0:
+            self._chk0(N)
+        return xi0, Xs, ids[:N].copy(), q0[: 3 * N].reshape(N, 3).copy(), Q[: 5 * N].reshape(N, 5).copy()
+
+    def set_sigma(self, S):
+        S = np.asfortranarray(S, dtype=np.float64)
+        self._chk0(self.lib.eqf_set_sigma(self.h, S.ctypes.data_as(c_double_p), S.shape[0]))
+
+    def set_sigma_diag(self, d):
+        d = _f64(d)
+        self._chk0(self.lib.eqf_set_sigma_diag(self.h, _dp(d), len(d)))
+
+    def get_sigma(self):
+        n = self.n
+        out = np.zeros((n, n), order="F")
+        self._chk0(self.lib.eqf_get_sigma(self.h, out.ctypes.data_as(c_double_p), n))
+        return out
+
+    def get_sigma_block(self, r0, c0, rows, cols):
+        out = np.zeros((rows, cols), order="F")
+        self._chk0(self.lib.eqf_get_sigma_block(self.h, r0, c0, rows, cols, out.ctypes.data_as(c_double_p)))
+        return out
+
+    def state_estimate(self):
+        s = np.zeros(23)
+        ids, p = np.zeros(self.cap, np.int32), np.zeros(3 * self.cap)
+        N = self.lib.eqf_state_estimate(self.h, _dp(s), _ip(ids), _dp(p), self.cap)
+        if N < 0:
+            self._chk0(N)
+        return s, ids[:N].copy(), p[: 3 * N].reshape(N, 3).copy()
+
+    def add_landmarks(self, ids, p, var):
+        ids, p = _i32(ids), _f64(p)
+        self._chk0(self.lib.eqf_add_landmarks(self.h, _ip(ids), _dp(p), len(ids), var))
+
+    def remove_landmarks(self, indices):
+        indices = _i32(indices)
+        self._chk0(self.lib.eqf_remove_landmarks(self.h, _ip(indices), len(indices)))
+
+    def remove_invalid_landmarks(self):
+        rc = self.lib.eqf_remove_invalid_landmarks(self.h)
+        if rc < 0:
+            self._chk0(rc)
+        return rc
+
+    def integrate_riccati_fast(self, imu13, dt, Qdiag12, Pdiag8):
+        imu13, Qd, Pd = _f64(imu13), _f64(Qdiag12), _f64(Pdiag8)
+        self._chk0(self.lib.eqf_integrate_riccati_fast(self.h, _dp(imu13), dt, _dp(Qd), _dp(Pd)))
+
+    def integrate_observer(self, imu13_k, dt_k, discrete=True):
+        imu13_k, dt_k = _f64(imu13_k).reshape(-1, 13), _f64(dt_k).reshape(-1)
+        self._chk0(self.lib.eqf_integrate_observer(self.h, _dp(imu13_k), _dp(dt_k), len(dt_k), int(discrete)))
+
+    def outlier_stats(self, cam, ids, y):
+        ids, y = _i32(ids), _f64(y)
+        N = self.N
+        a, p, d = np.zeros(N), np.zeros(N), np.zeros(N)
+        self._chk0(self.lib.eqf_outlier_stats(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), _dp(a), _dp(p), _dp(d)))
+        return a, p, d
+
+    def vision_update(self, cam, ids, y, meas_var, use_equivariant=True, discrete=False):
+        ids, y = _i32(ids), _f64(y)
+        self._chk0(self.lib.eqf_vision_update(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), meas_var, int(use_equivariant), int(discrete)))
+
+    def last_gamma(self):
+        out = np.zeros(self.n + 64)
+        k = self.lib.eqf_last_gamma(self.h, _dp(out), len(out))
+        if k < 0:
+            self._chk0(k)
+        return out[:k].copy()
+
+    def debug_matrices_AB(self, imu13):
+        imu13 = _f64(imu13)
+        n = self.n
+        A, B = np.zeros((n, n), order="F"), np.zeros((n, 12), order="F")
+        self._chk0(self.lib.eqf_debug_matrices_AB(self.h, _dp(imu13), A.ctypes.data_as(c_double_p), B.ctypes.data_as(c_double_p)))
+        return A, B
+
+    def debug_matrix_C(self, cam, ids, y, use_equivariant=True):
+        ids, y = _i32(ids), _f64(y)
+        M, n = len(ids), self.n
+        Cm, yt = np.zeros((2 * M, n), order="F"), np.zeros(2 * M)
+        self._chk0(self.lib.eqf_debug_matrix_C(self.h, C.byref(cam), _ip(ids), _dp(y), M, int(use_equivariant), Cm.ctypes.data_as(c_double_p), _dp(yt)))
+        return Cm, yt
+
+    def mfma_f64_peak(self):
+        t = C.c_double()
+        self._chk0(self.lib.eqf_mfma_f64_peak(self.h, C.byref(t)))
+        return t.value
+
+    def kernel_times(self, cap=4096):
+        which = np.zeros(cap, np.int32)
+        us = np.zeros(cap, np.float32)
+        k = self.lib.eqf_last_kernel_times(self.h, _ip(which), us.ctypes.data_as(C.POINTER(C.c_float)), cap)
+        return [(self.lib.eqf_kernel_name(int(which[i])).decode(), float(us[i])) for i in range(k)]

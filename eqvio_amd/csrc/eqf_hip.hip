@@ -1,0 +1,1078 @@
+// eqf_hip.hip — context + C-ABI of the MI355X EqF core (see include/eqf_hip.h). gfx950 only.
+#include "eqf_hip.h"
+#include "eqf_kernels.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace eqf;
+
+namespace {
+
+enum KName {
+    KN_ASSEMBLE = 0,
+    KN_OBSERVER,
+    KN_PROP_G,
+    KN_PROP_MAIN,
+    KN_MEASURE,
+    KN_STATS,
+    KN_BUILD_Z,
+    KN_CHOL_PANEL,
+    KN_CHOL_UPDATE,
+    KN_GAMMA,
+    KN_SYRK,
+    KN_LIFT,
+    KN_DENSE_GEMM,
+    KN_MISC,
+    KN_COUNT
+};
+const char* kNames[KN_COUNT] = {"k_assemble_AB", "k_observer",    "k_propagate_G", "k_propagate_main", "k_measure", "k_outlier_stats", "k_build_Z",
+                                "k_chol_panel",  "k_chol_update", "k_gamma",       "k_syrk_sub",       "k_lift",    "k_gemm_nt",       "misc"};
+
+int roundup(int x, int m) { return (x + m - 1) / m * m; }
+int pick_ld(int x) {
+    int ld = roundup(x, 16);
+    if (ld % 128 == 0)
+        ld += 16; // avoid power-of-two column strides (channel / cache-set aliasing)
+    return ld;
+}
+
+struct SensorState { // host-resident 46 doubles
+    V3 bgyr, bacc;
+    Pose pose;
+    V3 vel;
+    Pose cam;
+};
+struct GroupSensor {
+    V3 bgyr, bacc; // beta
+    Pose A;
+    V3 w;
+    Pose B;
+};
+SensorState unpack_sensor(const double* s) {
+    SensorState r;
+    r.bgyr = v3(s[0], s[1], s[2]);
+    r.bacc = v3(s[3], s[4], s[5]);
+    r.pose = Pose{Qt{s[6], s[7], s[8], s[9]}, v3(s[10], s[11], s[12])};
+    r.vel = v3(s[13], s[14], s[15]);
+    r.cam = Pose{Qt{s[16], s[17], s[18], s[19]}, v3(s[20], s[21], s[22])};
+    return r;
+}
+void pack_pose(const Pose& p, double* q, double* x) {
+    q[0] = p.R.w;
+    q[1] = p.R.x;
+    q[2] = p.R.y;
+    q[3] = p.R.z;
+    x[0] = p.x.x;
+    x[1] = p.x.y;
+    x[2] = p.x.z;
+}
+void pack_v3(V3 v, double* d) {
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+}
+void pack_sensor(const SensorState& r, double* s) {
+    pack_v3(r.bgyr, s);
+    pack_v3(r.bacc, s + 3);
+    pack_pose(r.pose, s + 6, s + 10);
+    pack_v3(r.vel, s + 13);
+    pack_pose(r.cam, s + 16, s + 20);
+}
+GroupSensor unpack_group(const double* s) {
+    GroupSensor g;
+    g.bgyr = v3(s[0], s[1], s[2]);
+    g.bacc = v3(s[3], s[4], s[5]);
+    g.A = Pose{Qt{s[6], s[7], s[8], s[9]}, v3(s[10], s[11], s[12])};
+    g.w = v3(s[13], s[14], s[15]);
+    g.B = Pose{Qt{s[16], s[17], s[18], s[19]}, v3(s[20], s[21], s[22])};
+    return g;
+}
+void pack_group(const GroupSensor& g, double* s) {
+    pack_v3(g.bgyr, s);
+    pack_v3(g.bacc, s + 3);
+    pack_pose(g.A, s + 6, s + 10);
+    pack_v3(g.w, s + 13);
+    pack_pose(g.B, s + 16, s + 20);
+}
+// sensorStateGroupAction (src/mathematical/VIOGroup.cpp:25-32)
+SensorState sensor_action(const GroupSensor& X, const SensorState& s) {
+    SensorState r;
+    r.bgyr = s.bgyr + X.bgyr;
+    r.bacc = s.bacc + X.bacc;
+    r.pose = pose_mul(s.pose, X.A);
+    r.vel = q_rot(q_inv(X.A.R), s.vel - X.w);
+    r.cam = pose_mul(pose_mul(pose_inv(X.A), s.cam), X.B);
+    return r;
+}
+// VIOGroup::operator* on the sensor part (VIOGroup.cpp:71-92): r = a * b
+GroupSensor group_mul(const GroupSensor& a, const GroupSensor& b) {
+    GroupSensor r;
+    r.bgyr = a.bgyr + b.bgyr;
+    r.bacc = a.bacc + b.bacc;
+    r.A = pose_mul(a.A, b.A);
+    r.B = pose_mul(a.B, b.B);
+    r.w = a.w + q_rot(a.A.R, b.w);
+    return r;
+}
+
+} // namespace
+
+struct eqf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int chart = 0;
+    int Ncap = 0, ncap = 0, ld = 0;
+    int mcap = 0, ldz = 0;
+    int N = 0;
+    std::vector<int> ids;
+    SensorState xi0;
+    GroupSensor X;
+    // device
+    double* d_lm[2] = {nullptr, nullptr}; // each: q0 (3 planes), Qq (4 planes), Qa (1 plane) = 8*Ncap
+    int lmcur = 0;
+    double* d_sigma[2] = {nullptr, nullptr};
+    int cur = 0;
+    double *d_Al = nullptr, *d_Bl = nullptr, *d_G = nullptr;
+    Common* d_common = nullptr;
+    ObsStep* d_steps = nullptr;
+    double *d_C = nullptr, *d_ytil = nullptr, *d_y = nullptr;
+    int *d_lmidx = nullptr, *d_measof = nullptr, *d_keep = nullptr;
+    double *d_Z = nullptr, *d_gamma = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
+    int* d_flags = nullptr;
+    // pinned host staging
+    Common* h_common = nullptr;
+    ObsStep* h_steps = nullptr;
+    double* h_buf = nullptr; // general staging, size hbuf_doubles
+    size_t hbuf_doubles = 0;
+    int* h_ibuf = nullptr;
+    int* h_flags = nullptr;
+    static constexpr int kMaxSteps = 256;
+    // options
+    int opt_dense = 0, opt_check = 0, opt_timing = 0;
+    std::vector<double> last_gamma;
+    // timing
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> tev;
+    std::vector<hipEvent_t> evpool;
+    size_t evused = 0;
+
+    double* q0() { return d_lm[lmcur]; }
+    double* Qq() { return d_lm[lmcur] + 3 * (size_t)Ncap; }
+    double* Qa() { return d_lm[lmcur] + 7 * (size_t)Ncap; }
+    double* sigma() { return d_sigma[cur]; }
+    int n() const { return 21 + 3 * N; }
+};
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            std::fprintf(stderr, "[eqf_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (int)_e;                                                                            \
+        }                                                                                              \
+    } while (0)
+
+namespace {
+
+hipEvent_t get_event(eqf_ctx* c) {
+    if (c->evused == c->evpool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        c->evpool.push_back(e);
+    }
+    return c->evpool[c->evused++];
+}
+struct KTimer {
+    eqf_ctx* c;
+    int which;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    KTimer(eqf_ctx* ctx, int w) : c(ctx), which(w) {
+        if (c->opt_timing) {
+            e0 = get_event(c);
+            e1 = get_event(c);
+            hipEventRecord(e0, c->stream);
+        }
+    }
+    ~KTimer() {
+        if (c->opt_timing) {
+            hipEventRecord(e1, c->stream);
+            c->tev.push_back({which, {e0, e1}});
+        }
+    }
+};
+void timing_reset(eqf_ctx* c) {
+    c->tev.clear();
+    c->evused = 0;
+}
+
+int blocks(int n, int b) { return (n + b - 1) / b; }
+
+Cam make_cam(const eqvio_camera* c) { return Cam{c->fx, c->fy, c->cx, c->cy}; }
+
+// Sensor-level terms of A and B (EqFStateMatrixA_euclid / EqFInputMatrixB_euclid sensor rows and the per-landmark
+// common factors; coordinateSuite/euclid.cpp:99-233 — identical for the inverse-depth suite, invdepth.cpp:47-63,152-166)
+void compute_common(const eqf_ctx* c, const double* imu13, Common& cm) {
+    const SensorState xh = sensor_action(c->X, c->xi0);
+    const V3 gyr = v3(imu13[1], imu13[2], imu13[3]) - xh.bgyr; // v_est = imu - bias (IMUVelocity.cpp:52-58)
+    const V6 U_I{gyr, xh.vel};
+    const M3 R_A = q_mat(c->X.A.R);
+    const M3 R_IC = q_mat(xh.cam.R);
+    const M3 RTic = transpose(R_IC);
+    auto put = [](const M3& A, double* d) {
+        const double a[9] = {A.a00, A.a01, A.a02, A.a10, A.a11, A.a12, A.a20, A.a21, A.a22};
+        std::memcpy(d, a, sizeof(a));
+    };
+    put(RTic * transpose(R_A), cm.Mv);
+    put(RTic, cm.RTic);
+    put(RTic * skew(xh.cam.x), cm.RTicSx);
+    // ad( Ad_{T0^-1} Ad_A U_I )
+    const V6 U1 = Ad_apply(pose_inv(c->xi0.cam), Ad_apply(c->X.A, U_I));
+    const M6 adT = se3_adjoint(U1);
+    const M6 CT = m6_mul(se3_Adjoint(pose_inv(c->X.B)), adT);
+    std::memcpy(cm.CT, CT.a, sizeof(cm.CT));
+    const V6 U_C = Ad_apply(pose_inv(xh.cam), U_I);
+    pack_v3(U_C.v, cm.vC);
+    // B sensor rows (21 x 12, row-major)
+    std::memset(cm.Bs, 0, sizeof(cm.Bs));
+    auto setB = [&](int r0, int c0, const M3& A) {
+        const double a[9] = {A.a00, A.a01, A.a02, A.a10, A.a11, A.a12, A.a20, A.a21, A.a22};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                cm.Bs[(r0 + i) * 12 + c0 + j] = a[3 * i + j];
+    };
+    for (int i = 0; i < 6; ++i)
+        cm.Bs[i * 12 + 6 + i] = 1.0;
+    setB(6, 0, R_A);
+    setB(9, 0, skew(c->X.A.x) * R_A);
+    setB(12, 0, R_A * skew(xh.vel));
+    setB(12, 3, R_A);
+    // A sensor block (21 x 21, row-major)
+    std::memset(cm.Ass, 0, sizeof(cm.Ass));
+    for (int r = 0; r < 21; ++r)
+        for (int cc = 0; cc < 6; ++cc)
+            cm.Ass[r * 21 + cc] = -cm.Bs[r * 12 + cc];
+    for (int i = 0; i < 3; ++i)
+        cm.Ass[(9 + i) * 21 + 12 + i] = 1.0;
+    const V3 gdir = q_rot(q_inv(c->xi0.pose.R), v3(0, 0, 1)); // xi0.sensor.gravityDir()
+    const M3 Gs = (-kGravity) * skew(gdir);
+    const double g[9] = {Gs.a00, Gs.a01, Gs.a02, Gs.a10, Gs.a11, Gs.a12, Gs.a20, Gs.a21, Gs.a22};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            cm.Ass[(12 + i) * 21 + 6 + j] = g[3 * i + j];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j)
+            cm.Ass[(15 + i) * 21 + 15 + j] = adT.a[i * 6 + j];
+}
+
+int upload_common(eqf_ctx* c, const double* imu13) {
+    compute_common(c, imu13, *c->h_common);
+    HIPCHK(hipMemcpyAsync(c->d_common, c->h_common, sizeof(Common), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int launch_assemble(eqf_ctx* c) {
+    if (c->N == 0)
+        return 0;
+    KTimer t(c, KN_ASSEMBLE);
+    hipLaunchKernelGGL(k_assemble_AB, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, c->N, c->Ncap, c->chart, c->d_common, c->q0(), c->Qq(), c->Qa(), c->d_Al,
+                       c->d_Bl);
+    return (int)hipGetLastError();
+}
+int read_flags(eqf_ctx* c) {
+    HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int index_of(const eqf_ctx* c, int id) {
+    for (int i = 0; i < c->N; ++i)
+        if (c->ids[i] == id)
+            return i;
+    return -1;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* eqf_error_string(int code) {
+    switch (code) {
+    case EQF_OK:
+        return "ok";
+    case EQF_E_NONFINITE:
+        return "non-finite value in Sigma or X";
+    case EQF_E_NOT_SPD:
+        return "innovation covariance S is not positive definite (Cholesky pivot <= 0)";
+    case EQF_E_BAD_ARG:
+        return "bad argument";
+    case EQF_E_CAPACITY:
+        return "landmark capacity exceeded";
+    case EQF_E_NO_DEVICE:
+        return "no gfx950 (MI355X) HIP device available: the EqF path has no CPU fallback";
+    case EQF_E_UNSUPPORTED:
+        return "option combination not supported by the device path";
+    default:
+        return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+const char* eqf_kernel_name(int which) { return (which >= 0 && which < KN_COUNT) ? kNames[which] : "?"; }
+
+int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choice) {
+    if (!out || max_landmarks < 1 || (coordinate_choice != EQVIO_COORD_EUCLIDEAN && coordinate_choice != EQVIO_COORD_INVDEPTH))
+        return coordinate_choice == EQVIO_COORD_NORMAL ? EQF_E_UNSUPPORTED : EQF_E_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device >= ndev)
+        return EQF_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return EQF_E_NO_DEVICE;
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        std::fprintf(stderr, "[eqf_hip] device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return EQF_E_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    eqf_ctx* c = new eqf_ctx();
+    c->device = device;
+    c->chart = coordinate_choice;
+    c->Ncap = roundup(max_landmarks, 16);
+    c->ncap = 21 + 3 * c->Ncap;
+    c->ld = pick_ld(c->ncap);
+    c->mcap = 2 * c->Ncap;
+    c->ldz = pick_ld(c->mcap + c->ncap + 1);
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t sig_bytes = sizeof(double) * (size_t)c->ld * c->ncap;
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(hipMalloc(&c->d_sigma[b], sig_bytes));
+        HIPCHK(hipMemsetAsync(c->d_sigma[b], 0, sig_bytes, c->stream));
+        HIPCHK(hipMalloc(&c->d_lm[b], sizeof(double) * 8 * (size_t)c->Ncap));
+        HIPCHK(hipMemsetAsync(c->d_lm[b], 0, sizeof(double) * 8 * (size_t)c->Ncap, c->stream));
+    }
+    HIPCHK(hipMalloc(&c->d_Al, sizeof(double) * 45 * (size_t)c->Ncap));
+    HIPCHK(hipMalloc(&c->d_Bl, sizeof(double) * 9 * (size_t)c->Ncap));
+    HIPCHK(hipMalloc(&c->d_G, sizeof(double) * 63 * (size_t)c->Ncap));
+    HIPCHK(hipMalloc(&c->d_common, sizeof(Common)));
+    HIPCHK(hipMalloc(&c->d_steps, sizeof(ObsStep) * eqf_ctx::kMaxSteps));
+    HIPCHK(hipMalloc(&c->d_C, sizeof(double) * 6 * (size_t)c->Ncap));
+    HIPCHK(hipMalloc(&c->d_ytil, sizeof(double) * c->mcap));
+    HIPCHK(hipMalloc(&c->d_y, sizeof(double) * c->mcap));
+    HIPCHK(hipMalloc(&c->d_lmidx, sizeof(int) * c->Ncap));
+    HIPCHK(hipMalloc(&c->d_measof, sizeof(int) * c->Ncap));
+    HIPCHK(hipMalloc(&c->d_keep, sizeof(int) * c->Ncap));
+    HIPCHK(hipMalloc(&c->d_Z, sizeof(double) * (size_t)c->ldz * c->mcap));
+    HIPCHK(hipMalloc(&c->d_gamma, sizeof(double) * c->ncap));
+    HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
+    HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
+    HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
+    HIPCHK(hipMalloc(&c->d_flags, sizeof(int) * 4));
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(int) * 4, c->stream));
+    HIPCHK(hipHostMalloc(&c->h_common, sizeof(Common)));
+    HIPCHK(hipHostMalloc(&c->h_steps, sizeof(ObsStep) * eqf_ctx::kMaxSteps));
+    c->hbuf_doubles = (size_t)c->ld * c->ncap; // large enough for a full Sigma transfer
+    HIPCHK(hipHostMalloc(&c->h_buf, sizeof(double) * c->hbuf_doubles));
+    HIPCHK(hipHostMalloc(&c->h_ibuf, sizeof(int) * 4 * (size_t)c->Ncap));
+    HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 4));
+    // identity state
+    const double s0[23] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
+    c->xi0 = unpack_sensor(s0);
+    c->X = unpack_group(s0);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c;
+    return EQF_OK;
+}
+
+void eqf_destroy(eqf_ctx* c) {
+    if (!c)
+        return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int b = 0; b < 2; ++b) {
+        hipFree(c->d_sigma[b]);
+        hipFree(c->d_lm[b]);
+    }
+    hipFree(c->d_Al);
+    hipFree(c->d_Bl);
+    hipFree(c->d_G);
+    hipFree(c->d_common);
+    hipFree(c->d_steps);
+    hipFree(c->d_C);
+    hipFree(c->d_ytil);
+    hipFree(c->d_y);
+    hipFree(c->d_lmidx);
+    hipFree(c->d_measof);
+    hipFree(c->d_keep);
+    hipFree(c->d_Z);
+    hipFree(c->d_gamma);
+    hipFree(c->d_est);
+    hipFree(c->d_stats);
+    hipFree(c->d_scratch);
+    hipFree(c->d_flags);
+    if (c->d_F)
+        hipFree(c->d_F);
+    if (c->d_tmp)
+        hipFree(c->d_tmp);
+    hipHostFree(c->h_common);
+    hipHostFree(c->h_steps);
+    hipHostFree(c->h_buf);
+    hipHostFree(c->h_ibuf);
+    hipHostFree(c->h_flags);
+    for (auto e : c->evpool)
+        hipEventDestroy(e);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int eqf_set_option(eqf_ctx* c, int option, int value) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    switch (option) {
+    case EQF_OPT_RICCATI_DENSE:
+        c->opt_dense = value;
+        return 0;
+    case EQF_OPT_CHECK_FINITE:
+        c->opt_check = value;
+        return 0;
+    case 100:
+        c->opt_timing = value;
+        timing_reset(c);
+        return 0;
+    default:
+        return EQF_E_BAD_ARG;
+    }
+}
+int eqf_synchronize(eqf_ctx* c) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int eqf_num_landmarks(const eqf_ctx* c) { return c->N; }
+void* eqf_stream(eqf_ctx* c) { return (void*)c->stream; }
+
+int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, const int* ids, const double* q0, const double* Q, int N) {
+    if (!c || N < 0 || (N > 0 && (!ids || !q0 || !Q)))
+        return EQF_E_BAD_ARG;
+    if (N > c->Ncap)
+        return EQF_E_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->xi0 = unpack_sensor(xi0_sensor);
+    c->X = unpack_group(X_sensor);
+    c->ids.assign(ids, ids + N);
+    c->N = N;
+    if (N > 0) {
+        std::memcpy(c->h_buf, q0, sizeof(double) * 3 * N);
+        std::memcpy(c->h_buf + 3 * N, Q, sizeof(double) * 5 * N);
+        HIPCHK(hipMemcpyAsync(c->d_scratch, c->h_buf, sizeof(double) * 8 * N, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_scatter_landmarks, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, 0, c->Ncap, c->d_scratch, c->d_scratch + 3 * N, c->q0(), c->Qq(),
+                           c->Qa());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int eqf_get_state(eqf_ctx* c, double* xi0_sensor, double* X_sensor, int* ids, double* q0, double* Q, int cap) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    if (xi0_sensor)
+        pack_sensor(c->xi0, xi0_sensor);
+    if (X_sensor)
+        pack_group(c->X, X_sensor);
+    const int N = c->N;
+    if (N > cap)
+        return EQF_E_CAPACITY;
+    if (N > 0) {
+        HIPCHK(hipSetDevice(c->device));
+        hipLaunchKernelGGL(k_gather_landmarks_aos, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->d_scratch);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->h_buf, c->d_scratch, sizeof(double) * 8 * N, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < N; ++i) {
+            if (ids)
+                ids[i] = c->ids[i];
+            if (q0)
+                std::memcpy(q0 + 3 * i, c->h_buf + 8 * i, sizeof(double) * 3);
+            if (Q)
+                std::memcpy(Q + 5 * i, c->h_buf + 8 * i + 3, sizeof(double) * 5);
+        }
+    }
+    return N;
+}
+
+int eqf_set_sigma(eqf_ctx* c, const double* sig, int n) {
+    if (!c || !sig || n != c->n())
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::memcpy(c->h_buf, sig, sizeof(double) * (size_t)n * n);
+    HIPCHK(hipMemcpy2DAsync(c->sigma(), sizeof(double) * c->ld, c->h_buf, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int eqf_set_sigma_diag(eqf_ctx* c, const double* diag, int n) {
+    if (!c || !diag || n != c->n())
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::memcpy(c->h_buf, diag, sizeof(double) * n);
+    HIPCHK(hipMemcpyAsync(c->d_gamma, c->h_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_set_diag, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->d_gamma, c->sigma());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int eqf_get_sigma_block(eqf_ctx* c, int r0, int c0, int rows, int cols, double* out) {
+    if (!c || !out || r0 < 0 || c0 < 0 || rows < 0 || cols < 0 || r0 + rows > c->n() || c0 + cols > c->n())
+        return EQF_E_BAD_ARG;
+    if (rows == 0 || cols == 0)
+        return 0;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy2DAsync(c->h_buf, sizeof(double) * rows, c->sigma() + r0 + (size_t)c0 * c->ld, sizeof(double) * c->ld, sizeof(double) * rows, cols,
+                            hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::memcpy(out, c->h_buf, sizeof(double) * (size_t)rows * cols);
+    return 0;
+}
+int eqf_get_sigma(eqf_ctx* c, double* sig, int n) {
+    if (!c || n != c->n())
+        return EQF_E_BAD_ARG;
+    return eqf_get_sigma_block(c, 0, 0, n, n, sig);
+}
+
+static int fetch_estimates(eqf_ctx* c) { // d_est -> h_buf (4 planes of stride N)
+    const int N = c->N;
+    if (N == 0)
+        return 0;
+    hipLaunchKernelGGL(k_estimate, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->d_est);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_est, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int eqf_state_estimate(eqf_ctx* c, double* sensor, int* ids, double* p, int cap) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    if (sensor)
+        pack_sensor(sensor_action(c->X, c->xi0), sensor);
+    const int N = c->N;
+    if (N > cap)
+        return EQF_E_CAPACITY;
+    if (N > 0 && (ids || p)) {
+        HIPCHK(hipSetDevice(c->device));
+        int rc = fetch_estimates(c);
+        if (rc)
+            return rc;
+        for (int i = 0; i < N; ++i) {
+            if (ids)
+                ids[i] = c->ids[i];
+            if (p) {
+                p[3 * i] = c->h_buf[i];
+                p[3 * i + 1] = c->h_buf[N + i];
+                p[3 * i + 2] = c->h_buf[2 * N + i];
+            }
+        }
+    }
+    return N;
+}
+
+int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double var) {
+    if (!c || k < 0 || (k > 0 && (!ids || !p)))
+        return EQF_E_BAD_ARG;
+    if (k == 0)
+        return 0;
+    if (c->N + k > c->Ncap)
+        return EQF_E_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream)); // staging reuse
+    std::memcpy(c->h_buf, p, sizeof(double) * 3 * k);
+    HIPCHK(hipMemcpyAsync(c->d_scratch, c->h_buf, sizeof(double) * 3 * k, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_scatter_landmarks, dim3(blocks(k, 64)), dim3(64), 0, c->stream, k, c->N, c->Ncap, c->d_scratch, (const double*)nullptr, c->q0(), c->Qq(),
+                       c->Qa());
+    HIPCHK(hipGetLastError());
+    const int nold = c->n();
+    const int nnew = nold + 3 * k;
+    hipLaunchKernelGGL(k_append_sigma, dim3(blocks(nnew, 256), nnew), dim3(256), 0, c->stream, nold, nnew, c->ld, var, c->sigma());
+    HIPCHK(hipGetLastError());
+    c->ids.insert(c->ids.end(), ids, ids + k);
+    c->N += k;
+    return 0;
+}
+
+int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
+    if (!c || k < 0 || (k > 0 && !indices))
+        return EQF_E_BAD_ARG;
+    if (k == 0)
+        return 0;
+    std::vector<char> drop(c->N, 0);
+    for (int t = 0; t < k; ++t) {
+        if (indices[t] < 0 || indices[t] >= c->N)
+            return EQF_E_BAD_ARG;
+        drop[indices[t]] = 1;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream)); // staging reuse
+    std::vector<int> newids;
+    int Nnew = 0;
+    for (int i = 0; i < c->N; ++i)
+        if (!drop[i]) {
+            c->h_ibuf[Nnew++] = i;
+            newids.push_back(c->ids[i]);
+        }
+    if (Nnew > 0)
+        HIPCHK(hipMemcpyAsync(c->d_keep, c->h_ibuf, sizeof(int) * Nnew, hipMemcpyHostToDevice, c->stream));
+    const int nnew = 21 + 3 * Nnew;
+    {
+        KTimer t(c, KN_MISC);
+        hipLaunchKernelGGL(k_compact_sigma, dim3(blocks(nnew, 256), nnew), dim3(256), 0, c->stream, nnew, c->ld, c->d_keep, c->d_sigma[c->cur], c->d_sigma[1 - c->cur]);
+        HIPCHK(hipGetLastError());
+        if (Nnew > 0) {
+            double* src = c->d_lm[c->lmcur];
+            double* dst = c->d_lm[1 - c->lmcur];
+            hipLaunchKernelGGL(k_compact_landmarks, dim3(blocks(Nnew, 64)), dim3(64), 0, c->stream, Nnew, c->Ncap, c->d_keep, src, src + 3 * (size_t)c->Ncap,
+                               src + 7 * (size_t)c->Ncap, dst, dst + 3 * (size_t)c->Ncap, dst + 7 * (size_t)c->Ncap);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    c->cur = 1 - c->cur;
+    c->lmcur = 1 - c->lmcur;
+    c->ids = newids;
+    c->N = Nnew;
+    return 0;
+}
+
+int eqf_remove_invalid_landmarks(eqf_ctx* c) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    if (c->N == 0)
+        return 0;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = fetch_estimates(c);
+    if (rc)
+        return rc;
+    std::vector<int> bad;
+    for (int i = 0; i < c->N; ++i)
+        if (c->h_buf[3 * c->N + i] != 0.0)
+            bad.push_back(i);
+    if (bad.empty())
+        return 0;
+    rc = eqf_remove_landmarks(c, bad.data(), (int)bad.size());
+    return rc ? rc : (int)bad.size();
+}
+
+int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
+    if (!c || !imu13 || !Qdiag12 || !Pdiag8)
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream)); // h_common reuse (v0: serialise)
+    int rc = upload_common(c, imu13);
+    if (rc)
+        return rc;
+    rc = launch_assemble(c);
+    if (rc)
+        return rc;
+    RiccatiArgs ra;
+    ra.dt = dt;
+    std::memcpy(ra.Qd, Qdiag12, sizeof(ra.Qd));
+    std::memcpy(ra.Pd, Pdiag8, sizeof(ra.Pd));
+    const int N = c->N, n = c->n();
+    double* Sin = c->d_sigma[c->cur];
+    double* Sout = c->d_sigma[1 - c->cur];
+    if (!c->opt_dense) {
+        if (N > 0) {
+            KTimer t(c, KN_PROP_G);
+            hipLaunchKernelGGL(k_propagate_G, dim3(blocks(N * 21, 256)), dim3(256), 0, c->stream, N, c->Ncap, c->ld, dt, Sin, c->d_Al, c->d_G);
+            HIPCHK(hipGetLastError());
+        }
+        const int nT = blocks(N, PT), nStrip = blocks(N * 21, 256);
+        KTimer t(c, KN_PROP_MAIN);
+        hipLaunchKernelGGL(k_propagate_main, dim3(nT * nT + nStrip + 1), dim3(256), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, Sin, Sout, c->d_Al, c->d_Bl, c->d_G,
+                           nT, nStrip);
+        HIPCHK(hipGetLastError());
+    } else {
+        // dense: F materialised, tmp = F Sigma (= (Sigma F^T)^T, Sigma symmetric), Sigma' = tmp F^T + noise
+        const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
+        if (!c->d_F)
+            HIPCHK(hipMalloc(&c->d_F, bytes));
+        if (!c->d_tmp)
+            HIPCHK(hipMalloc(&c->d_tmp, bytes));
+        KTimer t(c, KN_DENSE_GEMM);
+        hipLaunchKernelGGL(k_build_F, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, N, c->Ncap, n, c->ld, dt, c->d_common, c->d_Al, c->d_F);
+        HIPCHK(hipGetLastError());
+        // tmp[i][j] = sum_k F[i][k] Sigma[j][k]
+        hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(64), 0, c->stream, n, n, n, c->d_F, c->ld, Sin, c->ld, c->d_tmp, c->ld);
+        HIPCHK(hipGetLastError());
+        // Sout[i][j] = sum_k tmp[i][k] F[j][k]
+        hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(64), 0, c->stream, n, n, n, c->d_tmp, c->ld, c->d_F, c->ld, Sout, c->ld);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_add_noise, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, N, c->Ncap, n, c->ld, ra, c->d_common, c->d_Bl, Sout);
+        HIPCHK(hipGetLastError());
+    }
+    c->cur = 1 - c->cur;
+    if (c->opt_check) {
+        hipLaunchKernelGGL(k_check_finite, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), c->d_flags);
+        HIPCHK(hipGetLastError());
+        rc = read_flags(c);
+        if (rc)
+            return rc;
+        if (c->h_flags[1])
+            return EQF_E_NONFINITE;
+    }
+    return 0;
+}
+
+int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k, int k, int discreteLift) {
+    if (!c || k < 0 || (k > 0 && (!imu13_k || !dt_k)))
+        return EQF_E_BAD_ARG;
+    if (k == 0)
+        return 0;
+    HIPCHK(hipSetDevice(c->device));
+    int done = 0;
+    while (done < k) {
+        const int chunk = std::min(k - done, eqf_ctx::kMaxSteps);
+        HIPCHK(hipStreamSynchronize(c->stream)); // h_steps reuse (v0: serialise)
+        for (int s = 0; s < chunk; ++s) {
+            const double* imu = imu13_k + 13 * (done + s);
+            const double dt = dt_k[done + s];
+            // stateEstimate() sensor part and the lift (VIOGroup.cpp:190-271)
+            const SensorState xh = sensor_action(c->X, c->xi0);
+            const V3 gyr = v3(imu[1], imu[2], imu[3]) - xh.bgyr;
+            const V3 acc = v3(imu[4], imu[5], imu[6]) - xh.bacc;
+            const V3 gbv = v3(imu[7], imu[8], imu[9]), abv = v3(imu[10], imu[11], imu[12]);
+            const V3 gdir = q_rot(q_inv(xh.pose.R), v3(0, 0, 1));
+            GroupSensor L;
+            ObsStep& st = c->h_steps[s];
+            st.discrete = discreteLift ? 1 : 0;
+            st.dt = dt;
+            if (discreteLift) {
+                L.bgyr = dt * gbv;
+                L.bacc = dt * abv;
+                L.A.R = so3_exp(dt * gyr);
+                V3 x = dt * q_rot(xh.pose.R, xh.vel) + (0.5 * dt * dt) * (q_rot(xh.pose.R, acc) + v3(0, 0, -kGravity));
+                L.A.x = q_rot(q_inv(xh.pose.R), x);
+                L.B = pose_mul(pose_mul(pose_inv(xh.cam), L.A), xh.cam);
+                const V3 bodyVelDiff = acc - kGravity * gdir;
+                L.w = xh.vel - (xh.vel + dt * bodyVelDiff);
+                st.Tinv = pose_mul(pose_mul(pose_inv(xh.cam), pose_inv(L.A)), xh.cam);
+                st.omC = v3(0, 0, 0);
+                st.vC = v3(0, 0, 0);
+            } else {
+                // VIOExp(dt * liftVelocity) (VIOGroup.cpp:190-227, 273-290)
+                const V6 U_A{gyr, xh.vel};
+                const V6 U_B = Ad_apply(pose_inv(xh.cam), U_A);
+                const V3 u_w = -acc + kGravity * gdir;
+                L.bgyr = dt * gbv;
+                L.bacc = dt * abv;
+                const M3 V = so3_V(dt * U_A.w);
+                L.A = Pose{so3_exp(dt * U_A.w), V * (dt * U_A.v)};
+                L.w = V * (dt * u_w);
+                L.B = se3_exp(dt * U_B.w, dt * U_B.v);
+                st.Tinv = pose_identity();
+                st.omC = U_B.w;
+                st.vC = U_B.v;
+            }
+            c->X = group_mul(c->X, L);
+        }
+        if (c->N > 0) {
+            HIPCHK(hipMemcpyAsync(c->d_steps, c->h_steps, sizeof(ObsStep) * chunk, hipMemcpyHostToDevice, c->stream));
+            KTimer t(c, KN_OBSERVER);
+            hipLaunchKernelGGL(k_observer, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, c->N, c->Ncap, chunk, c->d_steps, c->q0(), c->Qq(), c->Qa());
+            HIPCHK(hipGetLastError());
+        }
+        done += chunk;
+    }
+    return 0;
+}
+
+// map ascending measurement ids to state indices; returns 0 or EQF_E_BAD_ARG
+static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, int* lmidx, int* measof) {
+    for (int i = 0; i < c->N; ++i)
+        measof[i] = -1;
+    for (int j = 0; j < M; ++j) {
+        if (j > 0 && ids[j] <= ids[j - 1])
+            return EQF_E_BAD_ARG; // must be strictly ascending (std::map order)
+        const int i = index_of(c, ids[j]);
+        lmidx[j] = i;
+        if (i >= 0)
+            measof[i] = j;
+        else if (require_all)
+            return EQF_E_BAD_ARG;
+    }
+    return 0;
+}
+
+int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double* absErr, double* probErr, double* depth2) {
+    if (!c || !cam || M < 0 || (M > 0 && (!ids || !y)) || cam->model != EQVIO_CAMERA_PINHOLE)
+        return EQF_E_BAD_ARG;
+    const int N = c->N;
+    if (N == 0)
+        return 0;
+    if (M > c->Ncap)
+        return EQF_E_CAPACITY;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int* lmidx = c->h_ibuf;
+    int* measof = c->h_ibuf + c->Ncap;
+    int rc = map_measurement(c, ids, M, false, lmidx, measof);
+    if (rc)
+        return rc;
+    std::memcpy(c->h_buf, y, sizeof(double) * 2 * M);
+    HIPCHK(hipMemcpyAsync(c->d_measof, measof, sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
+    if (M > 0)
+        HIPCHK(hipMemcpyAsync(c->d_y, c->h_buf, sizeof(double) * 2 * M, hipMemcpyHostToDevice, c->stream));
+    {
+        KTimer t(c, KN_STATS);
+        hipLaunchKernelGGL(k_outlier_stats, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), c->d_measof, c->d_y, c->q0(), c->Qq(),
+                           c->Qa(), c->sigma(), c->d_stats);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_stats, sizeof(double) * 3 * N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (absErr)
+        std::memcpy(absErr, c->h_buf, sizeof(double) * N);
+    if (probErr)
+        std::memcpy(probErr, c->h_buf + N, sizeof(double) * N);
+    if (depth2)
+        std::memcpy(depth2, c->h_buf + 2 * N, sizeof(double) * N);
+    return 0;
+}
+
+static int stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int* lmidx = c->h_ibuf;
+    int* measof = c->h_ibuf + c->Ncap;
+    int rc = map_measurement(c, ids, M, true, lmidx, measof);
+    if (rc)
+        return rc;
+    std::memcpy(c->h_buf, y, sizeof(double) * 2 * M);
+    HIPCHK(hipMemcpyAsync(c->d_lmidx, lmidx, sizeof(int) * M, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_y, c->h_buf, sizeof(double) * 2 * M, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEqv, int discreteCorr) {
+    if (!c || !cam || M < 0 || (M > 0 && (!ids || !y)) || cam->model != EQVIO_CAMERA_PINHOLE)
+        return EQF_E_BAD_ARG;
+    if (M == 0)
+        return 0; // VIO_eqf.cpp:108-109
+    if (M > c->N)
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = stage_measurement(c, ids, y, M);
+    if (rc)
+        return rc;
+    const int N = c->N, n = c->n(), m = 2 * M;
+    const int rows = m + n + 1;
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(int) * 4, c->stream));
+    {
+        KTimer t(c, KN_MEASURE);
+        hipLaunchKernelGGL(k_measure, dim3(blocks(M, 64)), dim3(64), 0, c->stream, M, c->Ncap, c->Ncap, c->chart, make_cam(cam), useEqv, c->d_lmidx, c->d_y, c->q0(), c->Qq(),
+                           c->Qa(), c->d_C, c->d_ytil);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        KTimer t(c, KN_BUILD_Z);
+        hipLaunchKernelGGL(k_build_Z, dim3(blocks(n + M + 1, 256), M), dim3(256), 0, c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx, c->sigma(), c->d_C,
+                           c->d_ytil, c->d_Z);
+        HIPCHK(hipGetLastError());
+    }
+    constexpr int NB = 32;
+    for (int kb = 0; kb < m; kb += NB) {
+        const int w = std::min(NB, m - kb);
+        {
+            KTimer t(c, KN_CHOL_PANEL);
+            const int below = rows - (kb + w);
+            hipLaunchKernelGGL(k_chol_panel<NB>, dim3(std::max(1, blocks(below, 64))), dim3(64), 0, c->stream, rows, kb, w, c->ldz, c->d_Z, c->d_flags);
+            HIPCHK(hipGetLastError());
+        }
+        if (kb + w < m) {
+            KTimer t(c, KN_CHOL_UPDATE);
+            const int c0 = kb + w;
+            hipLaunchKernelGGL(k_chol_update, dim3(blocks(rows - c0, 32), blocks(m - c0, 32)), dim3(64), 0, c->stream, rows, m, kb, w, c->ldz, c->d_Z);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    {
+        KTimer t(c, KN_GAMMA);
+        hipLaunchKernelGGL(k_gamma, dim3(blocks(n, 256)), dim3(256), 0, c->stream, n, m, c->ldz, c->d_Z, c->d_gamma);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        KTimer t(c, KN_SYRK);
+        const int nt = blocks(n, 32);
+        hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64), 0, c->stream, n, m, c->ld, c->ldz, c->d_Z, c->sigma(), nt);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        KTimer t(c, KN_LIFT);
+        hipLaunchKernelGGL(k_lift, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(), c->d_est);
+        HIPCHK(hipGetLastError());
+    }
+    if (c->opt_check) {
+        hipLaunchKernelGGL(k_check_finite, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), c->d_flags);
+        HIPCHK(hipGetLastError());
+    }
+    // Gamma (n) + flags back; the sensor part of Delta is lifted on the host
+    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_gamma, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    rc = read_flags(c);
+    if (rc)
+        return rc;
+    c->last_gamma.assign(c->h_buf, c->h_buf + n);
+    const double* g = c->h_buf;
+    GroupSensor D;
+    D.bgyr = v3(g[0], g[1], g[2]);
+    D.bacc = v3(g[3], g[4], g[5]);
+    const V3 gw = v3(g[6], g[7], g[8]), gv = v3(g[9], g[10], g[11]), gvel = v3(g[12], g[13], g[14]);
+    const V3 cw = v3(g[15], g[16], g[17]), cv = v3(g[18], g[19], g[20]);
+    if (discreteCorr) {
+        // liftInnovationDiscrete sensor part (euclid.cpp:74-79 == invdepth.cpp:228-233)
+        D.A = se3_exp(gw, gv);
+        D.w = c->xi0.vel - q_rot(D.A.R, c->xi0.vel + gvel);
+        D.B = pose_mul(pose_mul(pose_mul(pose_inv(c->xi0.cam), D.A), c->xi0.cam), se3_exp(cw, cv));
+    } else {
+        // VIOExp(liftInnovation) sensor part (euclid.cpp:40-51, VIOGroup.cpp:273-283)
+        const V3 u_w = -gvel - cross(gw, c->xi0.vel);
+        const V6 UB0 = Ad_apply(pose_inv(c->xi0.cam), V6{gw, gv});
+        const M3 V = so3_V(gw);
+        D.A = Pose{so3_exp(gw), V * gv};
+        D.w = V * u_w;
+        D.B = se3_exp(cw + UB0.w, cv + UB0.v);
+    }
+    c->X = group_mul(D, c->X);
+    if (c->h_flags[0])
+        return EQF_E_NOT_SPD;
+    if (c->h_flags[1])
+        return EQF_E_NONFINITE;
+    for (int i = 0; i < 21; ++i)
+        if (!(g[i] - g[i] == 0.0))
+            return EQF_E_NONFINITE;
+    return 0;
+}
+
+int eqf_last_gamma(eqf_ctx* c, double* out, int cap) {
+    if (!c || !out)
+        return EQF_E_BAD_ARG;
+    if ((int)c->last_gamma.size() > cap)
+        return EQF_E_CAPACITY;
+    std::memcpy(out, c->last_gamma.data(), sizeof(double) * c->last_gamma.size());
+    return (int)c->last_gamma.size();
+}
+
+int eqf_debug_matrices_AB(eqf_ctx* c, const double* imu13, double* A_out, double* B_out) {
+    if (!c || !imu13)
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = upload_common(c, imu13);
+    if (rc)
+        return rc;
+    rc = launch_assemble(c);
+    if (rc)
+        return rc;
+    const int N = c->N, n = c->n(), Ncap = c->Ncap;
+    std::vector<double> Al(45 * (size_t)Ncap), Bl(9 * (size_t)Ncap);
+    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_Al, sizeof(double) * 45 * Ncap, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_buf + 45 * (size_t)Ncap, c->d_Bl, sizeof(double) * 9 * Ncap, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::memcpy(Al.data(), c->h_buf, sizeof(double) * 45 * Ncap);
+    std::memcpy(Bl.data(), c->h_buf + 45 * (size_t)Ncap, sizeof(double) * 9 * Ncap);
+    const Common& cm = *c->h_common;
+    if (A_out) {
+        std::fill(A_out, A_out + (size_t)n * n, 0.0);
+        for (int r = 0; r < 21; ++r)
+            for (int cc = 0; cc < 21; ++cc)
+                A_out[r + (size_t)cc * n] = cm.Ass[r * 21 + cc];
+        for (int i = 0; i < N; ++i)
+            for (int r = 0; r < 3; ++r) {
+                for (int e = 0; e < 12; ++e)
+                    A_out[21 + 3 * i + r + (size_t)al_col(e) * n] = Al[(r * 15 + e) * (size_t)Ncap + i];
+                for (int cc = 0; cc < 3; ++cc)
+                    A_out[21 + 3 * i + r + (size_t)(21 + 3 * i + cc) * n] = Al[(r * 15 + 12 + cc) * (size_t)Ncap + i];
+            }
+    }
+    if (B_out) {
+        std::fill(B_out, B_out + (size_t)n * 12, 0.0);
+        for (int r = 0; r < 21; ++r)
+            for (int cc = 0; cc < 12; ++cc)
+                B_out[r + (size_t)cc * n] = cm.Bs[r * 12 + cc];
+        for (int i = 0; i < N; ++i)
+            for (int r = 0; r < 3; ++r)
+                for (int cc = 0; cc < 3; ++cc)
+                    B_out[21 + 3 * i + r + (size_t)cc * n] = Bl[(r * 3 + cc) * (size_t)Ncap + i];
+    }
+    return 0;
+}
+
+int eqf_debug_matrix_C(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, int useEqv, double* C_out, double* ytilde_out) {
+    if (!c || !cam || M <= 0 || !ids || !y)
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = stage_measurement(c, ids, y, M);
+    if (rc)
+        return rc;
+    std::vector<int> lmidx(c->h_ibuf, c->h_ibuf + M);
+    hipLaunchKernelGGL(k_measure, dim3(blocks(M, 64)), dim3(64), 0, c->stream, M, c->Ncap, c->Ncap, c->chart, make_cam(cam), useEqv, c->d_lmidx, c->d_y, c->q0(), c->Qq(), c->Qa(),
+                       c->d_C, c->d_ytil);
+    HIPCHK(hipGetLastError());
+    const int Ncap = c->Ncap, n = c->n();
+    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_C, sizeof(double) * 6 * Ncap, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_buf + 6 * (size_t)Ncap, c->d_ytil, sizeof(double) * 2 * M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (C_out) {
+        std::fill(C_out, C_out + (size_t)2 * M * n, 0.0);
+        for (int j = 0; j < M; ++j)
+            for (int k = 0; k < 2; ++k)
+                for (int cc = 0; cc < 3; ++cc)
+                    C_out[2 * j + k + (size_t)(21 + 3 * lmidx[j] + cc) * (2 * M)] = c->h_buf[(k * 3 + cc) * (size_t)Ncap + j];
+    }
+    if (ytilde_out)
+        std::memcpy(ytilde_out, c->h_buf + 6 * (size_t)Ncap, sizeof(double) * 2 * M);
+    return 0;
+}
+
+int eqf_mfma_f64_peak(eqf_ctx* c, double* tflops) {
+    if (!c || !tflops)
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const int nblk = 256 * 8, iters = 4096;
+    double* d_out = nullptr;
+    HIPCHK(hipMalloc(&d_out, sizeof(double) * nblk * 256));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, c->stream, 64, d_out); // warm-up
+    double best = 0;
+    for (int rep = 0; rep < 5; ++rep) {
+        HIPCHK(hipEventRecord(e0, c->stream));
+        hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, c->stream, iters, d_out);
+        HIPCHK(hipEventRecord(e1, c->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        const double flops = (double)nblk * 4 /*waves*/ * iters * 4 /*mfma*/ * (2.0 * 16 * 16 * 4);
+        best = std::max(best, flops / (ms * 1e-3) / 1e12);
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(d_out);
+    *tflops = best;
+    return 0;
+}
+
+int eqf_last_kernel_times(eqf_ctx* c, int* which, float* usec, int cap) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int cnt = 0;
+    for (auto& t : c->tev) {
+        if (cnt >= cap)
+            break;
+        float ms = 0;
+        hipEventElapsedTime(&ms, t.second.first, t.second.second);
+        which[cnt] = t.first;
+        usec[cnt] = ms * 1000.0f;
+        ++cnt;
+    }
+    timing_reset(c);
+    return cnt;
+}
+
+} // extern "C"

@@ -1,0 +1,929 @@
+// HIP kernels of the MI355X EqF path (gfx950 only). Included by eqf_hip.hip.
+//
+// Data layout in HBM (all fp64):
+//   Sigma      : n x n column-major, leading dimension ld (fixed by capacity), two buffers (ping-pong:
+//                propagate and landmark compaction are out-of-place, the vision update is in-place)
+//   q0, Qq, Qa : per-landmark origin point, SOT(3) quaternion and scale as SoA planes of stride Ncap
+//                (q0: 3 planes, Qq: 4 planes (w,x,y,z), Qa: 1 plane) -> lane i reads plane[i]: coalesced
+//   Al, Bl     : packed per-landmark rows of the EqF state/input matrices, SoA planes of stride Ncap:
+//                Al 45 planes = 3 rows x 15 cols (cols 0:3 | 12:15 | 15:21 of A, then the own 3x3 block),
+//                Bl 9 planes  = 3 x 3 (cols 0:3 of B)                      [SURVEY.md §8(a) a3, a4]
+//   Z          : (m + n + 1) x m column-major, ld = ldz: rows [0,m) = S, [m,m+n) = T = Sigma C^T,
+//                row m+n = yTilde^T. Right-looking blocked Cholesky of the S part applied to all rows
+//                leaves [L ; W = T L^-T ; z^T = (L^-1 yTilde)^T].  Then Gamma = W z, Sigma -= W W^T.
+#pragma once
+#include "eqf_math.hpp"
+#include "eqvio_types.h"
+#include <hip/hip_runtime.h>
+
+namespace eqf {
+
+// Sensor-level terms of the EqF matrices, computed once per call on the host (O(1) work) and staged to HBM.
+struct Common {
+    double Mv[9];     // R_IC^T R_A^T                     (euclid.cpp:134-139)
+    double RTic[9];   // R_IC^T                            (euclid.cpp:222-230)
+    double RTicSx[9]; // R_IC^T skew(x_IC)
+    double CT[36];    // Ad_{B^-1} ad(Ad_{T0^-1} Ad_A U_I) (euclid.cpp:141-148)
+    double vC[3];     // linear part of Ad_{T_IC^-1} U_I   (euclid.cpp:150-152)
+    double Ass[441];  // sensor block of A, row-major 21x21
+    double Bs[252];   // sensor rows of B, row-major 21x12
+};
+struct RiccatiArgs {
+    double dt;
+    double Qd[12];
+    double Pd[8];
+};
+// One observer step (integrateObserverState) as the landmark kernel needs it.
+struct ObsStep {
+    int discrete;
+    double dt;
+    Pose Tinv; // T_IC^-1 Lambda.A^-1 T_IC   (VIOGroup.cpp:254)
+    V3 omC, vC; // U_C = Ad_{T_IC^-1} U_A    (VIOGroup.cpp:207-216), continuous lift only
+};
+
+__device__ __forceinline__ V3 ld3(const double* base, int stride, int i) { return V3{base[i], base[stride + i], base[2 * stride + i]}; }
+__device__ __forceinline__ Qt ldq(const double* base, int stride, int i) { return Qt{base[i], base[stride + i], base[2 * stride + i], base[3 * stride + i]}; }
+__device__ __forceinline__ M3 ldm3(const double* p) { return M3{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]}; }
+__device__ __forceinline__ void st_plane9(double* base, int stride, int i, int plane0, const M3& A) {
+    base[(plane0 + 0) * stride + i] = A.a00;
+    base[(plane0 + 1) * stride + i] = A.a01;
+    base[(plane0 + 2) * stride + i] = A.a02;
+    base[(plane0 + 3) * stride + i] = A.a10;
+    base[(plane0 + 4) * stride + i] = A.a11;
+    base[(plane0 + 5) * stride + i] = A.a12;
+    base[(plane0 + 6) * stride + i] = A.a20;
+    base[(plane0 + 7) * stride + i] = A.a21;
+    base[(plane0 + 8) * stride + i] = A.a22;
+}
+
+// column index in A of packed column e (0..11) of the landmark-sensor block
+__host__ __device__ __forceinline__ int al_col(int e) { return e < 3 ? e : (e < 6 ? 12 + (e - 3) : 15 + (e - 6)); }
+
+// ---------------------------------------------------------------------------------------------------
+// K1: per-landmark rows of A and B (EqFStateMatrixA / EqFInputMatrixB, euclid.cpp:99-233, invdepth.cpp:36-181)
+// One lane per landmark; the sensor-level terms are staged in LDS once per workgroup.
+__global__ void __launch_bounds__(64) k_assemble_AB(int N, int Ncap, int chart, const Common* __restrict__ cmg, const double* __restrict__ q0,
+                                                    const double* __restrict__ Qq, const double* __restrict__ Qa, double* __restrict__ Al,
+                                                    double* __restrict__ Bl) {
+    __shared__ double s_cm[9 + 9 + 9 + 36 + 3];
+    {
+        const double* src = cmg->Mv; // Mv, RTic, RTicSx, CT, vC are contiguous
+        for (int t = threadIdx.x; t < 66; t += blockDim.x)
+            s_cm[t] = src[t];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const M3 Mv = ldm3(s_cm), RTic = ldm3(s_cm + 9), RTicSx = ldm3(s_cm + 18);
+    const double* CT = s_cm + 27;
+    const V3 vC{s_cm[63], s_cm[64], s_cm[65]};
+
+    const V3 p0 = ld3(q0, Ncap, i);
+    const Qt q = ldq(Qq, Ncap, i);
+    const double a = Qa[i];
+    const M3 RQ = q_mat(q);
+    const M3 Qhat = a * RQ;
+    const V3 qh = (1.0 / a) * (transpose(RQ) * p0); // Q^-1 * q0
+
+    M3 Bblk = Qhat * (skew(qh) * RTic + RTicSx);
+    M3 A_v = (-1.0) * (Qhat * Mv);
+    // [skew(q0) R_Q, -a R_Q] * CT  (3x6 * 6x6)
+    const M3 T0 = skew(p0) * RQ;
+    const M3 T1 = (-a) * RQ;
+    const double t[3][6] = {{T0.a00, T0.a01, T0.a02, T1.a00, T1.a01, T1.a02},
+                            {T0.a10, T0.a11, T0.a12, T1.a10, T1.a11, T1.a12},
+                            {T0.a20, T0.a21, T0.a22, T1.a20, T1.a21, T1.a22}};
+    double Ac[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                s += t[r][k] * CT[k * 6 + c];
+            Ac[r][c] = s;
+        }
+    const M3 inner = skew(qh) * skew(vC) - 2.0 * outer(vC, qh) + outer(qh, vC);
+    const M3 QhatInv = (1.0 / a) * transpose(RQ);
+    M3 A_q = (-1.0 / norm2(qh)) * (Qhat * inner * QhatInv);
+
+    if (chart == EQVIO_COORD_INVDEPTH) {
+        const M3 e2i = conv_euc2ind(p0);
+        const M3 i2e = conv_ind2euc(p0);
+        Bblk = e2i * Bblk;
+        A_v = e2i * A_v;
+        const double e[3][3] = {{e2i.a00, e2i.a01, e2i.a02}, {e2i.a10, e2i.a11, e2i.a12}, {e2i.a20, e2i.a21, e2i.a22}};
+        double Ac2[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                Ac2[r][c] = e[r][0] * Ac[0][c] + e[r][1] * Ac[1][c] + e[r][2] * Ac[2][c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                Ac[r][c] = Ac2[r][c];
+        A_q = e2i * A_q * i2e;
+    }
+    // Al planes: row r, packed col c -> plane r*15 + c
+    const M3 A_b = (-1.0) * Bblk;
+    const double ab[9] = {A_b.a00, A_b.a01, A_b.a02, A_b.a10, A_b.a11, A_b.a12, A_b.a20, A_b.a21, A_b.a22};
+    const double av[9] = {A_v.a00, A_v.a01, A_v.a02, A_v.a10, A_v.a11, A_v.a12, A_v.a20, A_v.a21, A_v.a22};
+    const double aq[9] = {A_q.a00, A_q.a01, A_q.a02, A_q.a10, A_q.a11, A_q.a12, A_q.a20, A_q.a21, A_q.a22};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            Al[(r * 15 + c) * Ncap + i] = ab[r * 3 + c];
+            Al[(r * 15 + 3 + c) * Ncap + i] = av[r * 3 + c];
+            Al[(r * 15 + 12 + c) * Ncap + i] = aq[r * 3 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            Al[(r * 15 + 6 + c) * Ncap + i] = Ac[r][c];
+    }
+    st_plane9(Bl, Ncap, i, 0, Bblk);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4: landmark part of k observer steps X <- X * Lambda (VIO_eqf.cpp:47-60, VIOGroup.cpp:190-271, 71-92)
+__global__ void __launch_bounds__(64) k_observer(int N, int Ncap, int k, const ObsStep* __restrict__ steps, const double* __restrict__ q0,
+                                                 double* __restrict__ Qq, double* __restrict__ Qa) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const V3 p0 = ld3(q0, Ncap, i);
+    Qt q = ldq(Qq, Ncap, i);
+    double a = Qa[i];
+    for (int s = 0; s < k; ++s) {
+        const ObsStep st = steps[s];
+        const V3 ph = (1.0 / a) * q_rot(q_inv(q), p0); // current estimate q_hat_i
+        Qt Lq;
+        double La;
+        if (st.discrete) {
+            const V3 p1 = pose_act(st.Tinv, ph);
+            Lq = so3_from_vectors(normalized(p1), normalized(ph));
+            La = norm(ph) / norm(p1);
+        } else {
+            const double ip2 = 1.0 / norm2(ph);
+            const V3 Wr = st.omC + ip2 * cross(ph, st.vC);
+            const double Ws = ip2 * dot(ph, st.vC);
+            Lq = so3_exp(st.dt * Wr);
+            La = exp(st.dt * Ws);
+        }
+        q = q_mul(q, Lq);
+        a = a * La;
+    }
+    Qq[i] = q.w;
+    Qq[Ncap + i] = q.x;
+    Qq[2 * Ncap + i] = q.y;
+    Qq[3 * Ncap + i] = q.z;
+    Qa[i] = a;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2a: G_i = (F Sigma)[l_i, 0:21] = dt*A_ls_i Sigma_ss + (I + dt*A_qi) Sigma_{l_i,s}   (3 x 21 per landmark)
+__global__ void __launch_bounds__(256) k_propagate_G(int N, int Ncap, int ld, double dt, const double* __restrict__ Sig, const double* __restrict__ Al,
+                                                     double* __restrict__ G) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * 21)
+        return;
+    const int i = t % N, c = t / N;
+    const int l = 21 + 3 * i;
+    const double s0 = Sig[l + (size_t)c * ld], s1 = Sig[l + 1 + (size_t)c * ld], s2 = Sig[l + 2 + (size_t)c * ld];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0;
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+            acc += Al[(r * 15 + e) * Ncap + i] * Sig[al_col(e) + (size_t)c * ld];
+        acc *= dt;
+        const double d0 = dt * Al[(r * 15 + 12) * Ncap + i] + (r == 0 ? 1.0 : 0.0);
+        const double d1 = dt * Al[(r * 15 + 13) * Ncap + i] + (r == 1 ? 1.0 : 0.0);
+        const double d2 = dt * Al[(r * 15 + 14) * Ncap + i] + (r == 2 ? 1.0 : 0.0);
+        acc += d0 * s0 + d1 * s1 + d2 * s2;
+        G[(r * 21 + c) * Ncap + i] = acc;
+    }
+}
+
+// K2b: Sigma' = F Sigma F^T + dt (B Q B^T + P) in arrow form (integrateRiccatiStateFast, VIO_eqf.cpp:62-72).
+// Block roles by blockIdx.x: [0, nT*nT) landmark-landmark tiles of 16x16 landmarks (one 3x3 block per lane),
+// then strip blocks (landmark-sensor 3x21 blocks and their transposes), then one sensor-sensor block.
+constexpr int PT = 16; // landmarks per tile side
+__global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
+                                                        const double* __restrict__ Sig, double* __restrict__ Sout, const double* __restrict__ Al,
+                                                        const double* __restrict__ Bl, const double* __restrict__ G, int nT, int nStrip) {
+    const double dt = ra.dt;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 8];
+    if (b < nT * nT) {
+        const int bi = b % nT, bj = b / nT;
+        // per-i arrays: G (63), Fls (36), D (9), Bl (9) ; per-j arrays: Ssj (63), Fls (36), D (9), Bl (9). layout [e][PT]
+        double* sGi = sm;
+        double* sFi = sGi + 63 * PT;
+        double* sDi = sFi + 36 * PT;
+        double* sBi = sDi + 9 * PT;
+        double* sSj = sBi + 9 * PT;
+        double* sFj = sSj + 63 * PT;
+        double* sDj = sFj + 36 * PT;
+        double* sBj = sDj + 9 * PT;
+        for (int t = tid; t < 63 * PT; t += 256) {
+            const int e = t / PT, x = t % PT;
+            const int i = bi * PT + x, j = bj * PT + x;
+            sGi[t] = i < N ? G[e * Ncap + i] : 0.0;
+            // Sigma[k][l_j + c'] with e = k*3 + c'
+            const int kk = e / 3, cc = e % 3;
+            sSj[t] = j < N ? Sig[kk + (size_t)(21 + 3 * j + cc) * ld] : 0.0;
+        }
+        for (int t = tid; t < 36 * PT; t += 256) {
+            const int e = t / PT, x = t % PT;
+            const int r = e / 12, c = e % 12;
+            const int i = bi * PT + x, j = bj * PT + x;
+            sFi[t] = i < N ? dt * Al[(r * 15 + c) * Ncap + i] : 0.0;
+            sFj[t] = j < N ? dt * Al[(r * 15 + c) * Ncap + j] : 0.0;
+        }
+        for (int t = tid; t < 9 * PT; t += 256) {
+            const int e = t / PT, x = t % PT;
+            const int r = e / 3, c = e % 3;
+            const int i = bi * PT + x, j = bj * PT + x;
+            const double eye = (r == c) ? 1.0 : 0.0;
+            sDi[t] = i < N ? dt * Al[(r * 15 + 12 + c) * Ncap + i] + eye : 0.0;
+            sDj[t] = j < N ? dt * Al[(r * 15 + 12 + c) * Ncap + j] + eye : 0.0;
+            sBi[t] = i < N ? Bl[e * Ncap + i] : 0.0;
+            sBj[t] = j < N ? Bl[e * Ncap + j] : 0.0;
+        }
+        __syncthreads();
+        const int ti = tid % PT, tj = tid / PT;
+        const int i = bi * PT + ti, j = bj * PT + tj;
+        if (i >= N || j >= N)
+            return;
+        const int li = 21 + 3 * i, lj = 21 + 3 * j;
+        // Sigma_ij
+        double Sij[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Sij[k][c] = Sig[li + k + (size_t)(lj + c) * ld];
+        // E = Fls_i Sigma_sj + D_i Sigma_ij
+        double E[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double s = 0;
+#pragma unroll
+                for (int e = 0; e < 12; ++e)
+                    s += sFi[(r * 12 + e) * PT + ti] * sSj[(al_col(e) * 3 + c) * PT + tj];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    s += sDi[(r * 3 + k) * PT + ti] * Sij[k][c];
+                E[r][c] = s;
+            }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double s = 0;
+#pragma unroll
+                for (int e = 0; e < 12; ++e)
+                    s += sGi[(r * 21 + al_col(e)) * PT + ti] * sFj[(c * 12 + e) * PT + tj];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    s += E[r][k] * sDj[(c * 3 + k) * PT + tj];
+                double bq = 0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    bq += sBi[(r * 3 + q) * PT + ti] * ra.Qd[q] * sBj[(c * 3 + q) * PT + tj];
+                s += dt * bq;
+                if (i == j && r == c)
+                    s += dt * ra.Pd[7];
+                Sout[li + r + (size_t)(lj + c) * ld] = s;
+            }
+        return;
+    }
+    if (b < nT * nT + nStrip) {
+        // landmark-sensor strips: Sigma'[l_i + r][c] = sum_k G_i[r][k] Fss[c][k] + dt sum_q Bl_i[r][q] Qd[q] Bs[c][q]
+        const int t = (b - nT * nT) * 256 + tid;
+        if (t >= N * 21)
+            return;
+        const int i = t % N, c = t / N;
+        const int li = 21 + 3 * i;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double s = 0;
+            for (int k = 0; k < 21; ++k) {
+                const double f = dt * cm->Ass[c * 21 + k] + (k == c ? 1.0 : 0.0);
+                s += G[(r * 21 + k) * Ncap + i] * f;
+            }
+            double bq = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                bq += Bl[(r * 3 + q) * Ncap + i] * ra.Qd[q] * cm->Bs[c * 12 + q];
+            s += dt * bq;
+            Sout[li + r + (size_t)c * ld] = s;
+            Sout[c + (size_t)(li + r) * ld] = s;
+        }
+        return;
+    }
+    // sensor-sensor block
+    {
+        double* sF = sm;        // 441
+        double* sS = sm + 441;  // 441
+        double* sT = sm + 882;  // 441  (F Sigma_ss)
+        for (int t = tid; t < 441; t += 256) {
+            const int r = t / 21, c = t % 21;
+            sF[t] = dt * cm->Ass[t] + (r == c ? 1.0 : 0.0);
+            sS[t] = Sig[r + (size_t)c * ld];
+        }
+        __syncthreads();
+        for (int t = tid; t < 441; t += 256) {
+            const int r = t / 21, c = t % 21;
+            double s = 0;
+            for (int k = 0; k < 21; ++k)
+                s += sF[r * 21 + k] * sS[k * 21 + c];
+            sT[t] = s;
+        }
+        __syncthreads();
+        for (int t = tid; t < 441; t += 256) {
+            const int r = t / 21, c = t % 21;
+            double s = 0;
+            for (int k = 0; k < 21; ++k)
+                s += sT[r * 21 + k] * sF[c * 21 + k];
+            double bq = 0;
+            for (int q = 0; q < 12; ++q)
+                bq += cm->Bs[r * 12 + q] * ra.Qd[q] * cm->Bs[c * 12 + q];
+            s += dt * bq;
+            if (r == c)
+                s += dt * ra.Pd[r / 3];
+            Sout[r + (size_t)c * ld] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: per measurement j: yHat, yTilde and the 2x3 block of C (measureSystemState VIOState.cpp:70-78,
+// EqFoutputMatrixCiStar euclid.cpp:162-184, invdepth.cpp:255-266, outputMatrixCi EqFMatrices.cpp:84-89).
+// Optionally the outlier statistics of VIOFilter::removeOutliers (VIOFilter.cpp:304-334).
+struct MeasOut {
+    double c[6];
+    double yt[2];
+    V3 qh;
+};
+__device__ __forceinline__ MeasOut measure_one(int chart, const Cam& cam, V3 p0, Qt q, double a, double yu, double yv, bool star) {
+    MeasOut o;
+    const M3 RQ = q_mat(q);
+    const V3 qh = (1.0 / a) * (transpose(RQ) * p0);
+    o.qh = qh;
+    double hu, hv;
+    cam_project(cam, qh, hu, hv);
+    o.yt[0] = yu - hu;
+    o.yt[1] = yv - hv;
+    const V3 yHat = normalized(qh);
+    const V3 yTru = star ? cam_undistort(cam, yu, yv) : cam_undistort(cam, hu, hv);
+    V3 a0, a1, b0, b1;
+    cam_jac_skew(cam, yTru, a0, a1);
+    cam_jac_skew(cam, yHat, b0, b1);
+    const V3 g0 = 0.5 * (a0 + b0), g1 = 0.5 * (a1 + b1);
+    const double iq2 = 1.0 / norm2(p0);
+    V3 c0 = iq2 * cross(p0, RQ * g0);
+    V3 c1 = iq2 * cross(p0, RQ * g1);
+    if (chart == EQVIO_COORD_INVDEPTH) {
+        const M3 Mt = transpose(ind2euc_r0(p0));
+        c0 = Mt * c0;
+        c1 = Mt * c1;
+    }
+    o.c[0] = c0.x;
+    o.c[1] = c0.y;
+    o.c[2] = c0.z;
+    o.c[3] = c1.x;
+    o.c[4] = c1.y;
+    o.c[5] = c1.z;
+    return o;
+}
+__global__ void __launch_bounds__(64) k_measure(int M, int Mcap, int Ncap, int chart, Cam cam, int star, const int* __restrict__ lmidx,
+                                                const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
+                                                const double* __restrict__ Qa, double* __restrict__ C, double* __restrict__ ytil) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M)
+        return;
+    const int i = lmidx[j];
+    const MeasOut o = measure_one(chart, cam, ld3(q0, Ncap, i), ldq(Qq, Ncap, i), Qa[i], y[2 * j], y[2 * j + 1], star != 0);
+#pragma unroll
+    for (int e = 0; e < 6; ++e)
+        C[e * Mcap + j] = o.c[e];
+    ytil[2 * j] = o.yt[0];
+    ytil[2 * j + 1] = o.yt[1];
+}
+// stats: out[0..N) absErr, out[N..2N) probErr, out[2N..3N) |q_hat|^2 ; unmeasured -> -1 (meas_of[i] = j or -1)
+__global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, int chart, Cam cam, const int* __restrict__ meas_of,
+                                                      const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
+                                                      const double* __restrict__ Qa, const double* __restrict__ Sig, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const V3 p0 = ld3(q0, Ncap, i);
+    const Qt q = ldq(Qq, Ncap, i);
+    const double a = Qa[i];
+    const int j = meas_of[i];
+    if (j < 0) {
+        const V3 qh = (1.0 / a) * q_rot(q_inv(q), p0);
+        out[i] = -1.0;
+        out[N + i] = -1.0;
+        out[2 * N + i] = norm2(qh);
+        return;
+    }
+    const MeasOut o = measure_one(chart, cam, p0, q, a, y[2 * j], y[2 * j + 1], false);
+    const int l = 21 + 3 * i;
+    double S[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            S[r][c] = Sig[l + r + (size_t)(l + c) * ld];
+    // cov = C0 S C0^T
+    double CS[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            CS[r][c] = o.c[r * 3 + 0] * S[0][c] + o.c[r * 3 + 1] * S[1][c] + o.c[r * 3 + 2] * S[2][c];
+    const double v00 = CS[0][0] * o.c[0] + CS[0][1] * o.c[1] + CS[0][2] * o.c[2];
+    const double v01 = CS[0][0] * o.c[3] + CS[0][1] * o.c[4] + CS[0][2] * o.c[5];
+    const double v10 = CS[1][0] * o.c[0] + CS[1][1] * o.c[1] + CS[1][2] * o.c[2];
+    const double v11 = CS[1][0] * o.c[3] + CS[1][1] * o.c[4] + CS[1][2] * o.c[5];
+    const double det = v00 * v11 - v01 * v10;
+    // inverse2 * yt
+    const double t0 = (v11 / det) * o.yt[0] + (-v01 / det) * o.yt[1];
+    const double t1 = (-v10 / det) * o.yt[0] + (v00 / det) * o.yt[1];
+    out[i] = sqrt(o.yt[0] * o.yt[0] + o.yt[1] * o.yt[1]);
+    out[N + i] = o.yt[0] * t0 + o.yt[1] * t1;
+    out[2 * N + i] = norm2(o.qh);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K8a: build Z = [S ; T ; yTilde^T] from Sigma and the packed C blocks, exploiting the 2x3 block sparsity of C:
+//   T[:, 2j:2j+2] = Sigma[:, l_j:l_j+3] C_j^T          (6 n M flops instead of 2 n^2 m)
+//   S[2i:2i+2, 2j:2j+2] = C_i Sigma[l_i.., l_j..] C_j^T + delta_ij R
+// grid.y = measurement j; grid.x covers "row items": t < n -> row of T, n <= t < n+M -> block row i of S, t == n+M -> y row
+__global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
+                                                 const double* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
+                                                 double* __restrict__ Z) {
+    const int j = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = 2 * M;
+    const int lj = 21 + 3 * lmidx[j];
+    double cj[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e)
+        cj[e] = C[e * Mcap + j];
+    if (t < n) {
+        const double s0 = Sig[t + (size_t)lj * ld], s1 = Sig[t + (size_t)(lj + 1) * ld], s2 = Sig[t + (size_t)(lj + 2) * ld];
+        Z[m + t + (size_t)(2 * j) * ldz] = s0 * cj[0] + s1 * cj[1] + s2 * cj[2];
+        Z[m + t + (size_t)(2 * j + 1) * ldz] = s0 * cj[3] + s1 * cj[4] + s2 * cj[5];
+    } else if (t < n + M) {
+        const int i = t - n;
+        const int li = 21 + 3 * lmidx[i];
+        double ci[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+            ci[e] = C[e * Mcap + i];
+        double CS[2][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double s0 = Sig[li + (size_t)(lj + c) * ld], s1 = Sig[li + 1 + (size_t)(lj + c) * ld], s2 = Sig[li + 2 + (size_t)(lj + c) * ld];
+            CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
+            CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                double v = CS[a][0] * cj[3 * bb] + CS[a][1] * cj[3 * bb + 1] + CS[a][2] * cj[3 * bb + 2];
+                if (i == j && a == bb)
+                    v += meas_var;
+                Z[2 * i + a + (size_t)(2 * j + bb) * ldz] = v;
+            }
+    } else if (t == n + M) {
+        Z[m + n + (size_t)(2 * j) * ldz] = ytil[2 * j];
+        Z[m + n + (size_t)(2 * j + 1) * ldz] = ytil[2 * j + 1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K8b: one panel of the right-looking blocked Cholesky on Z (panel width NB, columns [kb, kb+w)).
+// Every workgroup re-factors the w x w diagonal block in LDS (redundant, identical arithmetic, no inter-WG
+// synchronisation needed), then solves its 64 rows below the block: X <- X L_kk^-T. Block 0 writes L_kk back.
+// flags[0] is set when a pivot is not positive (EQF_E_NOT_SPD).
+template <int NB>
+__global__ void __launch_bounds__(64) k_chol_panel(int rows, int kb, int w, int ldz, double* __restrict__ Z, int* __restrict__ flags) {
+    __shared__ double sL[NB * (NB + 1)];
+    __shared__ double sd;
+    const int lane = threadIdx.x;
+    constexpr int LDL = NB + 1;
+    // load lower triangle of the diagonal block, column-major sL[r + c*LDL]
+    for (int t = lane; t < w * w; t += 64) {
+        const int r = t % w, c = t / w;
+        sL[r + c * LDL] = (r >= c) ? Z[kb + r + (size_t)(kb + c) * ldz] : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < w; ++j) {
+        // left-looking column j: s_r = a_rj - sum_{p<j} L_rp L_jp, rows r >= j
+        double s = 0.0;
+        const int r = lane;
+        if (r >= j && r < w) {
+            s = sL[r + j * LDL];
+            for (int p = 0; p < j; ++p)
+                s -= sL[r + p * LDL] * sL[j + p * LDL];
+        }
+        if (r == j) {
+            if (!(s > 0.0)) {
+                flags[0] = 1;
+                s = 1.0; // keep going with finite numbers; the caller reports EQF_E_NOT_SPD
+            }
+            sd = sqrt(s);
+        }
+        __syncthreads();
+        const double d = sd;
+        if (r >= j && r < w)
+            sL[r + j * LDL] = (r == j) ? d : s / d;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        for (int t = lane; t < w * w; t += 64) {
+            const int r = t % w, c = t / w;
+            if (r >= c)
+                Z[kb + r + (size_t)(kb + c) * ldz] = sL[r + c * LDL];
+        }
+    }
+    // rows below the diagonal block
+    const int row = kb + w + blockIdx.x * 64 + lane;
+    if (row >= rows)
+        return;
+    double x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        x[j] = (j < w) ? Z[row + (size_t)(kb + j) * ldz] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j < w) {
+            double s = x[j];
+#pragma unroll
+            for (int p = 0; p < NB; ++p)
+                if (p < j)
+                    s -= x[p] * sL[j + p * LDL];
+            x[j] = s / sL[j + j * LDL];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        if (j < w)
+            Z[row + (size_t)(kb + j) * ldz] = x[j];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fp64 MFMA tile helper. v_mfma_f64_16x16x4_f64: lane l supplies A[row = l&15][k = l>>4] and
+// B[k = l>>4][col = l&15]; the 4 results of lane l are D[row = (l>>4) + 4r][col = l&15]
+// (cdna_hip_programming.md §3). We feed the "J" operand as A and the "I" operand as B so that a lane's
+// results are C[i = i0 + (l&15)][j = j0 + (l>>4) + 4r]: 16 consecutive lanes touch 16 consecutive doubles of a
+// column-major C (128-byte segments), and both operand loads P[x0 + (l&15) + (k0 + (l>>4)) * ld] are likewise
+// 128-byte contiguous per k.
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// C[i][j] (+/-)= sum_k P[i][k] * Qm[j][k]   for a 32x32 tile per wave (2x2 MFMA tiles), K multiple of 4 after
+// zero-predication. rowsP/rowsQ bound the valid operand rows.
+__device__ __forceinline__ void mfma_tile_32x32(const double* __restrict__ P, int ldp, int i0, int rowsP, const double* __restrict__ Qm, int ldq, int j0,
+                                                int rowsQ, int k0, int k1, d4 acc[2][2]) {
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int ia = i0 + lr, ib = i0 + 16 + lr;
+    const int ja = j0 + lr, jb = j0 + 16 + lr;
+    const bool via = ia < rowsP, vib = ib < rowsP, vja = ja < rowsQ, vjb = jb < rowsQ;
+    for (int k = k0; k < k1; k += 4) {
+        const int kk = k + lk;
+        const bool vk = kk < k1;
+        const double pa = (via && vk) ? P[ia + (size_t)kk * ldp] : 0.0;
+        const double pb = (vib && vk) ? P[ib + (size_t)kk * ldp] : 0.0;
+        const double qa = (vja && vk) ? Qm[ja + (size_t)kk * ldq] : 0.0;
+        const double qb = (vjb && vk) ? Qm[jb + (size_t)kk * ldq] : 0.0;
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pa, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pb, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pa, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pb, acc[1][1], 0, 0, 0);
+    }
+}
+
+// K8c: trailing update of the blocked Cholesky: Z[i][j] -= sum_{p in panel} Z[i][p] Z[j][p]
+// for j in [kb+w, m), i in [j-tile.., rows). One wave per 32x32 tile; tiles entirely above the diagonal of the
+// S part are skipped.
+__global__ void __launch_bounds__(64) k_chol_update(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z) {
+    const int c0 = kb + w;
+    const int j0 = c0 + blockIdx.y * 32;
+    const int i0 = c0 + blockIdx.x * 32;
+    if (j0 >= m || i0 >= rows)
+        return;
+    if (i0 + 31 < j0)
+        return; // strictly upper tile of the symmetric part: never read
+    d4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    const double* Pp = Z + (size_t)kb * ldz;
+    mfma_tile_32x32(Pp, ldz, i0, rows, Pp, ldz, j0, m, 0, w, acc);
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 16 * ti + lr;
+                const int j = j0 + 16 * tj + lk + 4 * r;
+                if (i < rows && j < m)
+                    Z[i + (size_t)j * ldz] -= acc[ti][tj][r];
+            }
+}
+
+// K8d: Gamma = W z  (Gamma = K yTilde = T S^-1 yTilde = W L^-1 yTilde)
+__global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const double* __restrict__ Z, double* __restrict__ gamma) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n)
+        return;
+    const double* W = Z + m;
+    const double* z = Z + m + n;
+    double s = 0;
+    for (int p = 0; p < m; ++p)
+        s += W[r + (size_t)p * ldz] * z[(size_t)p * ldz];
+    gamma[r] = s;
+}
+
+// K9: Sigma <- Sigma - W W^T  ( = Sigma - K C Sigma, VIO_eqf.cpp:131 ), lower tiles computed, mirrored.
+// One wave per 32x32 tile; blockIdx.x enumerates lower-triangular tiles.
+__global__ void __launch_bounds__(64) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Z, double* __restrict__ Sig, int nt) {
+    // decode (bi >= bj) from linear index
+    int b = blockIdx.x;
+    int bj = 0;
+    {
+        // row-major over columns: column bj has (nt - bj) tiles
+        int rem = b;
+        while (rem >= nt - bj) {
+            rem -= nt - bj;
+            ++bj;
+        }
+        b = rem;
+    }
+    const int bi = bj + b;
+    const int i0 = bi * 32, j0 = bj * 32;
+    d4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    const double* W = Z + m;
+    mfma_tile_32x32(W, ldz, i0, n, W, ldz, j0, n, 0, m, acc);
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 16 * ti + lr;
+                const int j = j0 + 16 * tj + lk + 4 * r;
+                if (i < n && j < n) {
+                    const double v = Sig[i + (size_t)j * ld] - acc[ti][tj][r];
+                    Sig[i + (size_t)j * ld] = v;
+                    if (bi != bj)
+                        Sig[j + (size_t)i * ld] = v;
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K10: landmark part of X <- Delta * X with Delta lifted from Gamma (liftInnovation / liftInnovationDiscrete,
+// euclid.cpp:36-97, invdepth.cpp:183-253; VIOExp VIOGroup.cpp:273-290; X = Delta * X VIO_eqf.cpp:130).
+// Also writes the new estimates q_hat_i and a flag per landmark with Q_i.a outside (1e-8, 1e8]
+// (removeInvalidLandmarks, VIO_eqf.cpp:213-223) into `est` (4 planes of stride N: qx, qy, qz, invalid).
+__global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
+                                             double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const V3 p0 = ld3(q0, Ncap, i);
+    const V3 g{gamma[21 + 3 * i], gamma[21 + 3 * i + 1], gamma[21 + 3 * i + 2]};
+    Qt Dq;
+    double Da;
+    if (discrete) {
+        const V3 q1 = (chart == EQVIO_COORD_INVDEPTH) ? invdepth_chart_inv(g, p0) : p0 + g;
+        Dq = so3_from_vectors(normalized(q1), normalized(p0));
+        Da = norm(p0) / norm(q1);
+    } else {
+        const V3 ge = (chart == EQVIO_COORD_INVDEPTH) ? ind2euc_r0(p0) * g : g;
+        const double iq2 = 1.0 / norm2(p0);
+        const V3 Wr = (-iq2) * cross(p0, ge);
+        const double Ws = -iq2 * dot(p0, ge);
+        Dq = so3_exp(Wr);
+        Da = exp(Ws);
+    }
+    const Qt q = q_mul(Dq, ldq(Qq, Ncap, i));
+    const double a = Da * Qa[i];
+    Qq[i] = q.w;
+    Qq[Ncap + i] = q.x;
+    Qq[2 * Ncap + i] = q.y;
+    Qq[3 * Ncap + i] = q.z;
+    Qa[i] = a;
+    const V3 qh = (1.0 / a) * q_rot(q_inv(q), p0);
+    est[i] = qh.x;
+    est[N + i] = qh.y;
+    est[2 * N + i] = qh.z;
+    est[3 * N + i] = (a <= 1e-8 || a > 1e8 || !(a == a)) ? 1.0 : 0.0;
+}
+// q_hat_i = Q_i^-1 q0_i for all landmarks (stateGroupAction, VIOGroup.cpp:44-52)
+__global__ void __launch_bounds__(64) k_estimate(int N, int Ncap, const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
+                                                 double* __restrict__ est) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const double a = Qa[i];
+    const V3 qh = (1.0 / a) * q_rot(q_inv(ldq(Qq, Ncap, i)), ld3(q0, Ncap, i));
+    est[i] = qh.x;
+    est[N + i] = qh.y;
+    est[2 * N + i] = qh.z;
+    est[3 * N + i] = (a <= 1e-8 || a > 1e8 || !(a == a)) ? 1.0 : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// landmark bookkeeping on the device
+// AoS (host boundary) <-> SoA planes
+__global__ void k_scatter_landmarks(int k, int dst0, int Ncap, const double* __restrict__ p_aos, const double* __restrict__ Q_aos, double* __restrict__ q0,
+                                    double* __restrict__ Qq, double* __restrict__ Qa) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k)
+        return;
+    const int i = dst0 + t;
+    for (int c = 0; c < 3; ++c)
+        q0[c * Ncap + i] = p_aos[3 * t + c];
+    if (Q_aos) {
+        for (int c = 0; c < 4; ++c)
+            Qq[c * Ncap + i] = Q_aos[5 * t + c];
+        Qa[i] = Q_aos[5 * t + 4];
+    } else {
+        Qq[i] = 1.0;
+        Qq[Ncap + i] = 0.0;
+        Qq[2 * Ncap + i] = 0.0;
+        Qq[3 * Ncap + i] = 0.0;
+        Qa[i] = 1.0;
+    }
+}
+__global__ void k_gather_landmarks_aos(int N, int Ncap, const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
+                                       double* __restrict__ out /* 8 doubles per landmark: p[3], q[4], a */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    for (int c = 0; c < 3; ++c)
+        out[8 * i + c] = q0[c * Ncap + i];
+    for (int c = 0; c < 4; ++c)
+        out[8 * i + 3 + c] = Qq[c * Ncap + i];
+    out[8 * i + 7] = Qa[i];
+}
+// removal of landmarks: new index -> old index map `keep` (length Nnew). Sigma_new = Sigma_old[map, map]
+// (removeRows/removeCols, VIO_eqf.cpp:27-45) written to the other buffer.
+__global__ void __launch_bounds__(256) k_compact_sigma(int nnew, int ld, const int* __restrict__ keep, const double* __restrict__ Sin, double* __restrict__ Sout) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= nnew)
+        return;
+    const int ro = r < 21 ? r : 21 + 3 * keep[(r - 21) / 3] + (r - 21) % 3;
+    const int co = c < 21 ? c : 21 + 3 * keep[(c - 21) / 3] + (c - 21) % 3;
+    Sout[r + (size_t)c * ld] = Sin[ro + (size_t)co * ld];
+}
+__global__ void k_compact_landmarks(int Nnew, int Ncap, const int* __restrict__ keep, const double* __restrict__ q0i, const double* __restrict__ Qqi,
+                                    const double* __restrict__ Qai, double* __restrict__ q0o, double* __restrict__ Qqo, double* __restrict__ Qao) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nnew)
+        return;
+    const int o = keep[i];
+    for (int c = 0; c < 3; ++c)
+        q0o[c * Ncap + i] = q0i[c * Ncap + o];
+    for (int c = 0; c < 4; ++c)
+        Qqo[c * Ncap + i] = Qqi[c * Ncap + o];
+    Qao[i] = Qai[o];
+}
+// append: zero the new strips, put var on the new diagonal (addNewLandmarks, VIO_eqf.cpp:239-244)
+__global__ void __launch_bounds__(256) k_append_sigma(int nold, int nnew, int ld, double var, double* __restrict__ Sig) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= nnew || c >= nnew)
+        return;
+    if (r < nold && c < nold)
+        return;
+    Sig[r + (size_t)c * ld] = (r == c) ? var : 0.0;
+}
+__global__ void __launch_bounds__(256) k_set_diag(int n, int ld, const double* __restrict__ diag, double* __restrict__ Sig) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= n)
+        return;
+    Sig[r + (size_t)c * ld] = (r == c) ? diag[r] : 0.0;
+}
+// count non-finite entries of Sigma (the reference's assert(!Sigma.hasNaN()))
+__global__ void __launch_bounds__(256) k_check_finite(int n, int ld, const double* __restrict__ Sig, int* __restrict__ flags) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= n)
+        return;
+    const double v = Sig[r + (size_t)c * ld];
+    if (!(v - v == 0.0))
+        flags[1] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dense fp64 MFMA GEMM used by the dense-Riccati mode (EQF_OPT_RICCATI_DENSE): C = A * B^T with A (Mr x K),
+// B (Nc x K), all column-major. One wave per 32x32 tile.
+__global__ void __launch_bounds__(64) k_gemm_nt(int Mr, int Nc, int K, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                                double* __restrict__ Cm, int ldc) {
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    d4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    mfma_tile_32x32(A, lda, i0, Mr, B, ldb, j0, Nc, 0, K, acc);
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 16 * ti + lr;
+                const int j = j0 + 16 * tj + lk + 4 * r;
+                if (i < Mr && j < Nc)
+                    Cm[i + (size_t)j * ldc] = acc[ti][tj][r];
+            }
+}
+// F = I + dt*A materialised dense (row i, col j) column-major, from the packed blocks (dense-Riccati mode)
+__global__ void __launch_bounds__(256) k_build_F(int N, int Ncap, int n, int ldf, double dt, const Common* __restrict__ cm, const double* __restrict__ Al,
+                                                 double* __restrict__ F) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= n)
+        return;
+    double v = 0.0;
+    if (r < 21) {
+        if (c < 21)
+            v = dt * cm->Ass[r * 21 + c];
+    } else {
+        const int i = (r - 21) / 3, rr = (r - 21) % 3;
+        if (c < 21) {
+            int e = -1;
+            if (c < 3)
+                e = c;
+            else if (c >= 12 && c < 15)
+                e = 3 + (c - 12);
+            else if (c >= 15)
+                e = 6 + (c - 15);
+            if (e >= 0)
+                v = dt * Al[(rr * 15 + e) * Ncap + i];
+        } else if ((c - 21) / 3 == i) {
+            v = dt * Al[(rr * 15 + 12 + (c - 21) % 3) * Ncap + i];
+        }
+    }
+    if (r == c)
+        v += 1.0;
+    F[r + (size_t)c * ldf] = v;
+}
+// Sigma' = M + dt (B Q B^T + P) elementwise finish for the dense mode (M = F Sigma F^T already in Sout)
+__global__ void __launch_bounds__(256) k_add_noise(int N, int Ncap, int n, int ld, RiccatiArgs ra, const Common* __restrict__ cm, const double* __restrict__ Bl,
+                                                   double* __restrict__ Sout) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= n)
+        return;
+    auto brow = [&](int x, int q) -> double {
+        if (x < 21)
+            return cm->Bs[x * 12 + q];
+        if (q >= 3)
+            return 0.0;
+        return Bl[(((x - 21) % 3) * 3 + q) * Ncap + (x - 21) / 3];
+    };
+    double bq = 0;
+    for (int q = 0; q < 12; ++q)
+        bq += brow(r, q) * ra.Qd[q] * brow(c, q);
+    double v = Sout[r + (size_t)c * ld] + ra.dt * bq;
+    if (r == c)
+        v += ra.dt * (r < 21 ? ra.Pd[r / 3] : ra.Pd[7]);
+    Sout[r + (size_t)c * ld] = v;
+}
+
+// fp64 MFMA issue-rate micro-benchmark: 4 independent accumulators per wave, no memory traffic.
+__global__ void __launch_bounds__(256) k_mfma_peak(int iters, double* __restrict__ out) {
+    d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a3, 0, 0, 0);
+    }
+    const d4 s = a0 + a1 + a2 + a3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+} // namespace eqf

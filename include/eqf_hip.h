@@ -1,0 +1,117 @@
+/* eqf_hip.h — C-ABI of the MI355X (gfx950) EqF core: "VIO_eqf on the GPU".
+ *
+ * One eqf_ctx = one reference `struct VIO_eqf` (include/eqvio/mathematical/VIO_eqf.h:34-134): the origin
+ * xi0, the observer state X and the Riccati matrix Sigma. Sigma (n x n fp64, n = 21 + 3N) and the
+ * per-landmark arrays (q0_i, Q_i) are DEVICE resident; the 46 doubles of sensor-level state (xi0.sensor,
+ * X.{beta,A,w,B}) are host resident inside the context. Every entry point replaces one VIO_eqf member (cited).
+ * Plain pointers and sizes only; flat layouts are those of eqvio_types.h. All matrices column-major
+ * (Eigen default). Measurement arrays must be sorted by ASCENDING id — the row order the reference gets from
+ * std::map (src/mathematical/VisionMeasurement.cpp:72-79, src/mathematical/EqFMatrices.cpp:58-66).
+ *
+ * Return value: 0 = ok; >0 = hipError_t; <0 = EQF_E_*. No exceptions, no callbacks, no global state; a
+ * context is bound to one HIP device + one stream and must be used from one thread at a time.
+ * The library FAILS (EQF_E_NO_DEVICE) when no gfx950 device is present: there is no CPU fallback.
+ */
+#ifndef EQF_HIP_H
+#define EQF_HIP_H
+#include "eqvio_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eqf_ctx eqf_ctx;
+
+enum {
+    EQF_OK = 0,
+    EQF_E_NONFINITE = -1,  /* NaN/Inf detected in Sigma or X (the reference's assert(!hasNaN())) */
+    EQF_E_NOT_SPD = -2,    /* Cholesky pivot <= 0 in S = C Sigma C^T + R */
+    EQF_E_BAD_ARG = -3,
+    EQF_E_CAPACITY = -4,   /* more landmarks than max_landmarks */
+    EQF_E_NO_DEVICE = -5,
+    EQF_E_UNSUPPORTED = -6 /* option combination not implemented on the device path */
+};
+
+/* options for eqf_set_option */
+enum {
+    EQF_OPT_RICCATI_DENSE = 1, /* 1: propagate with two dense fp64 MFMA GEMMs (F Sigma F^T, F materialised);
+                                  0 (default): structure-exploiting arrow-form kernel */
+    EQF_OPT_CHECK_FINITE = 2   /* 1: scan Sigma/X for non-finite values after propagate/update */
+};
+
+const char* eqf_error_string(int code);
+
+/* lifecycle. coordinate_choice: EQVIO_COORD_EUCLIDEAN | EQVIO_COORD_INVDEPTH
+ * (EqFCoordinateSuite selection, include/eqvio/mathematical/EqFMatrices.h:81-90). */
+int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choice);
+void eqf_destroy(eqf_ctx* ctx);
+int eqf_set_option(eqf_ctx* ctx, int option, int value);
+int eqf_synchronize(eqf_ctx* ctx);
+int eqf_num_landmarks(const eqf_ctx* ctx);
+/* the HIP stream the context launches on (hipStream_t as void*), for event timing by the caller */
+void* eqf_stream(eqf_ctx* ctx);
+
+/* VIO_eqf::xi0 / VIO_eqf::X (public data members, VIO_eqf.h:37-38). ids/q0/Q are per landmark (3 and 5
+ * doubles, AoS on this boundary; SoA on the device). */
+int eqf_set_state(eqf_ctx* ctx, const double* xi0_sensor, const double* X_sensor, const int* ids, const double* q0, const double* Q, int N);
+int eqf_get_state(eqf_ctx* ctx, double* xi0_sensor, double* X_sensor, int* ids, double* q0, double* Q, int cap); /* returns N or <0 */
+
+/* VIO_eqf::Sigma (VIO_eqf.h:39-40); n must equal 21 + 3N. */
+int eqf_set_sigma(eqf_ctx* ctx, const double* sigma_colmajor, int n);
+int eqf_set_sigma_diag(eqf_ctx* ctx, const double* diag, int n);
+int eqf_get_sigma(eqf_ctx* ctx, double* sigma_colmajor, int n);
+int eqf_get_sigma_block(eqf_ctx* ctx, int r0, int c0, int rows, int cols, double* out_colmajor);
+
+/* VIO_eqf::stateEstimate = stateGroupAction(X, xi0) (src/mathematical/VIO_eqf.cpp:137,
+ * src/mathematical/VIOGroup.cpp:25-55). Returns N or <0. */
+int eqf_state_estimate(eqf_ctx* ctx, double* sensor, int* ids, double* p, int cap);
+
+/* VIO_eqf::addNewLandmarks (VIO_eqf.cpp:225-245): appends k landmarks with Q = identity and
+ * newLandmarkCov = var * I (the only form the reference's callers use, src/VIOFilter.cpp:129-130, 274-276). */
+int eqf_add_landmarks(eqf_ctx* ctx, const int* ids, const double* p, int k, double var);
+/* VIO_eqf::removeLandmarkByIndex (VIO_eqf.cpp:172-178) for k indices at once (one compaction pass of Sigma). */
+int eqf_remove_landmarks(eqf_ctx* ctx, const int* indices, int k);
+/* VIO_eqf::removeInvalidLandmarks (VIO_eqf.cpp:213-223). Returns the number removed (>=0) or <0. */
+int eqf_remove_invalid_landmarks(eqf_ctx* ctx);
+
+/* VIO_eqf::integrateRiccatiStateFast (VIO_eqf.cpp:62-72). Q = diag(Qdiag12) (constructInputGainMatrix,
+ * VIOFilterSettings.h:192-201), P = diag: Pdiag8 = the 7 sensor 3-blocks + the per-landmark value
+ * (constructStateGainMatrix, :176-190). imu13 = IMUVelocity. */
+int eqf_integrate_riccati_fast(eqf_ctx* ctx, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8);
+/* VIO_eqf::integrateObserverState (VIO_eqf.cpp:47-60) applied for k consecutive samples
+ * (the loop of VIOFilter::integrateUpToTime, src/VIOFilter.cpp:160-178). */
+int eqf_integrate_observer(eqf_ctx* ctx, const double* imu13_k, const double* dt_k, int k, int discreteLift);
+
+/* Per-landmark statistics VIOFilter::removeOutliers needs (src/VIOFilter.cpp:304-334), for all measured
+ * landmarks in one pass: absErr = ||y - yHat||, probErr = yTilde^T (C0 Sigma_ii C0^T)^-1 yTilde with
+ * C0 = outputMatrixCi (VIO_eqf::getOutputCovById, VIO_eqf.cpp:196-211); depth2 = |q_hat|^2 for
+ * getMedianSceneDepth (src/VIOFilter.cpp:366-380). Outputs are indexed by STATE landmark index (length N);
+ * unmeasured landmarks get -1 in absErr/probErr. */
+int eqf_outlier_stats(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double* absErr, double* probErr, double* depth2);
+
+/* VIO_eqf::performVisionUpdate (VIO_eqf.cpp:105-135): yTilde, C, S = C Sigma C^T + R, K = Sigma C^T S^-1,
+ * Gamma = K yTilde, X <- Delta * X, Sigma <- Sigma - K C Sigma; R = meas_var * I
+ * (constructOutputGainMatrix, VIOFilterSettings.h:203-206). Every measured id must be a state landmark. */
+int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEquivariantOutput, int discreteCorrection);
+/* Gamma of the last update (n doubles) — for parity checks. */
+int eqf_last_gamma(eqf_ctx* ctx, double* out, int cap);
+
+/* EqF matrices as the device assembled them, expanded to the reference's dense layout for parity tests:
+ * A (n x n), B (n x 12) from stateMatrixA / inputMatrixB (coordinateSuite/euclid.cpp:99-233,
+ * invdepth.cpp:36-181); C (2M x n) from outputMatrixC (EqFMatrices.cpp:43-82). Column-major. */
+int eqf_debug_matrices_AB(eqf_ctx* ctx, const double* imu13, double* A_out, double* B_out);
+int eqf_debug_matrix_C(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, int useEquivariantOutput, double* C_out, double* ytilde_out);
+
+/* fp64 MFMA micro-benchmark (v_mfma_f64_16x16x4_f64 issue rate): returns achieved TFLOP/s over the whole
+ * chip; used by bench.py to state the roofline peak it prices against. */
+int eqf_mfma_f64_peak(eqf_ctx* ctx, double* tflops);
+
+/* per-kernel timing of the last frame's launches on the context's stream (HIP events); fills up to cap
+ * (name index, microseconds) pairs; see eqf_kernel_name. Enabled with eqf_set_option(ctx, 100, 1). */
+int eqf_last_kernel_times(eqf_ctx* ctx, int* which, float* usec, int cap);
+const char* eqf_kernel_name(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,64 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every symbol include/eqf_hip.h declares.
+No compute calls here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(eqf_[A-Za-z0-9_]+|eqvio_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+
+    g.build()
+    return True
+
+
+def test_eqf_hip_exports_every_declared_symbol(built):
+    lib = ctypes.CDLL(os.path.join(ROOT, "eqvio_amd", "lib", "libeqf_hip.so"))
+    names = declared_symbols("eqf_hip.h")
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/eqf_hip.h but not exported"
+
+
+def test_binding_declares_the_same_symbols(built):
+    from eqvio_amd.capi import load_eqf_lib
+
+    lib = load_eqf_lib()
+    assert sorted(lib._declared) == declared_symbols("eqf_hip.h")
+
+
+def test_no_device_is_a_loud_error(built):
+    """On a box without a gfx950 device the product path must fail, not fall back."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from eqvio_amd.capi import EqfCore, EqfError
+
+    with pytest.raises(EqfError) as e:
+        EqfCore(8)
+    assert e.value.code == -5
+
+
+def test_product_does_not_import_oracle():
+    """oracle/ is test infrastructure: nothing under eqvio_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("eqvio_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hpp", ".h", ".hip", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"oracle[/_.]|liboracle|orc_", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
