@@ -145,6 +145,7 @@ def load_eqf_lib():
         "eqf_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
         "eqf_synchronize": (C.c_int, [vp]),
         "eqf_num_landmarks": (C.c_int, [vp]),
+        "eqf_get_ids": (C.c_int, [vp, c_int_p, C.c_int]),
         "eqf_stream": (vp, [vp]),
         "eqf_set_state": (C.c_int, [vp, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p, C.c_int]),
         "eqf_get_state": (C.c_int, [vp, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p, C.c_int]),
@@ -319,3 +320,141 @@ class EqfCore:
         us = np.zeros(cap, np.float32)
         k = self.lib.eqf_last_kernel_times(self.h, _ip(which), us.ctypes.data_as(C.POINTER(C.c_float)), cap)
         return [(self.lib.eqf_kernel_name(int(which[i])).decode(), float(us[i])) for i in range(k)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# include/eqvio_filter.h : the host-side VIOFilter mirror (libeqvio_filter.so)
+_flib = None
+
+
+def load_filter_lib():
+    global _flib
+    if _flib is not None:
+        return _flib
+    load_eqf_lib()
+    path = os.path.join(LIB_DIR, "libeqvio_filter.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: run __graft_entry__.build()")
+    lib = C.CDLL(path)
+    vp, P = C.c_void_p, C.POINTER
+    protos = {
+        "eqvio_filter_create": (C.c_int, [P(vp), P(Settings), C.c_int, C.c_int]),
+        "eqvio_filter_create_from_state": (C.c_int, [P(vp), P(Settings), C.c_int, C.c_int, c_double_p, c_int_p, c_double_p, C.c_int, C.c_double]),
+        "eqvio_filter_destroy": (None, [vp]),
+        "eqvio_filter_last_error": (C.c_char_p, [vp]),
+        "eqvio_filter_process_imu": (C.c_int, [vp, c_double_p]),
+        "eqvio_filter_process_vision": (C.c_int, [vp, C.c_double, P(Camera), c_int_p, c_double_p, C.c_int]),
+        "eqvio_filter_state_estimate": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int]),
+        "eqvio_filter_get_time": (C.c_double, [vp]),
+        "eqvio_filter_is_initialised": (C.c_int, [vp]),
+        "eqvio_filter_set_state": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int]),
+        "eqvio_filter_set_landmarks": (C.c_int, [vp, c_int_p, c_double_p, C.c_int]),
+        "eqvio_filter_augment_landmark_states": (C.c_int, [vp, c_int_p, C.c_int, c_double_p, c_int_p, c_double_p, C.c_int]),
+        "eqvio_filter_get_eqf": (C.c_int, [vp, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p, C.c_int]),
+        "eqvio_filter_sigma_dim": (C.c_int, [vp]),
+        "eqvio_filter_get_sigma": (C.c_int, [vp, c_double_p, C.c_int]),
+        "eqvio_filter_core": (vp, [vp]),
+        "eqvio_filter_last_timing": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
+        "eqvio_filter_run_frames": (C.c_int, [vp, P(Camera), C.c_int, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, c_double_p]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib._declared = sorted(protos)
+    _flib = lib
+    return lib
+
+
+class VIOFilter:
+    """The reference's class VIOFilter (include/eqvio/VIOFilter.h:36-192) on one MI355X, through include/eqvio_filter.h."""
+
+    def __init__(self, settings, max_landmarks=256, device=0, sensor=None, ids=None, p=None, time=0.0):
+        self.lib = load_filter_lib()
+        self.h = C.c_void_p()
+        self.cap = max_landmarks + 64
+        if sensor is None:
+            rc = self.lib.eqvio_filter_create(C.byref(self.h), C.byref(settings), device, max_landmarks)
+        else:
+            sensor, ids, p = _f64(sensor), _i32(ids), _f64(p)
+            rc = self.lib.eqvio_filter_create_from_state(C.byref(self.h), C.byref(settings), device, max_landmarks, _dp(sensor), _ip(ids), _dp(p), len(ids), time)
+        self._chk(rc)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("eqvio_filter: " + self.lib.eqvio_filter_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.eqvio_filter_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_imu(self, imu13):
+        imu13 = _f64(imu13)
+        self._chk(self.lib.eqvio_filter_process_imu(self.h, _dp(imu13)))
+
+    def process_vision(self, stamp, cam, ids, y):
+        ids, y = _i32(ids), _f64(y)
+        self._chk(self.lib.eqvio_filter_process_vision(self.h, stamp, C.byref(cam), _ip(ids), _dp(y), len(ids)))
+
+    def state_estimate(self):
+        s, ids, p = np.zeros(23), np.zeros(self.cap, np.int32), np.zeros(3 * self.cap)
+        N = self.lib.eqvio_filter_state_estimate(self.h, _dp(s), _ip(ids), _dp(p), self.cap)
+        if N < 0:
+            self._chk(-1)
+        return s, ids[:N].copy(), p[: 3 * N].reshape(N, 3).copy()
+
+    def get_time(self):
+        return self.lib.eqvio_filter_get_time(self.h)
+
+    def is_initialised(self):
+        return bool(self.lib.eqvio_filter_is_initialised(self.h))
+
+    def set_state(self, sensor, ids, p):
+        sensor, ids, p = _f64(sensor), _i32(ids), _f64(p)
+        self._chk(self.lib.eqvio_filter_set_state(self.h, _dp(sensor), _ip(ids), _dp(p), len(ids)))
+
+    def set_landmarks(self, ids, p):
+        ids, p = _i32(ids), _f64(p)
+        self._chk(self.lib.eqvio_filter_set_landmarks(self.h, _ip(ids), _dp(p), len(ids)))
+
+    def augment_landmark_states(self, new_ids, sensor, ids, p):
+        new_ids, sensor, ids, p = _i32(new_ids), _f64(sensor), _i32(ids), _f64(p)
+        self._chk(self.lib.eqvio_filter_augment_landmark_states(self.h, _ip(new_ids), len(new_ids), _dp(sensor), _ip(ids), _dp(p), len(ids)))
+
+    def get_eqf(self):
+        xi0, Xs = np.zeros(23), np.zeros(23)
+        ids, q0, Q = np.zeros(self.cap, np.int32), np.zeros(3 * self.cap), np.zeros(5 * self.cap)
+        N = self.lib.eqvio_filter_get_eqf(self.h, _dp(xi0), _dp(Xs), _ip(ids), _dp(q0), _dp(Q), self.cap)
+        if N < 0:
+            raise RuntimeError("eqvio_filter_get_eqf failed")
+        return xi0, Xs, ids[:N].copy(), q0[: 3 * N].reshape(N, 3).copy(), Q[: 5 * N].reshape(N, 5).copy()
+
+    def get_sigma(self):
+        n = self.lib.eqvio_filter_sigma_dim(self.h)
+        out = np.zeros((n, n), order="F")
+        if self.lib.eqvio_filter_get_sigma(self.h, out.ctypes.data_as(c_double_p), n) != 0:
+            raise RuntimeError("eqvio_filter_get_sigma failed")
+        return out
+
+    def core_handle(self):
+        return self.lib.eqvio_filter_core(self.h)
+
+    def last_timing(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.lib.eqvio_filter_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return {"propagation": a.value, "preprocessing": b.value, "correction": c.value}
+
+    def run_frames(self, cam, imu_counts, imu13_all, stamps, meas_counts, ids_all, y_all):
+        imu_counts, imu13_all, stamps = _i32(imu_counts), _f64(imu13_all), _f64(stamps)
+        meas_counts, ids_all, y_all = _i32(meas_counts), _i32(ids_all), _f64(y_all)
+        done = self.lib.eqvio_filter_run_frames(self.h, C.byref(cam), len(stamps), _ip(imu_counts), _dp(imu13_all), _dp(stamps), _ip(meas_counts), _ip(ids_all), _dp(y_all))
+        if done < 0:
+            self._chk(-1)
+        return done

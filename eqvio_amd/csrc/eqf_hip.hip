@@ -153,6 +153,8 @@ struct eqf_ctx {
     // options
     int opt_dense = 0, opt_check = 0, opt_timing = 0;
     std::vector<double> last_gamma;
+    std::vector<double> est_cache; // 4 planes of stride N (q_hat xyz, invalid flag), valid after a vision update
+    bool est_valid = false;
     // timing
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> tev;
     std::vector<hipEvent_t> evpool;
@@ -444,6 +446,15 @@ int eqf_synchronize(eqf_ctx* c) {
     return 0;
 }
 int eqf_num_landmarks(const eqf_ctx* c) { return c->N; }
+int eqf_get_ids(const eqf_ctx* c, int* ids, int cap) {
+    if (!c || (!ids && c->N > 0))
+        return EQF_E_BAD_ARG;
+    if (c->N > cap)
+        return EQF_E_CAPACITY;
+    for (int i = 0; i < c->N; ++i)
+        ids[i] = c->ids[i];
+    return c->N;
+}
 void* eqf_stream(eqf_ctx* c) { return (void*)c->stream; }
 
 int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, const int* ids, const double* q0, const double* Q, int N) {
@@ -453,6 +464,7 @@ int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, 
         return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->est_valid = false;
     c->xi0 = unpack_sensor(xi0_sensor);
     c->X = unpack_group(X_sensor);
     c->ids.assign(ids, ids + N);
@@ -541,6 +553,10 @@ static int fetch_estimates(eqf_ctx* c) { // d_est -> h_buf (4 planes of stride N
     const int N = c->N;
     if (N == 0)
         return 0;
+    if (c->est_valid && (int)c->est_cache.size() == 4 * N) {
+        std::memcpy(c->h_buf, c->est_cache.data(), sizeof(double) * 4 * N);
+        return 0;
+    }
     hipLaunchKernelGGL(k_estimate, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->d_est);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_buf, c->d_est, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, c->stream));
@@ -594,6 +610,7 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
     HIPCHK(hipGetLastError());
     c->ids.insert(c->ids.end(), ids, ids + k);
     c->N += k;
+    c->est_valid = false;
     return 0;
 }
 
@@ -636,6 +653,7 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
     c->lmcur = 1 - c->lmcur;
     c->ids = newids;
     c->N = Nnew;
+    c->est_valid = false;
     return 0;
 }
 
@@ -725,6 +743,7 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
     if (k == 0)
         return 0;
     HIPCHK(hipSetDevice(c->device));
+    c->est_valid = false;
     int done = 0;
     while (done < k) {
         const int chunk = std::min(k - done, eqf_ctx::kMaxSteps);
@@ -910,12 +929,16 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         hipLaunchKernelGGL(k_check_finite, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), c->d_flags);
         HIPCHK(hipGetLastError());
     }
-    // Gamma (n) + flags back; the sensor part of Delta is lifted on the host
+    // Gamma (n) + new estimates / invalid flags (4N) + status flags back in one synchronisation; the sensor part
+    // of Delta is lifted on the host
     HIPCHK(hipMemcpyAsync(c->h_buf, c->d_gamma, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_buf + n, c->d_est, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, c->stream));
     rc = read_flags(c);
     if (rc)
         return rc;
     c->last_gamma.assign(c->h_buf, c->h_buf + n);
+    c->est_cache.assign(c->h_buf + n, c->h_buf + n + 4 * N);
+    c->est_valid = true;
     const double* g = c->h_buf;
     GroupSensor D;
     D.bgyr = v3(g[0], g[1], g[2]);

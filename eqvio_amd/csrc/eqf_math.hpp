@@ -79,9 +79,15 @@ HD M3 m3_cols(V3 c0, V3 c1, V3 c2) { return M3{c0.x, c1.x, c2.x, c0.y, c1.y, c2.
 
 // ---- SO(3) as quaternion
 HD Qt q_identity() { return Qt{1, 0, 0, 0}; }
+HD Qt q_unit(Qt q) {
+    const double n = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    return Qt{q.w * n, q.x * n, q.y * n, q.z * n};
+}
+// Composition re-normalises: with conjugate-as-inverse, B <- T^-1 A T (VIOGroup.cpp:249) would otherwise
+// triple any norm error per IMU step and diverge within a few frames.
 HD Qt q_mul(Qt a, Qt b) {
-    return Qt{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-              a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+    return q_unit(Qt{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+                     a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x});
 }
 HD Qt q_inv(Qt a) { return Qt{a.w, -a.x, -a.y, -a.z}; }
 HD V3 q_rot(Qt q, V3 v) { // v + 2w(u x v) + 2 u x (u x v)
@@ -125,12 +131,12 @@ HD Qt so3_from_vectors(V3 a, V3 b) {
         ax = normalized(ax);
         const double w2 = (1.0 + c) * 0.5;
         const double s = sqrt(1.0 - w2);
-        return Qt{sqrt(w2), ax.x * s, ax.y * s, ax.z * s};
+        return q_unit(Qt{sqrt(w2), ax.x * s, ax.y * s, ax.z * s});
     }
     const V3 ax = cross(v0, v1);
     const double s = sqrt((1.0 + c) * 2.0);
     const double invs = 1.0 / s;
-    return Qt{s * 0.5, ax.x * invs, ax.y * invs, ax.z * invs};
+    return q_unit(Qt{s * 0.5, ax.x * invs, ax.y * invs, ax.z * invs});
 }
 // V(omega): exp_SE3(omega, v) = (exp omega, V v)
 HD M3 so3_V(V3 om) {

@@ -1,0 +1,629 @@
+// Host-side control logic of the filter (mirror of src/VIOFilter.cpp and the VIO_eqf bookkeeping of
+// src/mathematical/VIO_eqf.cpp); every matrix operation goes through the C-ABI of include/eqf_hip.h.
+#include "VIOFilter.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace eqvio_amd {
+
+using namespace eqf;
+
+thread_local LoopTimer loopTimer;
+
+// ---------------------------------------------------------------- LoopTimer (src/LoopTimer.cpp:20-43)
+void LoopTimer::startTiming(const std::string& label) { timerStartPoints.at(label) = timer_clock::now(); }
+void LoopTimer::endTiming(const std::string& label) {
+    const timer_clock::time_point now = timer_clock::now();
+    currentLoopTimingData.timings[label] = now - timerStartPoints.at(label);
+}
+void LoopTimer::startLoop() {
+    for (const auto& kv : timerStartPoints)
+        currentLoopTimingData.timings[kv.first] = timer_duration(0);
+    currentLoopTimingData.loopTimeStart = timer_clock::now() - timerOrigin;
+}
+void LoopTimer::initialise(const std::vector<std::string>& headers) {
+    const timer_clock::time_point now = timer_clock::now();
+    for (const std::string& h : headers)
+        timerStartPoints[h] = now;
+}
+
+// ---------------------------------------------------------------- small value types
+std::vector<int> VIOState::getIds() const {
+    std::vector<int> ids(cameraLandmarks.size());
+    std::transform(cameraLandmarks.begin(), cameraLandmarks.end(), ids.begin(), [](const Landmark& lm) { return lm.id; });
+    return ids;
+}
+std::vector<int> VisionMeasurement::getIds() const {
+    std::vector<int> ids;
+    ids.reserve(camCoordinates.size());
+    for (const auto& kv : camCoordinates)
+        ids.push_back(kv.first);
+    return ids;
+}
+IMUVelocity IMUVelocity::operator+(const IMUVelocity& o) const { // src/mathematical/IMUVelocity.cpp:42-50
+    IMUVelocity r;
+    r.stamp = (stamp > 0) ? stamp : o.stamp;
+    r.gyr = gyr + o.gyr;
+    r.acc = acc + o.acc;
+    r.gyrBiasVel = gyrBiasVel + o.gyrBiasVel;
+    r.accBiasVel = accBiasVel + o.accBiasVel;
+    return r;
+}
+IMUVelocity IMUVelocity::operator*(const double& c) const { // IMUVelocity.cpp:69-77
+    IMUVelocity r;
+    r.stamp = stamp;
+    r.gyr = c * gyr;
+    r.acc = c * acc;
+    r.gyrBiasVel = c * gyrBiasVel;
+    r.accBiasVel = c * accBiasVel;
+    return r;
+}
+void IMUVelocity::pack(double* v) const {
+    v[0] = stamp;
+    const V3 parts[4] = {gyr, acc, gyrBiasVel, accBiasVel};
+    for (int b = 0; b < 4; ++b) {
+        v[1 + 3 * b] = parts[b].x;
+        v[2 + 3 * b] = parts[b].y;
+        v[3 + 3 * b] = parts[b].z;
+    }
+}
+
+namespace {
+void packPose(const Pose& p, double* q7) {
+    q7[0] = p.R.w;
+    q7[1] = p.R.x;
+    q7[2] = p.R.y;
+    q7[3] = p.R.z;
+    q7[4] = p.x.x;
+    q7[5] = p.x.y;
+    q7[6] = p.x.z;
+}
+Pose unpackPose(const double* q7) { return Pose{Qt{q7[0], q7[1], q7[2], q7[3]}, V3{q7[4], q7[5], q7[6]}}; }
+void packSensor(const VIOSensorState& s, double* d) {
+    std::memcpy(d, s.inputBias.data(), sizeof(double) * 6);
+    packPose(s.pose, d + 6);
+    d[13] = s.velocity.x;
+    d[14] = s.velocity.y;
+    d[15] = s.velocity.z;
+    packPose(s.cameraOffset, d + 16);
+}
+VIOSensorState unpackSensor(const double* d) {
+    VIOSensorState s;
+    std::memcpy(s.inputBias.data(), d, sizeof(double) * 6);
+    s.pose = unpackPose(d + 6);
+    s.velocity = V3{d[13], d[14], d[15]};
+    s.cameraOffset = unpackPose(d + 16);
+    return s;
+}
+void flatten(const VisionMeasurement& m, std::vector<int>& ids, std::vector<double>& y) {
+    ids.clear();
+    y.clear();
+    for (const auto& kv : m.camCoordinates) {
+        ids.push_back(kv.first);
+        y.push_back(kv.second[0]);
+        y.push_back(kv.second[1]);
+    }
+}
+} // namespace
+
+// ---------------------------------------------------------------- VIO_eqf (device backed)
+VIO_eqf::~VIO_eqf() {
+    if (ctx)
+        eqf_destroy(ctx);
+}
+void VIO_eqf::check(int rc, const char* what) const {
+    if (rc != 0)
+        throw std::runtime_error(std::string("eqf_hip: ") + what + ": " + eqf_error_string(rc));
+}
+void VIO_eqf::create(int device, int maxLandmarks, CoordinateChoice cc) {
+    if (ctx) {
+        eqf_destroy(ctx);
+        ctx = nullptr;
+    }
+    coordinateChoice = cc;
+    check(eqf_create(&ctx, device, maxLandmarks, (int)cc), "eqf_create");
+    ids_.clear();
+}
+void VIO_eqf::set(const VIOState& xi0, const VIOGroup& X) {
+    const int N = (int)xi0.cameraLandmarks.size();
+    if ((int)X.Q.size() != N || (int)X.id.size() != N)
+        throw std::invalid_argument("VIO_eqf::set: xi0 and X landmark counts differ");
+    double s[23], g[23];
+    packSensor(xi0.sensor, s);
+    std::memcpy(g, X.beta.data(), sizeof(double) * 6);
+    packPose(X.A, g + 6);
+    g[13] = X.w.x;
+    g[14] = X.w.y;
+    g[15] = X.w.z;
+    packPose(X.B, g + 16);
+    std::vector<double> q0(3 * N), Q(5 * N);
+    ids_.resize(N);
+    for (int i = 0; i < N; ++i) {
+        if (X.id[i] != xi0.cameraLandmarks[i].id)
+            throw std::invalid_argument("VIO_eqf::set: xi0 and X ids are not aligned");
+        ids_[i] = X.id[i];
+        q0[3 * i] = xi0.cameraLandmarks[i].p.x;
+        q0[3 * i + 1] = xi0.cameraLandmarks[i].p.y;
+        q0[3 * i + 2] = xi0.cameraLandmarks[i].p.z;
+        Q[5 * i] = X.Q[i].R.w;
+        Q[5 * i + 1] = X.Q[i].R.x;
+        Q[5 * i + 2] = X.Q[i].R.y;
+        Q[5 * i + 3] = X.Q[i].R.z;
+        Q[5 * i + 4] = X.Q[i].a;
+    }
+    check(eqf_set_state(ctx, s, g, ids_.data(), q0.data(), Q.data(), N), "eqf_set_state");
+}
+VIOState VIO_eqf::xi0() const {
+    const int N = numLandmarks();
+    double s[23], g[23];
+    std::vector<int> ids(N + 1);
+    std::vector<double> q0(3 * N + 3), Q(5 * N + 5);
+    const int rc = eqf_get_state(ctx, s, g, ids.data(), q0.data(), Q.data(), N);
+    if (rc < 0)
+        check(rc, "eqf_get_state");
+    VIOState xi;
+    xi.sensor = unpackSensor(s);
+    xi.cameraLandmarks.resize(N);
+    for (int i = 0; i < N; ++i)
+        xi.cameraLandmarks[i] = Landmark{V3{q0[3 * i], q0[3 * i + 1], q0[3 * i + 2]}, ids[i]};
+    return xi;
+}
+VIOGroup VIO_eqf::X() const {
+    const int N = numLandmarks();
+    double s[23], g[23];
+    std::vector<int> ids(N + 1);
+    std::vector<double> q0(3 * N + 3), Q(5 * N + 5);
+    const int rc = eqf_get_state(ctx, s, g, ids.data(), q0.data(), Q.data(), N);
+    if (rc < 0)
+        check(rc, "eqf_get_state");
+    VIOGroup X;
+    std::memcpy(X.beta.data(), g, sizeof(double) * 6);
+    X.A = unpackPose(g + 6);
+    X.w = V3{g[13], g[14], g[15]};
+    X.B = unpackPose(g + 16);
+    X.id.assign(ids.begin(), ids.begin() + N);
+    X.Q.resize(N);
+    for (int i = 0; i < N; ++i)
+        X.Q[i] = SOT3{Qt{Q[5 * i], Q[5 * i + 1], Q[5 * i + 2], Q[5 * i + 3]}, Q[5 * i + 4]};
+    return X;
+}
+MatrixXd VIO_eqf::Sigma() const {
+    MatrixXd S;
+    S.r = S.c = 21 + 3 * numLandmarks();
+    S.d.resize((size_t)S.r * S.c);
+    check(eqf_get_sigma(ctx, S.d.data(), S.r), "eqf_get_sigma");
+    return S;
+}
+void VIO_eqf::setSigma(const MatrixXd& S) { check(eqf_set_sigma(ctx, S.d.data(), S.r), "eqf_set_sigma"); }
+void VIO_eqf::setSigmaDiag(const std::vector<double>& diag) { check(eqf_set_sigma_diag(ctx, diag.data(), (int)diag.size()), "eqf_set_sigma_diag"); }
+
+void VIO_eqf::addNewLandmarks(std::vector<Landmark>& newLandmarks, double var) { // VIO_eqf.cpp:225-245
+    const int k = (int)newLandmarks.size();
+    if (k == 0)
+        return;
+    std::vector<int> ids(k);
+    std::vector<double> p(3 * k);
+    for (int i = 0; i < k; ++i) {
+        ids[i] = newLandmarks[i].id;
+        p[3 * i] = newLandmarks[i].p.x;
+        p[3 * i + 1] = newLandmarks[i].p.y;
+        p[3 * i + 2] = newLandmarks[i].p.z;
+    }
+    check(eqf_add_landmarks(ctx, ids.data(), p.data(), k, var), "eqf_add_landmarks");
+    ids_.insert(ids_.end(), ids.begin(), ids.end());
+}
+void VIO_eqf::removeLandmarksByIndex(const std::vector<int>& idx) {
+    if (idx.empty())
+        return;
+    check(eqf_remove_landmarks(ctx, idx.data(), (int)idx.size()), "eqf_remove_landmarks");
+    std::vector<char> drop(ids_.size(), 0);
+    for (int i : idx)
+        drop[i] = 1;
+    std::vector<int> kept;
+    for (size_t i = 0; i < ids_.size(); ++i)
+        if (!drop[i])
+            kept.push_back(ids_[i]);
+    ids_ = kept;
+}
+void VIO_eqf::removeLandmarkByIndex(const int& idx) { removeLandmarksByIndex({idx}); } // VIO_eqf.cpp:172-178
+void VIO_eqf::removeLandmarkById(const int& id) {                                      // VIO_eqf.cpp:180-186
+    const auto it = std::find(ids_.begin(), ids_.end(), id);
+    if (it == ids_.end())
+        throw std::out_of_range("VIO_eqf::removeLandmarkById: unknown id");
+    removeLandmarkByIndex((int)std::distance(ids_.begin(), it));
+}
+void VIO_eqf::removeInvalidLandmarks() { // VIO_eqf.cpp:213-223
+    const int rc = eqf_remove_invalid_landmarks(ctx);
+    if (rc < 0)
+        check(rc, "eqf_remove_invalid_landmarks");
+    if (rc > 0) {
+        ids_.resize(eqf_num_landmarks(ctx));
+        eqf_get_ids(ctx, ids_.data(), (int)ids_.size());
+    }
+}
+std::array<double, 9> VIO_eqf::getLandmarkCovById(const int& id) const { // VIO_eqf.cpp:188-194 (column-major 3x3)
+    const auto it = std::find(ids_.begin(), ids_.end(), id);
+    if (it == ids_.end())
+        throw std::out_of_range("VIO_eqf::getLandmarkCovById: unknown id");
+    const int i = (int)std::distance(ids_.begin(), it);
+    std::array<double, 9> blk{};
+    check(eqf_get_sigma_block(ctx, 21 + 3 * i, 21 + 3 * i, 3, 3, blk.data()), "eqf_get_sigma_block");
+    return blk;
+}
+void VIO_eqf::integrateObserverStates(const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift) {
+    const int k = (int)imus.size();
+    if (k == 0)
+        return;
+    std::vector<double> flat(13 * (size_t)k);
+    for (int i = 0; i < k; ++i)
+        imus[i].pack(flat.data() + 13 * i);
+    check(eqf_integrate_observer(ctx, flat.data(), dts.data(), k, discreteLift ? 1 : 0), "eqf_integrate_observer");
+}
+void VIO_eqf::integrateObserverState(const IMUVelocity& imu, const double& dt, const bool& discreteLift) { // VIO_eqf.cpp:47-60
+    integrateObserverStates({imu}, {dt}, discreteLift);
+}
+void VIO_eqf::integrateRiccatiStateFast(const IMUVelocity& imu, const double& dt, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8) { // :62-72
+    double v[13];
+    imu.pack(v);
+    check(eqf_integrate_riccati_fast(ctx, v, dt, Qd.data(), Pd8.data()), "eqf_integrate_riccati_fast");
+}
+void VIO_eqf::performVisionUpdate(const VisionMeasurement& m, double var, const bool& useEqv, const bool& discreteCorrection) { // :105-135
+    if (m.camCoordinates.empty())
+        return;
+    std::vector<int> ids;
+    std::vector<double> y;
+    flatten(m, ids, y);
+    check(eqf_vision_update(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), var, useEqv ? 1 : 0, discreteCorrection ? 1 : 0), "eqf_vision_update");
+}
+VIOState VIO_eqf::stateEstimate() const { // :137
+    const int N = numLandmarks();
+    double s[23];
+    std::vector<int> ids(N + 1);
+    std::vector<double> p(3 * N + 3);
+    const int rc = eqf_state_estimate(ctx, s, ids.data(), p.data(), N);
+    if (rc < 0)
+        check(rc, "eqf_state_estimate");
+    VIOState xi;
+    xi.sensor = unpackSensor(s);
+    xi.cameraLandmarks.resize(N);
+    for (int i = 0; i < N; ++i)
+        xi.cameraLandmarks[i] = Landmark{V3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}, ids[i]};
+    return xi;
+}
+void VIO_eqf::outlierStats(const VisionMeasurement& m, std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2) const {
+    const int N = numLandmarks();
+    absErr.assign(N, -1.0);
+    probErr.assign(N, -1.0);
+    depth2.assign(N, 0.0);
+    if (N == 0)
+        return;
+    std::vector<int> ids;
+    std::vector<double> y;
+    flatten(m, ids, y);
+    check(eqf_outlier_stats(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), absErr.data(), probErr.data(), depth2.data()), "eqf_outlier_stats");
+}
+
+// ---------------------------------------------------------------- Settings (VIOFilterSettings.h)
+VIOFilter::Settings::Settings(const eqvio_settings& s) {
+    biasOmegaProcessVariance = s.biasOmegaProcessVariance;
+    biasAccelProcessVariance = s.biasAccelProcessVariance;
+    attitudeProcessVariance = s.attitudeProcessVariance;
+    positionProcessVariance = s.positionProcessVariance;
+    velocityProcessVariance = s.velocityProcessVariance;
+    cameraAttitudeProcessVariance = s.cameraAttitudeProcessVariance;
+    cameraPositionProcessVariance = s.cameraPositionProcessVariance;
+    pointProcessVariance = s.pointProcessVariance;
+    velGyrNoise = s.velGyrNoise;
+    velAccNoise = s.velAccNoise;
+    velGyrBiasWalk = s.velGyrBiasWalk;
+    velAccBiasWalk = s.velAccBiasWalk;
+    measurementNoise = s.measurementNoise;
+    outlierThresholdAbs = s.outlierThresholdAbs;
+    outlierThresholdProb = s.outlierThresholdProb;
+    featureRetention = s.featureRetention;
+    initialAttitudeVariance = s.initialAttitudeVariance;
+    initialPositionVariance = s.initialPositionVariance;
+    initialVelocityVariance = s.initialVelocityVariance;
+    initialCameraAttitudeVariance = s.initialCameraAttitudeVariance;
+    initialCameraPositionVariance = s.initialCameraPositionVariance;
+    initialPointVariance = s.initialPointVariance;
+    initialPointDepthVariance = s.initialPointDepthVariance;
+    initialBiasOmegaVariance = s.initialBiasOmegaVariance;
+    initialBiasAccelVariance = s.initialBiasAccelVariance;
+    initialSceneDepth = s.initialSceneDepth;
+    useDiscreteInnovationLift = s.useDiscreteInnovationLift != 0;
+    useDiscreteVelocityLift = s.useDiscreteVelocityLift != 0;
+    useDiscreteStateMatrix = s.useDiscreteStateMatrix != 0;
+    fastRiccati = s.fastRiccati != 0;
+    useMedianDepth = s.useMedianDepth != 0;
+    useFeaturePredictions = s.useFeaturePredictions != 0;
+    useEquivariantOutput = s.useEquivariantOutput != 0;
+    removeLostLandmarks = s.removeLostLandmarks != 0;
+    if (s.coordinateChoice < 0 || s.coordinateChoice > 2) // coordinateSelection, VIOFilterSettings.h:33-46
+        throw std::runtime_error("Invalid coordinate choice. Valid choices are Euclidean, InvDepth, Normal.");
+    coordinateChoice = (CoordinateChoice)s.coordinateChoice;
+    cameraOffset = unpackPose(s.cameraOffset);
+}
+std::vector<double> VIOFilter::Settings::constructInitialStateCovarianceDiag(const size_t& N) const { // :208-229
+    std::vector<double> d(21 + 3 * N, initialPointVariance);
+    const double v[7] = {initialBiasOmegaVariance, initialBiasAccelVariance, initialAttitudeVariance, initialPositionVariance,
+                         initialVelocityVariance,  initialCameraAttitudeVariance, initialCameraPositionVariance};
+    for (int b = 0; b < 7; ++b)
+        for (int k = 0; k < 3; ++k)
+            d[3 * b + k] = v[b];
+    if (initialPointDepthVariance > 0)
+        for (size_t i = 0; i < N; ++i)
+            d[21 + 3 * i + 2] = initialPointDepthVariance;
+    return d;
+}
+std::array<double, 8> VIOFilter::Settings::constructStateGainDiag8() const { // :176-190
+    return {biasOmegaProcessVariance, biasAccelProcessVariance,      attitudeProcessVariance,       positionProcessVariance,
+            velocityProcessVariance,  cameraAttitudeProcessVariance, cameraPositionProcessVariance, pointProcessVariance};
+}
+std::array<double, 12> VIOFilter::Settings::constructInputGainDiag() const { // :192-201
+    std::array<double, 12> q{};
+    const double v[4] = {velGyrNoise * velGyrNoise, velAccNoise * velAccNoise, velGyrBiasWalk * velGyrBiasWalk, velAccBiasWalk * velAccBiasWalk};
+    for (int b = 0; b < 4; ++b)
+        for (int k = 0; k < 3; ++k)
+            q[3 * b + k] = v[b];
+    return q;
+}
+
+// ---------------------------------------------------------------- VIOFilter (src/VIOFilter.cpp)
+VIOFilter::~VIOFilter() = default;
+
+VIOFilter::VIOFilter(const VIOFilter::Settings& s) { // :31-41
+    settings = std::make_unique<VIOFilter::Settings>(s);
+    filterState.create(s.device, s.maxLandmarks, s.coordinateChoice);
+    VIOState xi0;
+    xi0.sensor.cameraOffset = s.cameraOffset;
+    filterState.set(xi0, VIOGroup());
+    filterState.setSigmaDiag(settings->constructInitialStateCovarianceDiag());
+}
+VIOFilter::VIOFilter(const VIOState& xi0, const VIOFilter::Settings& s, const double& time) { // :43-56
+    settings = std::make_unique<VIOFilter::Settings>(s);
+    filterState.create(s.device, std::max<int>(s.maxLandmarks, (int)xi0.cameraLandmarks.size()), s.coordinateChoice);
+    VIOGroup X;
+    for (const Landmark& lm : xi0.cameraLandmarks) {
+        X.Q.emplace_back(SOT3());
+        X.id.emplace_back(lm.id);
+    }
+    filterState.set(xi0, X);
+    filterState.setSigmaDiag(settings->constructInitialStateCovarianceDiag(xi0.cameraLandmarks.size()));
+    filterState.currentTime = time;
+    initialisedFlag = true;
+}
+void VIOFilter::processIMUData(const IMUVelocity& imu) { // :58-63
+    if (!initialisedFlag)
+        initialiseFromIMUData(imu);
+    velocityBuffer.emplace_back(imu);
+}
+void VIOFilter::initialiseFromIMUData(const IMUVelocity& imu) { // :65-78
+    VIOState xi0 = filterState.xi0();
+    const VIOGroup X = filterState.X();
+    xi0.sensor.inputBias.fill(0.0);
+    xi0.sensor.pose = pose_identity();
+    xi0.sensor.velocity = V3{0, 0, 0};
+    initialisedFlag = true;
+    xi0.sensor.pose.R = so3_from_vectors(normalized(imu.acc), V3{0, 0, 1});
+    filterState.set(xi0, X);
+    filterState.currentTime = imu.stamp;
+}
+void VIOFilter::setState(const VIOState& xi) { // :80-92
+    VIOGroup X;
+    X.id = xi.getIds();
+    X.Q.assign(X.id.size(), SOT3());
+    filterState.set(xi, X);
+    const int N = (int)xi.cameraLandmarks.size();
+    std::vector<double> d = settings->constructInitialStateCovarianceDiag(0);
+    d.resize(21 + 3 * N, 1.0 * settings->initialPointVariance);
+    filterState.setSigmaDiag(d);
+    initialisedFlag = true;
+}
+void VIOFilter::setLandmarks(const std::vector<Landmark>& lms) { // :94-110
+    // The reference overwrites the landmark block of Sigma in place and keeps the sensor block and the cross terms
+    // (which requires the landmark count to be unchanged). Same here: read Sigma back, patch, write.
+    MatrixXd S = filterState.Sigma();
+    const std::vector<double> full = settings->constructInitialStateCovarianceDiag(lms.size());
+    const int k = 3 * (int)lms.size();
+    if (21 + k != S.r)
+        throw std::invalid_argument("VIOFilter::setLandmarks: landmark count differs from the filter state");
+    for (int j = 0; j < k; ++j)
+        for (int i = 0; i < k; ++i)
+            S(21 + i, 21 + j) = (i == j) ? full[21 + i] : 0.0;
+    VIOState xi0 = filterState.xi0();
+    VIOGroup X = filterState.X();
+    xi0.cameraLandmarks = lms;
+    X.Q.assign(lms.size(), SOT3());
+    X.id.clear();
+    for (const Landmark& lm : lms)
+        X.id.emplace_back(lm.id);
+    filterState.set(xi0, X);
+    filterState.setSigma(S);
+}
+void VIOFilter::augmentLandmarkStates(const std::vector<int>& newIds, const VIOState& provided) { // :112-132
+    removeOldLandmarks(newIds);
+    std::vector<Landmark> newLandmarks;
+    const std::vector<int>& have = filterState.ids();
+    for (const int& id : newIds) {
+        if (std::find(have.begin(), have.end(), id) != have.end())
+            continue;
+        const auto it2 = std::find_if(provided.cameraLandmarks.begin(), provided.cameraLandmarks.end(), [&id](const Landmark& lm) { return lm.id == id; });
+        if (it2 == provided.cameraLandmarks.end())
+            throw std::out_of_range("augmentLandmarkStates: id missing from the provided state");
+        newLandmarks.emplace_back(*it2);
+    }
+    filterState.addNewLandmarks(newLandmarks, settings->initialPointVariance);
+}
+bool VIOFilter::integrateUpToTime(const double& newTime) { // :134-192
+    if (newTime <= filterState.currentTime || filterState.currentTime < 0 || velocityBuffer.empty())
+        return false;
+    std::vector<double> dts(velocityBuffer.size());
+    for (size_t i = 0; i < velocityBuffer.size(); ++i) {
+        const double t0 = std::max(velocityBuffer.at(i).stamp, filterState.currentTime);
+        const double t1 = i + 1 < velocityBuffer.size() ? std::min(velocityBuffer.at(i + 1).stamp, newTime) : newTime;
+        dts[i] = std::max(t1 - t0, 0.0);
+    }
+    if (settings->fastRiccati) {
+        double accumulatedTime = 0;
+        IMUVelocity accumulatedVelocity = IMUVelocity::Zero();
+        for (size_t i = 0; i < velocityBuffer.size(); ++i) {
+            accumulatedTime += dts[i];
+            accumulatedVelocity = accumulatedVelocity + velocityBuffer.at(i) * dts[i];
+        }
+        accumulatedVelocity = accumulatedVelocity * (1.0 / accumulatedTime);
+        filterState.integrateRiccatiStateFast(accumulatedVelocity, accumulatedTime, settings->constructInputGainDiag(), settings->constructStateGainDiag8());
+    } else {
+        // integrateRiccatiStateAccurate / Discrete (VIO_eqf.cpp:74-103) are not on the device path yet
+        // ("lower priority" / "oracle only"); fail loudly instead of falling back.
+        throw std::runtime_error("VIOFilter: settings.fastRiccati = false is not supported by the MI355X path (EQF_E_UNSUPPORTED)");
+    }
+    // The observer steps do not depend on the Riccati state (VIOFilter.cpp:138): all samples in one device call.
+    filterState.integrateObserverStates(velocityBuffer, dts, settings->useDiscreteVelocityLift);
+    filterState.currentTime = newTime;
+    auto it = std::find_if(velocityBuffer.begin(), velocityBuffer.end(), [this](const IMUVelocity& v) { return v.stamp >= this->filterState.currentTime; });
+    if (it != velocityBuffer.begin()) {
+        --it;
+        velocityBuffer.erase(velocityBuffer.begin(), it);
+    }
+    return true;
+}
+void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :194-241
+    loopTimer.startTiming("propagation");
+    const bool integrationFlag = integrateUpToTime(measurement.stamp);
+    if (!integrationFlag || !initialisedFlag)
+        return;
+    loopTimer.endTiming("propagation");
+
+    loopTimer.startTiming("preprocessing");
+    if (settings->removeLostLandmarks)
+        removeOldLandmarks(measurement.getIds());
+    VisionMeasurement matchedMeasurement = measurement;
+    std::vector<double> depth2;
+    removeOutliers(matchedMeasurement, depth2);
+    addNewLandmarks(matchedMeasurement, &depth2);
+    loopTimer.endTiming("preprocessing");
+
+    if (matchedMeasurement.camCoordinates.empty())
+        return;
+
+    loopTimer.startTiming("correction");
+    if (!settings->removeLostLandmarks) {
+        // the reference tolerates state landmarks without a measurement (zero block columns of C,
+        // EqFMatrices.cpp:61-78) but not measurements without a landmark; same contract here.
+    }
+    filterState.performVisionUpdate(matchedMeasurement, settings->constructOutputGainVar(), settings->useEquivariantOutput, settings->useDiscreteInnovationLift);
+    filterState.removeInvalidLandmarks();
+    loopTimer.endTiming("correction");
+}
+VIOState VIOFilter::stateEstimate() const { return filterState.stateEstimate(); }
+const VIO_eqf& VIOFilter::viewEqFState() const { return filterState; }
+double VIOFilter::getTime() const { return filterState.currentTime; }
+VisionMeasurement VIOFilter::getFeaturePredictions(const GICameraPtr&, const double&) { // :247-252
+    if (settings->useFeaturePredictions)
+        throw std::runtime_error("VIOFilter::getFeaturePredictions: useFeaturePredictions is not supported by the MI355X path yet");
+    return VisionMeasurement();
+}
+void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2) { // :258-278
+    std::vector<Landmark> newLandmarks;
+    const std::vector<int>& have = filterState.ids();
+    for (const auto& cc : measurement.camCoordinates) {
+        const int& ccId = cc.first;
+        if (std::none_of(have.begin(), have.end(), [&ccId](const int& i) { return i == ccId; })) {
+            const V3 bearing = measurement.cameraPtr->undistortPoint(cc.second[0], cc.second[1]);
+            newLandmarks.emplace_back(Landmark{bearing, ccId});
+        }
+    }
+    if (newLandmarks.empty())
+        return;
+    const double initialDepth = settings->useMedianDepth ? getMedianSceneDepth(depth2) : settings->initialSceneDepth;
+    for (Landmark& blm : newLandmarks)
+        blm.p = initialDepth * blm.p;
+    filterState.addNewLandmarks(newLandmarks, settings->initialPointVariance);
+}
+void VIOFilter::removeOldLandmarks(const std::vector<int>& measurementIds) { // :280-302
+    const std::vector<int>& have = filterState.ids();
+    std::vector<int> lost;
+    for (int i = 0; i < (int)have.size(); ++i)
+        if (std::find(measurementIds.begin(), measurementIds.end(), have[i]) == measurementIds.end())
+            lost.push_back(i);
+    filterState.removeLandmarksByIndex(lost); // one compaction pass instead of one per landmark
+}
+void VIOFilter::removeOutliers(VisionMeasurement& measurement, std::vector<double>& depth2) { // :304-364
+    const size_t maxOutliers = (size_t)((1.0 - settings->featureRetention) * measurement.camCoordinates.size());
+    std::vector<double> absErr, probErr;
+    filterState.outlierStats(measurement, absErr, probErr, depth2);
+    const std::vector<int>& ids = filterState.ids();
+    std::vector<int> proposedOutliers;
+    std::map<int, double> absoluteOutliers, probabilisticOutliers;
+    // the reference iterates yHat (a std::map) in ascending id order for both passes
+    std::vector<int> order(ids.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&ids](int a, int b) { return ids[a] < ids[b]; });
+    for (const int i : order) {
+        if (absErr[i] < 0)
+            continue; // not measured
+        if (absErr[i] > settings->outlierThresholdAbs) {
+            absoluteOutliers[ids[i]] = absErr[i];
+            proposedOutliers.emplace_back(ids[i]);
+        }
+    }
+    for (const int i : order) {
+        if (absErr[i] < 0 || absoluteOutliers.count(ids[i]))
+            continue;
+        if (probErr[i] > settings->outlierThresholdProb) {
+            probabilisticOutliers[ids[i]] = probErr[i];
+            proposedOutliers.emplace_back(ids[i]);
+        }
+    }
+    std::sort(proposedOutliers.begin(), proposedOutliers.end(), [&absoluteOutliers, &probabilisticOutliers](const int& a, const int& b) {
+        if (absoluteOutliers.count(a)) {
+            if (absoluteOutliers.count(b))
+                return absoluteOutliers.at(a) < absoluteOutliers.at(b);
+            return false;
+        }
+        if (absoluteOutliers.count(b))
+            return true;
+        return probabilisticOutliers.at(a) < probabilisticOutliers.at(b);
+    });
+    std::reverse(proposedOutliers.begin(), proposedOutliers.end());
+    if (proposedOutliers.size() > maxOutliers)
+        proposedOutliers.erase(proposedOutliers.begin() + maxOutliers, proposedOutliers.end());
+    if (proposedOutliers.empty())
+        return;
+    std::vector<int> idx;
+    for (const int lmId : proposedOutliers) {
+        idx.push_back((int)std::distance(ids.begin(), std::find(ids.begin(), ids.end(), lmId)));
+        measurement.camCoordinates.erase(lmId);
+    }
+    // keep depth2 aligned with the compacted state
+    std::vector<char> drop(ids.size(), 0);
+    for (int i : idx)
+        drop[i] = 1;
+    std::vector<double> d2;
+    for (size_t i = 0; i < drop.size(); ++i)
+        if (!drop[i])
+            d2.push_back(depth2[i]);
+    depth2 = d2;
+    filterState.removeLandmarksByIndex(idx);
+}
+double VIOFilter::getMedianSceneDepth(const std::vector<double>* depth2) const { // :366-380
+    std::vector<double> depthsSquared;
+    if (depth2) {
+        depthsSquared = *depth2;
+    } else {
+        const VIOState est = stateEstimate();
+        for (const Landmark& lm : est.cameraLandmarks)
+            depthsSquared.push_back(norm2(lm.p));
+    }
+    const auto midway = depthsSquared.begin() + depthsSquared.size() / 2;
+    std::nth_element(depthsSquared.begin(), midway, depthsSquared.end());
+    double medianDepth = settings->initialSceneDepth;
+    if (!(midway == depthsSquared.end()))
+        medianDepth = std::pow(*midway, 0.5);
+    return medianDepth;
+}
+
+} // namespace eqvio_amd

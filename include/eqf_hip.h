@@ -48,6 +48,8 @@ void eqf_destroy(eqf_ctx* ctx);
 int eqf_set_option(eqf_ctx* ctx, int option, int value);
 int eqf_synchronize(eqf_ctx* ctx);
 int eqf_num_landmarks(const eqf_ctx* ctx);
+/* VIO_eqf::X.id (VIOGroup.h:38): the landmark ids in state order. Host-side only, no device work. Returns N or <0. */
+int eqf_get_ids(const eqf_ctx* ctx, int* ids, int cap);
 /* the HIP stream the context launches on (hipStream_t as void*), for event timing by the caller */
 void* eqf_stream(eqf_ctx* ctx);
 

@@ -40,10 +40,19 @@ struct SO3 {
         uv = uv + uv;
         return v + w * uv + cross(u, uv);
     }
+    // Composition keeps the element unit-norm (re-normalised after every product). Restatement decision:
+    // without it the conjugation pattern B <- T^-1 A T of liftVelocityDiscrete (VIOGroup.cpp:249) triples any
+    // norm error per IMU step (|T^-1 A T| = |T|^2 when inverse() is the conjugate) and X.B blows up within a few
+    // frames; LiePP's own policy cannot be checked here (source absent), the reference evidently runs for minutes.
     SO3 operator*(const SO3& o) const {
         return fromQuat(
-            w * o.w - x * o.x - y * o.y - z * o.z, w * o.x + x * o.w + y * o.z - z * o.y,
-            w * o.y + y * o.w + z * o.x - x * o.z, w * o.z + z * o.w + x * o.y - y * o.x);
+                   w * o.w - x * o.x - y * o.y - z * o.z, w * o.x + x * o.w + y * o.z - z * o.y,
+                   w * o.y + y * o.w + z * o.x - x * o.z, w * o.z + z * o.w + x * o.y - y * o.x)
+            .normalizedQuat();
+    }
+    SO3 normalizedQuat() const {
+        const double n = 1.0 / std::sqrt(w * w + x * x + y * y + z * z);
+        return fromQuat(w * n, x * n, y * n, z * n);
     }
     SO3 inverse() const { return fromQuat(w, -x, -y, -z); }
     Mat3 asMatrix() const {
@@ -141,12 +150,12 @@ struct SO3 {
             axis = axis.normalized();
             const double w2 = (1.0 + c) * 0.5;
             const double s = std::sqrt(1.0 - w2);
-            return fromQuat(std::sqrt(w2), axis(0) * s, axis(1) * s, axis(2) * s);
+            return fromQuat(std::sqrt(w2), axis(0) * s, axis(1) * s, axis(2) * s).normalizedQuat();
         }
         const Vec3 axis = cross(v0, v1);
         const double s = std::sqrt((1.0 + c) * 2.0);
         const double invs = 1.0 / s;
-        return fromQuat(s * 0.5, axis(0) * invs, axis(1) * invs, axis(2) * invs);
+        return fromQuat(s * 0.5, axis(0) * invs, axis(1) * invs, axis(2) * invs).normalizedQuat();
     }
     bool hasNaN() const { return std::isnan(w) || std::isnan(x) || std::isnan(y) || std::isnan(z); }
 };
