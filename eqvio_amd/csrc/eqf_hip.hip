@@ -29,7 +29,7 @@ enum KName {
     KN_COUNT
 };
 const char* kNames[KN_COUNT] = {"k_assemble_AB", "k_observer",    "k_propagate_G", "k_propagate_main", "k_measure", "k_outlier_stats", "k_build_Z",
-                                "k_chol_panel",  "k_chol_update", "k_gamma",       "k_syrk_sub",       "k_lift",    "k_gemm_nt",       "misc"};
+                                "k_chol_step",   "k_chol_first", "k_gamma",       "k_syrk_sub",       "k_lift",    "k_gemm_nt",       "misc"};
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
 int pick_ld(int x) {
@@ -140,7 +140,7 @@ struct eqf_ctx {
     ObsStep* d_steps = nullptr;
     double *d_C = nullptr, *d_ytil = nullptr, *d_y = nullptr;
     int *d_lmidx = nullptr, *d_measof = nullptr, *d_keep = nullptr;
-    double *d_Z = nullptr, *d_gamma = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
+    double *d_Z = nullptr, *d_W = nullptr, *d_Linv = nullptr, *d_gamma = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
     int* d_flags = nullptr;
     // pinned host staging
     Common* h_common = nullptr;
@@ -361,6 +361,8 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipMalloc(&c->d_measof, sizeof(int) * c->Ncap));
     HIPCHK(hipMalloc(&c->d_keep, sizeof(int) * c->Ncap));
     HIPCHK(hipMalloc(&c->d_Z, sizeof(double) * (size_t)c->ldz * c->mcap));
+    HIPCHK(hipMalloc(&c->d_W, sizeof(double) * (size_t)c->ldz * c->mcap));
+    HIPCHK(hipMalloc(&c->d_Linv, sizeof(double) * 2048));
     HIPCHK(hipMalloc(&c->d_gamma, sizeof(double) * c->ncap));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
@@ -403,6 +405,8 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_measof);
     hipFree(c->d_keep);
     hipFree(c->d_Z);
+    hipFree(c->d_W);
+    hipFree(c->d_Linv);
     hipFree(c->d_gamma);
     hipFree(c->d_est);
     hipFree(c->d_stats);
@@ -716,10 +720,10 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
         hipLaunchKernelGGL(k_build_F, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, N, c->Ncap, n, c->ld, dt, c->d_common, c->d_Al, c->d_F);
         HIPCHK(hipGetLastError());
         // tmp[i][j] = sum_k F[i][k] Sigma[j][k]
-        hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(64), 0, c->stream, n, n, n, c->d_F, c->ld, Sin, c->ld, c->d_tmp, c->ld);
+        hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(256), 0, c->stream, n, n, n, c->d_F, c->ld, Sin, c->ld, c->d_tmp, c->ld);
         HIPCHK(hipGetLastError());
         // Sout[i][j] = sum_k tmp[i][k] F[j][k]
-        hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(64), 0, c->stream, n, n, n, c->d_tmp, c->ld, c->d_F, c->ld, Sout, c->ld);
+        hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(256), 0, c->stream, n, n, n, c->d_tmp, c->ld, c->d_F, c->ld, Sout, c->ld);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_add_noise, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, N, c->Ncap, n, c->ld, ra, c->d_common, c->d_Bl, Sout);
         HIPCHK(hipGetLastError());
@@ -894,30 +898,35 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         HIPCHK(hipGetLastError());
     }
     constexpr int NB = 32;
-    for (int kb = 0; kb < m; kb += NB) {
+    {
+        KTimer t(c, KN_CHOL_UPDATE);
+        hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, std::min(NB, m), c->ldz, c->d_Z, c->d_Linv, c->d_flags);
+        HIPCHK(hipGetLastError());
+    }
+    int step = 0;
+    for (int kb = 0; kb < m; kb += NB, ++step) {
         const int w = std::min(NB, m - kb);
-        {
-            KTimer t(c, KN_CHOL_PANEL);
-            const int below = rows - (kb + w);
-            hipLaunchKernelGGL(k_chol_panel<NB>, dim3(std::max(1, blocks(below, 64))), dim3(64), 0, c->stream, rows, kb, w, c->ldz, c->d_Z, c->d_flags);
-            HIPCHK(hipGetLastError());
+        const int c0 = kb + w;
+        double* Lin = c->d_Linv + 1024 * (step & 1);
+        double* Lout = c->d_Linv + 1024 * ((step + 1) & 1);
+        KTimer t(c, KN_CHOL_PANEL);
+        if (c0 < m) {
+            hipLaunchKernelGGL(k_chol_step, dim3(blocks(rows - c0, 32), blocks(m - c0, 32)), dim3(256), 0, c->stream, rows, m, kb, w, c->ldz, c->d_Z, c->d_W, Lin, Lout,
+                               c->d_flags, 1);
+        } else {
+            hipLaunchKernelGGL(k_chol_step, dim3(blocks(rows - c0, 32), 1), dim3(256), 0, c->stream, rows, m, kb, w, c->ldz, c->d_Z, c->d_W, Lin, Lout, c->d_flags, 0);
         }
-        if (kb + w < m) {
-            KTimer t(c, KN_CHOL_UPDATE);
-            const int c0 = kb + w;
-            hipLaunchKernelGGL(k_chol_update, dim3(blocks(rows - c0, 32), blocks(m - c0, 32)), dim3(64), 0, c->stream, rows, m, kb, w, c->ldz, c->d_Z);
-            HIPCHK(hipGetLastError());
-        }
+        HIPCHK(hipGetLastError());
     }
     {
         KTimer t(c, KN_GAMMA);
-        hipLaunchKernelGGL(k_gamma, dim3(blocks(n, 256)), dim3(256), 0, c->stream, n, m, c->ldz, c->d_Z, c->d_gamma);
+        hipLaunchKernelGGL(k_gamma, dim3(blocks(n, 64)), dim3(256), 0, c->stream, n, m, c->ldz, c->d_W, c->d_gamma);
         HIPCHK(hipGetLastError());
     }
     {
         KTimer t(c, KN_SYRK);
         const int nt = blocks(n, 32);
-        hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64), 0, c->stream, n, m, c->ld, c->ldz, c->d_Z, c->sigma(), nt);
+        hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, c->sigma(), nt);
         HIPCHK(hipGetLastError());
     }
     {

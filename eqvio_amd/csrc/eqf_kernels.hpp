@@ -515,187 +515,381 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K8b: one panel of the right-looking blocked Cholesky on Z (panel width NB, columns [kb, kb+w)).
-// Every workgroup re-factors the w x w diagonal block in LDS (redundant, identical arithmetic, no inter-WG
-// synchronisation needed), then solves its 64 rows below the block: X <- X L_kk^-T. Block 0 writes L_kk back.
+// K8b: blocked right-looking factorisation of Z = [S ; T ; y^T], ONE kernel launch per 32-column panel.
+//
+// Step k (panel = columns [kb, kb+w), c0 = kb + w): workgroup (bi, bj) owns the 32x32 trailing tile rows
+// i0 = c0 + 32 bi, cols j0 = c0 + 32 bj and, with no inter-workgroup synchronisation,
+//   1. reads L_kk^-1 (32x32, published by the previous launch) into LDS;
+//   2. P_I = Z[I, panel] L^-T and P_J = Z[J, panel] L^-T on fp64 MFMA (Z operand straight from L2) -> LDS;
+//   3. Z[I, J] -= P_I P_J^T on fp64 MFMA from LDS;
+//   4. workgroups with bj == 0 store the rows >= m of P_I (final W = T L^-T and z^T = y^T L^-T) to Wout;
+//   5. the workgroup that owns the NEXT diagonal tile (bi = bj = 0) keeps its updated tile on chip, eliminates it
+//      (square-root-free right-looking LDL^T, the tile distributed over the registers of its 256 lanes, pivot
+//      column / row exchanged through a double-buffered LDS line: one barrier per pivot) while applying the same row
+//      operations to an identity, and publishes L_{k+1}^-1 = diag(d)^-1/2 Lu^-1 for the next launch.
+// Only that one workgroup runs the pivot chain, alone on its CU; all others have exited. The chain of 400 pivots
+// is the critical path of the whole vision update (SURVEY.md §7 "hard parts").
+// The last panel (c0 >= m) runs with update = 0: steps 1, 2 (P_I only) and 4.
 // flags[0] is set when a pivot is not positive (EQF_E_NOT_SPD).
-template <int NB>
-__global__ void __launch_bounds__(64) k_chol_panel(int rows, int kb, int w, int ldz, double* __restrict__ Z, int* __restrict__ flags) {
-    __shared__ double sL[NB * (NB + 1)];
-    __shared__ double sd;
-    const int lane = threadIdx.x;
-    constexpr int LDL = NB + 1;
-    // load lower triangle of the diagonal block, column-major sL[r + c*LDL]
-    for (int t = lane; t < w * w; t += 64) {
-        const int r = t % w, c = t / w;
-        sL[r + c * LDL] = (r >= c) ? Z[kb + r + (size_t)(kb + c) * ldz] : 0.0;
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int CH_LDP = 48; // MFMA operand tiles in LDS: k and k+1 columns 32 dwords apart -> conflict-free ds_read_b64
+
+// full-precision reciprocal from v_rcp_f64 + two Newton steps (shorter dependent chain than an IEEE division)
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+
+// Eliminate a w x w SPD tile (w even) held as a[k] = D[r][g + 8k] (r = tid & 31, g = tid >> 5; entries with
+// col > row or outside w are identity padding) and write L^-1 (32x32 column-major, zero above the diagonal) to LinvOut.
+//
+// Block LDL^T with 2x2 pivots: per round the owners publish columns j, j+1 of the partially eliminated tile and rows
+// j, j+1 of M = Lu^-1 through a double-buffered LDS line (ONE barrier per two pivots); every lane inverts the 2x2 pivot
+// block itself (closed form, one reciprocal) while its other LDS reads are in flight, then updates its registers
+// branch-free. L = Lu blkdiag(chol(D_b)) is the Cholesky factor, so L^-1 = blkdiag(chol(D_b)^-1) M exactly.
+// sbuf: >= LDL_SBUF doubles of LDS. Must be called by all 256 lanes of the workgroup.
+constexpr int LDL_LINE = 2 * 32 + 2 * 32; // (colA, colB) interleaved pairs, then (rowA, rowB) interleaved pairs
+constexpr int LDL_SBUF = 32 * 33 + 64;    // >= 2 * LDL_LINE, and room for the final M exchange
+struct alignas(16) dpair {
+    double x, y;
+};
+__device__ __forceinline__ void ldl_inverse_tile(double a[4], int w, double* __restrict__ LinvOut, int* __restrict__ flags, double* __restrict__ sbuf) {
+    const int tid = threadIdx.x;
+    const int r = tid & 31, g = tid >> 5;
+    double mreg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        mreg[k] = (r == g + 8 * k) ? 1.0 : 0.0;
+    // triangle mask of this lane's four columns (c <= r): the strictly upper entries are identity padding and stay so
+    double tri[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        tri[k] = (g + 8 * k <= r) ? 1.0 : 0.0;
+    double p11 = 1.0, p21 = 0.0, p22 = 1.0; // pivot block of this lane's row pair, captured when it is published
+    // NOT unrolled: this code runs once per launch; straight-line unrolling only adds instruction fetch.
+#pragma unroll 1
+    for (int j = 0; j < w; j += 2) {
+        dpair* col = reinterpret_cast<dpair*>(sbuf + ((j >> 1) & 1) * LDL_LINE); // col[r] = (A[r][j], A[r][j+1])
+        dpair* row = col + 32;                                                    // row[c] = (M[j][c], M[j+1][c])
+        const int ka = j >> 3; // j and j+1 share the register slot (j even)
+        const double asel = ka == 0 ? a[0] : (ka == 1 ? a[1] : (ka == 2 ? a[2] : a[3]));
+        if (g == (j & 7))
+            col[r].x = asel;
+        if (g == ((j + 1) & 7))
+            col[r].y = asel;
+        if (r == j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                row[g + 8 * k].x = mreg[k];
+        }
+        if (r == j + 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                row[g + 8 * k].y = mreg[k];
+        }
+        __syncthreads();
+        const dpair dj = col[j], dj1 = col[j + 1]; // d11 = dj.x, d21 = dj1.x, d22 = dj1.y
+        const dpair me = col[r];
+        dpair cc[4], rr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cc[k] = col[g + 8 * k];
+            rr[k] = row[g + 8 * k];
+        }
+        // all eleven LDS reads must be in flight together (one latency): pin the values so the compiler cannot
+        // stagger "read, wait, use, read, wait, use" through reused registers
+        asm volatile("" : "+v"(cc[0].x), "+v"(cc[0].y), "+v"(cc[1].x), "+v"(cc[1].y), "+v"(cc[2].x), "+v"(cc[2].y), "+v"(cc[3].x), "+v"(cc[3].y));
+        asm volatile("" : "+v"(rr[0].x), "+v"(rr[0].y), "+v"(rr[1].x), "+v"(rr[1].y), "+v"(rr[2].x), "+v"(rr[2].y), "+v"(rr[3].x), "+v"(rr[3].y));
+        const double d11 = dj.x, d21 = dj1.x, d22 = dj1.y;
+        if ((r >> 1) == (j >> 1)) {
+            p11 = d11;
+            p21 = d21;
+            p22 = d22;
+        }
+        const double idet = (r > j + 1) ? fast_rcp(fma(d11, d22, -d21 * d21)) : 0.0; // rows of / above the pivot block: no-op
+        // (f1, f2) = (A[r][j], A[r][j+1]) * D^-1
+        const double f1 = (me.x * d22 - me.y * d21) * idet;
+        const double f2 = (me.y * d11 - me.x * d21) * idet;
+        // M needs no mask: rows j, j+1 of M are zero right of their diagonal, so columns > j+1 are untouched;
+        // A: columns <= j+1 are dead after this round (never read again), only the triangle mask is needed.
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double t1 = f1 * tri[k], t2 = f2 * tri[k];
+            a[k] = fma(-t2, cc[k].y, fma(-t1, cc[k].x, a[k]));
+            mreg[k] = fma(-f2, rr[k].y, fma(-f1, rr[k].x, mreg[k]));
+        }
+    }
+    // L^-1 = blkdiag(C_b^-1) M with C_b = chol(D_b): row j -> M[j]/l11 ; row j+1 -> (M[j+1] - (l21/l11) M[j]) / l22
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        sbuf[r + (g + 8 * k) * 33] = mreg[k];
+    __syncthreads();
+    const bool ok = (p11 > 0.0) && (fma(p11, p22, -p21 * p21) > 0.0);
+    if (g == 0 && r < w && !ok)
+        flags[0] = 1;
+    const double il11 = 1.0 / sqrt(ok ? p11 : 1.0);
+    const double l21 = ok ? p21 * il11 : 0.0;
+    const double il22 = 1.0 / sqrt(ok ? p22 - l21 * l21 : 1.0);
+    const bool odd = (r & 1) != 0;
+    const double s_self = odd ? il22 : il11;
+    const double s_prev = odd ? -(l21 * il11) * il22 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = g + 8 * k;
+        const double mprev = sbuf[(r & ~1) + c * 33];
+        const double v = fma(s_prev, mprev, s_self * mreg[k]);
+        LinvOut[r + 32 * c] = (c <= r) ? v : 0.0;
+    }
+}
+
+// L_00^-1 for the first panel (the only elimination that is not the tail of a step kernel). One workgroup.
+__global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags) {
+    __shared__ double sbuf[LDL_SBUF];
+    const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = g + 8 * k;
+        a[k] = (r < w && c < w && r >= c) ? Z[r + (size_t)c * ldz] : ((r == c) ? 1.0 : 0.0);
+    }
+    ldl_inverse_tile(a, w, LinvOut, flags, sbuf);
+}
+
+__global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
+                                                   const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update) {
+    const int c0 = kb + w;
+    const int i0 = c0 + blockIdx.x * 32;
+    const int j0 = c0 + blockIdx.y * 32;
+    if (update && (i0 + 31 < j0))
+        return; // strictly upper tile of the symmetric part: never read
+    __shared__ double sLinv[32 * CH_LDP];
+    __shared__ double sPI[32 * CH_LDP];
+    __shared__ double sPJ[32 * CH_LDP];
+    __shared__ double sbuf[LDL_SBUF];
+    const int tid = threadIdx.x;
+    const int r = tid & 31, g = tid >> 5;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const bool diag_tile = update && (i0 == j0);
+    const bool needJ = update && !diag_tile;
+    // 0. issue every global load up front: L^-1, the panel rows of I and J in MFMA operand layout
+    //    (Zp[row][p], p = 4 st + lk) and the output tile
+    double lv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        lv[k] = LinvIn[r + 32 * (g + 8 * k)];
+    const int ihP = wave & 1;
+    double opI[8], opJ[8];
+    {
+        const int rowI = i0 + 16 * ihP + lr, rowJ = j0 + 16 * ihP + lr;
+        const int rowIc = min(rowI, rows - 1), rowJc = min(rowJ, m - 1);
+        const double zI = rowI < rows ? 1.0 : 0.0, zJ = (needJ && rowJ < m) ? 1.0 : 0.0;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int p = 4 * st + lk;
+            const int pc = min(p, w - 1);
+            const double zp = p < w ? 1.0 : 0.0;
+            opI[st] = Z[rowIc + (size_t)(kb + pc) * ldz] * (zI * zp);
+            opJ[st] = needJ ? Z[rowJc + (size_t)(kb + pc) * ldz] * (zJ * zp) : 0.0;
+        }
+    }
+    const int ihU = wave & 1, jhU = wave >> 1;
+    double zt[4];
+    {
+        const int i = min(i0 + 16 * ihU + lr, rows - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = min(j0 + 16 * jhU + lk + 4 * q, m - 1);
+            zt[q] = update ? Z[i + (size_t)j * ldz] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        sLinv[r + (g + 8 * k) * CH_LDP] = lv[k];
+    __syncthreads();
+    // 2. P = Zpanel * Linv^T : P[i][c] = sum_p Zp[i][p] Linv[c][p]; wave -> 16x16 sub-tile (ih, ch) of P_I and of P_J
+    {
+        const int ch = wave >> 1;
+        d4 accI = {0, 0, 0, 0}, accJ = {0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const double b = sLinv[16 * ch + lr + (4 * st + lk) * CH_LDP]; // J operand: Linv[c][p]
+            accI = __builtin_amdgcn_mfma_f64_16x16x4f64(b, opI[st], accI, 0, 0, 0);
+            if (needJ)
+                accJ = __builtin_amdgcn_mfma_f64_16x16x4f64(b, opJ[st], accJ, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sPI[16 * ihP + lr + (16 * ch + lk + 4 * q) * CH_LDP] = accI[q]; // P[i][c], c = 16 ch + lk + 4 q
+            if (needJ)
+                sPJ[16 * ihP + lr + (16 * ch + lk + 4 * q) * CH_LDP] = accJ[q];
+        }
     }
     __syncthreads();
-    for (int j = 0; j < w; ++j) {
-        // left-looking column j: s_r = a_rj - sum_{p<j} L_rp L_jp, rows r >= j
-        double s = 0.0;
-        const int r = lane;
-        if (r >= j && r < w) {
-            s = sL[r + j * LDL];
-            for (int p = 0; p < j; ++p)
-                s -= sL[r + p * LDL] * sL[j + p * LDL];
-        }
-        if (r == j) {
-            if (!(s > 0.0)) {
-                flags[0] = 1;
-                s = 1.0; // keep going with finite numbers; the caller reports EQF_E_NOT_SPD
+    // 4. final W / z rows of this panel
+    if (blockIdx.y == 0) {
+        const int row = i0 + r;
+        if (row < rows && row >= m) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = g + 8 * k;
+                if (c < w)
+                    Wout[row + (size_t)(kb + c) * ldz] = sPI[r + c * CH_LDP];
             }
-            sd = sqrt(s);
-        }
-        __syncthreads();
-        const double d = sd;
-        if (r >= j && r < w)
-            sL[r + j * LDL] = (r == j) ? d : s / d;
-        __syncthreads();
-    }
-    if (blockIdx.x == 0) {
-        for (int t = lane; t < w * w; t += 64) {
-            const int r = t % w, c = t / w;
-            if (r >= c)
-                Z[kb + r + (size_t)(kb + c) * ldz] = sL[r + c * LDL];
         }
     }
-    // rows below the diagonal block
-    const int row = kb + w + blockIdx.x * 64 + lane;
-    if (row >= rows)
+    if (!update)
         return;
-    double x[NB];
+    // 3. Z[I, J] -= P_I P_J^T : wave -> 16x16 sub-tile (ihU, jhU), K = 32
+    const bool next_diag = (blockIdx.x == 0 && blockIdx.y == 0);
+    {
+        const double* pj = diag_tile ? sPI : sPJ;
+        d4 acc = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-        x[j] = (j < w) ? Z[row + (size_t)(kb + j) * ldz] : 0.0;
+        for (int st = 0; st < 8; ++st) {
+            const int c = 4 * st + lk;
+            const double a = sPI[16 * ihU + lr + c * CH_LDP];
+            const double b = pj[16 * jhU + lr + c * CH_LDP];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);
+        }
+        const int i = i0 + 16 * ihU + lr;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (j < w) {
-            double s = x[j];
-#pragma unroll
-            for (int p = 0; p < NB; ++p)
-                if (p < j)
-                    s -= x[p] * sL[j + p * LDL];
-            x[j] = s / sL[j + j * LDL];
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + 16 * jhU + lk + 4 * q;
+            const double v = zt[q] - acc[q];
+            if (i < rows && j < m)
+                Z[i + (size_t)j * ldz] = v;
+            if (next_diag)
+                sPJ[16 * ihU + lr + (16 * jhU + lk + 4 * q) * CH_LDP] = v; // keep the updated next-diagonal tile on chip
         }
     }
+    if (!next_diag)
+        return;
+    // 5. eliminate the next diagonal tile D_{k+1} = Z[c0 : c0 + w2, c0 : c0 + w2] and publish its inverse factor
+    __syncthreads();
+    const int w2 = min(32, m - c0);
+    double a[4];
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-        if (j < w)
-            Z[row + (size_t)(kb + j) * ldz] = x[j];
+    for (int k = 0; k < 4; ++k) {
+        const int c = g + 8 * k;
+        a[k] = (r < w2 && c < w2 && r >= c) ? sPJ[r + c * CH_LDP] : ((r == c) ? 1.0 : 0.0);
+    }
+    ldl_inverse_tile(a, w2, LinvOut, flags, sbuf);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// fp64 MFMA tile helper. v_mfma_f64_16x16x4_f64: lane l supplies A[row = l&15][k = l>>4] and
+// fp64 MFMA tile core. v_mfma_f64_16x16x4_f64: lane l supplies A[row = l&15][k = l>>4] and
 // B[k = l>>4][col = l&15]; the 4 results of lane l are D[row = (l>>4) + 4r][col = l&15]
 // (cdna_hip_programming.md §3). We feed the "J" operand as A and the "I" operand as B so that a lane's
-// results are C[i = i0 + (l&15)][j = j0 + (l>>4) + 4r]: 16 consecutive lanes touch 16 consecutive doubles of a
-// column-major C (128-byte segments), and both operand loads P[x0 + (l&15) + (k0 + (l>>4)) * ld] are likewise
-// 128-byte contiguous per k.
-typedef double d4 __attribute__((ext_vector_type(4)));
+// results are C[i = i0 + (l&15)][j = j0 + (l>>4) + 4r]; both operand loads P[x0 + (l&15) + (k0 + (l>>4)) * ld]
+// are 128-byte contiguous per k, straight from L2 (the working set is L2 / Infinity-Cache resident).
+//
+// One workgroup (4 waves) owns one 32x32 output tile; the K range is split across the 4 waves (wave w takes the
+// k4-steps congruent to w mod 4) and the partial tiles are reduced through LDS in a fixed order (deterministic).
+// Out-of-range operand rows / k are clamped for the load and zeroed by a multiplier so every load is unconditional.
 
-// C[i][j] (+/-)= sum_k P[i][k] * Qm[j][k]   for a 32x32 tile per wave (2x2 MFMA tiles), K multiple of 4 after
-// zero-predication. rowsP/rowsQ bound the valid operand rows.
-__device__ __forceinline__ void mfma_tile_32x32(const double* __restrict__ P, int ldp, int i0, int rowsP, const double* __restrict__ Qm, int ldq, int j0,
-                                                int rowsQ, int k0, int k1, d4 acc[2][2]) {
-    const int lane = threadIdx.x & 63;
+struct TileRed {
+    double v[4]; // element e of lane t: (i = t & 31, j = (t >> 5) + 8 e)
+};
+__device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__ P, int ldp, int i0, int rowsP, const double* __restrict__ Qm, int ldq, int j0,
+                                                      int rowsQ, int K, double* __restrict__ sred /* 4*1024 doubles */) {
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
-    const int ia = i0 + lr, ib = i0 + 16 + lr;
-    const int ja = j0 + lr, jb = j0 + 16 + lr;
-    const bool via = ia < rowsP, vib = ib < rowsP, vja = ja < rowsQ, vjb = jb < rowsQ;
-    for (int k = k0; k < k1; k += 4) {
-        const int kk = k + lk;
-        const bool vk = kk < k1;
-        const double pa = (via && vk) ? P[ia + (size_t)kk * ldp] : 0.0;
-        const double pb = (vib && vk) ? P[ib + (size_t)kk * ldp] : 0.0;
-        const double qa = (vja && vk) ? Qm[ja + (size_t)kk * ldq] : 0.0;
-        const double qb = (vjb && vk) ? Qm[jb + (size_t)kk * ldq] : 0.0;
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pa, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pb, acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pa, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pb, acc[1][1], 0, 0, 0);
+    const int ia = min(i0 + lr, rowsP - 1), ib = min(i0 + 16 + lr, rowsP - 1);
+    const int ja = min(j0 + lr, rowsQ - 1), jb = min(j0 + 16 + lr, rowsQ - 1);
+    const double zia = (i0 + lr < rowsP) ? 1.0 : 0.0, zib = (i0 + 16 + lr < rowsP) ? 1.0 : 0.0;
+    const double zja = (j0 + lr < rowsQ) ? 1.0 : 0.0, zjb = (j0 + 16 + lr < rowsQ) ? 1.0 : 0.0;
+    d4 acc00 = {0, 0, 0, 0}, acc10 = acc00, acc01 = acc00, acc11 = acc00;
+    const int nsteps = (K + 3) >> 2;
+#pragma unroll 4
+    for (int st = wave; st < nsteps; st += 4) {
+        const int kk = 4 * st + lk;
+        const int kc = min(kk, K - 1);
+        const double zk = kk < K ? 1.0 : 0.0;
+        const double pa = P[ia + (size_t)kc * ldp] * (zia * zk);
+        const double pb = P[ib + (size_t)kc * ldp] * (zib * zk);
+        const double qa = Qm[ja + (size_t)kc * ldq] * zja;
+        const double qb = Qm[jb + (size_t)kc * ldq] * zjb;
+        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pa, acc00, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pb, acc10, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pa, acc01, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pb, acc11, 0, 0, 0);
     }
+    double* mine = sred + wave * 1024;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = lk + 4 * r;
+        mine[lr + 32 * j] = acc00[r];
+        mine[16 + lr + 32 * j] = acc10[r];
+        mine[lr + 32 * (16 + j)] = acc01[r];
+        mine[16 + lr + 32 * (16 + j)] = acc11[r];
+    }
+    __syncthreads();
+    TileRed out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = (tid & 31) + 32 * ((tid >> 5) + 8 * e);
+        out.v[e] = (sred[idx] + sred[1024 + idx]) + (sred[2048 + idx] + sred[3072 + idx]);
+    }
+    return out;
 }
 
-// K8c: trailing update of the blocked Cholesky: Z[i][j] -= sum_{p in panel} Z[i][p] Z[j][p]
-// for j in [kb+w, m), i in [j-tile.., rows). One wave per 32x32 tile; tiles entirely above the diagonal of the
-// S part are skipped.
-__global__ void __launch_bounds__(64) k_chol_update(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z) {
-    const int c0 = kb + w;
-    const int j0 = c0 + blockIdx.y * 32;
-    const int i0 = c0 + blockIdx.x * 32;
-    if (j0 >= m || i0 >= rows)
-        return;
-    if (i0 + 31 < j0)
-        return; // strictly upper tile of the symmetric part: never read
-    d4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-    const double* Pp = Z + (size_t)kb * ldz;
-    mfma_tile_32x32(Pp, ldz, i0, rows, Pp, ldz, j0, m, 0, w, acc);
-    const int lane = threadIdx.x & 63;
-    const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + 16 * ti + lr;
-                const int j = j0 + 16 * tj + lk + 4 * r;
-                if (i < rows && j < m)
-                    Z[i + (size_t)j * ldz] -= acc[ti][tj][r];
-            }
+// K8d: Gamma = W z  (Gamma = K yTilde = T S^-1 yTilde = W L^-1 yTilde). 64 rows per workgroup, the m columns split
+// over 4 lane groups, reduced through LDS.
+__global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const double* __restrict__ Wb, double* __restrict__ gamma) {
+    __shared__ double sp[256];
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int seg = threadIdx.x >> 6;
+    const double* W = Wb + m;
+    const double* z = Wb + m + n;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (r < n) {
+        int p = seg;
+        for (; p + 12 < m; p += 16) {
+            s0 += W[r + (size_t)p * ldz] * z[(size_t)p * ldz];
+            s1 += W[r + (size_t)(p + 4) * ldz] * z[(size_t)(p + 4) * ldz];
+            s2 += W[r + (size_t)(p + 8) * ldz] * z[(size_t)(p + 8) * ldz];
+            s3 += W[r + (size_t)(p + 12) * ldz] * z[(size_t)(p + 12) * ldz];
+        }
+        for (; p < m; p += 4)
+            s0 += W[r + (size_t)p * ldz] * z[(size_t)p * ldz];
+    }
+    sp[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (seg == 0 && r < n)
+        gamma[r] = (sp[threadIdx.x] + sp[64 + threadIdx.x]) + (sp[128 + threadIdx.x] + sp[192 + threadIdx.x]);
 }
 
-// K8d: Gamma = W z  (Gamma = K yTilde = T S^-1 yTilde = W L^-1 yTilde)
-__global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const double* __restrict__ Z, double* __restrict__ gamma) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n)
-        return;
-    const double* W = Z + m;
-    const double* z = Z + m + n;
-    double s = 0;
-    for (int p = 0; p < m; ++p)
-        s += W[r + (size_t)p * ldz] * z[(size_t)p * ldz];
-    gamma[r] = s;
-}
-
-// K9: Sigma <- Sigma - W W^T  ( = Sigma - K C Sigma, VIO_eqf.cpp:131 ), lower tiles computed, mirrored.
-// One wave per 32x32 tile; blockIdx.x enumerates lower-triangular tiles.
-__global__ void __launch_bounds__(64) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Z, double* __restrict__ Sig, int nt) {
-    // decode (bi >= bj) from linear index
+// K9: Sigma <- Sigma - W W^T  ( = Sigma - K C Sigma, VIO_eqf.cpp:131 ): lower 32x32 tiles computed (one workgroup
+// each, K = m split over its 4 waves), the strictly-lower ones mirrored so Sigma stays exactly symmetric.
+__global__ void __launch_bounds__(256) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, double* __restrict__ Sig, int nt) {
+    __shared__ double sred[4096];
     int b = blockIdx.x;
     int bj = 0;
-    {
-        // row-major over columns: column bj has (nt - bj) tiles
-        int rem = b;
-        while (rem >= nt - bj) {
-            rem -= nt - bj;
-            ++bj;
-        }
-        b = rem;
+    while (b >= nt - bj) { // column bj holds (nt - bj) lower tiles
+        b -= nt - bj;
+        ++bj;
     }
     const int bi = bj + b;
     const int i0 = bi * 32, j0 = bj * 32;
-    d4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-    const double* W = Z + m;
-    mfma_tile_32x32(W, ldz, i0, n, W, ldz, j0, n, 0, m, acc);
-    const int lane = threadIdx.x & 63;
-    const int lr = lane & 15, lk = lane >> 4;
+    const double* W = Wb + m;
+    const TileRed t = mfma_tile32_splitk(W, ldz, i0, n, W, ldz, j0, n, m, sred);
+    const int i = i0 + (threadIdx.x & 31);
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + 16 * ti + lr;
-                const int j = j0 + 16 * tj + lk + 4 * r;
-                if (i < n && j < n) {
-                    const double v = Sig[i + (size_t)j * ld] - acc[ti][tj][r];
-                    Sig[i + (size_t)j * ld] = v;
-                    if (bi != bj)
-                        Sig[j + (size_t)i * ld] = v;
-                }
-            }
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + (threadIdx.x >> 5) + 8 * e;
+        if (i < n && j < n && (bi != bj || i >= j)) {
+            const double v = Sig[i + (size_t)j * ld] - t.v[e];
+            Sig[i + (size_t)j * ld] = v;
+            if (i != j)
+                Sig[j + (size_t)i * ld] = v;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -838,25 +1032,19 @@ __global__ void __launch_bounds__(256) k_check_finite(int n, int ld, const doubl
 
 // ---------------------------------------------------------------------------------------------------
 // Dense fp64 MFMA GEMM used by the dense-Riccati mode (EQF_OPT_RICCATI_DENSE): C = A * B^T with A (Mr x K),
-// B (Nc x K), all column-major. One wave per 32x32 tile.
-__global__ void __launch_bounds__(64) k_gemm_nt(int Mr, int Nc, int K, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
-                                                double* __restrict__ Cm, int ldc) {
+// B (Nc x K), all column-major. One workgroup per 32x32 tile (K split over its 4 waves).
+__global__ void __launch_bounds__(256) k_gemm_nt(int Mr, int Nc, int K, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                                 double* __restrict__ Cm, int ldc) {
+    __shared__ double sred[4096];
     const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
-    d4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-    mfma_tile_32x32(A, lda, i0, Mr, B, ldb, j0, Nc, 0, K, acc);
-    const int lane = threadIdx.x & 63;
-    const int lr = lane & 15, lk = lane >> 4;
+    const TileRed t = mfma_tile32_splitk(A, lda, i0, Mr, B, ldb, j0, Nc, K, sred);
+    const int i = i0 + (threadIdx.x & 31);
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + 16 * ti + lr;
-                const int j = j0 + 16 * tj + lk + 4 * r;
-                if (i < Mr && j < Nc)
-                    Cm[i + (size_t)j * ldc] = acc[ti][tj][r];
-            }
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + (threadIdx.x >> 5) + 8 * e;
+        if (i < Mr && j < Nc)
+            Cm[i + (size_t)j * ldc] = t.v[e];
+    }
 }
 // F = I + dt*A materialised dense (row i, col j) column-major, from the packed blocks (dense-Riccati mode)
 __global__ void __launch_bounds__(256) k_build_F(int N, int Ncap, int n, int ldf, double dt, const Common* __restrict__ cm, const double* __restrict__ Al,
