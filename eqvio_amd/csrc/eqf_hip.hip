@@ -123,6 +123,11 @@ GroupSensor group_mul(const GroupSensor& a, const GroupSensor& b) {
 struct eqf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // landmark part of the observer steps, concurrent with the Riccati propagation
+    hipEvent_t ev_assembled = nullptr, ev_observer = nullptr, ev_early = nullptr;
+    bool ev_assembled_early = false; // ev_early marks "k_assemble_AB done" of the latest Riccati call
+    bool obs_pending = false;
+    bool busy_common = false, busy_steps = false, busy_meas = false; // pinned packets still referenced by queued kernels
     int chart = 0;
     int Ncap = 0, ncap = 0, ld = 0;
     int mcap = 0, ldz = 0;
@@ -149,10 +154,17 @@ struct eqf_ctx {
     size_t hbuf_doubles = 0;
     int* h_ibuf = nullptr;
     int* h_flags = nullptr;
-    static constexpr int kMaxSteps = 256;
+    int* h_lmidx = nullptr;  // pinned measurement packet: lmidx[Ncap], measof[Ncap]
+    double* h_y = nullptr;   //   y[2 Ncap]
+    double* h_res = nullptr; // pinned result packet: stats[3 Ncap] | est[4 Ncap] | gamma[32]
+    int* h_resflags = nullptr;
+    static constexpr int kMaxSteps = kObsChunk;
+    CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
     int opt_dense = 0, opt_check = 0, opt_timing = 0;
     std::vector<double> last_gamma;
+    int n_at_update = 0;
+    bool gamma_stale = false; // d_gamma holds a newer Gamma than last_gamma (fetched lazily by eqf_last_gamma)
     std::vector<double> est_cache; // 4 planes of stride N (q_hat xyz, invalid flag), valid after a vision update
     bool est_valid = false;
     // timing
@@ -211,6 +223,26 @@ void timing_reset(eqf_ctx* c) {
 
 int blocks(int n, int b) { return (n + b - 1) / b; }
 
+// full synchronisation of the context: everything queued has finished, every pinned packet is free again
+int sync_ctx(eqf_ctx* c) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->obs_pending) {
+        HIPCHK(hipStreamSynchronize(c->stream2));
+        c->obs_pending = false;
+    }
+    c->busy_common = c->busy_steps = c->busy_meas = false;
+    return 0;
+}
+// make the main stream wait for the observer kernel before anything that reads / writes the landmark arrays
+int join_observer(eqf_ctx* c) {
+    c->ev_assembled_early = false; // the caller is about to queue a kernel that touches the landmark arrays
+    if (c->obs_pending) {
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_observer, 0));
+        c->obs_pending = false;
+    }
+    return 0;
+}
+
 Cam make_cam(const eqvio_camera* c) { return Cam{c->fx, c->fy, c->cx, c->cy}; }
 
 // Sensor-level terms of A and B (EqFStateMatrixA_euclid / EqFInputMatrixB_euclid sensor rows and the per-landmark
@@ -266,24 +298,34 @@ void compute_common(const eqf_ctx* c, const double* imu13, Common& cm) {
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j)
             cm.Ass[(15 + i) * 21 + 15 + j] = adT.a[i * 6 + j];
+    // kernel-argument form
+    CommonK& ck = const_cast<eqf_ctx*>(c)->ck;
+    std::memcpy(ck.lm, cm.Mv, sizeof(double) * 66); // Mv, RTic, RTicSx, CT, vC are contiguous in Common
+    put(R_A, ck.RA);
+    put(skew(c->X.A.x) * R_A, ck.SxRA);
+    put(R_A * skew(xh.vel), ck.RAsv);
+    std::memcpy(ck.G, g, sizeof(g));
+    std::memcpy(ck.adT, adT.a, sizeof(ck.adT));
 }
 
 int upload_common(eqf_ctx* c, const double* imu13) {
-    compute_common(c, imu13, *c->h_common);
-    HIPCHK(hipMemcpyAsync(c->d_common, c->h_common, sizeof(Common), hipMemcpyHostToDevice, c->stream));
+    compute_common(c, imu13, *c->h_common); // h_common is host-only now (debug expansion); the kernels get c->ck by value
     return 0;
 }
 int launch_assemble(eqf_ctx* c) {
-    if (c->N == 0)
-        return 0;
     KTimer t(c, KN_ASSEMBLE);
-    hipLaunchKernelGGL(k_assemble_AB, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, c->N, c->Ncap, c->chart, c->d_common, c->q0(), c->Qq(), c->Qa(), c->d_Al,
-                       c->d_Bl);
+    int r = join_observer(c);
+    if (r)
+        return r;
+    hipLaunchKernelGGL(k_assemble_AB, dim3(std::max(1, blocks(c->N, 64))), dim3(64), 0, c->stream, c->ck, c->N, c->Ncap, c->chart, c->d_common, c->q0(), c->Qq(),
+                       c->Qa(), c->d_Al, c->d_Bl);
+    HIPCHK(hipEventRecord(c->ev_early, c->stream));
+    c->ev_assembled_early = true;
     return (int)hipGetLastError();
 }
 int read_flags(eqf_ctx* c) {
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
 }
 int index_of(const eqf_ctx* c, int id) {
@@ -342,6 +384,10 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     c->mcap = 2 * c->Ncap;
     c->ldz = pick_ld(c->mcap + c->ncap + 1);
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_assembled, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_observer, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming));
     const size_t sig_bytes = sizeof(double) * (size_t)c->ld * c->ncap;
     for (int b = 0; b < 2; ++b) {
         HIPCHK(hipMalloc(&c->d_sigma[b], sig_bytes));
@@ -375,11 +421,15 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipHostMalloc(&c->h_buf, sizeof(double) * c->hbuf_doubles));
     HIPCHK(hipHostMalloc(&c->h_ibuf, sizeof(int) * 4 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 4));
+    HIPCHK(hipHostMalloc(&c->h_lmidx, sizeof(int) * 2 * (size_t)c->Ncap));
+    HIPCHK(hipHostMalloc(&c->h_y, sizeof(double) * 2 * (size_t)c->Ncap));
+    HIPCHK(hipHostMalloc(&c->h_res, sizeof(double) * (7 * (size_t)c->Ncap + 32)));
+    HIPCHK(hipHostMalloc(&c->h_resflags, sizeof(int) * 4));
     // identity state
     const double s0[23] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     c->xi0 = unpack_sensor(s0);
     c->X = unpack_group(s0);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     *out = c;
     return EQF_OK;
 }
@@ -389,6 +439,7 @@ void eqf_destroy(eqf_ctx* c) {
         return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->stream2);
     for (int b = 0; b < 2; ++b) {
         hipFree(c->d_sigma[b]);
         hipFree(c->d_lm[b]);
@@ -421,6 +472,14 @@ void eqf_destroy(eqf_ctx* c) {
     hipHostFree(c->h_buf);
     hipHostFree(c->h_ibuf);
     hipHostFree(c->h_flags);
+    hipHostFree(c->h_lmidx);
+    hipHostFree(c->h_y);
+    hipHostFree(c->h_res);
+    hipHostFree(c->h_resflags);
+    hipEventDestroy(c->ev_assembled);
+    hipEventDestroy(c->ev_observer);
+    hipEventDestroy(c->ev_early);
+    hipStreamDestroy(c->stream2);
     for (auto e : c->evpool)
         hipEventDestroy(e);
     hipStreamDestroy(c->stream);
@@ -446,7 +505,7 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     }
 }
 int eqf_synchronize(eqf_ctx* c) {
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
 }
 int eqf_num_landmarks(const eqf_ctx* c) { return c->N; }
@@ -467,7 +526,7 @@ int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, 
     if (N > c->Ncap)
         return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     c->est_valid = false;
     c->xi0 = unpack_sensor(xi0_sensor);
     c->X = unpack_group(X_sensor);
@@ -480,7 +539,7 @@ int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, 
         hipLaunchKernelGGL(k_scatter_landmarks, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, 0, c->Ncap, c->d_scratch, c->d_scratch + 3 * N, c->q0(), c->Qq(),
                            c->Qa());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        { int _r = sync_ctx(c); if (_r) return _r; }
     }
     return 0;
 }
@@ -497,10 +556,11 @@ int eqf_get_state(eqf_ctx* c, double* xi0_sensor, double* X_sensor, int* ids, do
         return EQF_E_CAPACITY;
     if (N > 0) {
         HIPCHK(hipSetDevice(c->device));
+        { int _r = join_observer(c); if (_r) return _r; }
         hipLaunchKernelGGL(k_gather_landmarks_aos, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->d_scratch);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->h_buf, c->d_scratch, sizeof(double) * 8 * N, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        { int _r = sync_ctx(c); if (_r) return _r; }
         for (int i = 0; i < N; ++i) {
             if (ids)
                 ids[i] = c->ids[i];
@@ -517,22 +577,22 @@ int eqf_set_sigma(eqf_ctx* c, const double* sig, int n) {
     if (!c || !sig || n != c->n())
         return EQF_E_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(c->h_buf, sig, sizeof(double) * (size_t)n * n);
     HIPCHK(hipMemcpy2DAsync(c->sigma(), sizeof(double) * c->ld, c->h_buf, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
 }
 int eqf_set_sigma_diag(eqf_ctx* c, const double* diag, int n) {
     if (!c || !diag || n != c->n())
         return EQF_E_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(c->h_buf, diag, sizeof(double) * n);
     HIPCHK(hipMemcpyAsync(c->d_gamma, c->h_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_set_diag, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->d_gamma, c->sigma());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
 }
 int eqf_get_sigma_block(eqf_ctx* c, int r0, int c0, int rows, int cols, double* out) {
@@ -543,7 +603,7 @@ int eqf_get_sigma_block(eqf_ctx* c, int r0, int c0, int rows, int cols, double* 
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy2DAsync(c->h_buf, sizeof(double) * rows, c->sigma() + r0 + (size_t)c0 * c->ld, sizeof(double) * c->ld, sizeof(double) * rows, cols,
                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(out, c->h_buf, sizeof(double) * (size_t)rows * cols);
     return 0;
 }
@@ -561,10 +621,11 @@ static int fetch_estimates(eqf_ctx* c) { // d_est -> h_buf (4 planes of stride N
         std::memcpy(c->h_buf, c->est_cache.data(), sizeof(double) * 4 * N);
         return 0;
     }
+    { int _r = join_observer(c); if (_r) return _r; }
     hipLaunchKernelGGL(k_estimate, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->d_est);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_buf, c->d_est, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
 }
 
@@ -602,7 +663,7 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
     if (c->N + k > c->Ncap)
         return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream)); // staging reuse
+    { int _r = sync_ctx(c); if (_r) return _r; } // staging reuse
     std::memcpy(c->h_buf, p, sizeof(double) * 3 * k);
     HIPCHK(hipMemcpyAsync(c->d_scratch, c->h_buf, sizeof(double) * 3 * k, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_scatter_landmarks, dim3(blocks(k, 64)), dim3(64), 0, c->stream, k, c->N, c->Ncap, c->d_scratch, (const double*)nullptr, c->q0(), c->Qq(),
@@ -630,7 +691,7 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
         drop[indices[t]] = 1;
     }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream)); // staging reuse
+    { int _r = sync_ctx(c); if (_r) return _r; } // staging reuse
     std::vector<int> newids;
     int Nnew = 0;
     for (int i = 0; i < c->N; ++i)
@@ -684,7 +745,6 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
     if (!c || !imu13 || !Qdiag12 || !Pdiag8)
         return EQF_E_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream)); // h_common reuse (v0: serialise)
     int rc = upload_common(c, imu13);
     if (rc)
         return rc;
@@ -751,7 +811,7 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
     int done = 0;
     while (done < k) {
         const int chunk = std::min(k - done, eqf_ctx::kMaxSteps);
-        HIPCHK(hipStreamSynchronize(c->stream)); // h_steps reuse (v0: serialise)
+        ObsSteps steps_arg;
         for (int s = 0; s < chunk; ++s) {
             const double* imu = imu13_k + 13 * (done + s);
             const double dt = dt_k[done + s];
@@ -762,7 +822,7 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
             const V3 gbv = v3(imu[7], imu[8], imu[9]), abv = v3(imu[10], imu[11], imu[12]);
             const V3 gdir = q_rot(q_inv(xh.pose.R), v3(0, 0, 1));
             GroupSensor L;
-            ObsStep& st = c->h_steps[s];
+            ObsStep& st = steps_arg.s[s];
             st.discrete = discreteLift ? 1 : 0;
             st.dt = dt;
             if (discreteLift) {
@@ -795,10 +855,18 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
             c->X = group_mul(c->X, L);
         }
         if (c->N > 0) {
-            HIPCHK(hipMemcpyAsync(c->d_steps, c->h_steps, sizeof(ObsStep) * chunk, hipMemcpyHostToDevice, c->stream));
-            KTimer t(c, KN_OBSERVER);
-            hipLaunchKernelGGL(k_observer, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, c->N, c->Ncap, chunk, c->d_steps, c->q0(), c->Qq(), c->Qa());
+            // The landmark part runs on the second stream: it only has to wait for the last kernel that READS Q on the
+            // main stream (k_assemble_AB of a preceding Riccati call, ev_assembled), so it overlaps the Sigma
+            // propagation kernels (they touch Sigma / Al / Bl / G only). The steps are read zero-copy from the pinned packet.
+            if (c->obs_pending)
+                HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_observer, 0));
+            HIPCHK(hipEventRecord(c->ev_assembled, c->stream)); // everything queued so far on the main stream
+            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_assembled_early ? c->ev_early : c->ev_assembled, 0));
+            c->ev_assembled_early = false;
+            hipLaunchKernelGGL(k_observer, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream2, steps_arg, c->N, c->Ncap, chunk, c->q0(), c->Qq(), c->Qa());
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev_observer, c->stream2));
+            c->obs_pending = true;
         }
         done += chunk;
     }
@@ -831,44 +899,53 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     if (M > c->Ncap)
         return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    int* lmidx = c->h_ibuf;
-    int* measof = c->h_ibuf + c->Ncap;
+    if (c->busy_meas) {
+        int r = sync_ctx(c);
+        if (r)
+            return r;
+    }
+    int* lmidx = c->h_lmidx;
+    int* measof = c->h_lmidx + c->Ncap;
     int rc = map_measurement(c, ids, M, false, lmidx, measof);
     if (rc)
         return rc;
-    std::memcpy(c->h_buf, y, sizeof(double) * 2 * M);
-    HIPCHK(hipMemcpyAsync(c->d_measof, measof, sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
-    if (M > 0)
-        HIPCHK(hipMemcpyAsync(c->d_y, c->h_buf, sizeof(double) * 2 * M, hipMemcpyHostToDevice, c->stream));
+    std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
+    rc = join_observer(c);
+    if (rc)
+        return rc;
     {
         KTimer t(c, KN_STATS);
-        hipLaunchKernelGGL(k_outlier_stats, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), c->d_measof, c->d_y, c->q0(), c->Qq(),
-                           c->Qa(), c->sigma(), c->d_stats);
+        c->busy_meas = true;
+        hipLaunchKernelGGL(k_outlier_stats, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), measof, c->h_y, c->q0(), c->Qq(), c->Qa(),
+                           c->sigma(), c->h_res);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_stats, sizeof(double) * 3 * N, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = sync_ctx(c);
+    if (rc)
+        return rc;
     if (absErr)
-        std::memcpy(absErr, c->h_buf, sizeof(double) * N);
+        std::memcpy(absErr, c->h_res, sizeof(double) * N);
     if (probErr)
-        std::memcpy(probErr, c->h_buf + N, sizeof(double) * N);
+        std::memcpy(probErr, c->h_res + N, sizeof(double) * N);
     if (depth2)
-        std::memcpy(depth2, c->h_buf + 2 * N, sizeof(double) * N);
+        std::memcpy(depth2, c->h_res + 2 * N, sizeof(double) * N);
     return 0;
 }
 
 static int stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    int* lmidx = c->h_ibuf;
-    int* measof = c->h_ibuf + c->Ncap;
+    if (c->busy_meas) {
+        int r = sync_ctx(c);
+        if (r)
+            return r;
+    }
+    int* lmidx = c->h_lmidx;
+    int* measof = c->h_lmidx + c->Ncap;
     int rc = map_measurement(c, ids, M, true, lmidx, measof);
     if (rc)
         return rc;
-    std::memcpy(c->h_buf, y, sizeof(double) * 2 * M);
-    HIPCHK(hipMemcpyAsync(c->d_lmidx, lmidx, sizeof(int) * M, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_y, c->h_buf, sizeof(double) * 2 * M, hipMemcpyHostToDevice, c->stream));
-    return 0;
+    std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
+    c->busy_meas = true;
+    return join_observer(c);
 }
 
 int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEqv, int discreteCorr) {
@@ -884,11 +961,10 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         return rc;
     const int N = c->N, n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
-    HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(int) * 4, c->stream));
     {
         KTimer t(c, KN_MEASURE);
-        hipLaunchKernelGGL(k_measure, dim3(blocks(M, 64)), dim3(64), 0, c->stream, M, c->Ncap, c->Ncap, c->chart, make_cam(cam), useEqv, c->d_lmidx, c->d_y, c->q0(), c->Qq(),
-                           c->Qa(), c->d_C, c->d_ytil);
+        hipLaunchKernelGGL(k_measure, dim3(blocks(M, 64)), dim3(64), 0, c->stream, M, c->Ncap, c->Ncap, c->chart, make_cam(cam), useEqv, c->h_lmidx, c->h_y, c->q0(), c->Qq(),
+                           c->Qa(), c->d_C, c->d_ytil, c->d_lmidx, c->d_flags);
         HIPCHK(hipGetLastError());
     }
     {
@@ -931,23 +1007,27 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     }
     {
         KTimer t(c, KN_LIFT);
-        hipLaunchKernelGGL(k_lift, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(), c->d_est);
+        hipLaunchKernelGGL(k_lift, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),
+                           c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags);
         HIPCHK(hipGetLastError());
     }
     if (c->opt_check) {
         hipLaunchKernelGGL(k_check_finite, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), c->d_flags);
         HIPCHK(hipGetLastError());
     }
-    // Gamma (n) + new estimates / invalid flags (4N) + status flags back in one synchronisation; the sensor part
-    // of Delta is lifted on the host
-    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_gamma, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_buf + n, c->d_est, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, c->stream));
-    rc = read_flags(c);
+    // The lift kernel wrote Gamma's sensor part, the new estimates / invalid flags (4N) and the status flags straight
+    // into the pinned result packet: one stream synchronisation, no copy kernels. The sensor part of Delta is lifted
+    // on the host.
+    rc = sync_ctx(c);
     if (rc)
         return rc;
-    c->last_gamma.assign(c->h_buf, c->h_buf + n);
-    c->est_cache.assign(c->h_buf + n, c->h_buf + n + 4 * N);
+    c->h_flags[0] = c->h_resflags[0];
+    c->h_flags[1] = c->h_resflags[1];
+    c->gamma_stale = true;
+    c->n_at_update = n;
+    c->est_cache.assign(c->h_res + 3 * (size_t)c->Ncap, c->h_res + 3 * (size_t)c->Ncap + 4 * N);
     c->est_valid = true;
+    std::memcpy(c->h_buf, c->h_res + 7 * (size_t)c->Ncap, sizeof(double) * 21);
     const double* g = c->h_buf;
     GroupSensor D;
     D.bgyr = v3(g[0], g[1], g[2]);
@@ -982,6 +1062,13 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
 int eqf_last_gamma(eqf_ctx* c, double* out, int cap) {
     if (!c || !out)
         return EQF_E_BAD_ARG;
+    if (c->gamma_stale) {
+        const int n = c->n_at_update;
+        HIPCHK(hipMemcpyAsync(c->h_buf, c->d_gamma, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        { int _r = sync_ctx(c); if (_r) return _r; }
+        c->last_gamma.assign(c->h_buf, c->h_buf + n);
+        c->gamma_stale = false;
+    }
     if ((int)c->last_gamma.size() > cap)
         return EQF_E_CAPACITY;
     std::memcpy(out, c->last_gamma.data(), sizeof(double) * c->last_gamma.size());
@@ -992,7 +1079,7 @@ int eqf_debug_matrices_AB(eqf_ctx* c, const double* imu13, double* A_out, double
     if (!c || !imu13)
         return EQF_E_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     int rc = upload_common(c, imu13);
     if (rc)
         return rc;
@@ -1003,7 +1090,7 @@ int eqf_debug_matrices_AB(eqf_ctx* c, const double* imu13, double* A_out, double
     std::vector<double> Al(45 * (size_t)Ncap), Bl(9 * (size_t)Ncap);
     HIPCHK(hipMemcpyAsync(c->h_buf, c->d_Al, sizeof(double) * 45 * Ncap, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_buf + 45 * (size_t)Ncap, c->d_Bl, sizeof(double) * 9 * Ncap, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(Al.data(), c->h_buf, sizeof(double) * 45 * Ncap);
     std::memcpy(Bl.data(), c->h_buf + 45 * (size_t)Ncap, sizeof(double) * 9 * Ncap);
     const Common& cm = *c->h_common;
@@ -1040,14 +1127,14 @@ int eqf_debug_matrix_C(eqf_ctx* c, const eqvio_camera* cam, const int* ids, cons
     int rc = stage_measurement(c, ids, y, M);
     if (rc)
         return rc;
-    std::vector<int> lmidx(c->h_ibuf, c->h_ibuf + M);
-    hipLaunchKernelGGL(k_measure, dim3(blocks(M, 64)), dim3(64), 0, c->stream, M, c->Ncap, c->Ncap, c->chart, make_cam(cam), useEqv, c->d_lmidx, c->d_y, c->q0(), c->Qq(), c->Qa(),
-                       c->d_C, c->d_ytil);
+    std::vector<int> lmidx(c->h_lmidx, c->h_lmidx + M);
+    hipLaunchKernelGGL(k_measure, dim3(blocks(M, 64)), dim3(64), 0, c->stream, M, c->Ncap, c->Ncap, c->chart, make_cam(cam), useEqv, c->h_lmidx, c->h_y, c->q0(), c->Qq(), c->Qa(),
+                       c->d_C, c->d_ytil, c->d_lmidx, c->d_flags);
     HIPCHK(hipGetLastError());
     const int Ncap = c->Ncap, n = c->n();
     HIPCHK(hipMemcpyAsync(c->h_buf, c->d_C, sizeof(double) * 6 * Ncap, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_buf + 6 * (size_t)Ncap, c->d_ytil, sizeof(double) * 2 * M, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     if (C_out) {
         std::fill(C_out, C_out + (size_t)2 * M * n, 0.0);
         for (int j = 0; j < M; ++j)
@@ -1092,7 +1179,7 @@ int eqf_mfma_f64_peak(eqf_ctx* c, double* tflops) {
 int eqf_last_kernel_times(eqf_ctx* c, int* which, float* usec, int cap) {
     if (!c)
         return EQF_E_BAD_ARG;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
     int cnt = 0;
     for (auto& t : c->tev) {
         if (cnt >= cap)

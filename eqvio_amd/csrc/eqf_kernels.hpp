@@ -28,6 +28,17 @@ struct Common {
     double Ass[441];  // sensor block of A, row-major 21x21
     double Bs[252];   // sensor rows of B, row-major 21x12
 };
+// The same terms in the compact form that travels as a KERNEL ARGUMENT (1.1 KB): no staging copy, no PCIe read.
+// Workgroup 0 of k_assemble_AB expands it into the Common record in HBM for the propagate kernels.
+struct CommonK {
+    double lm[66];   // Mv, RTic, RTicSx, CT, vC (the per-landmark factors, in Common's order)
+    double RA[9];    // R_A
+    double SxRA[9];  // skew(x_A) R_A
+    double RAsv[9];  // R_A skew(v_hat)
+    double G[9];     // -g skew(R_0^T e3)
+    double adT[36];  // ad(Ad_{T0^-1} Ad_A U_I)
+};
+constexpr int kObsChunk = 24; // observer steps per launch (kernel-argument budget)
 struct RiccatiArgs {
     double dt;
     double Qd[12];
@@ -62,14 +73,52 @@ __host__ __device__ __forceinline__ int al_col(int e) { return e < 3 ? e : (e < 
 // ---------------------------------------------------------------------------------------------------
 // K1: per-landmark rows of A and B (EqFStateMatrixA / EqFInputMatrixB, euclid.cpp:99-233, invdepth.cpp:36-181)
 // One lane per landmark; the sensor-level terms are staged in LDS once per workgroup.
-__global__ void __launch_bounds__(64) k_assemble_AB(int N, int Ncap, int chart, const Common* __restrict__ cmg, const double* __restrict__ q0,
-                                                    const double* __restrict__ Qq, const double* __restrict__ Qa, double* __restrict__ Al,
-                                                    double* __restrict__ Bl) {
+__global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int Ncap, int chart, Common* __restrict__ cmdev,
+                                                    const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
+                                                    double* __restrict__ Al, double* __restrict__ Bl) {
+    // The sensor-level terms arrive as a kernel argument. Workgroup 0 expands the sensor blocks A_ss (21x21) and
+    // B_s (21x12) into HBM for the propagate kernels (block layout of euclid.cpp:103-109, 186-233).
     __shared__ double s_cm[9 + 9 + 9 + 36 + 3];
+    for (int t = threadIdx.x; t < 66; t += blockDim.x)
+        s_cm[t] = ck.lm[t];
     {
-        const double* src = cmg->Mv; // Mv, RTic, RTicSx, CT, vC are contiguous
-        for (int t = threadIdx.x; t < 66; t += blockDim.x)
-            s_cm[t] = src[t];
+        const int gt = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+        for (int t = gt; t < 252; t += gs) {
+            const int r = t / 12, c = t % 12;
+            double v = 0.0;
+            if (r < 6)
+                v = (c == 6 + r) ? 1.0 : 0.0;
+            else if (r < 9 && c < 3)
+                v = ck.RA[(r - 6) * 3 + c];
+            else if (r >= 9 && r < 12 && c < 3)
+                v = ck.SxRA[(r - 9) * 3 + c];
+            else if (r >= 12 && r < 15 && c < 3)
+                v = ck.RAsv[(r - 12) * 3 + c];
+            else if (r >= 12 && r < 15 && c >= 3 && c < 6)
+                v = ck.RA[(r - 12) * 3 + (c - 3)];
+            cmdev->Bs[t] = v;
+        }
+        for (int t = gt; t < 441; t += gs) {
+            const int r = t / 21, c = t % 21;
+            double v = 0.0;
+            if (c < 6) { // -B[:, 0:6]
+                if (r >= 6 && r < 9 && c < 3)
+                    v = -ck.RA[(r - 6) * 3 + c];
+                else if (r >= 9 && r < 12 && c < 3)
+                    v = -ck.SxRA[(r - 9) * 3 + c];
+                else if (r >= 12 && r < 15 && c < 3)
+                    v = -ck.RAsv[(r - 12) * 3 + c];
+                else if (r >= 12 && r < 15 && c >= 3)
+                    v = -ck.RA[(r - 12) * 3 + (c - 3)];
+            } else if (r >= 9 && r < 12 && c == r + 3) {
+                v = 1.0;
+            } else if (r >= 12 && r < 15 && c >= 6 && c < 9) {
+                v = ck.G[(r - 12) * 3 + (c - 6)];
+            } else if (r >= 15 && c >= 15) {
+                v = ck.adT[(r - 15) * 6 + (c - 15)];
+            }
+            cmdev->Ass[t] = v;
+        }
     }
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,8 +199,12 @@ __global__ void __launch_bounds__(64) k_assemble_AB(int N, int Ncap, int chart, 
 
 // ---------------------------------------------------------------------------------------------------
 // K4: landmark part of k observer steps X <- X * Lambda (VIO_eqf.cpp:47-60, VIOGroup.cpp:190-271, 71-92)
-__global__ void __launch_bounds__(64) k_observer(int N, int Ncap, int k, const ObsStep* __restrict__ steps, const double* __restrict__ q0,
+struct ObsSteps {
+    ObsStep s[kObsChunk];
+};
+__global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N, int Ncap, int k, const double* __restrict__ q0,
                                                  double* __restrict__ Qq, double* __restrict__ Qa) {
+    const ObsStep* steps = steps_arg.s;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
@@ -407,11 +460,18 @@ __device__ __forceinline__ MeasOut measure_one(int chart, const Cam& cam, V3 p0,
 }
 __global__ void __launch_bounds__(64) k_measure(int M, int Mcap, int Ncap, int chart, Cam cam, int star, const int* __restrict__ lmidx,
                                                 const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
-                                                const double* __restrict__ Qa, double* __restrict__ C, double* __restrict__ ytil) {
+                                                const double* __restrict__ Qa, double* __restrict__ C, double* __restrict__ ytil,
+                                                int* __restrict__ lmidx_dev, int* __restrict__ flags) {
+    // lmidx / y live in the pinned host packet (read once, zero-copy); lmidx is mirrored to HBM for k_build_Z.
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) {
+        flags[0] = 0;
+        flags[1] = 0;
+    }
     if (j >= M)
         return;
     const int i = lmidx[j];
+    lmidx_dev[j] = i;
     const MeasOut o = measure_one(chart, cam, ld3(q0, Ncap, i), ldq(Qq, Ncap, i), Qa[i], y[2 * j], y[2 * j + 1], star != 0);
 #pragma unroll
     for (int e = 0; e < 6; ++e)
@@ -898,8 +958,17 @@ __global__ void __launch_bounds__(256) k_syrk_sub(int n, int m, int ld, int ldz,
 // Also writes the new estimates q_hat_i and a flag per landmark with Q_i.a outside (1e-8, 1e8]
 // (removeInvalidLandmarks, VIO_eqf.cpp:213-223) into `est` (4 planes of stride N: qx, qy, qz, invalid).
 __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
-                                             double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est) {
+                                             double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
+                                             const int* __restrict__ flags, int* __restrict__ flags_host) {
+    // est / gamma_host / flags_host point into the pinned host packet: the results reach the host with the stream
+    // synchronisation alone, no copy kernels.
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 21)
+        gamma_host[i] = gamma[i];
+    if (i == 0) {
+        flags_host[0] = flags[0];
+        flags_host[1] = flags[1];
+    }
     if (i >= N)
         return;
     const V3 p0 = ld3(q0, Ncap, i);
