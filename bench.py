@@ -154,27 +154,15 @@ def main():
     lib = load_eqf_lib()
     core = flt.core_handle()
 
-    def barrier():
+    from eqvio_amd.replicas import timed_replica_run
+
+    def sync():
         lib.eqf_synchronize(core)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
         torch.cuda.synchronize()
 
     if args.warmup:
         flt.run_frames(cam, *warm)
-    barrier()
-    t0 = time.perf_counter()
-    done = flt.run_frames(cam, *timed)
-    lib.eqf_synchronize(core)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    assert done == args.steps
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    barrier()
+    value, elapsed, _ = timed_replica_run(lambda: flt.run_frames(cam, *timed), sync, args.steps, dist=dist, device=torch.device("cuda", local_rank))
 
     # post-run sanity: the state is finite and Sigma is symmetric positive definite
     S = flt.get_sigma()
@@ -182,7 +170,6 @@ def main():
     assert np.linalg.eigvalsh(0.5 * (S + S.T)).min() > 0
 
     n, m = 21 + 3 * N, 2 * N
-    value = args.steps * world_size / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
     frame_flops = flops_propagate(n) + flops_update(n, m)
 

@@ -31,6 +31,18 @@ def test_eqf_hip_exports_every_declared_symbol(built):
         assert hasattr(lib, n), f"{n} declared in include/eqf_hip.h but not exported"
 
 
+def test_filter_lib_exports_every_declared_symbol(built):
+    ctypes.CDLL(os.path.join(ROOT, "eqvio_amd", "lib", "libeqf_hip.so"), mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(os.path.join(ROOT, "eqvio_amd", "lib", "libeqvio_filter.so"))
+    names = [n for n in declared_symbols("eqvio_filter.h") if n.startswith("eqvio_filter_")]
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/eqvio_filter.h but not exported"
+    from eqvio_amd.capi import load_filter_lib
+
+    assert sorted(load_filter_lib()._declared) == sorted(names)
+
+
 def test_binding_declares_the_same_symbols(built):
     from eqvio_amd.capi import load_eqf_lib
 
