@@ -224,10 +224,29 @@ void timing_reset(eqf_ctx* c) {
 int blocks(int n, int b) { return (n + b - 1) / b; }
 
 // full synchronisation of the context: everything queued has finished, every pinned packet is free again
+// Busy-wait on the stream: the frame has two host decision points and an interrupt-driven hipStreamSynchronize
+// costs tens of microseconds of wake-up latency each time; the caller thread is dedicated to its filter anyway.
+int spin_stream(hipStream_t st) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess)
+            return 0;
+        if (e != hipErrorNotReady) {
+            std::fprintf(stderr, "[eqf_hip] stream error: %s\n", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+}
 int sync_ctx(eqf_ctx* c) {
-    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        int r = spin_stream(c->stream);
+        if (r)
+            return r;
+    }
     if (c->obs_pending) {
-        HIPCHK(hipStreamSynchronize(c->stream2));
+        int r = spin_stream(c->stream2);
+        if (r)
+            return r;
         c->obs_pending = false;
     }
     c->busy_common = c->busy_steps = c->busy_meas = false;

@@ -603,120 +603,185 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return fma(r, e, r);
 }
 
-// Eliminate a w x w SPD tile (w even) held as a[k] = D[r][g + 8k] (r = tid & 31, g = tid >> 5; entries with
-// col > row or outside w are identity padding) and write L^-1 (32x32 column-major, zero above the diagonal) to LinvOut.
-//
-// Block LDL^T with 2x2 pivots: per round the owners publish columns j, j+1 of the partially eliminated tile and rows
-// j, j+1 of M = Lu^-1 through a double-buffered LDS line (ONE barrier per two pivots); every lane inverts the 2x2 pivot
-// block itself (closed form, one reciprocal) while its other LDS reads are in flight, then updates its registers
-// branch-free. L = Lu blkdiag(chol(D_b)) is the Cholesky factor, so L^-1 = blkdiag(chol(D_b)^-1) M exactly.
-// sbuf: >= LDL_SBUF doubles of LDS. Must be called by all 256 lanes of the workgroup.
-constexpr int LDL_LINE = 2 * 32 + 2 * 32; // (colA, colB) interleaved pairs, then (rowA, rowB) interleaved pairs
-constexpr int LDL_SBUF = 32 * 33 + 64;    // >= 2 * LDL_LINE, and room for the final M exchange
+// full-precision 1/sqrt from v_rsq_f64 + two Newton steps (an IEEE sqrt followed by a division is ~10x longer a chain)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+// ---- inverse Cholesky factor of a 32x32 SPD tile, blocked 16 + 16 -----------------------------------------------
+// D = [[D11, .],[D21, D22]]:  L11^-1 by a 16x16 elimination;  L21 = D21 L11^-T (MFMA);  S22 = D22 - L21 L21^T (MFMA);
+// L22^-1 by a second 16x16 elimination;  L^-1 = [[L11^-1, 0], [-L22^-1 L21 L11^-1, L22^-1]] (two MFMA products).
+// The 16x16 eliminations are block LDL^T with 2x2 pivots, ONE element of the tile and one of M = Lu^-1 per lane
+// (256 lanes), pivot columns / rows exchanged through a double-buffered LDS line: one barrier per two pivots and
+// ~20 VALU ops per round, so a round is bound by its dependent chain (barrier + LDS + reciprocal), not by issue.
 struct alignas(16) dpair {
     double x, y;
 };
-__device__ __forceinline__ void ldl_inverse_tile(double a[4], int w, double* __restrict__ LinvOut, int* __restrict__ flags, double* __restrict__ sbuf) {
-    const int tid = threadIdx.x;
-    const int r = tid & 31, g = tid >> 5;
-    double mreg[4];
+// 16x16x16 product on one wave: C[i][c] = sum_p I[i][p] * J[c][p], I at Ib[i + p*ldi], J at Jb[c + p*ldj].
+// Lane (lr = lane & 15, lk = lane >> 4) returns C[lr][lk + 4q], q = 0..3.
+__device__ __forceinline__ d4 mfma16_nt(const double* __restrict__ Ib, int ldi, const double* __restrict__ Jb, int ldj) {
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    d4 acc = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        mreg[k] = (r == g + 8 * k) ? 1.0 : 0.0;
-    // triangle mask of this lane's four columns (c <= r): the strictly upper entries are identity padding and stay so
-    double tri[4];
+    for (int st = 0; st < 4; ++st) {
+        const int p = 4 * st + lk;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Jb[lr + p * ldj], Ib[lr + p * ldi], acc, 0, 0, 0);
+    }
+    return acc;
+}
+// 16x16 elimination on ONE wave: lane (r = lane & 15, cq = lane >> 4) owns the four entries D[r][cq + 4k], k = 0..3
+// (identity padding where col > row or outside the tile) and receives Linv[r][cq + 4k] (0 above the diagonal).
+// Block LDL^T with 2x2 pivots. Every round the lanes write their entries of the partially eliminated tile and of
+// M = Lu^-1 to LDS UNCONDITIONALLY (no divergent branches) and read back the pivot block, their row's multipliers and
+// the pivot rows; a single wave needs NO barrier for that: the LDS executes one wave's accesses in program order.
+// sA: tile row-major [r*18 + c] (so (A[r][j], A[r][j+1]) is one 16-byte read; row stride 18 doubles = 36 banks keeps the 16
+// lanes of a column on distinct banks), sM: M column-major [c*16 + r].
+__device__ __forceinline__ void ldl16_inverse_wave(double a[4], double out[4], int* __restrict__ flags, bool check_row, double* __restrict__ sA,
+                                                    double* __restrict__ sM) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, cq = lane >> 4;
+    double mm[4], tri[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        tri[k] = (g + 8 * k <= r) ? 1.0 : 0.0;
-    double p11 = 1.0, p21 = 0.0, p22 = 1.0; // pivot block of this lane's row pair, captured when it is published
-    // NOT unrolled: this code runs once per launch; straight-line unrolling only adds instruction fetch.
+    for (int k = 0; k < 4; ++k) {
+        mm[k] = (r == cq + 4 * k) ? 1.0 : 0.0;
+        tri[k] = (cq + 4 * k <= r) ? 1.0 : 0.0;
+    }
+    double p11 = 1.0, p21 = 0.0, p22 = 1.0;
 #pragma unroll 1
-    for (int j = 0; j < w; j += 2) {
-        dpair* col = reinterpret_cast<dpair*>(sbuf + ((j >> 1) & 1) * LDL_LINE); // col[r] = (A[r][j], A[r][j+1])
-        dpair* row = col + 32;                                                    // row[c] = (M[j][c], M[j+1][c])
-        const int ka = j >> 3; // j and j+1 share the register slot (j even)
-        const double asel = ka == 0 ? a[0] : (ka == 1 ? a[1] : (ka == 2 ? a[2] : a[3]));
-        if (g == (j & 7))
-            col[r].x = asel;
-        if (g == ((j + 1) & 7))
-            col[r].y = asel;
-        if (r == j) {
+    for (int j = 0; j < 16; j += 2) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                row[g + 8 * k].x = mreg[k];
+        for (int k = 0; k < 4; ++k) {
+            sA[r * 18 + cq + 4 * k] = a[k];
+            sM[(cq + 4 * k) * 16 + r] = mm[k];
         }
-        if (r == j + 1) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                row[g + 8 * k].y = mreg[k];
-        }
-        __syncthreads();
-        const dpair dj = col[j], dj1 = col[j + 1]; // d11 = dj.x, d21 = dj1.x, d22 = dj1.y
-        const dpair me = col[r];
+        const dpair dj = *reinterpret_cast<const dpair*>(sA + j * 18 + j);        // (A[j][j], .)
+        const dpair dj1 = *reinterpret_cast<const dpair*>(sA + (j + 1) * 18 + j); // (A[j+1][j], A[j+1][j+1])
+        const dpair me = *reinterpret_cast<const dpair*>(sA + r * 18 + j);        // (A[r][j], A[r][j+1])
         dpair cc[4], rr[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            cc[k] = col[g + 8 * k];
-            rr[k] = row[g + 8 * k];
+            cc[k] = *reinterpret_cast<const dpair*>(sA + (cq + 4 * k) * 18 + j); // (A[c][j], A[c][j+1])
+            rr[k] = *reinterpret_cast<const dpair*>(sM + (cq + 4 * k) * 16 + j); // (M[j][c], M[j+1][c])
         }
-        // all eleven LDS reads must be in flight together (one latency): pin the values so the compiler cannot
-        // stagger "read, wait, use, read, wait, use" through reused registers
-        asm volatile("" : "+v"(cc[0].x), "+v"(cc[0].y), "+v"(cc[1].x), "+v"(cc[1].y), "+v"(cc[2].x), "+v"(cc[2].y), "+v"(cc[3].x), "+v"(cc[3].y));
-        asm volatile("" : "+v"(rr[0].x), "+v"(rr[0].y), "+v"(rr[1].x), "+v"(rr[1].y), "+v"(rr[2].x), "+v"(rr[2].y), "+v"(rr[3].x), "+v"(rr[3].y));
         const double d11 = dj.x, d21 = dj1.x, d22 = dj1.y;
         if ((r >> 1) == (j >> 1)) {
             p11 = d11;
             p21 = d21;
             p22 = d22;
         }
-        const double idet = (r > j + 1) ? fast_rcp(fma(d11, d22, -d21 * d21)) : 0.0; // rows of / above the pivot block: no-op
-        // (f1, f2) = (A[r][j], A[r][j+1]) * D^-1
-        const double f1 = (me.x * d22 - me.y * d21) * idet;
+        const double idet = (r > j + 1) ? fast_rcp(fma(d11, d22, -d21 * d21)) : 0.0;
+        const double f1 = (me.x * d22 - me.y * d21) * idet; // (A[r][j], A[r][j+1]) * D^-1
         const double f2 = (me.y * d11 - me.x * d21) * idet;
-        // M needs no mask: rows j, j+1 of M are zero right of their diagonal, so columns > j+1 are untouched;
-        // A: columns <= j+1 are dead after this round (never read again), only the triangle mask is needed.
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const double t1 = f1 * tri[k], t2 = f2 * tri[k];
-            a[k] = fma(-t2, cc[k].y, fma(-t1, cc[k].x, a[k]));
-            mreg[k] = fma(-f2, rr[k].y, fma(-f1, rr[k].x, mreg[k]));
+            a[k] = fma(-f2 * tri[k], cc[k].y, fma(-f1 * tri[k], cc[k].x, a[k]));
+            mm[k] = fma(-f2, rr[k].y, fma(-f1, rr[k].x, mm[k]));
         }
     }
-    // L^-1 = blkdiag(C_b^-1) M with C_b = chol(D_b): row j -> M[j]/l11 ; row j+1 -> (M[j+1] - (l21/l11) M[j]) / l22
-    __syncthreads();
+    // Linv = blkdiag(chol(D_b)^-1) M : row j -> M[j]/l11 ; row j+1 -> (M[j+1] - (l21/l11) M[j]) / l22
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        sbuf[r + (g + 8 * k) * 33] = mreg[k];
-    __syncthreads();
+        sM[(cq + 4 * k) * 16 + r] = mm[k];
     const bool ok = (p11 > 0.0) && (fma(p11, p22, -p21 * p21) > 0.0);
-    if (g == 0 && r < w && !ok)
+    if (cq == 0 && check_row && !ok)
         flags[0] = 1;
-    const double il11 = 1.0 / sqrt(ok ? p11 : 1.0);
+    const double il11 = fast_rsqrt(ok ? p11 : 1.0);
     const double l21 = ok ? p21 * il11 : 0.0;
-    const double il22 = 1.0 / sqrt(ok ? p22 - l21 * l21 : 1.0);
+    const double il22 = fast_rsqrt(ok ? p22 - l21 * l21 : 1.0);
     const bool odd = (r & 1) != 0;
     const double s_self = odd ? il22 : il11;
     const double s_prev = odd ? -(l21 * il11) * il22 : 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int c = g + 8 * k;
-        const double mprev = sbuf[(r & ~1) + c * 33];
-        const double v = fma(s_prev, mprev, s_self * mreg[k]);
-        LinvOut[r + 32 * c] = (c <= r) ? v : 0.0;
+        const int c = cq + 4 * k;
+        const double mprev = sM[c * 16 + (r & ~1)];
+        out[k] = (c <= r) ? fma(s_prev, mprev, s_self * mm[k]) : 0.0;
+    }
+}
+// Tile D at sD[r + c*ldd] (lower triangle valid, rows/cols >= w are identity padding, w even). Writes Linv (32x32
+// column-major) to LinvOut. swork: LDL_SBUF doubles of LDS. Call after a workgroup barrier; only wave 0 does the work
+// (the whole chain is sequential; one wave avoids every barrier), the other waves return immediately.
+constexpr int LDL_SBUF = 7 * 256 + 32;
+__device__ __forceinline__ void ldl_inverse_tile(const double* __restrict__ sD, int ldd, int w, double* __restrict__ LinvOut, int* __restrict__ flags,
+                                                 double* __restrict__ swork) {
+    if (threadIdx.x >= 64)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    double* sA = swork;            // elimination exchange (16 x 18)
+    double* sM = swork + 288;
+    double* sLi11 = swork + 544;   // L11inv[r + c*16]
+    double* sLi11T = sLi11 + 256;  // L11inv[r][c] at [c + r*16]
+    double* sL21 = sLi11T + 256;   // L21[i + p*16]
+    double* sYJ = sL21 + 256;      // Y[p][c] at [c + p*16],  Y = L21 L11inv
+    double* sS22 = sYJ + 256;      // S22 ; later L22inv[i + p*16]
+    double a[4], o[4];
+    // A. first diagonal block
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lk + 4 * k;
+        a[k] = (lr >= c) ? sD[lr + c * ldd] : ((lr == c) ? 1.0 : 0.0);
+    }
+    ldl16_inverse_wave(a, o, flags, lr < w, sA, sM);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lk + 4 * k;
+        sLi11[lr + c * 16] = o[k];
+        sLi11T[c + lr * 16] = o[k];
+        LinvOut[lr + 32 * c] = o[k];
+        LinvOut[lr + 32 * (c + 16)] = 0.0;
+    }
+    // B. L21 = D21 L11inv^T ; S22 = D22 - L21 L21^T ; Y = L21 L11inv   (fp64 MFMA 16x16x4)
+    {
+        const d4 l21 = mfma16_nt(sD + 16, ldd, sLi11, 16); // I = D21 rows (16 + i), J[c][p] = L11inv[c][p]
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            sL21[lr + (lk + 4 * q) * 16] = l21[q];
+    }
+    {
+        const d4 s = mfma16_nt(sL21, 16, sL21, 16);
+        const d4 y = mfma16_nt(sL21, 16, sLi11T, 16); // J[c][p] = L11inv[p][c]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lr, j = lk + 4 * q;
+            const double d22 = (i >= j) ? sD[16 + i + (16 + j) * ldd] : 0.0;
+            a[q] = (i >= j) ? d22 - s[q] : ((i == j) ? 1.0 : 0.0); // Schur complement entry S22[i][j], j = lk + 4q
+            sYJ[j + i * 16] = y[q];                                // Y[i][j] stored for use as J[c = j][p = i]
+        }
+    }
+    // C. second diagonal block (the lane -> entry mapping of the MFMA result is the elimination's own mapping)
+    ldl16_inverse_wave(a, o, flags, 16 + lr < w, sA, sM);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lk + 4 * k;
+        sS22[lr + c * 16] = o[k];
+        LinvOut[16 + lr + 32 * (16 + c)] = o[k];
+    }
+    // D. X = -L22inv Y
+    {
+        const d4 x = mfma16_nt(sS22, 16, sYJ, 16); // X[i][c] = sum_p L22inv[i][p] Y[p][c]
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            LinvOut[16 + lr + 32 * (lk + 4 * q)] = -x[q];
     }
 }
 
 // L_00^-1 for the first panel (the only elimination that is not the tail of a step kernel). One workgroup.
 __global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags) {
-    __shared__ double sbuf[LDL_SBUF];
+    __shared__ double sD[32 * 33];
+    __shared__ double swork[LDL_SBUF];
     const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
-    double a[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = g + 8 * k;
-        a[k] = (r < w && c < w && r >= c) ? Z[r + (size_t)c * ldz] : ((r == c) ? 1.0 : 0.0);
+        sD[r + c * 33] = (r < w && c < w && r >= c) ? Z[r + (size_t)c * ldz] : ((r == c) ? 1.0 : 0.0);
     }
-    ldl_inverse_tile(a, w, LinvOut, flags, sbuf);
+    __syncthreads();
+    ldl_inverse_tile(sD, 33, w, LinvOut, flags, swork);
 }
 
 __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
@@ -729,7 +794,7 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     __shared__ double sLinv[32 * CH_LDP];
     __shared__ double sPI[32 * CH_LDP];
     __shared__ double sPJ[32 * CH_LDP];
-    __shared__ double sbuf[LDL_SBUF];
+    __shared__ double swork[LDL_SBUF];
     const int tid = threadIdx.x;
     const int r = tid & 31, g = tid >> 5;
     const int wave = tid >> 6, lane = tid & 63;
@@ -829,16 +894,18 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     }
     if (!next_diag)
         return;
-    // 5. eliminate the next diagonal tile D_{k+1} = Z[c0 : c0 + w2, c0 : c0 + w2] and publish its inverse factor
+    // 5. eliminate the next diagonal tile D_{k+1} = Z[c0 : c0 + w2, c0 : c0 + w2] (kept in sPJ) and publish its inverse factor
     __syncthreads();
     const int w2 = min(32, m - c0);
-    double a[4];
+    // identity padding outside the w2 x w2 block (rows / cols beyond m belong to T, not to S)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = g + 8 * k;
-        a[k] = (r < w2 && c < w2 && r >= c) ? sPJ[r + c * CH_LDP] : ((r == c) ? 1.0 : 0.0);
+        if (r >= w2 || c >= w2)
+            sPJ[r + c * CH_LDP] = (r == c) ? 1.0 : 0.0;
     }
-    ldl_inverse_tile(a, w2, LinvOut, flags, sbuf);
+    __syncthreads();
+    ldl_inverse_tile(sPJ, CH_LDP, w2, LinvOut, flags, swork);
 }
 
 // ---------------------------------------------------------------------------------------------------

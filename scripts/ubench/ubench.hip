@@ -16,14 +16,14 @@ __global__ void __launch_bounds__(256) k_valu_peak(int iters, double* out) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 __global__ void __launch_bounds__(256) k_ldl_cycles(int w, int ldz, const double* Z, double* Linv, int* flags, long long* cyc) {
-    __shared__ double sbuf[LDL_SBUF];
+    __shared__ double sD[32 * 33];
+    __shared__ double swork[LDL_SBUF];
     const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
-    double a[4];
-    for (int k = 0; k < 4; ++k) { const int c = g + 8 * k; a[k] = (r < w && c < w && r >= c) ? Z[r + (size_t)c * ldz] : ((r == c) ? 1.0 : 0.0); }
+    for (int k = 0; k < 4; ++k) { const int c = g + 8 * k; sD[r + c * 33] = (r < w && c < w && r >= c) ? Z[r + (size_t)c * ldz] : ((r == c) ? 1.0 : 0.0); }
     __syncthreads();
     const long long t0 = clock64();
     const long long w0 = wall_clock64();
-    ldl_inverse_tile(a, w, Linv, flags, sbuf);
+    ldl_inverse_tile(sD, 33, w, Linv, flags, swork);
     __syncthreads();
     if (threadIdx.x == 0) { cyc[0] = clock64() - t0; cyc[1] = wall_clock64() - w0; }
 }
