@@ -250,7 +250,7 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
     lib.eqf_mfma_f64_peak(core, C.byref(tpeak))
     # kernel families and their algorithmic (dense-formulation) flops per frame
     fam = {
-        "cholesky+trsm chain (k_chol_panel + k_chol_update)": (["k_chol_panel", "k_chol_update", "k_chol_step"], m**3 / 3.0 + 2.0 * n * m * m),
+        "cholesky+trsm chain (k_chol_first + k_chol_step)": (["k_chol_first", "k_chol_step"], m**3 / 3.0 + 2.0 * n * m * m),
         "Sigma -= K T^T (k_syrk_sub)": (["k_syrk_sub"], 2.0 * n * n * m),
         "T = Sigma C^T, S = C T + R (k_build_Z)": (["k_build_Z"], 2.0 * n * n * m + 2.0 * n * m * m),
         "propagate F Sigma F^T (k_propagate_G + k_propagate_main | k_gemm_nt)": (["k_propagate_G", "k_propagate_main", "k_gemm_nt"], flops_propagate(n)),
@@ -260,6 +260,18 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
     dom_us = fam_time[dom]
     dom_launches = sum(launches.get(kn, 0.0) for kn in fam[dom][0])
     achieved = fam[dom][1] / (dom_us * 1e-6) / 1e12
+    # HBM-side traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with the
+    # same bench command; bench.py cannot run the profiler on itself)
+    traffic, traffic_note = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")))["kernels"]
+        kn = [k_ for k_ in fam[dom][0] if k_ in pmc and launches.get(k_, 0) > 0]
+        if kn:
+            tot_l = sum(launches[k_] for k_ in kn)
+            traffic = 1024.0 * sum((pmc[k_]["fetch_kib_per_launch"] + pmc[k_]["write_kib_per_launch"]) * launches[k_] for k_ in kn) / tot_l
+            traffic_note = "bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r01_v3_pmc_*.csv (N=200)"
+    except Exception:
+        pass
     return {
         "bound": "mfma",
         "kernel": dom,
@@ -267,7 +279,8 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_note": traffic_note,
         "launches_per_frame": dom_launches,
         "avg_launch_us": dom_us / max(dom_launches, 1.0),
         "algorithmic_flops_per_launch": fam[dom][1] / max(dom_launches, 1.0),

@@ -1014,14 +1014,9 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         HIPCHK(hipGetLastError());
     }
     {
-        KTimer t(c, KN_GAMMA);
-        hipLaunchKernelGGL(k_gamma, dim3(blocks(n, 64)), dim3(256), 0, c->stream, n, m, c->ldz, c->d_W, c->d_gamma);
-        HIPCHK(hipGetLastError());
-    }
-    {
         KTimer t(c, KN_SYRK);
         const int nt = blocks(n, 32);
-        hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, c->sigma(), nt);
+        hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, c->sigma(), nt, c->d_gamma);
         HIPCHK(hipGetLastError());
     }
     {

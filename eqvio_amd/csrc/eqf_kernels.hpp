@@ -922,8 +922,12 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
 struct TileRed {
     double v[4]; // element e of lane t: (i = t & 31, j = (t >> 5) + 8 e)
 };
+// If zvec != nullptr the workgroup also returns, in gv_out (valid in lanes 0..31 of the workgroup), the GEMV by-product
+// g[i0 + t] = sum_k P[i0 + t][k] * zvec[k * ldzv] from the operand values it loads anyway.
+template <bool WITH_GEMV>
 __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__ P, int ldp, int i0, int rowsP, const double* __restrict__ Qm, int ldq, int j0,
-                                                      int rowsQ, int K, double* __restrict__ sred /* 4*1024 doubles */) {
+                                                      int rowsQ, int K, double* __restrict__ sred /* 4*1024 doubles */, const double* __restrict__ zvec = nullptr,
+                                                      int ldzv = 0, double* gv_out = nullptr) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
@@ -932,6 +936,7 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
     const double zia = (i0 + lr < rowsP) ? 1.0 : 0.0, zib = (i0 + 16 + lr < rowsP) ? 1.0 : 0.0;
     const double zja = (j0 + lr < rowsQ) ? 1.0 : 0.0, zjb = (j0 + 16 + lr < rowsQ) ? 1.0 : 0.0;
     d4 acc00 = {0, 0, 0, 0}, acc10 = acc00, acc01 = acc00, acc11 = acc00;
+    double ga = 0.0, gb = 0.0;
     const int nsteps = (K + 3) >> 2;
 #pragma unroll 4
     for (int st = wave; st < nsteps; st += 4) {
@@ -942,6 +947,11 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
         const double pb = P[ib + (size_t)kc * ldp] * (zib * zk);
         const double qa = Qm[ja + (size_t)kc * ldq] * zja;
         const double qb = Qm[jb + (size_t)kc * ldq] * zjb;
+        if (WITH_GEMV) {
+            const double zv = zvec[(size_t)kc * ldzv];
+            ga = fma(pa, zv, ga);
+            gb = fma(pb, zv, gb);
+        }
         acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pa, acc00, 0, 0, 0);
         acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pb, acc10, 0, 0, 0);
         acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pa, acc01, 0, 0, 0);
@@ -962,6 +972,20 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
     for (int e = 0; e < 4; ++e) {
         const int idx = (tid & 31) + 32 * ((tid >> 5) + 8 * e);
         out.v[e] = (sred[idx] + sred[1024 + idx]) + (sred[2048 + idx] + sred[3072 + idx]);
+    }
+    if (WITH_GEMV) {
+        // partial sums: per wave, per lk group (4), rows 0..15 (ga) and 16..31 (gb): reduce 16 partials per row via LDS
+        __syncthreads();
+        sred[(wave * 4 + lk) * 32 + lr] = ga;
+        sred[(wave * 4 + lk) * 32 + 16 + lr] = gb;
+        __syncthreads();
+        if (tid < 32) {
+            double g = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                g += sred[q * 32 + tid];
+            *gv_out = g;
+        }
     }
     return out;
 }
@@ -994,7 +1018,8 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 
 // K9: Sigma <- Sigma - W W^T  ( = Sigma - K C Sigma, VIO_eqf.cpp:131 ): lower 32x32 tiles computed (one workgroup
 // each, K = m split over its 4 waves), the strictly-lower ones mirrored so Sigma stays exactly symmetric.
-__global__ void __launch_bounds__(256) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, double* __restrict__ Sig, int nt) {
+__global__ void __launch_bounds__(256) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, double* __restrict__ Sig, int nt,
+                                                  double* __restrict__ gamma) {
     __shared__ double sred[4096];
     int b = blockIdx.x;
     int bj = 0;
@@ -1005,7 +1030,15 @@ __global__ void __launch_bounds__(256) k_syrk_sub(int n, int m, int ld, int ldz,
     const int bi = bj + b;
     const int i0 = bi * 32, j0 = bj * 32;
     const double* W = Wb + m;
-    const TileRed t = mfma_tile32_splitk(W, ldz, i0, n, W, ldz, j0, n, m, sred);
+    // diagonal tiles also produce Gamma[i0 : i0+32] = W[rows] z  (Gamma = K yTilde = W L^-1 yTilde, VIO_eqf.cpp:119)
+    double gv = 0.0;
+    TileRed t;
+    if (bi == bj)
+        t = mfma_tile32_splitk<true>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
+    else
+        t = mfma_tile32_splitk<false>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
+    if (bi == bj && threadIdx.x < 32 && i0 + threadIdx.x < n)
+        gamma[i0 + threadIdx.x] = gv;
     const int i = i0 + (threadIdx.x & 31);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1173,7 +1206,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(int Mr, int Nc, int K, const do
                                                  double* __restrict__ Cm, int ldc) {
     __shared__ double sred[4096];
     const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
-    const TileRed t = mfma_tile32_splitk(A, lda, i0, Mr, B, ldb, j0, Nc, K, sred);
+    const TileRed t = mfma_tile32_splitk<false>(A, lda, i0, Mr, B, ldb, j0, Nc, K, sred);
     const int i = i0 + (threadIdx.x & 31);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

@@ -528,10 +528,11 @@ VisionMeasurement VIOFilter::getFeaturePredictions(const GICameraPtr&, const dou
 }
 void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2) { // :258-278
     std::vector<Landmark> newLandmarks;
-    const std::vector<int>& have = filterState.ids();
+    std::vector<int> have = filterState.ids(); // sorted copy: O(M log N) membership instead of the reference's O(M N) scan
+    std::sort(have.begin(), have.end());
     for (const auto& cc : measurement.camCoordinates) {
         const int& ccId = cc.first;
-        if (std::none_of(have.begin(), have.end(), [&ccId](const int& i) { return i == ccId; })) {
+        if (!std::binary_search(have.begin(), have.end(), ccId)) {
             const V3 bearing = measurement.cameraPtr->undistortPoint(cc.second[0], cc.second[1]);
             newLandmarks.emplace_back(Landmark{bearing, ccId});
         }
@@ -546,9 +547,13 @@ void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std:
 void VIOFilter::removeOldLandmarks(const std::vector<int>& measurementIds) { // :280-302
     const std::vector<int>& have = filterState.ids();
     std::vector<int> lost;
-    for (int i = 0; i < (int)have.size(); ++i)
-        if (std::find(measurementIds.begin(), measurementIds.end(), have[i]) == measurementIds.end())
+    const bool sorted = std::is_sorted(measurementIds.begin(), measurementIds.end()); // ids from a VisionMeasurement are
+    for (int i = 0; i < (int)have.size(); ++i) {
+        const bool found = sorted ? std::binary_search(measurementIds.begin(), measurementIds.end(), have[i])
+                                  : std::find(measurementIds.begin(), measurementIds.end(), have[i]) != measurementIds.end();
+        if (!found)
             lost.push_back(i);
+    }
     filterState.removeLandmarksByIndex(lost); // one compaction pass instead of one per landmark
 }
 void VIOFilter::removeOutliers(VisionMeasurement& measurement, std::vector<double>& depth2) { // :304-364
