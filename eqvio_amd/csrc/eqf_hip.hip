@@ -167,6 +167,10 @@ struct eqf_ctx {
     bool gamma_stale = false; // d_gamma holds a newer Gamma than last_gamma (fetched lazily by eqf_last_gamma)
     std::vector<double> est_cache; // 4 planes of stride N (q_hat xyz, invalid flag), valid after a vision update
     bool est_valid = false;
+    // C / yTilde / lmidx already on the device for exactly this measurement (written by k_outlier_stats)
+    bool meas_valid = false;
+    int meas_star = 0;
+    std::vector<int> meas_ids;
     // timing
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> tev;
     std::vector<hipEvent_t> evpool;
@@ -547,6 +551,7 @@ int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, 
     HIPCHK(hipSetDevice(c->device));
     { int _r = sync_ctx(c); if (_r) return _r; }
     c->est_valid = false;
+    c->meas_valid = false;
     c->xi0 = unpack_sensor(xi0_sensor);
     c->X = unpack_group(X_sensor);
     c->ids.assign(ids, ids + N);
@@ -695,6 +700,7 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
     c->ids.insert(c->ids.end(), ids, ids + k);
     c->N += k;
     c->est_valid = false;
+    c->meas_valid = false;
     return 0;
 }
 
@@ -738,6 +744,7 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
     c->ids = newids;
     c->N = Nnew;
     c->est_valid = false;
+    c->meas_valid = false;
     return 0;
 }
 
@@ -827,6 +834,7 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
         return 0;
     HIPCHK(hipSetDevice(c->device));
     c->est_valid = false;
+    c->meas_valid = false;
     int done = 0;
     while (done < k) {
         const int chunk = std::min(k - done, eqf_ctx::kMaxSteps);
@@ -936,8 +944,16 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         KTimer t(c, KN_STATS);
         c->busy_meas = true;
         hipLaunchKernelGGL(k_outlier_stats, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), measof, c->h_y, c->q0(), c->Qq(), c->Qa(),
-                           c->sigma(), c->h_res);
+                           c->sigma(), c->h_res, 1, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags);
         HIPCHK(hipGetLastError());
+    }
+    {
+        bool all_known = true;
+        for (int j = 0; j < M; ++j)
+            all_known = all_known && (lmidx[j] >= 0);
+        c->meas_valid = all_known;
+        c->meas_star = 1;
+        c->meas_ids.assign(ids, ids + M);
     }
     rc = sync_ctx(c);
     if (rc)
@@ -975,12 +991,18 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     if (M > c->N)
         return EQF_E_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
-    int rc = stage_measurement(c, ids, y, M);
-    if (rc)
-        return rc;
+    const bool reuse = c->meas_valid && c->meas_star == (useEqv ? 1 : 0) && (int)c->meas_ids.size() == M && std::equal(ids, ids + M, c->meas_ids.begin()) &&
+                       std::memcmp(c->h_y, y, sizeof(double) * 2 * M) == 0;
+    int rc = 0;
+    if (!reuse) {
+        rc = stage_measurement(c, ids, y, M);
+        if (rc)
+            return rc;
+    }
+    c->meas_valid = false;
     const int N = c->N, n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
-    {
+    if (!reuse) {
         KTimer t(c, KN_MEASURE);
         hipLaunchKernelGGL(k_measure, dim3(blocks(M, 64)), dim3(64), 0, c->stream, M, c->Ncap, c->Ncap, c->chart, make_cam(cam), useEqv, c->h_lmidx, c->h_y, c->q0(), c->Qq(),
                            c->Qa(), c->d_C, c->d_ytil, c->d_lmidx, c->d_flags);

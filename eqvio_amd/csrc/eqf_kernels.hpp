@@ -480,10 +480,17 @@ __global__ void __launch_bounds__(64) k_measure(int M, int Mcap, int Ncap, int c
     ytil[2 * j + 1] = o.yt[1];
 }
 // stats: out[0..N) absErr, out[N..2N) probErr, out[2N..3N) |q_hat|^2 ; unmeasured -> -1 (meas_of[i] = j or -1)
+// It also emits what k_measure would (C blocks, residuals, index map) for the same measurement, so that the vision
+// update can skip k_measure when the host removes / adds no landmark in between (the common case).
 __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, int chart, Cam cam, const int* __restrict__ meas_of,
                                                       const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
-                                                      const double* __restrict__ Qa, const double* __restrict__ Sig, double* __restrict__ out) {
+                                                      const double* __restrict__ Qa, const double* __restrict__ Sig, double* __restrict__ out, int star,
+                                                      double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        flags[0] = 0;
+        flags[1] = 0;
+    }
     if (i >= N)
         return;
     const V3 p0 = ld3(q0, Ncap, i);
@@ -498,6 +505,15 @@ __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, i
         return;
     }
     const MeasOut o = measure_one(chart, cam, p0, q, a, y[2 * j], y[2 * j + 1], false);
+    {
+        const MeasOut os = star ? measure_one(chart, cam, p0, q, a, y[2 * j], y[2 * j + 1], true) : o;
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+            C[e * Ncap + j] = os.c[e];
+        ytil[2 * j] = os.yt[0];
+        ytil[2 * j + 1] = os.yt[1];
+        lmidx_dev[j] = i;
+    }
     const int l = 21 + 3 * i;
     double S[3][3];
 #pragma unroll
