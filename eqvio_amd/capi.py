@@ -162,6 +162,7 @@ def load_eqf_lib():
         "eqf_outlier_stats": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]),
         "eqf_vision_update": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_int]),
         "eqf_last_gamma": (C.c_int, [vp, c_double_p, C.c_int]),
+        "eqf_compute_nees": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p]),
         "eqf_debug_matrices_AB": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
         "eqf_debug_matrix_C": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p]),
         "eqf_mfma_f64_peak": (C.c_int, [vp, c_double_p]),
@@ -296,6 +297,12 @@ class EqfCore:
             self._chk0(k)
         return out[:k].copy()
 
+    def compute_nees(self, sensor, ids, p):
+        sensor, ids, p = _f64(sensor), _i32(ids), _f64(p)
+        out = C.c_double()
+        self._chk0(self.lib.eqf_compute_nees(self.h, _dp(sensor), _ip(ids), _dp(p), len(ids), C.byref(out)))
+        return out.value
+
     def debug_matrices_AB(self, imu13):
         imu13 = _f64(imu13)
         n = self.n
@@ -353,6 +360,7 @@ def load_filter_lib():
         "eqvio_filter_get_eqf": (C.c_int, [vp, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p, C.c_int]),
         "eqvio_filter_sigma_dim": (C.c_int, [vp]),
         "eqvio_filter_get_sigma": (C.c_int, [vp, c_double_p, C.c_int]),
+        "eqvio_filter_compute_nees": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p]),
         "eqvio_filter_core": (vp, [vp]),
         "eqvio_filter_last_timing": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
         "eqvio_filter_run_frames": (C.c_int, [vp, P(Camera), C.c_int, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, c_double_p]),
@@ -442,6 +450,12 @@ class VIOFilter:
         if self.lib.eqvio_filter_get_sigma(self.h, out.ctypes.data_as(c_double_p), n) != 0:
             raise RuntimeError("eqvio_filter_get_sigma failed")
         return out
+
+    def compute_nees(self, sensor, ids, p):
+        sensor, ids, p = _f64(sensor), _i32(ids), _f64(p)
+        out = C.c_double()
+        self._chk(self.lib.eqvio_filter_compute_nees(self.h, _dp(sensor), _ip(ids), _dp(p), len(ids), C.byref(out)))
+        return out.value
 
     def core_handle(self):
         return self.lib.eqvio_filter_core(self.h)

@@ -145,6 +145,8 @@ struct eqf_ctx {
     ObsStep* d_steps = nullptr;
     double *d_C = nullptr, *d_ytil = nullptr, *d_y = nullptr;
     int *d_lmidx = nullptr, *d_measof = nullptr, *d_keep = nullptr;
+    double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
+    int ldzn = 0;
     double *d_Z = nullptr, *d_W = nullptr, *d_Linv = nullptr, *d_gamma = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
     int* d_flags = nullptr;
     // pinned host staging
@@ -432,7 +434,7 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipMalloc(&c->d_Z, sizeof(double) * (size_t)c->ldz * c->mcap));
     HIPCHK(hipMalloc(&c->d_W, sizeof(double) * (size_t)c->ldz * c->mcap));
     HIPCHK(hipMalloc(&c->d_Linv, sizeof(double) * 2048));
-    HIPCHK(hipMalloc(&c->d_gamma, sizeof(double) * c->ncap));
+    HIPCHK(hipMalloc(&c->d_gamma, sizeof(double) * (c->ncap + 8)));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
@@ -486,6 +488,10 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_stats);
     hipFree(c->d_scratch);
     hipFree(c->d_flags);
+    if (c->d_Zn)
+        hipFree(c->d_Zn);
+    if (c->d_Wn)
+        hipFree(c->d_Wn);
     if (c->d_F)
         hipFree(c->d_F);
     if (c->d_tmp)
@@ -900,6 +906,32 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
     return 0;
 }
 
+// Blocked right-looking factorisation of Z (rows x m, leading dimension ldz): one launch per 32-column panel
+// (k_chol_step), preceded by the elimination of the first diagonal tile. Rows >= m of W receive Z[rows >= m] L^-T.
+static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double* W) {
+    constexpr int NB = 32;
+    {
+        KTimer t(c, KN_CHOL_UPDATE);
+        hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, std::min(NB, m), ldz, Z, c->d_Linv, c->d_flags);
+        HIPCHK(hipGetLastError());
+    }
+    int step = 0;
+    for (int kb = 0; kb < m; kb += NB, ++step) {
+        const int w = std::min(NB, m - kb);
+        const int c0 = kb + w;
+        double* Lin = c->d_Linv + 1024 * (step & 1);
+        double* Lout = c->d_Linv + 1024 * ((step + 1) & 1);
+        KTimer t(c, KN_CHOL_PANEL);
+        if (c0 < m) {
+            hipLaunchKernelGGL(k_chol_step, dim3(blocks(rows - c0, 32), blocks(m - c0, 32)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, 1);
+        } else {
+            hipLaunchKernelGGL(k_chol_step, dim3(blocks(rows - c0, 32), 1), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, 0);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
 // map ascending measurement ids to state indices; returns 0 or EQF_E_BAD_ARG
 static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, int* lmidx, int* measof) {
     for (int i = 0; i < c->N; ++i)
@@ -1014,27 +1046,9 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
                            c->d_ytil, c->d_Z);
         HIPCHK(hipGetLastError());
     }
-    constexpr int NB = 32;
-    {
-        KTimer t(c, KN_CHOL_UPDATE);
-        hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, std::min(NB, m), c->ldz, c->d_Z, c->d_Linv, c->d_flags);
-        HIPCHK(hipGetLastError());
-    }
-    int step = 0;
-    for (int kb = 0; kb < m; kb += NB, ++step) {
-        const int w = std::min(NB, m - kb);
-        const int c0 = kb + w;
-        double* Lin = c->d_Linv + 1024 * (step & 1);
-        double* Lout = c->d_Linv + 1024 * ((step + 1) & 1);
-        KTimer t(c, KN_CHOL_PANEL);
-        if (c0 < m) {
-            hipLaunchKernelGGL(k_chol_step, dim3(blocks(rows - c0, 32), blocks(m - c0, 32)), dim3(256), 0, c->stream, rows, m, kb, w, c->ldz, c->d_Z, c->d_W, Lin, Lout,
-                               c->d_flags, 1);
-        } else {
-            hipLaunchKernelGGL(k_chol_step, dim3(blocks(rows - c0, 32), 1), dim3(256), 0, c->stream, rows, m, kb, w, c->ldz, c->d_Z, c->d_W, Lin, Lout, c->d_flags, 0);
-        }
-        HIPCHK(hipGetLastError());
-    }
+    rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W);
+    if (rc)
+        return rc;
     {
         KTimer t(c, KN_SYRK);
         const int nt = blocks(n, 32);
@@ -1109,6 +1123,80 @@ int eqf_last_gamma(eqf_ctx* c, double* out, int cap) {
         return EQF_E_CAPACITY;
     std::memcpy(out, c->last_gamma.data(), sizeof(double) * c->last_gamma.size());
     return (int)c->last_gamma.size();
+}
+
+int eqf_compute_nees(eqf_ctx* c, const double* ts, const int* tids, const double* tp, int ntrue, double* nees) {
+    if (!c || !ts || !nees || ntrue < 0 || (ntrue > 0 && (!tids || !tp)))
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const int N = c->N, n = c->n();
+    const int np = n + (n & 1); // even dimension for the 2x2-pivot elimination: pad with a unit diagonal entry
+    // landmark group elements from the device
+    std::vector<double> q0(3 * (size_t)N + 3), Q(5 * (size_t)N + 5);
+    std::vector<int> ids(N + 1);
+    double s0[23], g0[23];
+    int rc = eqf_get_state(c, s0, g0, ids.data(), q0.data(), Q.data(), N);
+    if (rc < 0)
+        return rc;
+    // stateError = stateGroupAction(X^-1, truncated true state) (VIOGroup.cpp:25-55, 108-120)
+    const SensorState tsn = unpack_sensor(ts);
+    GroupSensor Xi;
+    Xi.bgyr = -c->X.bgyr;
+    Xi.bacc = -c->X.bacc;
+    Xi.A = pose_inv(c->X.A);
+    Xi.B = pose_inv(c->X.B);
+    Xi.w = -q_rot(q_inv(c->X.A.R), c->X.w);
+    const SensorState se = sensor_action(Xi, tsn);
+    std::vector<double> eps(np, 0.0);
+    // sensorChart_std (VIOState.cpp:104-113)
+    const V3 db = se.bgyr - c->xi0.bgyr, da = se.bacc - c->xi0.bacc, dv = se.vel - c->xi0.vel;
+    V3 om, tr, omc, trc;
+    se3_log(pose_mul(pose_inv(c->xi0.pose), se.pose), om, tr);
+    se3_log(pose_mul(pose_inv(c->xi0.cam), se.cam), omc, trc);
+    const V3 parts[7] = {db, da, om, tr, dv, omc, trc};
+    for (int b = 0; b < 7; ++b)
+        pack_v3(parts[b], eps.data() + 3 * b);
+    for (int i = 0; i < N; ++i) {
+        int jt = -1;
+        for (int t = 0; t < ntrue; ++t)
+            if (tids[t] == ids[i]) {
+                jt = t;
+                break;
+            }
+        if (jt < 0)
+            return EQF_E_BAD_ARG; // the reference asserts the true state holds every filter landmark
+        const V3 ptrue = v3(tp[3 * jt], tp[3 * jt + 1], tp[3 * jt + 2]);
+        const Qt qi{Q[5 * i], Q[5 * i + 1], Q[5 * i + 2], Q[5 * i + 3]};
+        const V3 pe = Q[5 * i + 4] * q_rot(qi, ptrue); // (Q_i^-1)^-1 * p = a R p
+        const V3 e = point_chart(c->chart == EQVIO_COORD_INVDEPTH, pe, v3(q0[3 * i], q0[3 * i + 1], q0[3 * i + 2]));
+        pack_v3(e, eps.data() + 21 + 3 * i);
+    }
+    // device: Z = [Sigma ; eps^T], factorise, NEES = |z|^2 / n
+    if (!c->d_Zn) {
+        const int npcap = c->ncap + 1;
+        c->ldzn = pick_ld(npcap + 1);
+        HIPCHK(hipMalloc(&c->d_Zn, sizeof(double) * (size_t)c->ldzn * npcap));
+        HIPCHK(hipMalloc(&c->d_Wn, sizeof(double) * (size_t)c->ldzn * npcap));
+    }
+    { int _r = sync_ctx(c); if (_r) return _r; }
+    std::memcpy(c->h_buf, eps.data(), sizeof(double) * np);
+    HIPCHK(hipMemcpyAsync(c->d_gamma, c->h_buf, sizeof(double) * np, hipMemcpyHostToDevice, c->stream)); // d_gamma as staging (ncap >= np? see below)
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(int) * 4, c->stream));
+    hipLaunchKernelGGL(k_build_nees, dim3(blocks(np + 1, 256), np), dim3(256), 0, c->stream, n, np, c->ld, c->ldzn, c->sigma(), c->d_gamma, c->d_Zn);
+    HIPCHK(hipGetLastError());
+    rc = launch_chain(c, np + 1, np, c->ldzn, c->d_Zn, c->d_Wn);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k_sumsq_row, dim3(1), dim3(256), 0, c->stream, np, c->ldzn, c->d_Wn, np, c->d_stats);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_stats, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    rc = read_flags(c);
+    if (rc)
+        return rc;
+    if (c->h_flags[0])
+        return EQF_E_NOT_SPD;
+    *nees = c->h_buf[0] / (double)n;
+    return 0;
 }
 
 int eqf_debug_matrices_AB(eqf_ctx* c, const double* imu13, double* A_out, double* B_out) {

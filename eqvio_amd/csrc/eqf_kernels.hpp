@@ -1285,6 +1285,40 @@ __global__ void __launch_bounds__(256) k_add_noise(int N, int Ncap, int n, int l
     Sout[r + (size_t)c * ld] = v;
 }
 
+// NEES support: Z = [Sigma (lower, padded to even dimension np with a unit diagonal) ; eps^T] for the factorisation chain
+__global__ void __launch_bounds__(256) k_build_nees(int n, int np, int ld, int ldzn, const double* __restrict__ Sig, const double* __restrict__ eps,
+                                                    double* __restrict__ Z) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r > np || c >= np)
+        return;
+    double v;
+    if (r == np)
+        v = c < n ? eps[c] : 0.0;
+    else if (r < n && c < n)
+        v = Sig[r + (size_t)c * ld];
+    else
+        v = (r == c) ? 1.0 : 0.0;
+    Z[r + (size_t)c * ldzn] = v;
+}
+__global__ void __launch_bounds__(256) k_sumsq_row(int np, int ldzn, const double* __restrict__ Wb, int row, double* __restrict__ out) {
+    __shared__ double sp[256];
+    double s = 0;
+    for (int c = threadIdx.x; c < np; c += 256) {
+        const double v = Wb[row + (size_t)c * ldzn];
+        s += v * v;
+    }
+    sp[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st)
+            sp[threadIdx.x] += sp[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[0] = sp[0];
+}
+
 // fp64 MFMA issue-rate micro-benchmark: 4 independent accumulators per wave, no memory traffic.
 __global__ void __launch_bounds__(256) k_mfma_peak(int iters, double* __restrict__ out) {
     d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;

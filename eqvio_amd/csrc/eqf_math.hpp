@@ -154,6 +154,32 @@ HD M3 so3_V(V3 om) {
     return m3_identity() + A * Om + B * (Om * Om);
 }
 
+// rotation vector of a unit quaternion, |omega| in [0, pi]
+HD V3 so3_log(Qt q) {
+    double qw = q.w;
+    V3 v{q.x, q.y, q.z};
+    if (qw < 0) {
+        qw = -qw;
+        v = -v;
+    }
+    const double n = norm(v);
+    if (n < 1e-10)
+        return (2.0 / qw * (1.0 - n * n / (3.0 * qw * qw))) * v;
+    return (2.0 * atan2(n, qw) / n) * v;
+}
+HD M3 so3_Vinv(V3 om) {
+    const double th = norm(om);
+    const M3 Om = skew(om);
+    double Cc;
+    if (th < 1e-4) {
+        const double t2 = th * th;
+        Cc = 1.0 / 12.0 + t2 / 720.0 + t2 * t2 / 30240.0;
+    } else {
+        Cc = (1.0 - 0.5 * th * sin(th) / (1.0 - cos(th))) / (th * th);
+    }
+    return m3_identity() - 0.5 * Om + Cc * (Om * Om);
+}
+
 // ---- SE(3)
 HD Pose pose_identity() { return Pose{q_identity(), V3{0, 0, 0}}; }
 HD Pose pose_mul(const Pose& a, const Pose& b) { return Pose{q_mul(a.R, b.R), a.x + q_rot(a.R, b.x)}; }
@@ -163,6 +189,11 @@ HD Pose pose_inv(const Pose& a) {
 }
 HD V3 pose_act(const Pose& a, V3 p) { return q_rot(a.R, p) + a.x; }
 HD Pose se3_exp(V3 om, V3 v) { return Pose{so3_exp(om), so3_V(om) * v}; }
+
+HD void se3_log(const Pose& P, V3& om, V3& v) {
+    om = so3_log(P.R);
+    v = so3_Vinv(om) * P.x;
+}
 
 // 6-vector (omega, v) and 6x6 matrices (row-major) for Adjoint / adjoint algebra on the host side
 struct V6 {
@@ -282,6 +313,23 @@ HD M3 ind2euc_r0(V3 q0) {
     V3 c0, c1;
     stereo_invdiff0(y0, c0, c1);
     return m3_cols(r0 * c0, r0 * c1, (-r0) * q0);
+}
+// sphereChart_stereo(eta, pole) (VIOState.cpp:282-287): stereographic coordinates of eta about the pole
+HD void stereo_chart(V3 eta, V3 pole, double& s0, double& s1) {
+    const Qt R = so3_from_vectors(-pole, V3{0, 0, 1});
+    const V3 e = q_rot(R, eta);
+    const double k = 1.0 / (1.0 - e.z);
+    s0 = e.x * k;
+    s1 = e.y * k;
+}
+// pointChart_invdepth / pointChart_euclid forward (VIOState.cpp:153-172): coordinates of q about q0
+HD V3 point_chart(int invdepth, V3 q, V3 q0) {
+    if (!invdepth)
+        return q - q0;
+    const double rho = 1.0 / norm(q), rho0 = 1.0 / norm(q0);
+    double s0, s1;
+    stereo_chart(rho * q, rho0 * q0, s0, s1);
+    return V3{s0, s1, rho - rho0};
 }
 HD V3 e3_project_sphere_inv(double y0, double y1) { // VIOState.cpp:253-258
     const double k = 2.0 / (y0 * y0 + y1 * y1 + 1.0);

@@ -292,6 +292,22 @@ VIOState VIO_eqf::stateEstimate() const { // :137
         xi.cameraLandmarks[i] = Landmark{V3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}, ids[i]};
     return xi;
 }
+double VIO_eqf::computeNEES(const VIOState& trueState) const { // VIO_eqf.cpp:153-170
+    double s[23];
+    packSensor(trueState.sensor, s);
+    const int Nt = (int)trueState.cameraLandmarks.size();
+    std::vector<int> ids(Nt + 1);
+    std::vector<double> p(3 * Nt + 3);
+    for (int i = 0; i < Nt; ++i) {
+        ids[i] = trueState.cameraLandmarks[i].id;
+        p[3 * i] = trueState.cameraLandmarks[i].p.x;
+        p[3 * i + 1] = trueState.cameraLandmarks[i].p.y;
+        p[3 * i + 2] = trueState.cameraLandmarks[i].p.z;
+    }
+    double nees = 0;
+    check(eqf_compute_nees(ctx, s, ids.data(), p.data(), Nt, &nees), "eqf_compute_nees");
+    return nees;
+}
 void VIO_eqf::outlierStats(const VisionMeasurement& m, std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2) const {
     const int N = numLandmarks();
     absErr.assign(N, -1.0);

@@ -154,6 +154,7 @@ struct VIO_eqf {
     void integrateRiccatiStateFast(const IMUVelocity& imuVelocity, const double& dt, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8);
     void performVisionUpdate(const VisionMeasurement& measurement, double outputGainVar, const bool& useEquivariantOutput = true, const bool& discreteCorrection = false);
     VIOState stateEstimate() const;
+    double computeNEES(const VIOState& trueState) const; // VIO_eqf.cpp:153-170, factorised on the device
     // per-landmark quantities VIOFilter::removeOutliers / getMedianSceneDepth need, all landmarks at once
     void outlierStats(const VisionMeasurement& measurement, std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2) const;
 

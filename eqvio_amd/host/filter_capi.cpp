@@ -159,6 +159,9 @@ int eqvio_filter_get_eqf(eqvio_filter* f, double* xi0_sensor, double* X_sensor, 
 }
 int eqvio_filter_sigma_dim(const eqvio_filter* f) { return 21 + 3 * f->filter->viewEqFState().numLandmarks(); }
 int eqvio_filter_get_sigma(eqvio_filter* f, double* out, int n) { return eqf_get_sigma(f->filter->eqfState().ctx, out, n) == 0 ? 0 : -1; }
+int eqvio_filter_compute_nees(eqvio_filter* f, const double* ts, const int* tids, const double* tp, int nt, double* nees) {
+    return guarded(f, [&] { *nees = f->filter->viewEqFState().computeNEES(unpackState(ts, tids, tp, nt)); });
+}
 eqf_ctx* eqvio_filter_core(eqvio_filter* f) { return f->filter->eqfState().ctx; }
 int eqvio_filter_last_timing(const eqvio_filter* f, double* a, double* b, double* c) {
     if (a)

@@ -98,6 +98,11 @@ int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, con
 /* Gamma of the last update (n doubles) — for parity checks. */
 int eqf_last_gamma(eqf_ctx* ctx, double* out, int cap);
 
+/* VIO_eqf::computeNEES (VIO_eqf.cpp:153-170): eps = stateChart(stateGroupAction(X^-1, trueState restricted to X.id), xi0),
+ * NEES = eps^T Sigma^-1 eps / dim. The true state must contain every landmark id of the filter state. Sigma^-1 eps is
+ * never formed: Sigma = L L^T is factorised with the same blocked chain as the vision update and NEES = |L^-1 eps|^2 / n. */
+int eqf_compute_nees(eqf_ctx* ctx, const double* true_sensor, const int* true_ids, const double* true_p, int n_true, double* nees);
+
 /* EqF matrices as the device assembled them, expanded to the reference's dense layout for parity tests:
  * A (n x n), B (n x 12) from stateMatrixA / inputMatrixB (coordinateSuite/euclid.cpp:99-233,
  * invdepth.cpp:36-181); C (2M x n) from outputMatrixC (EqFMatrices.cpp:43-82). Column-major. */

@@ -42,6 +42,8 @@ int eqvio_filter_augment_landmark_states(eqvio_filter* f, const int* new_ids, in
 int eqvio_filter_get_eqf(eqvio_filter* f, double* xi0_sensor, double* X_sensor, int* ids, double* q0, double* Q, int cap); /* returns N or -1 */
 int eqvio_filter_sigma_dim(const eqvio_filter* f);
 int eqvio_filter_get_sigma(eqvio_filter* f, double* out_colmajor, int n);
+/* viewEqFState().computeNEES(trueState) (src/main_sim.cpp:148, VIO_eqf.cpp:153-170) */
+int eqvio_filter_compute_nees(eqvio_filter* f, const double* true_sensor, const int* true_ids, const double* true_p, int n_true, double* nees);
 /* the device context behind viewEqFState(), for the eqf_* entry points */
 eqf_ctx* eqvio_filter_core(eqvio_filter* f);
 /* loopTimer sections of the last processVisionData (VIOFilter.cpp:196-236), seconds */

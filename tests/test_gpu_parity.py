@@ -263,3 +263,29 @@ def test_headline_size_properties(N):
     assert np.max(np.abs(S_post - S_post.T)) <= 1e-12 * np.max(np.abs(S_post))
     assert np.all(np.diag(S_post) <= np.diag(S_prior) * (1 + 1e-12))
     assert np.all(np.linalg.eigvalsh(0.5 * (S_post + S_post.T)) > 0)
+
+
+@pytest.mark.parametrize("chart", list(CHARTS))
+@pytest.mark.parametrize("N", [0, 3, 20, 45])
+def test_compute_nees(chart, N):
+    """eqf_compute_nees (chain factorisation of Sigma, n odd or even) vs VIO_eqf::computeNEES (VIO_eqf.cpp:153-170,
+    dense LU inverse). The 'true' state holds more landmarks than the filter, in a different order."""
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=900 + N, cap=max(N, 4))
+    s_e, ids_e, p_e = orc.state_estimate()
+    true_sensor = s_e.copy()
+    true_sensor[0:6] += rng.normal(size=6) * 0.01
+    true_sensor[10:13] += rng.normal(size=3) * 0.05
+    true_sensor[13:16] += rng.normal(size=3) * 0.05
+    extra = 4
+    true_ids = np.concatenate([ids_e, 100000 + np.arange(extra)]).astype(np.int32)
+    true_p = np.concatenate([p_e * (1.0 + 0.02 * rng.normal(size=(N, 1))) + rng.normal(size=(N, 3)) * 0.05, rng.normal(size=(extra, 3)) + [0, 0, 5]])
+    perm = rng.permutation(N + extra)
+    true_ids, true_p = true_ids[perm], true_p[perm]
+    nees_o = orc.compute_nees(true_sensor, true_ids, true_p)
+    nees_g = core.compute_nees(true_sensor, true_ids, true_p)
+    assert nees_o > 0
+    assert abs(nees_g - nees_o) <= 1e-9 * nees_o
+    # Sigma and X untouched
+    check_sigma(core, orc, 0.0)
+    with pytest.raises(EqfError):
+        core.compute_nees(true_sensor, true_ids[:1], true_p[:1]) if N > 1 else (_ for _ in ()).throw(EqfError(-3, "n/a"))
