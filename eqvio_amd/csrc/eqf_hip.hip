@@ -145,6 +145,8 @@ struct eqf_ctx {
     ObsStep* d_steps = nullptr;
     double *d_C = nullptr, *d_ytil = nullptr, *d_y = nullptr;
     int *d_lmidx = nullptr, *d_measof = nullptr, *d_keep = nullptr;
+    double *d_Ebuf = nullptr, *d_Yl = nullptr, *d_Fl = nullptr, *d_PhiB = nullptr; // accurate Riccati (lazily allocated)
+    int* d_expinfo = nullptr;
     double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
     int ldzn = 0;
     double *d_Z = nullptr, *d_W = nullptr, *d_Linv = nullptr, *d_gamma = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
@@ -488,6 +490,13 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_stats);
     hipFree(c->d_scratch);
     hipFree(c->d_flags);
+    if (c->d_Ebuf) {
+        hipFree(c->d_Ebuf);
+        hipFree(c->d_Yl);
+        hipFree(c->d_Fl);
+        hipFree(c->d_PhiB);
+        hipFree(c->d_expinfo);
+    }
     if (c->d_Zn)
         hipFree(c->d_Zn);
     if (c->d_Wn)
@@ -830,6 +839,54 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
         if (c->h_flags[1])
             return EQF_E_NONFINITE;
     }
+    return 0;
+}
+
+int eqf_integrate_riccati_accurate(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
+    if (!c || !imu13 || !Qdiag12 || !Pdiag8 || !(dt > 0.0))
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
+    if (!c->d_Ebuf) {
+        HIPCHK(hipMalloc(&c->d_Ebuf, sizeof(double) * (EXPM_SMAX + 2) * 21 * 33));
+        HIPCHK(hipMalloc(&c->d_Yl, sizeof(double) * 99 * (size_t)c->Ncap));
+        HIPCHK(hipMalloc(&c->d_Fl, sizeof(double) * 9 * (size_t)c->Ncap));
+        HIPCHK(hipMalloc(&c->d_PhiB, sizeof(double) * (size_t)c->ld * 12));
+        HIPCHK(hipMalloc(&c->d_expinfo, sizeof(int) * 4));
+    }
+    if (!c->d_F)
+        HIPCHK(hipMalloc(&c->d_F, bytes));
+    if (!c->d_tmp)
+        HIPCHK(hipMalloc(&c->d_tmp, bytes));
+    int rc = upload_common(c, imu13);
+    if (rc)
+        return rc;
+    rc = launch_assemble(c);
+    if (rc)
+        return rc;
+    RiccatiArgs ra;
+    ra.dt = dt;
+    std::memcpy(ra.Qd, Qdiag12, sizeof(ra.Qd));
+    std::memcpy(ra.Pd, Pdiag8, sizeof(ra.Pd));
+    const int N = c->N, n = c->n();
+    double* Sin = c->d_sigma[c->cur];
+    double* Sout = c->d_sigma[1 - c->cur];
+    KTimer t(c, KN_DENSE_GEMM);
+    hipLaunchKernelGGL(k_expm_sensor, dim3(1), dim3(256), 0, c->stream, N, c->Ncap, dt, c->d_common, c->d_Al, c->d_Bl, c->d_Ebuf, c->d_expinfo);
+    HIPCHK(hipGetLastError());
+    if (N > 0) {
+        hipLaunchKernelGGL(k_expm_landmarks, dim3(blocks(N, 4)), dim3(256), 0, c->stream, N, c->Ncap, dt, c->d_Al, c->d_Bl, c->d_Ebuf, c->d_expinfo, c->d_Yl, c->d_Fl);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_build_phi, dim3(blocks(n, 256), n + 12), dim3(256), 0, c->stream, N, c->Ncap, n, c->ld, c->d_Ebuf, c->d_expinfo, c->d_Yl, c->d_Fl, c->d_F, c->d_PhiB);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(256), 0, c->stream, n, n, n, c->d_F, c->ld, Sin, c->ld, c->d_tmp, c->ld);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(256), 0, c->stream, n, n, n, c->d_tmp, c->ld, c->d_F, c->ld, Sout, c->ld);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_add_noise_dense, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->ld, ra, c->d_PhiB, Sout);
+    HIPCHK(hipGetLastError());
+    c->cur = 1 - c->cur;
     return 0;
 }
 

@@ -1285,6 +1285,266 @@ __global__ void __launch_bounds__(256) k_add_noise(int N, int Ncap, int n, int l
     Sout[r + (size_t)c * ld] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Accurate Riccati (integrateRiccatiStateAccurate, VIO_eqf.cpp:74-91): exp(dt [[A, B],[0, 0]]) with the structure
+//   A = [[A_ss, 0],[A_ls, blkdiag(D_i)]]  =>  the exponential of the (n+12)^2 matrix is block lower triangular too:
+//   sensor part  E = exp(P),  P = dt [[A_ss, B_s],[0, 0]]  (33 x 33, only its first 21 rows are non-trivial),
+//   landmark i   [Y_i | F_i] with  exp(dt [[P/dt, 0],[R_i, D_i]]) = [[E, 0],[Y_i, F_i]],  R_i = [A_ls_i | B_l_i]  (3 x 33).
+// Both by Taylor series (degree EXPM_K) of the matrix scaled by 2^-s, then s squarings
+//   [[E,0],[Y,F]]^2 = [[E^2, 0],[Y E + F Y, F^2]].
+// expinfo[0] = s (chosen on the device from the infinity norm so that no host round trip is needed).
+constexpr int EXPM_K = 14;
+constexpr int EXPM_SMAX = 12;
+// One workgroup. Ebuf: (EXPM_SMAX + 1) x (21 x 33) row-major: Ebuf[0] = Ps = P / 2^s (scaled generator, top 21 rows),
+// Ebuf[1 + j] = E after j squarings (top 21 rows; rows 21..32 of every E are [0 I]). The final E is Ebuf[1 + s].
+__global__ void __launch_bounds__(256) k_expm_sensor(int N, int Ncap, double dt, const Common* __restrict__ cm, const double* __restrict__ Al,
+                                                     const double* __restrict__ Bl, double* __restrict__ Ebuf, int* __restrict__ expinfo) {
+    __shared__ double sP[21 * 33], sT[21 * 33], sE[21 * 33], sN[21 * 33];
+    __shared__ double sred[256];
+    __shared__ int s_s;
+    const int tid = threadIdx.x;
+    // infinity norm (max abs row sum) of dt [[A, B]]
+    double mx = 0.0;
+    for (int r = tid; r < 21; r += 256) {
+        double a = 0.0;
+        for (int c = 0; c < 21; ++c)
+            a += fabs(cm->Ass[r * 21 + c]);
+        for (int c = 0; c < 12; ++c)
+            a += fabs(cm->Bs[r * 12 + c]);
+        mx = fmax(mx, a);
+    }
+    for (int t = tid; t < 3 * N; t += 256) {
+        const int i = t / 3, r = t % 3;
+        double a = 0.0;
+        for (int e = 0; e < 15; ++e)
+            a += fabs(Al[(r * 15 + e) * Ncap + i]);
+        for (int e = 0; e < 3; ++e)
+            a += fabs(Bl[(r * 3 + e) * Ncap + i]);
+        mx = fmax(mx, a);
+    }
+    sred[tid] = mx;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st)
+            sred[tid] = fmax(sred[tid], sred[tid + st]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double nrm = dt * sred[0];
+        int sc = 0;
+        while (sc < EXPM_SMAX && ldexp(nrm, -sc) > 0.25)
+            ++sc;
+        s_s = sc;
+        expinfo[0] = sc;
+    }
+    __syncthreads();
+    const int sc = s_s;
+    const double scale = ldexp(dt, -sc);
+    for (int t = tid; t < 21 * 33; t += 256) {
+        const int r = t / 33, c = t % 33;
+        const double v = scale * (c < 21 ? cm->Ass[r * 21 + c] : cm->Bs[r * 12 + (c - 21)]);
+        sP[t] = v;
+        sT[t] = v;                   // current term Ps^k / k!
+        sE[t] = v + (r == c ? 1.0 : 0.0); // I + Ps
+        Ebuf[t] = v;
+    }
+    __syncthreads();
+    // Taylor: term_k = term_{k-1} Ps / k  (rows 21..32 of Ps are zero: the inner index runs over 21)
+    for (int k = 2; k <= EXPM_K; ++k) {
+        for (int t = tid; t < 21 * 33; t += 256) {
+            const int r = t / 33, c = t % 33;
+            double a = 0.0;
+            for (int q = 0; q < 21; ++q)
+                a += sT[r * 33 + q] * sP[q * 33 + c];
+            sN[t] = a / k;
+        }
+        __syncthreads();
+        for (int t = tid; t < 21 * 33; t += 256) {
+            sT[t] = sN[t];
+            sE[t] += sN[t];
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < 21 * 33; t += 256)
+        Ebuf[21 * 33 + t] = sE[t];
+    // squarings: E <- E E with E = [[E_top],[0 I]]  =>  top rows: E_top[:, 0:21] E_top + [0 | E_top[:, 21:33]]
+    for (int j = 0; j < sc; ++j) {
+        __syncthreads();
+        for (int t = tid; t < 21 * 33; t += 256) {
+            const int r = t / 33, c = t % 33;
+            double a = (c >= 21) ? sE[r * 33 + c] : 0.0;
+            for (int q = 0; q < 21; ++q)
+                a += sE[r * 33 + q] * sE[q * 33 + c];
+            sN[t] = a;
+        }
+        __syncthreads();
+        for (int t = tid; t < 21 * 33; t += 256) {
+            sE[t] = sN[t];
+            Ebuf[(2 + j) * 21 * 33 + t] = sN[t];
+        }
+    }
+}
+// One wave per landmark (4 per workgroup). Output per landmark: Yl 3 x 33 planes (Phi_ls | PhiB_l), Fl 3 x 3 planes.
+__global__ void __launch_bounds__(256) k_expm_landmarks(int N, int Ncap, double dt, const double* __restrict__ Al, const double* __restrict__ Bl,
+                                                        const double* __restrict__ Ebuf, const int* __restrict__ expinfo, double* __restrict__ Yl,
+                                                        double* __restrict__ Fl) {
+    __shared__ double sM[21 * 33];      // Ps, then E_j
+    __shared__ double sR[4][3 * 33 + 3]; // per wave: current 3 x 33 row block
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = blockIdx.x * 4 + wave;
+    const bool live = i < N;
+    const int sc = expinfo[0];
+    const double scale = ldexp(dt, -sc);
+    for (int t = tid; t < 21 * 33; t += 256)
+        sM[t] = Ebuf[t];
+    // R_s (3 x 33): cols 0:3 | 12:15 | 15:21 from Al, cols 21:24 from Bl; S_s = scale * D
+    double R[3] = {0, 0, 0};
+    const int c = lane; // column owned by this lane (c < 33)
+    if (live && c < 33) {
+        int e = -1;
+        if (c < 3)
+            e = c;
+        else if (c >= 12 && c < 15)
+            e = 3 + (c - 12);
+        else if (c >= 15 && c < 21)
+            e = 6 + (c - 15);
+        for (int r = 0; r < 3; ++r) {
+            if (e >= 0)
+                R[r] = scale * Al[(r * 15 + e) * Ncap + i];
+            else if (c >= 21 && c < 24)
+                R[r] = scale * Bl[(r * 3 + (c - 21)) * Ncap + i];
+        }
+    }
+    double S[9], Sp[9], F[9];
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) {
+            S[r * 3 + q] = live ? scale * Al[(r * 15 + 12 + q) * Ncap + i] : 0.0;
+            Sp[r * 3 + q] = (r == q) ? 1.0 : 0.0; // S^(k-1) / (k-1)!  (k = 1)
+            F[r * 3 + q] = ((r == q) ? 1.0 : 0.0) + S[r * 3 + q];
+        }
+    double T[3] = {R[0], R[1], R[2]}; // current term (3 x 33 block column c) : R_1
+    double Y[3] = {R[0], R[1], R[2]};
+    __syncthreads();
+    // term_k = (term_{k-1} Ps + Spow_{k-1} R) / k with Spow_{k-1} = S^(k-1)/(k-1)!
+    double Spow[9];
+    for (int q = 0; q < 9; ++q)
+        Spow[q] = S[q]; // S^1/1!
+    for (int k = 2; k <= EXPM_K; ++k) {
+        if (c < 33)
+            for (int r = 0; r < 3; ++r)
+                sR[wave][r * 33 + c] = T[r];
+        __syncthreads();
+        double nt[3] = {0, 0, 0};
+        if (c < 33) {
+            for (int q = 0; q < 21; ++q) {
+                const double p = sM[q * 33 + c];
+                nt[0] += sR[wave][q] * p;
+                nt[1] += sR[wave][33 + q] * p;
+                nt[2] += sR[wave][66 + q] * p;
+            }
+            for (int r = 0; r < 3; ++r)
+                nt[r] = (nt[r] + Spow[r * 3 + 0] * R[0] + Spow[r * 3 + 1] * R[1] + Spow[r * 3 + 2] * R[2]) / k;
+        }
+        // Spow_k = Spow_{k-1} S / k
+        double ns[9];
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q)
+                ns[r * 3 + q] = (Spow[r * 3 + 0] * S[0 * 3 + q] + Spow[r * 3 + 1] * S[1 * 3 + q] + Spow[r * 3 + 2] * S[2 * 3 + q]) / k;
+        __syncthreads();
+        for (int r = 0; r < 3; ++r) {
+            T[r] = nt[r];
+            Y[r] += nt[r];
+        }
+        for (int q = 0; q < 9; ++q) {
+            Spow[q] = ns[q];
+            F[q] += ns[q];
+        }
+    }
+    // squarings: Y <- Y E + F Y, F <- F F
+    for (int j = 0; j < sc; ++j) {
+        __syncthreads();
+        for (int t = tid; t < 21 * 33; t += 256)
+            sM[t] = Ebuf[(1 + j) * 21 * 33 + t];
+        if (c < 33)
+            for (int r = 0; r < 3; ++r)
+                sR[wave][r * 33 + c] = Y[r];
+        __syncthreads();
+        if (c < 33) {
+            double ny[3];
+            for (int r = 0; r < 3; ++r)
+                ny[r] = (c >= 21) ? sR[wave][r * 33 + c] : 0.0; // rows 21..32 of E are [0 I]
+            for (int q = 0; q < 21; ++q) {
+                const double p = sM[q * 33 + c];
+                ny[0] += sR[wave][q] * p;
+                ny[1] += sR[wave][33 + q] * p;
+                ny[2] += sR[wave][66 + q] * p;
+            }
+            for (int r = 0; r < 3; ++r)
+                ny[r] += F[r * 3 + 0] * Y[0] + F[r * 3 + 1] * Y[1] + F[r * 3 + 2] * Y[2];
+            for (int r = 0; r < 3; ++r)
+                Y[r] = ny[r];
+        }
+        double nf[9];
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q)
+                nf[r * 3 + q] = F[r * 3 + 0] * F[0 * 3 + q] + F[r * 3 + 1] * F[1 * 3 + q] + F[r * 3 + 2] * F[2 * 3 + q];
+        for (int q = 0; q < 9; ++q)
+            F[q] = nf[q];
+    }
+    if (live) {
+        if (c < 33)
+            for (int r = 0; r < 3; ++r)
+                Yl[(r * 33 + c) * Ncap + i] = Y[r];
+        if (lane < 9)
+            Fl[lane * Ncap + i] = F[lane];
+    }
+}
+// Dense Phi (n x n) and Phi_B (n x 12), column-major, from the structured exponential.
+__global__ void __launch_bounds__(256) k_build_phi(int N, int Ncap, int n, int ldf, const double* __restrict__ Ebuf, const int* __restrict__ expinfo,
+                                                   const double* __restrict__ Yl, const double* __restrict__ Fl, double* __restrict__ Phi,
+                                                   double* __restrict__ PhiB) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y; // 0 .. n + 12
+    if (r >= n)
+        return;
+    const double* E = Ebuf + (size_t)(1 + expinfo[0]) * 21 * 33;
+    double v = 0.0;
+    if (c < n) {
+        if (r < 21) {
+            if (c < 21)
+                v = E[r * 33 + c];
+        } else {
+            const int i = (r - 21) / 3, rr = (r - 21) % 3;
+            if (c < 21)
+                v = Yl[(rr * 33 + c) * Ncap + i];
+            else if ((c - 21) / 3 == i)
+                v = Fl[(rr * 3 + (c - 21) % 3) * Ncap + i];
+        }
+        Phi[r + (size_t)c * ldf] = v;
+    } else {
+        const int q = c - n;
+        if (r < 21)
+            v = E[r * 33 + 21 + q];
+        else
+            v = Yl[(((r - 21) % 3) * 33 + 21 + q) * Ncap + (r - 21) / 3];
+        PhiB[r + (size_t)q * ldf] = v;
+    }
+}
+// Sigma' = M + Phi_B diag(Q / dt) Phi_B^T + dt P   (M = Phi Sigma Phi^T already in Sout)
+__global__ void __launch_bounds__(256) k_add_noise_dense(int n, int ld, int ldf, RiccatiArgs ra, const double* __restrict__ PhiB, double* __restrict__ Sout) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= n)
+        return;
+    double bq = 0;
+    for (int q = 0; q < 12; ++q)
+        bq += PhiB[r + (size_t)q * ldf] * (ra.Qd[q] / ra.dt) * PhiB[c + (size_t)q * ldf];
+    double v = Sout[r + (size_t)c * ld] + bq;
+    if (r == c)
+        v += ra.dt * (r < 21 ? ra.Pd[r / 3] : ra.Pd[7]);
+    Sout[r + (size_t)c * ld] = v;
+}
+
 // NEES support: Z = [Sigma (lower, padded to even dimension np with a unit diagonal) ; eps^T] for the factorisation chain
 __global__ void __launch_bounds__(256) k_build_nees(int n, int np, int ld, int ldzn, const double* __restrict__ Sig, const double* __restrict__ eps,
                                                     double* __restrict__ Z) {

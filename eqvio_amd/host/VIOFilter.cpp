@@ -264,6 +264,11 @@ void VIO_eqf::integrateObserverStates(const std::vector<IMUVelocity>& imus, cons
 void VIO_eqf::integrateObserverState(const IMUVelocity& imu, const double& dt, const bool& discreteLift) { // VIO_eqf.cpp:47-60
     integrateObserverStates({imu}, {dt}, discreteLift);
 }
+void VIO_eqf::integrateRiccatiStateAccurate(const IMUVelocity& v, const double& dt, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8) {
+    double imu[13];
+    v.pack(imu);
+    check(eqf_integrate_riccati_accurate(ctx, imu, dt, Qd.data(), Pd8.data()), "integrateRiccatiStateAccurate");
+}
 void VIO_eqf::integrateRiccatiStateFast(const IMUVelocity& imu, const double& dt, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8) { // :62-72
     double v[13];
     imu.pack(v);
@@ -491,13 +496,18 @@ bool VIOFilter::integrateUpToTime(const double& newTime) { // :134-192
         }
         accumulatedVelocity = accumulatedVelocity * (1.0 / accumulatedTime);
         filterState.integrateRiccatiStateFast(accumulatedVelocity, accumulatedTime, settings->constructInputGainDiag(), settings->constructStateGainDiag8());
+        // The observer steps do not depend on the Riccati state (VIOFilter.cpp:138): all samples in one device call.
+        filterState.integrateObserverStates(velocityBuffer, dts, settings->useDiscreteVelocityLift);
     } else {
-        // integrateRiccatiStateAccurate / Discrete (VIO_eqf.cpp:74-103) are not on the device path yet
-        // ("lower priority" / "oracle only"); fail loudly instead of falling back.
-        throw std::runtime_error("VIOFilter: settings.fastRiccati = false is not supported by the MI355X path (EQF_E_UNSUPPORTED)");
+        if (settings->useDiscreteStateMatrix) // integrateRiccatiStateDiscrete (VIO_eqf.cpp:93-103): SURVEY.md §8 row a7, oracle only
+            throw std::runtime_error("VIOFilter: settings.useDiscreteStateMatrix = true is not supported by the MI355X path (EQF_E_UNSUPPORTED)");
+        // VIOFilter.cpp:128-139: per IMU sample, the accurate Riccati step at the current X, then the observer step
+        for (size_t i = 0; i < velocityBuffer.size(); ++i) {
+            if (dts[i] > 0)
+                filterState.integrateRiccatiStateAccurate(velocityBuffer.at(i), dts[i], settings->constructInputGainDiag(), settings->constructStateGainDiag8());
+            filterState.integrateObserverState(velocityBuffer.at(i), dts[i], settings->useDiscreteVelocityLift);
+        }
     }
-    // The observer steps do not depend on the Riccati state (VIOFilter.cpp:138): all samples in one device call.
-    filterState.integrateObserverStates(velocityBuffer, dts, settings->useDiscreteVelocityLift);
     filterState.currentTime = newTime;
     auto it = std::find_if(velocityBuffer.begin(), velocityBuffer.end(), [this](const IMUVelocity& v) { return v.stamp >= this->filterState.currentTime; });
     if (it != velocityBuffer.begin()) {

@@ -152,6 +152,7 @@ struct VIO_eqf {
     void integrateObserverState(const IMUVelocity& imuVelocity, const double& dt, const bool& discreteLift = true);
     void integrateObserverStates(const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift); // batched
     void integrateRiccatiStateFast(const IMUVelocity& imuVelocity, const double& dt, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8);
+    void integrateRiccatiStateAccurate(const IMUVelocity& imuVelocity, const double& dt, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8);
     void performVisionUpdate(const VisionMeasurement& measurement, double outputGainVar, const bool& useEquivariantOutput = true, const bool& discreteCorrection = false);
     VIOState stateEstimate() const;
     double computeNEES(const VIOState& trueState) const; // VIO_eqf.cpp:153-170, factorised on the device

@@ -80,6 +80,11 @@ int eqf_remove_invalid_landmarks(eqf_ctx* ctx);
  * VIOFilterSettings.h:192-201), P = diag: Pdiag8 = the 7 sensor 3-blocks + the per-landmark value
  * (constructStateGainMatrix, :176-190). imu13 = IMUVelocity. */
 int eqf_integrate_riccati_fast(eqf_ctx* ctx, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8);
+/* VIO_eqf::integrateRiccatiStateAccurate (VIO_eqf.cpp:74-91), one IMU sample:
+ * [Phi, Phi_B] from exp(dt [[A, B],[0, 0]]), Sigma <- Phi Sigma Phi^T + Phi_B (Q/dt) Phi_B^T + dt P.
+ * The exponential is evaluated in its block-triangular structure on the device; Phi Sigma Phi^T runs as two dense
+ * fp64 MFMA GEMMs. */
+int eqf_integrate_riccati_accurate(eqf_ctx* ctx, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8);
 /* VIO_eqf::integrateObserverState (VIO_eqf.cpp:47-60) applied for k consecutive samples
  * (the loop of VIOFilter::integrateUpToTime, src/VIOFilter.cpp:160-178). */
 int eqf_integrate_observer(eqf_ctx* ctx, const double* imu13_k, const double* dt_k, int k, int discreteLift);

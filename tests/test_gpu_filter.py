@@ -114,9 +114,29 @@ def test_outlier_rejection_decisions_match():
     assert removed_any
 
 
-def test_non_fast_riccati_is_refused_loudly():
+@pytest.mark.parametrize("chart", [COORD_EUCLIDEAN, COORD_INVDEPTH])
+def test_template_config_accurate_riccati(chart):
+    """20 features, the template's fastRiccati: false (EQVIO_config_template.yaml eqf block):
+    one accurate Riccati step per IMU sample, interleaved with the observer steps (VIOFilter.cpp:128-139)."""
+    world = SimWorld(seed=5, num_points=1000, max_features=20, trajectory="wave", noise_px=0.3)
+    settings = sim_settings(chart, fastRiccati=0)
+    ids0, _ = world.vision(0.0)
+    sensor, ids, p = world.true_state(0.0, ids0)
+    orc = OracleFilter(settings, sensor, ids, p, 0.0)
+    flt = VIOFilter(settings, max_landmarks=32, sensor=sensor, ids=ids, p=p, time=0.0)
+    for imus, stamp, mid, y in world.frames(25):
+        for s in range(len(imus)):
+            orc.process_imu(imus[s])
+            flt.process_imu(imus[s])
+        orc.process_vision(stamp, world.cam, mid, y)
+        flt.process_vision(stamp, world.cam, mid, y)
+        compare(flt, orc)
+
+
+def test_discrete_state_matrix_is_refused_loudly():
+    """Row a7 (integrateRiccatiStateDiscrete) is oracle-only: the product refuses it instead of falling back."""
     world = SimWorld(seed=1, num_points=100, max_features=5, trajectory="hover")
-    settings = sim_settings(COORD_EUCLIDEAN, fastRiccati=0)
+    settings = sim_settings(COORD_EUCLIDEAN, fastRiccati=0, useDiscreteStateMatrix=1)
     ids0, y0 = world.vision(0.0)
     sensor, ids, p = world.true_state(0.0, ids0)
     flt = VIOFilter(settings, max_landmarks=16, sensor=sensor, ids=ids, p=p, time=0.0)

@@ -109,6 +109,20 @@ def test_riccati_fast(chart, N):
 
 
 @pytest.mark.parametrize("chart", list(CHARTS))
+@pytest.mark.parametrize("N,dt", [(0, 0.005), (1, 0.005), (5, 0.05), (20, 0.005), (50, 0.005), (20, 0.7)])
+def test_riccati_accurate(chart, N, dt):
+    """Structured exp(dt [[A,B],[0,0]]) + dense MFMA GEMMs vs integrateRiccatiStateAccurate (VIO_eqf.cpp:74-91).
+    dt = 0.7 forces the scaling-and-squaring branch of the device exponential (several squarings)."""
+    rng, settings, orc, core, _ = make_pair(CHARTS[chart], N, seed=300 + N, cap=max(N, 4))
+    Qd, Pd = settings.input_gain_diag12(), settings.state_gain_diag8()
+    for rep in range(2):  # twice: the second call starts from a non-trivial ping-pong state
+        imu = random_imu(rng, bias_vel=True)
+        orc.integrate_riccati_accurate(imu, dt)
+        core.integrate_riccati_accurate(imu, dt, Qd, Pd)
+        check_sigma(core, orc, 1e-11)
+
+
+@pytest.mark.parametrize("chart", list(CHARTS))
 def test_riccati_dense_mode_matches_structured(chart):
     """EQF_OPT_RICCATI_DENSE (two fp64 MFMA GEMMs, F materialised) == arrow-form kernel == oracle."""
     N = 37
