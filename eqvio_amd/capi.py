@@ -477,3 +477,105 @@ class VIOFilter:
         if done < 0:
             self._chk(-1)
         return done
+
+
+# ---------------------------------------------------------------------------------------------------------
+# include/eqvio_sim.h : the synthetic-world data server (host only, also in libeqvio_filter.so)
+class SimSettings(C.Structure):
+    _fields_ = [("numPoints", C.c_int), ("wallDistance", C.c_double), ("randomSeed", C.c_uint), ("numWalls", C.c_int), ("maxFeatures", C.c_int),
+                ("initialNoise", C.c_int), ("inputNoise", C.c_int), ("outputNoise", C.c_int), ("duration", C.c_double), ("trajectory", C.c_int),
+                ("imuFreq", C.c_double), ("imageFreq", C.c_double)]
+
+    TRAJECTORIES = {"wave": 0, "square": 1, "sine": 2, "line": 3}
+
+    @classmethod
+    def defaults(cls, **kw):
+        s = cls()
+        _load_sim_protos().eqvio_sim_default_settings(C.byref(s))
+        for k, v in kw.items():
+            setattr(s, k, cls.TRAJECTORIES[v] if k == "trajectory" and isinstance(v, str) else v)
+        return s
+
+
+def _load_sim_protos():
+    lib = load_filter_lib()
+    if getattr(lib, "_sim_declared", None):
+        return lib
+    vp, P = C.c_void_p, C.POINTER
+    protos = {
+        "eqvio_sim_default_settings": (None, [P(SimSettings)]),
+        "eqvio_sim_create": (vp, [P(SimSettings), P(Settings)]),
+        "eqvio_sim_destroy": (None, [vp]),
+        "eqvio_sim_next_measurement_type": (C.c_int, [vp]),
+        "eqvio_sim_next_time": (C.c_double, [vp]),
+        "eqvio_sim_get_imu": (C.c_int, [vp, c_double_p]),
+        "eqvio_sim_get_vision": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int]),
+        "eqvio_sim_true_state": (C.c_int, [vp, C.c_double, C.c_int, c_double_p, c_int_p, c_double_p, C.c_int]),
+        "eqvio_sim_num_points": (C.c_int, [vp]),
+        "eqvio_sim_camera": (None, [vp, P(Camera)]),
+        "eqvio_sim_camera_offset": (None, [vp, c_double_p]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib._sim_declared = sorted(protos)
+    return lib
+
+
+class SimulationDataServer:
+    """The reference's SimulationDataServer + VIOSimulator (SimulationDataServer.h:25-70, VIOSimulator.h:29-106)."""
+    IMAGE, IMU, NONE = 0, 1, 2
+
+    def __init__(self, sim_settings, filter_settings):
+        self.lib = _load_sim_protos()
+        self.h = self.lib.eqvio_sim_create(C.byref(sim_settings), C.byref(filter_settings))
+        if not self.h:
+            raise RuntimeError("eqvio_sim_create failed")
+        self.num_points = self.lib.eqvio_sim_num_points(self.h)
+        self.max_features = sim_settings.maxFeatures
+        self.cam = Camera()
+        self.lib.eqvio_sim_camera(self.h, C.byref(self.cam))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.eqvio_sim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def next_measurement_type(self):
+        return self.lib.eqvio_sim_next_measurement_type(self.h)
+
+    def next_time(self):
+        return self.lib.eqvio_sim_next_time(self.h)
+
+    def get_imu(self):
+        out = np.zeros(13)
+        self.lib.eqvio_sim_get_imu(self.h, _dp(out))
+        return out
+
+    def get_vision(self):
+        cap = max(self.max_features, 1)
+        stamp, ids, y = C.c_double(), np.zeros(cap, np.int32), np.zeros(2 * cap)
+        m = self.lib.eqvio_sim_get_vision(self.h, C.byref(stamp), _ip(ids), _dp(y), cap)
+        if m < 0:
+            raise RuntimeError("eqvio_sim_get_vision: capacity")
+        return stamp.value, ids[:m].copy(), y[:2 * m].copy()
+
+    def true_state(self, stamp, with_noise=False):
+        cap = self.num_points
+        s, ids, p = np.zeros(23), np.zeros(cap, np.int32), np.zeros(3 * cap)
+        n = self.lib.eqvio_sim_true_state(self.h, stamp, int(with_noise), _dp(s), _ip(ids), _dp(p), cap)
+        if n < 0:
+            raise RuntimeError("eqvio_sim_true_state: capacity")
+        return s, ids[:n].copy(), p[:3 * n].reshape(n, 3).copy()
+
+    def camera_offset(self):
+        out = np.zeros(7)
+        self.lib.eqvio_sim_camera_offset(self.h, _dp(out))
+        return out

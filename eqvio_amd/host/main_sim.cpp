@@ -1,0 +1,146 @@
+// eqvio_sim: the reference's simulation main (src/main_sim.cpp:128-184) on the MI355X EqF path.
+// Same loop: Image -> [augmentLandmarkStates] -> processVisionData -> stateEstimate / computeNEES / write;
+// IMU -> processIMUData -> optional landmark reset. Configuration comes from --key value flags instead of a YAML file
+// (yaml-cpp and argparse are not in this image); defaults are the reference's.
+#include "VIOSimulator.hpp"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sys/stat.h>
+
+using namespace eqvio_amd;
+
+static void usage() {
+    std::puts("usage: eqvio_sim [--duration S] [--trajectory wave|square|sine|line] [--numPoints N] [--numWalls W] [--wallDistance D]\n"
+              "                 [--maxFeatures M] [--seed S] [--imuFreq HZ] [--imageFreq HZ] [--initialNoise] [--inputNoise] [--outputNoise]\n"
+              "                 [--coordinateChoice Euclidean|InvDepth] [--fastRiccati 0|1] [--fullState] [--landmarkReset S]\n"
+              "                 [--initialPointVariance V] [--measurementNoise PX] [--device D] [--output DIR] [--quiet]");
+}
+
+int main(int argc, char** argv) {
+    SimSettings sim;
+    sim.duration = 20.0;
+    VIOFilter::Settings fs;
+    bool fullState = false, quiet = false;
+    double landmarkResetTime = -1.0;
+    std::string outputDir;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> const char* {
+            if (i + 1 >= argc) {
+                usage();
+                std::exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "--duration") sim.duration = std::atof(val());
+        else if (a == "--trajectory") sim.trajectory = val();
+        else if (a == "--numPoints") sim.numPoints = std::atoi(val());
+        else if (a == "--numWalls") sim.numWalls = std::atoi(val());
+        else if (a == "--wallDistance") sim.wallDistance = std::atof(val());
+        else if (a == "--maxFeatures") sim.maxFeatures = (size_t)std::atoi(val());
+        else if (a == "--seed") sim.randomSeed = (uint32_t)std::strtoul(val(), nullptr, 10);
+        else if (a == "--imuFreq") sim.imuFreq = std::atof(val());
+        else if (a == "--imageFreq") sim.imageFreq = std::atof(val());
+        else if (a == "--initialNoise") sim.initialNoise = true;
+        else if (a == "--inputNoise") sim.inputNoise = true;
+        else if (a == "--outputNoise") sim.outputNoise = true;
+        else if (a == "--coordinateChoice") {
+            const std::string c = val();
+            if (c == "Euclidean") fs.coordinateChoice = CoordinateChoice::Euclidean;
+            else if (c == "InvDepth") fs.coordinateChoice = CoordinateChoice::InvDepth;
+            else {
+                std::fprintf(stderr, "Invalid coordinate choice. Valid choices here are Euclidean, InvDepth.\n");
+                return 2;
+            }
+        } else if (a == "--fastRiccati") fs.fastRiccati = std::atoi(val()) != 0;
+        else if (a == "--fullState") fullState = true;
+        else if (a == "--landmarkReset") landmarkResetTime = std::atof(val());
+        else if (a == "--initialPointVariance") fs.initialPointVariance = std::atof(val());
+        else if (a == "--measurementNoise") fs.measurementNoise = std::atof(val());
+        else if (a == "--device") fs.device = std::atoi(val());
+        else if (a == "--output") outputDir = val();
+        else if (a == "--quiet") quiet = true;
+        else {
+            usage();
+            return a == "--help" ? 0 : 2;
+        }
+    }
+    double lastLandmarkReset = landmarkResetTime > 0 ? 0.0 : std::nan("");
+
+    SimulationDataServer simDataServer(sim, fs);
+    loopTimer.initialise({"correction", "features", "preprocessing", "propagation", "total", "total vision update", "write output"});
+    // camera extrinsics provided by the data server override the filter settings (main_sim.cpp:97-101)
+    fs.cameraOffset = *simDataServer.cameraExtrinsics();
+    // the initial condition carries ALL world points (main_sim.cpp:105); the first augmentLandmarkStates trims it
+    fs.maxLandmarks = std::max(fs.maxLandmarks, sim.numPoints + (int)sim.maxFeatures);
+
+    std::ofstream stateFile, neesFile;
+    if (!outputDir.empty()) {
+        if (outputDir.back() != '/')
+            outputDir += '/';
+        mkdir(outputDir.c_str(), 0755);
+        stateFile.open(outputDir + "IMUState.csv"); // VIOWriter.cpp:33-44
+        stateFile << "time, px, py, pz, qw, qx, qy, qz, vx, vy, vz\n";
+        neesFile.open(outputDir + "consistency.csv");
+        neesFile << "time, NEES, position_error\n";
+    }
+
+    try {
+        VIOFilter filter(simDataServer.getInitialCondition(), fs);
+        int imuDataCounter = 0, visionDataCounter = 0;
+        double neesSum = 0, neesMax = 0, posErr = 0;
+        const auto loopStartTime = std::chrono::steady_clock::now();
+        if (!quiet)
+            std::cout << "NEES:\n";
+        while (true) {
+            const MeasurementType measType = simDataServer.nextMeasurementType();
+            if (measType == MeasurementType::None)
+                break;
+            if (measType == MeasurementType::Image) {
+                VisionMeasurement measData = simDataServer.getSimVision();
+                if (!fullState)
+                    filter.augmentLandmarkStates(measData.getIds(), simDataServer.getTrueState(measData.stamp, true));
+                filter.processVisionData(measData);
+                ++visionDataCounter;
+                const VIOState estimatedState = filter.stateEstimate();
+                const VIOState trueState = simDataServer.getTrueState(filter.getTime());
+                const double NEES = filter.viewEqFState().computeNEES(trueState);
+                neesSum += NEES;
+                neesMax = std::max(neesMax, NEES);
+                posErr = eqf::norm(estimatedState.sensor.pose.x - trueState.sensor.pose.x);
+                if (stateFile.is_open()) {
+                    const auto& P = estimatedState.sensor.pose;
+                    const auto& v = estimatedState.sensor.velocity;
+                    stateFile << std::setprecision(20) << filter.getTime() << ", " << std::setprecision(6) << P.x.x << ", " << P.x.y << ", " << P.x.z << ", " << P.R.w
+                              << ", " << P.R.x << ", " << P.R.y << ", " << P.R.z << ", " << v.x << ", " << v.y << ", " << v.z << '\n';
+                    neesFile << std::setprecision(20) << filter.getTime() << ", " << std::setprecision(6) << NEES << ", " << posErr << '\n';
+                }
+                if (!quiet)
+                    std::cout << '\r' << NEES << std::flush;
+            } else {
+                const IMUVelocity imuData = simDataServer.getIMU();
+                filter.processIMUData(imuData);
+                ++imuDataCounter;
+                if (filter.getTime() >= lastLandmarkReset + landmarkResetTime) { // false while lastLandmarkReset is NaN
+                    lastLandmarkReset += landmarkResetTime;
+                    filter.setLandmarks(simDataServer.getTrueState(filter.getTime(), true).cameraLandmarks);
+                }
+            }
+        }
+        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - loopStartTime).count();
+        std::cout << "\n\nProcessed " << imuDataCounter << " IMU and " << visionDataCounter << " vision measurements.\n"
+                  << "Time taken: " << elapsed << " seconds." << std::endl;
+        std::printf("mean NEES %.6g  max NEES %.6g  final position error %.6g m  landmarks %d  vision updates/s %.1f\n", neesSum / std::max(visionDataCounter, 1), neesMax,
+                    posErr, filter.viewEqFState().numLandmarks(), visionDataCounter / elapsed);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "eqvio_sim: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

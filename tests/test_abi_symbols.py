@@ -41,6 +41,11 @@ def test_filter_lib_exports_every_declared_symbol(built):
     from eqvio_amd.capi import load_filter_lib
 
     assert sorted(load_filter_lib()._declared) == sorted(names)
+    # the simulator's C view lives in the same library (include/eqvio_sim.h)
+    sim_names = [n for n in declared_symbols("eqvio_sim.h") if n.startswith("eqvio_sim_") and n != "eqvio_sim_settings"]
+    assert len(sim_names) >= 11
+    for n in sim_names:
+        assert hasattr(lib, n), f"{n} declared in include/eqvio_sim.h but not exported"
 
 
 def test_binding_declares_the_same_symbols(built):

@@ -1,0 +1,237 @@
+"""The synthetic-world data server (eqvio_amd/host/VIOSimulator.*, include/eqvio_sim.h), SURVEY.md §8 row f-1.
+
+CPU part: the measurement model of the reference's VIOSimulator / SimulationDataServer (src/VIOSimulator.cpp,
+src/dataserver/SimulationDataServer.cpp) checked through properties the reference's design implies, and the oracle
+filter driven main_sim-style (src/main_sim.cpp:128-184) by the C++ simulator.
+GPU part: the same run on the device filter, parity against the oracle frame by frame, and the eqvio_sim executable."""
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from eqvio_amd.capi import COORD_EUCLIDEAN, COORD_INVDEPTH, Settings, SimSettings, SimulationDataServer
+from oracle_binding import OracleFilter
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PI_REF = 3.14  # the reference's trajectory generators use 3.14, not pi (SimulationDataServer.cpp:58)
+
+
+def filter_settings(chart=COORD_EUCLIDEAN, **kw):
+    s = Settings.defaults()
+    s.coordinateChoice = chart
+    s.fastRiccati = 1
+    s.initialPointVariance = 1e-2
+    s.measurementNoise = 0.5
+    s.useMedianDepth = 1
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def make_server(fs=None, **kw):
+    fs = fs or filter_settings()
+    sim = SimSettings.defaults(**{"duration": 3.0, "randomSeed": 11, **kw})
+    srv = SimulationDataServer(sim, fs)
+    fs.cameraOffset[:] = srv.camera_offset()  # main_sim.cpp:97-101
+    return srv, fs
+
+
+def qrot(q, v):
+    w, u = q[0], np.asarray(q[1:4])
+    return v + 2 * w * np.cross(u, v) + 2 * np.cross(u, np.cross(u, v))
+
+
+def qmul(a, b):
+    return np.array([a[0] * b[0] - np.dot(a[1:], b[1:]), *(a[0] * b[1:] + b[0] * a[1:] + np.cross(a[1:], b[1:]))])
+
+
+def test_measurement_schedule():
+    """nextMeasurementType (SimulationDataServer.cpp:182-190): image first at equal stamps, 200 Hz IMU / 20 Hz image."""
+    srv, _ = make_server(duration=1.0)
+    kinds, stamps = [], []
+    while srv.next_measurement_type() != srv.NONE:
+        k = srv.next_measurement_type()
+        t = srv.next_time()
+        kinds.append(k)
+        stamps.append(t)
+        if k == srv.IMAGE:
+            st, _, _ = srv.get_vision()
+        else:
+            st = srv.get_imu()[0]
+        assert st == t
+    assert kinds[0] == srv.IMAGE and kinds[1] == srv.IMU
+    assert kinds.count(srv.IMAGE) == 20 and kinds.count(srv.IMU) == 200
+    assert stamps == sorted(stamps)
+    assert math.isnan(srv.next_time())
+
+
+def test_wave_trajectory_imu_and_state():
+    """wave trajectory (SimulationDataServer.cpp:45-65): yaw rate 2*3.14/20 rad/s about z; position on the unit circle
+    with a 0.2 m vertical wave; getIMU / getFullState differentiate it numerically (VIOSimulator.cpp:129-208, 272-309)."""
+    srv, _ = make_server(duration=2.0)
+    t0 = 0.5 / 200.0  # initialTime = 0.5 / imuFreq (SimulationDataServer.cpp:145)
+    for t in [0.3, 0.777, 1.5]:
+        s, ids, p = srv.true_state(t)
+        ang = PI_REF * 2 * (t + t0) / 20.0
+        np.testing.assert_allclose(s[10:13], [math.cos(ang), math.sin(ang), 0.2 * math.sin(10 * ang)], atol=1e-8)
+        np.testing.assert_allclose(s[6:10], [math.cos(ang / 2), 0, 0, math.sin(ang / 2)], atol=1e-9)
+        w = PI_REF * 2 / 20.0
+        v_in = np.array([-math.sin(ang) * w, math.cos(ang) * w, 2.0 * math.cos(10 * ang) * w])
+        np.testing.assert_allclose(qrot([s[6], -s[7], -s[8], -s[9]], v_in), s[13:16], atol=1e-6)
+        assert np.all(s[0:6] == 0)
+        assert len(ids) == 1000 and sorted(ids.tolist()) == list(range(1000))
+    while srv.next_measurement_type() != srv.NONE:
+        if srv.next_measurement_type() == srv.IMAGE:
+            srv.get_vision()
+            continue
+        imu = srv.get_imu()
+        t = imu[0]
+        if t < 0.05:
+            continue
+        ang = PI_REF * 2 * (t + t0) / 20.0
+        w = PI_REF * 2 / 20.0
+        np.testing.assert_allclose(imu[1:4], [0, 0, w], atol=1e-9)
+        a_in = np.array([-math.cos(ang) * w * w, -math.sin(ang) * w * w, -20.0 * math.sin(10 * ang) * w * w])
+        q = [math.cos(ang / 2), 0, 0, -math.sin(ang / 2)]  # R^-1
+        np.testing.assert_allclose(imu[4:7], qrot(q, a_in + np.array([0, 0, 9.80665])), atol=2e-4)
+        assert np.all(imu[7:13] == 0)
+
+
+@pytest.mark.parametrize("traj", ["wave", "square", "sine", "line"])
+def test_vision_matches_true_state(traj):
+    """getVision (VIOSimulator.cpp:210-268): at most maxFeatures visible points, ascending ids, pixels = projection of the
+    true camera-frame landmark (the pose interpolation differs from getFullState's cubic fit by O(dt^2) only)."""
+    srv, _ = make_server(duration=1.0, trajectory=traj, maxFeatures=25, numWalls=4)
+    cam = srv.cam
+    seen = 0
+    while srv.next_measurement_type() != srv.NONE:
+        if srv.next_measurement_type() == srv.IMU:
+            srv.get_imu()
+            continue
+        stamp, ids, y = srv.get_vision()
+        if stamp < 0.02:
+            continue  # the boundary handling at the first poses extrapolates (VIOSimulator.cpp:142-147)
+        assert len(ids) <= 25 and np.all(np.diff(ids) > 0)
+        s, tids, tp = srv.true_state(stamp)
+        lut = {int(i): k for k, i in enumerate(tids)}
+        for j, i in enumerate(ids):
+            q = tp[lut[int(i)]]
+            assert q[2] > 0
+            u, v = cam.fx * q[0] / q[2] + cam.cx, cam.fy * q[1] / q[2] + cam.cy
+            assert abs(u - y[2 * j]) < 5e-2 and abs(v - y[2 * j + 1]) < 5e-2
+            assert 0 <= y[2 * j] < cam.width and 0 <= y[2 * j + 1] < cam.height
+        seen += len(ids)
+    assert seen > 0
+
+
+def test_world_points_sit_on_the_walls():
+    """generateWorldPoints (VIOSimulator.cpp:65-127): numWalls = 1 puts every point on the +x wall of the trajectory box
+    (wallDistance outside the trajectory); numWalls = 4 uses the +x, +y, -y, -x walls in equal shares."""
+    for walls in (1, 4):
+        srv, _ = make_server(duration=1.0, numWalls=walls, wallDistance=2.0, numPoints=400)
+        s, ids, p = srv.true_state(0.5)
+        PC_R, PC_x = qmul(s[6:10], s[16:20]), s[10:13] + qrot(s[6:10], s[20:23])
+        world = np.array([qrot(PC_R, q) + PC_x for q in p])
+        world = world[np.argsort(ids)]  # undo the shuffle: wall index = (numWalls * id) // num
+        wall = (walls * np.arange(400)) // 400
+        assert np.ptp(world[wall == 0][:, 0]) < 1e-9 and world[wall == 0][0, 0] > 2.9  # x = max(traj x) + 2
+        if walls == 4:
+            assert np.ptp(world[wall == 1][:, 1]) < 1e-9 and np.ptp(world[wall == 2][:, 1]) < 1e-9 and np.ptp(world[wall == 3][:, 0]) < 1e-9
+            assert world[wall == 1][0, 1] > 0 > world[wall == 2][0, 1] and world[wall == 3][0, 0] < 0
+
+
+def test_seed_reproducibility_and_noise_flags():
+    a, _ = make_server(randomSeed=5)
+    b, _ = make_server(randomSeed=5)
+    c, _ = make_server(randomSeed=6)
+    assert np.array_equal(a.true_state(0.5)[2], b.true_state(0.5)[2])
+    assert not np.array_equal(a.true_state(0.5)[2], c.true_state(0.5)[2])
+    n, _ = make_server(randomSeed=5, inputNoise=1, outputNoise=1, initialNoise=1)
+    clean_imu, noisy_imu = a.get_imu() if a.next_measurement_type() == a.IMU else None, None
+    sa, _, pa = a.true_state(0.5, True)  # initialNoise off: withNoise has no effect
+    sn, _, pn = n.true_state(0.5, True)
+    assert np.array_equal(sa, a.true_state(0.5, False)[0])
+    assert not np.array_equal(sa, sn) and not np.array_equal(pa, pn)
+    assert np.array_equal(n.true_state(0.5, False)[0], sa)  # noise only when asked for
+
+
+def drive(srv, filters, frames, on_frame=None):
+    """main_sim.cpp:128-184: Image -> augmentLandmarkStates(ids, true state) -> processVisionData; IMU -> processIMUData."""
+    k = 0
+    while srv.next_measurement_type() != srv.NONE and k < frames:
+        if srv.next_measurement_type() == srv.IMU:
+            imu = srv.get_imu()
+            for f in filters:
+                f.process_imu(imu)
+            continue
+        stamp, ids, y = srv.get_vision()
+        s, tids, tp = srv.true_state(stamp, True)
+        for f in filters:
+            f.augment_landmark_states(ids, s, tids, tp)
+            f.process_vision(stamp, srv.cam, ids, y)
+        k += 1
+        if on_frame:
+            on_frame(stamp)
+
+
+@pytest.mark.parametrize("chart", [COORD_EUCLIDEAN, COORD_INVDEPTH])
+def test_oracle_filter_tracks_the_simulated_world(chart):
+    """The C++ simulator's data is self-consistent: the (CPU) oracle filter, started at the true state and driven
+    main_sim-style for 3 s with exact measurements, stays at the truth and is consistent (NEES well below 1)."""
+    fs = filter_settings(chart)
+    srv, fs = make_server(fs, duration=3.0, maxFeatures=20)
+    s0, ids0, p0 = srv.true_state(0.0, True)
+    orc = OracleFilter(fs, s0, ids0, p0, 0.0)
+    nees = []
+
+    def on_frame(stamp):
+        ts, tids, tp = srv.true_state(orc.get_time())
+        est, eids, ep = orc.state_estimate()
+        assert len(eids) <= 20
+        nees.append(orc.compute_nees(ts, tids, tp))
+        assert np.linalg.norm(est[10:13] - ts[10:13]) < 2e-2
+
+    drive(srv, [orc], 60, on_frame)
+    assert len(nees) == 60 and np.all(np.isfinite(nees)) and max(nees[5:]) < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chart,fast", [(COORD_EUCLIDEAN, 1), (COORD_INVDEPTH, 1), (COORD_EUCLIDEAN, 0)])
+def test_device_filter_matches_oracle_on_the_simulated_world(chart, fast):
+    """SURVEY.md §8(d) config 1 (main_sim, 20 features): device filter vs oracle, frame by frame, 1e-9."""
+    from eqvio_amd.capi import VIOFilter
+    from test_gpu_filter import compare
+
+    fs = filter_settings(chart, fastRiccati=fast)
+    srv, fs = make_server(fs, duration=2.0, maxFeatures=20, numWalls=4)
+    s0, ids0, p0 = srv.true_state(0.0, True)
+    orc = OracleFilter(fs, s0, ids0, p0, 0.0)
+    flt = VIOFilter(fs, max_landmarks=1024, sensor=s0, ids=ids0, p=p0, time=0.0)
+
+    def on_frame(stamp):
+        compare(flt, orc)
+        ts, tids, tp = srv.true_state(stamp)
+        a, b = flt.compute_nees(ts, tids, tp), orc.compute_nees(ts, tids, tp)
+        assert abs(a - b) <= 1e-7 * max(1.0, abs(b))
+
+    drive(srv, [orc, flt], 30 if fast else 12, on_frame)
+
+
+@pytest.mark.gpu
+def test_eqvio_sim_executable(tmp_path):
+    """The simulation main (eqvio_amd/host/main_sim.cpp) end to end, noisy measurements, InvDepth, fast Riccati."""
+    exe = os.path.join(ROOT, "eqvio_amd", "lib", "eqvio_sim")
+    out = subprocess.run([exe, "--duration", "5", "--maxFeatures", "30", "--numWalls", "4", "--seed", "3", "--coordinateChoice", "InvDepth", "--fastRiccati", "1",
+                          "--outputNoise", "--inputNoise", "--measurementNoise", "0.5", "--initialPointVariance", "0.01", "--quiet", "--output", str(tmp_path / "run")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "Processed 1000 IMU and 100 vision measurements." in out.stdout
+    m = re.search(r"mean NEES ([0-9.eE+-]+)\s+max NEES ([0-9.eE+-]+)\s+final position error ([0-9.eE+-]+)", out.stdout)
+    assert m, out.stdout
+    mean_nees, max_nees, pos_err = map(float, m.groups())
+    assert 0.0 < mean_nees < 3.0 and pos_err < 0.05
+    rows = (tmp_path / "run" / "IMUState.csv").read_text().strip().splitlines()
+    assert rows[0] == "time, px, py, pz, qw, qx, qy, qz, vx, vy, vz" and len(rows) == 101
