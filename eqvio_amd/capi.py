@@ -465,6 +465,12 @@ class VIOFilter:
     def core_handle(self):
         return self.lib.eqvio_filter_core(self.h)
 
+    def sigma_dim(self):
+        return self.lib.eqvio_filter_sigma_dim(self.h)
+
+    def synchronize(self):
+        load_eqf_lib().eqf_synchronize(self.core_handle())
+
     def last_timing(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         self.lib.eqvio_filter_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c))

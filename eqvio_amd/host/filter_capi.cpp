@@ -52,7 +52,12 @@ GICameraPtr makeCamera(const eqvio_camera* c) {
     return cam;
 }
 void initTimer() {
-    // the labels the reference's mains initialise (src/main_opt.cpp:139-141, src/main_sim.cpp:81-82)
+    // the labels the reference's mains initialise (src/main_opt.cpp:139-141, src/main_sim.cpp:81-82); loopTimer is
+    // thread_local here, so every thread that drives a filter initialises its own once
+    static thread_local bool done = false;
+    if (done)
+        return;
+    done = true;
     loopTimer.initialise({"correction", "features", "preprocessing", "propagation", "total", "total vision update", "write output"});
 }
 template <typename F> int guarded(eqvio_filter* f, F&& fn) {
@@ -116,6 +121,7 @@ static void grabTiming(eqvio_filter* f) {
 }
 int eqvio_filter_process_vision(eqvio_filter* f, double stamp, const eqvio_camera* cam, const int* ids, const double* y, int M) {
     return guarded(f, [&] {
+        initTimer();
         f->filter->processVisionData(makeMeasurement(stamp, makeCamera(cam), ids, y, M));
         grabTiming(f);
     });
@@ -176,6 +182,7 @@ int eqvio_filter_run_frames(eqvio_filter* f, const eqvio_camera* cam, int nframe
                             const int* meas_counts, const int* ids_all, const double* y_all) {
     int done = 0;
     const int rc = guarded(f, [&] {
+        initTimer();
         const GICameraPtr camPtr = makeCamera(cam);
         size_t io = 0, mo = 0;
         for (int j = 0; j < nframes; ++j) {
