@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_TIMING = 1, 2, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_TIMING = 1, 2, 3, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -467,6 +467,11 @@ class VIOFilter:
 
     def sigma_dim(self):
         return self.lib.eqvio_filter_sigma_dim(self.h)
+
+    def set_core_option(self, opt, val):
+        """eqf_set_option on the device context behind viewEqFState() (e.g. OPT_SIGMA_FP32)."""
+        if load_eqf_lib().eqf_set_option(self.core_handle(), opt, val) != 0:
+            raise RuntimeError("eqf_set_option failed")
 
     def synchronize(self):
         load_eqf_lib().eqf_synchronize(self.core_handle())

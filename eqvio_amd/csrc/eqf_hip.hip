@@ -165,7 +165,7 @@ struct eqf_ctx {
     static constexpr int kMaxSteps = kObsChunk;
     CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
-    int opt_dense = 0, opt_check = 0, opt_timing = 0;
+    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0;
     std::vector<double> last_gamma;
     int n_at_update = 0;
     bool gamma_stale = false; // d_gamma holds a newer Gamma than last_gamma (fetched lazily by eqf_last_gamma)
@@ -524,6 +524,15 @@ void eqf_destroy(eqf_ctx* c) {
     delete c;
 }
 
+static int round_sigma(eqf_ctx* c) {
+    if (!c->opt_f32 || c->n() == 0)
+        return 0;
+    const int n = c->n();
+    hipLaunchKernelGGL(k_round_f32, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma());
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int eqf_set_option(eqf_ctx* c, int option, int value) {
     if (!c)
         return EQF_E_BAD_ARG;
@@ -534,6 +543,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case EQF_OPT_CHECK_FINITE:
         c->opt_check = value;
         return 0;
+    case EQF_OPT_SIGMA_FP32:
+        c->opt_f32 = value;
+        return round_sigma(c);
     case 100:
         c->opt_timing = value;
         timing_reset(c);
@@ -619,6 +631,7 @@ int eqf_set_sigma(eqf_ctx* c, const double* sig, int n) {
     { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(c->h_buf, sig, sizeof(double) * (size_t)n * n);
     HIPCHK(hipMemcpy2DAsync(c->sigma(), sizeof(double) * c->ld, c->h_buf, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream));
+    { int _r = round_sigma(c); if (_r) return _r; }
     { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
 }
@@ -631,6 +644,7 @@ int eqf_set_sigma_diag(eqf_ctx* c, const double* diag, int n) {
     HIPCHK(hipMemcpyAsync(c->d_gamma, c->h_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_set_diag, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->d_gamma, c->sigma());
     HIPCHK(hipGetLastError());
+    { int _r = round_sigma(c); if (_r) return _r; }
     { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
 }
@@ -716,7 +730,7 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
     c->N += k;
     c->est_valid = false;
     c->meas_valid = false;
-    return 0;
+    return round_sigma(c);
 }
 
 int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
@@ -830,6 +844,7 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
         HIPCHK(hipGetLastError());
     }
     c->cur = 1 - c->cur;
+    { int _r = round_sigma(c); if (_r) return _r; }
     if (c->opt_check) {
         hipLaunchKernelGGL(k_check_finite, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), c->d_flags);
         HIPCHK(hipGetLastError());
@@ -887,7 +902,7 @@ int eqf_integrate_riccati_accurate(eqf_ctx* c, const double* imu13, double dt, c
     hipLaunchKernelGGL(k_add_noise_dense, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->ld, ra, c->d_PhiB, Sout);
     HIPCHK(hipGetLastError());
     c->cur = 1 - c->cur;
-    return 0;
+    return round_sigma(c);
 }
 
 int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k, int k, int discreteLift) {
@@ -1111,6 +1126,7 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         const int nt = blocks(n, 32);
         hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, c->sigma(), nt, c->d_gamma);
         HIPCHK(hipGetLastError());
+        { int _r = round_sigma(c); if (_r) return _r; }
     }
     {
         KTimer t(c, KN_LIFT);

@@ -1205,6 +1205,13 @@ __global__ void __launch_bounds__(256) k_set_diag(int n, int ld, const double* _
     Sig[r + (size_t)c * ld] = (r == c) ? diag[r] : 0.0;
 }
 // count non-finite entries of Sigma (the reference's assert(!Sigma.hasNaN()))
+// EQF_OPT_SIGMA_FP32: numerical model of an fp32 Sigma store - every element rounded to the nearest float
+__global__ void __launch_bounds__(256) k_round_f32(int n, int ld, double* __restrict__ Sig) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r < n)
+        Sig[r + (size_t)c * ld] = (double)(float)Sig[r + (size_t)c * ld];
+}
 __global__ void __launch_bounds__(256) k_check_finite(int n, int ld, const double* __restrict__ Sig, int* __restrict__ flags) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
