@@ -3,15 +3,13 @@
 // IMU -> processIMUData -> optional landmark reset. Configuration comes from --key value flags instead of a YAML file
 // (yaml-cpp and argparse are not in this image); defaults are the reference's.
 #include "VIOSimulator.hpp"
+#include "VIOWriter.hpp"
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <fstream>
-#include <iomanip>
 #include <iostream>
-#include <sys/stat.h>
 
 using namespace eqvio_amd;
 
@@ -80,16 +78,9 @@ int main(int argc, char** argv) {
     // the initial condition carries ALL world points (main_sim.cpp:105); the first augmentLandmarkStates trims it
     fs.maxLandmarks = std::max(fs.maxLandmarks, sim.numPoints + (int)sim.maxFeatures);
 
-    std::ofstream stateFile, neesFile;
-    if (!outputDir.empty()) {
-        if (outputDir.back() != '/')
-            outputDir += '/';
-        mkdir(outputDir.c_str(), 0755);
-        stateFile.open(outputDir + "IMUState.csv"); // VIOWriter.cpp:33-44
-        stateFile << "time, px, py, pz, qw, qx, qy, qz, vx, vy, vz\n";
-        neesFile.open(outputDir + "consistency.csv");
-        neesFile << "time, NEES, position_error\n";
-    }
+    std::unique_ptr<VIOWriter> vioWriter; // main_sim.cpp:108-122 (writeState)
+    if (!outputDir.empty())
+        vioWriter = std::make_unique<VIOWriter>(outputDir);
 
     try {
         VIOFilter filter(simDataServer.getInitialCondition(), fs);
@@ -103,6 +94,7 @@ int main(int argc, char** argv) {
             if (measType == MeasurementType::None)
                 break;
             if (measType == MeasurementType::Image) {
+                loopTimer.startLoop(); // as in main_opt.cpp:180: timing.csv gets one row per vision frame
                 VisionMeasurement measData = simDataServer.getSimVision();
                 if (!fullState)
                     filter.augmentLandmarkStates(measData.getIds(), simDataServer.getTrueState(measData.stamp, true));
@@ -114,12 +106,12 @@ int main(int argc, char** argv) {
                 neesSum += NEES;
                 neesMax = std::max(neesMax, NEES);
                 posErr = eqf::norm(estimatedState.sensor.pose.x - trueState.sensor.pose.x);
-                if (stateFile.is_open()) {
-                    const auto& P = estimatedState.sensor.pose;
-                    const auto& v = estimatedState.sensor.velocity;
-                    stateFile << std::setprecision(20) << filter.getTime() << ", " << std::setprecision(6) << P.x.x << ", " << P.x.y << ", " << P.x.z << ", " << P.R.w
-                              << ", " << P.R.x << ", " << P.R.y << ", " << P.R.z << ", " << v.x << ", " << v.y << ", " << v.z << '\n';
-                    neesFile << std::setprecision(20) << filter.getTime() << ", " << std::setprecision(6) << NEES << ", " << posErr << '\n';
+                if (vioWriter) { // main_sim.cpp:149-154
+                    vioWriter->writeStates(filter.getTime(), estimatedState);
+                    vioWriter->writeFeatures(measData);
+                    vioWriter->writeLandmarkError(filter.getTime(), trueState, estimatedState);
+                    vioWriter->writeConsistency(filter.getTime(), trueState, filter.viewEqFState());
+                    vioWriter->writeTiming(loopTimer.getLoopTimingData());
                 }
                 if (!quiet)
                     std::cout << '\r' << NEES << std::flush;

@@ -233,5 +233,26 @@ def test_eqvio_sim_executable(tmp_path):
     assert m, out.stdout
     mean_nees, max_nees, pos_err = map(float, m.groups())
     assert 0.0 < mean_nees < 3.0 and pos_err < 0.05
-    rows = (tmp_path / "run" / "IMUState.csv").read_text().strip().splitlines()
+    run = tmp_path / "run"
+    rows = (run / "IMUState.csv").read_text().strip().splitlines()
     assert rows[0] == "time, px, py, pz, qw, qx, qy, qz, vx, vy, vz" and len(rows) == 101
+    # the reference's writer formats (src/VIOWriter.cpp:33-228): one row per vision frame in every file
+    headers = {"camera.csv": "time, px, py, pz, qw, qx, qy, qz", "bias.csv": "time, bias_gyr_x, bias_gyr_y, bias_gyr_z, bias_acc_x, bias_acc_y, bias_acc_z",
+               "points.csv": "time, p1id, p1x, p1y, p1z, ...", "features.csv": "time, z1id, z1x, z1y, ...", "landmarkError.csv": "time, lm_err_1, lm_err_2, ...",
+               "nees.csv": "time, NEES, DoF, PoseNEES, AttitudeNEES",
+               "timing.csv": "time, correction, features, preprocessing, propagation, total, total vision update, write output"}
+    for name, header in headers.items():
+        lines = (run / name).read_text().strip().splitlines()
+        assert lines[0] == header and len(lines) == 101, name
+    for name in ["trueState.csv", "poseConsistency.csv", "cameraConsistency.csv", "biasConsistency.csv"]:
+        assert len((run / name).read_text().strip().splitlines()) == 101, name
+    nees = np.array([[float(v) for v in l.split(", ")] for l in (run / "nees.csv").read_text().strip().splitlines()[1:]])
+    assert abs(nees[:, 1].mean() - mean_nees) <= 1e-4 * mean_nees and np.all(nees[:, 2] == 21 + 3 * 30) and np.all(nees[:, 3] >= 0) and np.all(nees[:, 4] >= 0)
+    last_state = [float(v) for v in rows[-1].split(", ")]
+    assert abs(last_state[0] - 4.95) < 1e-12 and abs(np.linalg.norm(last_state[4:8]) - 1.0) < 1e-5
+    feat = (run / "features.csv").read_text().strip().splitlines()[-1].split(", ")
+    assert (len(feat) - 1) % 3 == 0 and (len(feat) - 1) // 3 == 30
+    pose_c = np.array([[float(v) for v in l.split(", ")] for l in (run / "poseConsistency.csv").read_text().strip().splitlines()[1:]])
+    assert pose_c.shape == (100, 13) and np.all(pose_c[:, 7:] > 0)  # variances
+    # errors within 5 sigma of the filter's own uncertainty almost always (consistency of the whole chain)
+    assert np.mean(np.abs(pose_c[10:, 1:7]) <= 5 * np.sqrt(pose_c[10:, 7:])) > 0.95
