@@ -4,6 +4,9 @@
 // (yaml-cpp and argparse are not in this image); defaults are the reference's.
 #include "VIOSimulator.hpp"
 #include "VIOWriter.hpp"
+#include "cli.hpp"
+#include <fstream>
+#include <iomanip>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -16,8 +19,8 @@ using namespace eqvio_amd;
 static void usage() {
     std::puts("usage: eqvio_sim [--duration S] [--trajectory wave|square|sine|line] [--numPoints N] [--numWalls W] [--wallDistance D]\n"
               "                 [--maxFeatures M] [--seed S] [--imuFreq HZ] [--imageFreq HZ] [--initialNoise] [--inputNoise] [--outputNoise]\n"
-              "                 [--coordinateChoice Euclidean|InvDepth] [--fastRiccati 0|1] [--fullState] [--landmarkReset S]\n"
-              "                 [--initialPointVariance V] [--measurementNoise PX] [--device D] [--output DIR] [--quiet]");
+              "                 [--fullState] [--landmarkReset S] [--output DIR] [--writeDataset DIR] [--quiet]\n"
+              "                 [--<eqf setting> VALUE ...]   (names of VIOFilter::Settings, e.g. --fastRiccati 1 --coordinateChoice InvDepth)");
 }
 
 int main(int argc, char** argv) {
@@ -26,10 +29,10 @@ int main(int argc, char** argv) {
     VIOFilter::Settings fs;
     bool fullState = false, quiet = false;
     double landmarkResetTime = -1.0;
-    std::string outputDir;
+    std::string outputDir, datasetDir;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
-        auto val = [&]() -> const char* {
+        std::function<const char*()> val = [&]() -> const char* {
             if (i + 1 >= argc) {
                 usage();
                 std::exit(2);
@@ -48,23 +51,13 @@ int main(int argc, char** argv) {
         else if (a == "--initialNoise") sim.initialNoise = true;
         else if (a == "--inputNoise") sim.inputNoise = true;
         else if (a == "--outputNoise") sim.outputNoise = true;
-        else if (a == "--coordinateChoice") {
-            const std::string c = val();
-            if (c == "Euclidean") fs.coordinateChoice = CoordinateChoice::Euclidean;
-            else if (c == "InvDepth") fs.coordinateChoice = CoordinateChoice::InvDepth;
-            else {
-                std::fprintf(stderr, "Invalid coordinate choice. Valid choices here are Euclidean, InvDepth.\n");
-                return 2;
-            }
-        } else if (a == "--fastRiccati") fs.fastRiccati = std::atoi(val()) != 0;
         else if (a == "--fullState") fullState = true;
         else if (a == "--landmarkReset") landmarkResetTime = std::atof(val());
-        else if (a == "--initialPointVariance") fs.initialPointVariance = std::atof(val());
-        else if (a == "--measurementNoise") fs.measurementNoise = std::atof(val());
-        else if (a == "--device") fs.device = std::atoi(val());
         else if (a == "--output") outputDir = val();
+        else if (a == "--writeDataset") datasetDir = val();
         else if (a == "--quiet") quiet = true;
-        else {
+        else if (parseFilterFlag(a, val, fs)) {
+        } else {
             usage();
             return a == "--help" ? 0 : 2;
         }
@@ -81,6 +74,19 @@ int main(int argc, char** argv) {
     std::unique_ptr<VIOWriter> vioWriter; // main_sim.cpp:108-122 (writeState)
     if (!outputDir.empty())
         vioWriter = std::make_unique<VIOWriter>(outputDir);
+
+    // --writeDataset DIR: the measurements of this run in the ASL layout eqvio_opt reads (imu.csv with ns stamps; the
+    // feature tracks are features.csv of --output), plus the ground-truth poses
+    std::ofstream imuOut, gtOut;
+    if (!datasetDir.empty()) {
+        if (datasetDir.back() != '/')
+            datasetDir += '/';
+        VIOWriter makeDir(datasetDir);
+        imuOut.open(datasetDir + "imu.csv");
+        imuOut << "#timestamp [ns],w_RS_S_x [rad s^-1],w_RS_S_y [rad s^-1],w_RS_S_z [rad s^-1],a_RS_S_x [m s^-2],a_RS_S_y [m s^-2],a_RS_S_z [m s^-2]\n";
+        gtOut.open(datasetDir + "groundtruth.csv");
+        gtOut << "#timestamp [ns],p_RS_R_x [m],p_RS_R_y [m],p_RS_R_z [m],q_RS_w [],q_RS_x [],q_RS_y [],q_RS_z []\n";
+    }
 
     try {
         VIOFilter filter(simDataServer.getInitialCondition(), fs);
@@ -117,6 +123,13 @@ int main(int argc, char** argv) {
                     std::cout << '\r' << NEES << std::flush;
             } else {
                 const IMUVelocity imuData = simDataServer.getIMU();
+                if (imuOut.is_open()) {
+                    imuOut << std::llround(imuData.stamp * 1e9) << std::setprecision(17) << ',' << imuData.gyr.x << ',' << imuData.gyr.y << ',' << imuData.gyr.z << ','
+                           << imuData.acc.x << ',' << imuData.acc.y << ',' << imuData.acc.z << '\n';
+                    const VIOState t = simDataServer.getTrueState(imuData.stamp);
+                    gtOut << std::llround(imuData.stamp * 1e9) << std::setprecision(17) << ',' << t.sensor.pose.x.x << ',' << t.sensor.pose.x.y << ',' << t.sensor.pose.x.z << ','
+                          << t.sensor.pose.R.w << ',' << t.sensor.pose.R.x << ',' << t.sensor.pose.R.y << ',' << t.sensor.pose.R.z << '\n';
+                }
                 filter.processIMUData(imuData);
                 ++imuDataCounter;
                 if (filter.getTime() >= lastLandmarkReset + landmarkResetTime) { // false while lastLandmarkReset is NaN
