@@ -165,7 +165,7 @@ struct eqf_ctx {
     static constexpr int kMaxSteps = kObsChunk;
     CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
-    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0;
+    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 1;
     std::vector<double> last_gamma;
     int n_at_update = 0;
     bool gamma_stale = false; // d_gamma holds a newer Gamma than last_gamma (fetched lazily by eqf_last_gamma)
@@ -542,6 +542,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_CHECK_FINITE:
         c->opt_check = value;
+        return 0;
+    case EQF_OPT_FUSED_UPDATE:
+        c->opt_fused = value;
         return 0;
     case EQF_OPT_SIGMA_FP32:
         c->opt_f32 = value;
@@ -980,7 +983,8 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
 
 // Blocked right-looking factorisation of Z (rows x m, leading dimension ldz): one launch per 32-column panel
 // (k_chol_step), preceded by the elimination of the first diagonal tile. Rows >= m of W receive Z[rows >= m] L^-T.
-static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double* W) {
+// nsig > 0: the covariance update Sigma -= W W^T and Gamma = W z ride along in the step kernels (see k_chol_step)
+static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double* W, int nsig = 0, double* Sig = nullptr, double* gamma = nullptr) {
     constexpr int NB = 32;
     {
         KTimer t(c, KN_CHOL_UPDATE);
@@ -994,11 +998,12 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
         double* Lin = c->d_Linv + 1024 * (step & 1);
         double* Lout = c->d_Linv + 1024 * ((step + 1) & 1);
         KTimer t(c, KN_CHOL_PANEL);
-        if (c0 < m) {
-            hipLaunchKernelGGL(k_chol_step, dim3(blocks(rows - c0, 32), blocks(m - c0, 32)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, 1);
-        } else {
-            hipLaunchKernelGGL(k_chol_step, dim3(blocks(rows - c0, 32), 1), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, 0);
-        }
+        const int gx = blocks(rows - c0, 32);
+        const int nyS = c0 < m ? blocks(m - c0, 32) : 1;
+        const int nts = blocks(nsig, 32);
+        const int nySig = nsig > 0 ? blocks(nts * (nts + 1) / 2, gx) : 0;
+        hipLaunchKernelGGL(k_chol_step, dim3(gx, nyS + nySig), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0, nyS, nsig, c->ld,
+                           Sig, gamma);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1118,16 +1123,20 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
                            c->d_ytil, c->d_Z);
         HIPCHK(hipGetLastError());
     }
-    rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W);
-    if (rc)
-        return rc;
-    {
+    if (c->opt_fused) {
+        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, n, c->sigma(), c->d_gamma);
+        if (rc)
+            return rc;
+    } else {
+        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W);
+        if (rc)
+            return rc;
         KTimer t(c, KN_SYRK);
         const int nt = blocks(n, 32);
         hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, c->sigma(), nt, c->d_gamma);
         HIPCHK(hipGetLastError());
-        { int _r = round_sigma(c); if (_r) return _r; }
     }
+    { int _r = round_sigma(c); if (_r) return _r; }
     {
         KTimer t(c, KN_LIFT);
         hipLaunchKernelGGL(k_lift, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),

@@ -726,6 +726,8 @@ __device__ __forceinline__ void ldl_inverse_tile(const double* __restrict__ sD, 
                                                  double* __restrict__ swork) {
     if (threadIdx.x >= 64)
         return;
+    // this wave is the critical path of the whole frame: win the issue arbitration against co-resident workgroups
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
     double* sA = swork;            // elimination exchange (16 x 18)
@@ -800,13 +802,37 @@ __global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double
     ldl_inverse_tile(sD, 33, w, LinvOut, flags, swork);
 }
 
+// Sigma fusion (nsig > 0): the workgroups with blockIdx.y >= nyS own the lower 32x32 tiles of Sigma and apply this
+// panel's share of the covariance update, Sigma -= W_k W_k^T (VIO_eqf.cpp:131 with K C Sigma = W W^T), in the shadow of
+// the diagonal-tile elimination; their diagonal tiles also accumulate Gamma += W_k z_k (VIO_eqf.cpp:119). In effect the
+// factorisation runs on [[S, T^T],[T, Sigma]] and stops after the S block: what is left in the corner is the Schur
+// complement Sigma - T S^-1 T^T.
 __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
-                                                   const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update) {
+                                                   const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update, int nyS,
+                                                   int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma) {
     const int c0 = kb + w;
-    const int i0 = c0 + blockIdx.x * 32;
-    const int j0 = c0 + blockIdx.y * 32;
-    if (update && (i0 + 31 < j0))
-        return; // strictly upper tile of the symmetric part: never read
+    int i0, j0, ilim = rows, jlim = m;
+    const bool sig = (int)blockIdx.y >= nyS;
+    if (sig) {
+        const int nt = (nsig + 31) >> 5;
+        int L = ((int)blockIdx.y - nyS) * (int)gridDim.x + (int)blockIdx.x;
+        if (L >= nt * (nt + 1) / 2)
+            return;
+        int bj = 0;
+        while (L >= nt - bj) { // column bj holds (nt - bj) lower tiles
+            L -= nt - bj;
+            ++bj;
+        }
+        i0 = m + 32 * (bj + L);
+        j0 = m + 32 * bj;
+        ilim = jlim = m + nsig;
+        update = 1;
+    } else {
+        i0 = c0 + blockIdx.x * 32;
+        j0 = c0 + blockIdx.y * 32;
+        if (update && (i0 + 31 < j0))
+            return; // strictly upper tile of the symmetric part: never read
+    }
     __shared__ double sLinv[32 * CH_LDP];
     __shared__ double sPI[32 * CH_LDP];
     __shared__ double sPJ[32 * CH_LDP];
@@ -827,8 +853,8 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     double opI[8], opJ[8];
     {
         const int rowI = i0 + 16 * ihP + lr, rowJ = j0 + 16 * ihP + lr;
-        const int rowIc = min(rowI, rows - 1), rowJc = min(rowJ, m - 1);
-        const double zI = rowI < rows ? 1.0 : 0.0, zJ = (needJ && rowJ < m) ? 1.0 : 0.0;
+        const int rowIc = min(rowI, ilim - 1), rowJc = min(rowJ, jlim - 1);
+        const double zI = rowI < ilim ? 1.0 : 0.0, zJ = (needJ && rowJ < jlim) ? 1.0 : 0.0;
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
             const int p = 4 * st + lk;
@@ -841,11 +867,11 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     const int ihU = wave & 1, jhU = wave >> 1;
     double zt[4];
     {
-        const int i = min(i0 + 16 * ihU + lr, rows - 1);
+        const int i = min(i0 + 16 * ihU + lr, ilim - 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int j = min(j0 + 16 * jhU + lk + 4 * q, m - 1);
-            zt[q] = update ? Z[i + (size_t)j * ldz] : 0.0;
+            const int j = min(j0 + 16 * jhU + lk + 4 * q, jlim - 1);
+            zt[q] = sig ? Sig[(i - m) + (size_t)(j - m) * ldsig] : (update ? Z[i + (size_t)j * ldz] : 0.0);
         }
     }
 #pragma unroll
@@ -872,7 +898,7 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     }
     __syncthreads();
     // 4. final W / z rows of this panel
-    if (blockIdx.y == 0) {
+    if (!sig && blockIdx.y == 0) {
         const int row = i0 + r;
         if (row < rows && row >= m) {
 #pragma unroll
@@ -885,8 +911,26 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     }
     if (!update)
         return;
+    if (sig && diag_tile) {
+        // Gamma[I] (+)= P_I z,  z_c = sum_p yTilde[p] Linv[c][p]  (the yTilde row of Z is row rows - 1)
+        if (tid < 32) {
+            double z = 0.0;
+            for (int p2 = 0; p2 < w; ++p2)
+                z = fma(Z[(rows - 1) + (size_t)(kb + p2) * ldz], sLinv[tid + p2 * CH_LDP], z);
+            swork[tid] = z;
+        }
+        __syncthreads();
+        if (tid < 32 && i0 + tid < ilim) {
+            double gsum = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c)
+                gsum = fma(sPI[tid + c * CH_LDP], swork[c], gsum);
+            const int gi = i0 + tid - m;
+            gamma[gi] = (kb == 0) ? gsum : gamma[gi] + gsum;
+        }
+    }
     // 3. Z[I, J] -= P_I P_J^T : wave -> 16x16 sub-tile (ihU, jhU), K = 32
-    const bool next_diag = (blockIdx.x == 0 && blockIdx.y == 0);
+    const bool next_diag = (!sig && blockIdx.x == 0 && blockIdx.y == 0);
     {
         const double* pj = diag_tile ? sPI : sPJ;
         d4 acc = {0, 0, 0, 0};
@@ -902,7 +946,13 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
         for (int q = 0; q < 4; ++q) {
             const int j = j0 + 16 * jhU + lk + 4 * q;
             const double v = zt[q] - acc[q];
-            if (i < rows && j < m)
+            if (sig) {
+                if (i < ilim && j < jlim && (!diag_tile || i >= j)) {
+                    Sig[(i - m) + (size_t)(j - m) * ldsig] = v;
+                    if (i != j)
+                        Sig[(j - m) + (size_t)(i - m) * ldsig] = v;
+                }
+            } else if (i < rows && j < m)
                 Z[i + (size_t)j * ldz] = v;
             if (next_diag)
                 sPJ[16 * ihU + lr + (16 * jhU + lk + 4 * q) * CH_LDP] = v; // keep the updated next-diagonal tile on chip
