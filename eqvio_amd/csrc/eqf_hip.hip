@@ -165,7 +165,7 @@ struct eqf_ctx {
     static constexpr int kMaxSteps = kObsChunk;
     CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
-    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 1;
+    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0;
     std::vector<double> last_gamma;
     int n_at_update = 0;
     bool gamma_stale = false; // d_gamma holds a newer Gamma than last_gamma (fetched lazily by eqf_last_gamma)

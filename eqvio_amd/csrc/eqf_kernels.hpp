@@ -649,59 +649,96 @@ __device__ __forceinline__ d4 mfma16_nt(const double* __restrict__ Ib, int ldi, 
     }
     return acc;
 }
-// 16x16 elimination on ONE wave: lane (r = lane & 15, cq = lane >> 4) owns the four entries D[r][cq + 4k], k = 0..3
-// (identity padding where col > row or outside the tile) and receives Linv[r][cq + 4k] (0 above the diagonal).
-// Block LDL^T with 2x2 pivots. Every round the lanes write their entries of the partially eliminated tile and of
-// M = Lu^-1 to LDS UNCONDITIONALLY (no divergent branches) and read back the pivot block, their row's multipliers and
-// the pivot rows; a single wave needs NO barrier for that: the LDS executes one wave's accesses in program order.
-// sA: tile row-major [r*18 + c] (so (A[r][j], A[r][j+1]) is one 16-byte read; row stride 18 doubles = 36 banks keeps the 16
-// lanes of a column on distinct banks), sM: M column-major [c*16 + r].
-__device__ __forceinline__ void ldl16_inverse_wave(double a[4], double out[4], int* __restrict__ flags, bool check_row, double* __restrict__ sA,
-                                                    double* __restrict__ sM) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 15, cq = lane >> 4;
-    double mm[4], tri[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        mm[k] = (r == cq + 4 * k) ? 1.0 : 0.0;
-        tri[k] = (cq + 4 * k <= r) ? 1.0 : 0.0;
-    }
-    double p11 = 1.0, p21 = 0.0, p22 = 1.0;
-#pragma unroll 1
-    for (int j = 0; j < 16; j += 2) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sA[r * 18 + cq + 4 * k] = a[k];
-            sM[(cq + 4 * k) * 16 + r] = mm[k];
-        }
-        const dpair dj = *reinterpret_cast<const dpair*>(sA + j * 18 + j);        // (A[j][j], .)
-        const dpair dj1 = *reinterpret_cast<const dpair*>(sA + (j + 1) * 18 + j); // (A[j+1][j], A[j+1][j+1])
-        const dpair me = *reinterpret_cast<const dpair*>(sA + r * 18 + j);        // (A[r][j], A[r][j+1])
-        dpair cc[4], rr[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cc[k] = *reinterpret_cast<const dpair*>(sA + (cq + 4 * k) * 18 + j); // (A[c][j], A[c][j+1])
-            rr[k] = *reinterpret_cast<const dpair*>(sM + (cq + 4 * k) * 16 + j); // (M[j][c], M[j+1][c])
-        }
-        const double d11 = dj.x, d21 = dj1.x, d22 = dj1.y;
-        if ((r >> 1) == (j >> 1)) {
-            p11 = d11;
-            p21 = d21;
-            p22 = d22;
-        }
-        const double idet = (r > j + 1) ? fast_rcp(fma(d11, d22, -d21 * d21)) : 0.0;
-        const double f1 = (me.x * d22 - me.y * d21) * idet; // (A[r][j], A[r][j+1]) * D^-1
-        const double f2 = (me.y * d11 - me.x * d21) * idet;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            a[k] = fma(-f2 * tri[k], cc[k].y, fma(-f1 * tri[k], cc[k].x, a[k]));
-            mm[k] = fma(-f2, rr[k].y, fma(-f1, rr[k].x, mm[k]));
-        }
-    }
-    // Linv = blkdiag(chol(D_b)^-1) M : row j -> M[j]/l11 ; row j+1 -> (M[j+1] - (l21/l11) M[j]) / l22
+// ---- cross-lane helpers for the register-resident elimination ----------------------------------------------------
+// DPP row_newbcast:J (gfx90a+): every lane of a 16-lane row receives the value lane J of ITS row holds.
+template <int J> __device__ __forceinline__ double row_bcast(double v) {
+    // 64-bit operand + row_newbcast -> one v_mov_b64_dpp (DP-ALU DPP). Every lane is written, so `old` is never used: an
+    // empty asm "defines" it, which spares the copy a tied old = source operand would cost.
+    double old;
+    asm volatile("" : "=v"(old));
+    return __builtin_amdgcn_update_dpp(old, v, 0x150 + J, 0xf, 0xf, false);
+}
+// odd lanes receive the value of the lane below them (quad_perm [0,0,2,2]); even lanes keep their own
+__device__ __forceinline__ double lane_below_for_odd(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xA0, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xA0, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int L> __device__ __forceinline__ double read_lane(double v) { // wave-uniform value of lane L
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), L), __builtin_amdgcn_readlane(__double2loint(v), L));
+}
+__device__ __forceinline__ double fetch_lane(double v, int byte_addr) { // value held by lane byte_addr / 4
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)));
+}
+// One 2x2-pivot round (pivot rows J, J+1) of the 16x16 block LDL^T below, everything in registers: lane (r, cq) holds
+// A[r][cq + 4k] of the SYMMETRIC partially eliminated tile and M[r][cq + 4k] of M = Lu^-1. The pivot rows reach the lanes
+// by DPP row broadcasts (A[c][J] = A[J][c] sits in lane J of the lane's own 16-lane row), the lane's own multiplier
+// entries A[r][J], A[r][J+1] by ds_bpermute, the pivot block by v_readlane: no LDS traffic in the loop.
+// Software pipelined: the round receives its pivot block / multiplier entries (fetched by the previous round right after
+// that round updated the two columns they live in) and fetches the next round's before finishing its own updates.
+struct PivotIn {
+    double d11, d21, d22, mex, mey;
+};
+template <int J> __device__ __forceinline__ PivotIn ldl16_fetch(const double (&a)[4], int r) {
+    PivotIn p;
+    p.d11 = read_lane<J + 16 * (J & 3)>(a[J >> 2]);
+    p.d21 = read_lane<J + 1 + 16 * (J & 3)>(a[J >> 2]);
+    p.d22 = read_lane<J + 1 + 16 * ((J + 1) & 3)>(a[(J + 1) >> 2]);
+    p.mex = fetch_lane(a[J >> 2], 4 * (r + 16 * (J & 3)));             // A[r][J]
+    p.mey = fetch_lane(a[(J + 1) >> 2], 4 * (r + 16 * ((J + 1) & 3))); // A[r][J+1]
+    return p;
+}
+template <int J> __device__ __forceinline__ PivotIn ldl16_round(double (&a)[4], double (&mm)[4], int r, const PivotIn in) {
+    const double idet = (r > J + 1) ? fast_rcp(fma(in.d11, in.d22, -in.d21 * in.d21)) : 0.0;
+    const double f1 = (in.mex * in.d22 - in.mey * in.d21) * idet; // (A[r][J], A[r][J+1]) * D^-1
+    const double f2 = (in.mey * in.d11 - in.mex * in.d21) * idet;
+    constexpr int kA = (J + 2) >> 2, kB = (J + 3) >> 2; // registers that hold columns J+2, J+3: the next pivot columns
+    a[kA & 3] = fma(-f2, row_bcast<J + 1>(a[kA & 3]), fma(-f1, row_bcast<J>(a[kA & 3]), a[kA & 3]));
+    if (kB != kA)
+        a[kB & 3] = fma(-f2, row_bcast<J + 1>(a[kB & 3]), fma(-f1, row_bcast<J>(a[kB & 3]), a[kB & 3]));
+    PivotIn next = in;
+    if (J + 2 < 16)
+        next = ldl16_fetch<(J + 2 < 16) ? J + 2 : 0>(a, r);
+    // Static pruning (J and k are compile-time): a register of A whose four columns 4k .. 4k+3 are all <= J+1 holds only
+    // eliminated columns (never read again); a register of M whose columns are all > J+1 still holds identity columns on
+    // which the pivot rows J, J+1 of M are zero. On average 4.6 of the 8 registers need the rank-2 update.
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        sM[(cq + 4 * k) * 16 + r] = mm[k];
+        if (k != (kA & 3) && k != (kB & 3) && 4 * k + 3 >= J + 2)
+            a[k] = fma(-f2, row_bcast<J + 1>(a[k]), fma(-f1, row_bcast<J>(a[k]), a[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (4 * k <= J + 1)
+            mm[k] = fma(-f2, row_bcast<J + 1>(mm[k]), fma(-f1, row_bcast<J>(mm[k]), mm[k]));
+    return next;
+}
+// 16x16 elimination on ONE wave: lane (r = lane & 15, cq = lane >> 4) owns the four entries D[r][cq + 4k], k = 0..3, of the
+// full symmetric tile (identity padding outside the tile) and receives Linv[r][cq + 4k] (0 above the diagonal).
+// Block LDL^T with 2x2 pivots while applying the same row operations to an identity (M = Lu^-1), then
+// Linv = blkdiag(chol(D_b)^-1) M. sX: 16 x 17 doubles of LDS, used once after the loop to hand every lane the pivot
+// block of its own row pair (rows stop changing after their own round, so the final tile still holds every pivot block).
+__device__ __forceinline__ void ldl16_inverse_wave(double (&a)[4], double (&out)[4], int* __restrict__ flags, bool check_row, double* __restrict__ sX) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, cq = lane >> 4;
+    double mm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        mm[k] = (r == cq + 4 * k) ? 1.0 : 0.0;
+    PivotIn pv = ldl16_fetch<0>(a, r);
+    pv = ldl16_round<0>(a, mm, r, pv);
+    pv = ldl16_round<2>(a, mm, r, pv);
+    pv = ldl16_round<4>(a, mm, r, pv);
+    pv = ldl16_round<6>(a, mm, r, pv);
+    pv = ldl16_round<8>(a, mm, r, pv);
+    pv = ldl16_round<10>(a, mm, r, pv);
+    pv = ldl16_round<12>(a, mm, r, pv); // the round of rows 14, 15 has no rows left to update
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        sX[r * 17 + cq + 4 * k] = a[k];
+    const int j = r & ~1;
+    const double p11 = sX[j * 17 + j], p21 = sX[(j + 1) * 17 + j], p22 = sX[(j + 1) * 17 + j + 1];
+    // Linv = blkdiag(chol(D_b)^-1) M : row j -> M[j]/l11 ; row j+1 -> (M[j+1] - (l21/l11) M[j]) / l22
     const bool ok = (p11 > 0.0) && (fma(p11, p22, -p21 * p21) > 0.0);
     if (cq == 0 && check_row && !ok)
         flags[0] = 1;
@@ -714,7 +751,7 @@ __device__ __forceinline__ void ldl16_inverse_wave(double a[4], double out[4], i
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = cq + 4 * k;
-        const double mprev = sM[c * 16 + (r & ~1)];
+        const double mprev = lane_below_for_odd(mm[k]);
         out[k] = (c <= r) ? fma(s_prev, mprev, s_self * mm[k]) : 0.0;
     }
 }
@@ -742,9 +779,9 @@ __device__ __forceinline__ void ldl_inverse_tile(const double* __restrict__ sD, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = lk + 4 * k;
-        a[k] = (lr >= c) ? sD[lr + c * ldd] : ((lr == c) ? 1.0 : 0.0);
+        a[k] = sD[max(lr, c) + min(lr, c) * ldd]; // symmetric fill from the valid lower triangle
     }
-    ldl16_inverse_wave(a, o, flags, lr < w, sA, sM);
+    ldl16_inverse_wave(a, o, flags, lr < w, sA);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = lk + 4 * k;
@@ -766,13 +803,13 @@ __device__ __forceinline__ void ldl_inverse_tile(const double* __restrict__ sD, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = lr, j = lk + 4 * q;
-            const double d22 = (i >= j) ? sD[16 + i + (16 + j) * ldd] : 0.0;
-            a[q] = (i >= j) ? d22 - s[q] : ((i == j) ? 1.0 : 0.0); // Schur complement entry S22[i][j], j = lk + 4q
+            const double d22 = sD[16 + max(i, j) + (16 + min(i, j)) * ldd];
+            a[q] = d22 - s[q]; // Schur complement entry S22[i][j], j = lk + 4q (L21 L21^T is symmetric to rounding)
             sYJ[j + i * 16] = y[q];                                // Y[i][j] stored for use as J[c = j][p = i]
         }
     }
     // C. second diagonal block (the lane -> entry mapping of the MFMA result is the elimination's own mapping)
-    ldl16_inverse_wave(a, o, flags, 16 + lr < w, sA, sM);
+    ldl16_inverse_wave(a, o, flags, 16 + lr < w, sA);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = lk + 4 * k;

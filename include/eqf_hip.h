@@ -37,8 +37,9 @@ enum {
     EQF_OPT_RICCATI_DENSE = 1, /* 1: propagate with two dense fp64 MFMA GEMMs (F Sigma F^T, F materialised);
                                   0 (default): structure-exploiting arrow-form kernel */
     EQF_OPT_CHECK_FINITE = 2,  /* 1: scan Sigma/X for non-finite values after propagate/update */
-    EQF_OPT_FUSED_UPDATE = 4,  /* 1 (default): Sigma -= W W^T and Gamma = W z ride along in the factorisation step kernels;
-                                  0: separate split-K SYRK kernel after the chain (kept for A/B measurements) */
+    EQF_OPT_FUSED_UPDATE = 4,  /* 1: Sigma -= W W^T and Gamma = W z ride along in the factorisation step kernels;
+                                  0 (default): one split-K SYRK kernel after the chain. Measured: the fused form re-dirties all
+                                  of Sigma in every step and the per-kernel write-back costs more than the saved launch. */
     EQF_OPT_SIGMA_FP32 = 3     /* 1: fp32-Sigma model (BASELINE config 5): Sigma is rounded to the nearest float every time it
                                   is stored (set, append, propagate, update); all arithmetic stays fp64. Storage itself is
                                   still 8 bytes per element in this round: this option answers the accuracy question only. */
