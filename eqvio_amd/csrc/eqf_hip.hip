@@ -1133,7 +1133,7 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
             return rc;
         KTimer t(c, KN_SYRK);
         const int nt = blocks(n, 32);
-        hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, c->sigma(), nt, c->d_gamma);
+        hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, c->sigma(), nt, c->d_gamma);
         HIPCHK(hipGetLastError());
     }
     { int _r = round_sigma(c); if (_r) return _r; }

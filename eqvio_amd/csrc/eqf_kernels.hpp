@@ -1027,7 +1027,7 @@ struct TileRed {
 };
 // If zvec != nullptr the workgroup also returns, in gv_out (valid in lanes 0..31 of the workgroup), the GEMV by-product
 // g[i0 + t] = sum_k P[i0 + t][k] * zvec[k * ldzv] from the operand values it loads anyway.
-template <bool WITH_GEMV>
+template <bool WITH_GEMV, int NW = 4>
 __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__ P, int ldp, int i0, int rowsP, const double* __restrict__ Qm, int ldq, int j0,
                                                       int rowsQ, int K, double* __restrict__ sred /* 4*1024 doubles */, const double* __restrict__ zvec = nullptr,
                                                       int ldzv = 0, double* gv_out = nullptr) {
@@ -1042,7 +1042,7 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
     double ga = 0.0, gb = 0.0;
     const int nsteps = (K + 3) >> 2;
 #pragma unroll 4
-    for (int st = wave; st < nsteps; st += 4) {
+    for (int st = wave; st < nsteps; st += NW) {
         const int kk = 4 * st + lk;
         const int kc = min(kk, K - 1);
         const double zk = kk < K ? 1.0 : 0.0;
@@ -1073,8 +1073,12 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
     TileRed out;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int idx = (tid & 31) + 32 * ((tid >> 5) + 8 * e);
-        out.v[e] = (sred[idx] + sred[1024 + idx]) + (sred[2048 + idx] + sred[3072 + idx]);
+        const int idx = (tid & 31) + 32 * (((tid & 255) >> 5) + 8 * e); // threads >= 256 (NW = 8) duplicate the first 256
+        double sum = 0.0; // fixed order: deterministic
+#pragma unroll
+        for (int q = 0; q < NW; q += 4)
+            sum += (sred[q * 1024 + idx] + sred[(q + 1) * 1024 + idx]) + (sred[(q + 2) * 1024 + idx] + sred[(q + 3) * 1024 + idx]);
+        out.v[e] = sum;
     }
     if (WITH_GEMV) {
         // partial sums: per wave, per lk group (4), rows 0..15 (ga) and 16..31 (gb): reduce 16 partials per row via LDS
@@ -1085,7 +1089,7 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
         if (tid < 32) {
             double g = 0.0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
+            for (int q = 0; q < 4 * NW; ++q)
                 g += sred[q * 32 + tid];
             *gv_out = g;
         }
@@ -1121,9 +1125,10 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 
 // K9: Sigma <- Sigma - W W^T  ( = Sigma - K C Sigma, VIO_eqf.cpp:131 ): lower 32x32 tiles computed (one workgroup
 // each, K = m split over its 4 waves), the strictly-lower ones mirrored so Sigma stays exactly symmetric.
-__global__ void __launch_bounds__(256) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, double* __restrict__ Sig, int nt,
+constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
+__global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, double* __restrict__ Sig, int nt,
                                                   double* __restrict__ gamma) {
-    __shared__ double sred[4096];
+    __shared__ double sred[1024 * SYRK_NW];
     int b = blockIdx.x;
     int bj = 0;
     while (b >= nt - bj) { // column bj holds (nt - bj) lower tiles
@@ -1137,11 +1142,13 @@ __global__ void __launch_bounds__(256) k_syrk_sub(int n, int m, int ld, int ldz,
     double gv = 0.0;
     TileRed t;
     if (bi == bj)
-        t = mfma_tile32_splitk<true>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
+        t = mfma_tile32_splitk<true, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
     else
-        t = mfma_tile32_splitk<false>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
+        t = mfma_tile32_splitk<false, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
     if (bi == bj && threadIdx.x < 32 && i0 + threadIdx.x < n)
         gamma[i0 + threadIdx.x] = gv;
+    if (threadIdx.x >= 256)
+        return;
     const int i = i0 + (threadIdx.x & 31);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
