@@ -1,0 +1,107 @@
+"""Edge cases of the C-ABI the reference's control flow relies on (VIO_eqf.cpp:105-135, 172-245) and the error contract of
+include/eqf_hip.h: empty and ragged measurements, empty landmark set, capacity, loud failures (never a silent fallback)."""
+import numpy as np
+import pytest
+
+from eqvio_amd.capi import OPT_CHECK_FINITE, EqfCore, EqfError
+from test_gpu_parity import check_sigma, check_state, make_pair
+from util import CHARTS, default_camera, random_imu, random_spd, reasonable_state, settings_for, synth_measurement
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("chart", list(CHARTS))
+def test_empty_measurement_is_a_no_op(chart):
+    """performVisionUpdate returns immediately on an empty measurement (VIO_eqf.cpp:108-109)."""
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], 7, seed=1)
+    cam = default_camera()
+    core.vision_update(cam, np.zeros(0, np.int32), np.zeros(0), settings.measurementNoise**2, True, False)
+    assert np.array_equal(core.get_sigma(), S)
+    check_state(core, orc)
+
+
+@pytest.mark.parametrize("chart", list(CHARTS))
+def test_no_landmarks_propagates_the_sensor_block_only(chart):
+    """N = 0: n = 21; propagation and observer steps work, outlier statistics of an empty state are empty."""
+    rng, settings, orc, core, _ = make_pair(CHARTS[chart], 0, seed=2, cap=8)
+    imu = random_imu(rng, bias_vel=True)
+    for f, g in ((orc.integrate_riccati_fast, lambda: core.integrate_riccati_fast(imu, 0.05, settings.input_gain_diag12(), settings.state_gain_diag8())),
+                 (orc.integrate_riccati_accurate, lambda: core.integrate_riccati_accurate(imu, 0.05, settings.input_gain_diag12(), settings.state_gain_diag8()))):
+        f(imu, 0.05)
+        g()
+        check_sigma(core, orc, 1e-11)
+    orc.integrate_observer(imu, 0.05, True)
+    core.integrate_observer(imu[None, :], np.array([0.05]), True)
+    check_state(core, orc)
+    a, p, d = core.outlier_stats(default_camera(), np.zeros(0, np.int32), np.zeros(0))
+    assert len(a) == len(p) == len(d) == 0
+    assert core.get_sigma().shape == (21, 21)
+
+
+def test_single_landmark_single_measurement():
+    """The smallest update: N = M = 1 (m = 2: one 2x2 pivot block, identity-padded tile)."""
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], 1, seed=3, cap=4, sigma="diag")
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0)
+    orc.vision_update(cam, mid, y)
+    core.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+    check_sigma(core, orc)
+    check_state(core, orc)
+
+
+def test_capacity_is_enforced():
+    N, cap = 14, 16  # the context rounds its capacity up to a multiple of 16 landmarks
+    rng = np.random.default_rng(4)
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N)
+    core = EqfCore(cap, CHARTS["euclid"])
+    core.set_state(xi0, Xs, ids, q0, Q)
+    core.set_sigma(random_spd(rng, 21 + 3 * N))
+    core.add_landmarks(np.array([100, 101], np.int32), rng.normal(size=(2, 3)) + [0, 0, 5], 1.0)  # exactly full
+    assert core.N == cap
+    with pytest.raises(EqfError) as e:
+        core.add_landmarks(np.array([102], np.int32), np.array([[0.0, 0.0, 5.0]]), 1.0)
+    assert e.value.code == -4  # EQF_E_CAPACITY
+    assert core.N == cap and core.get_sigma().shape == (21 + 3 * cap, 21 + 3 * cap)  # state untouched
+    xi0b, Xsb, idsb, q0b, Qb = reasonable_state(rng, 20)
+    with pytest.raises(EqfError):
+        EqfCore(16, CHARTS["euclid"]).set_state(xi0b, Xsb, idsb, q0b, Qb)  # more landmarks than the context can hold
+
+
+def test_indefinite_innovation_covariance_is_reported():
+    """The reference's LU inverse never fails; the factorisation here reports a non-positive pivot (EQF_E_NOT_SPD)
+    instead of producing garbage."""
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["euclid"], 5, seed=5)
+    core.set_sigma(-S)  # S_innov = C (-Sigma) C^T + R is indefinite for this Sigma
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0)
+    with pytest.raises(EqfError) as e:
+        core.vision_update(cam, mid, y, 1e-6, True, False)
+        core.synchronize()
+    assert e.value.code == -2  # EQF_E_NOT_SPD
+
+
+def test_non_finite_input_is_caught_when_checking_is_on():
+    """assert(!Sigma.hasNaN()) of the reference (VIO_eqf.cpp:70, 132) = EQF_OPT_CHECK_FINITE."""
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["euclid"], 4, seed=6)
+    core.set_option(OPT_CHECK_FINITE, 1)
+    S2 = S.copy()
+    S2[3, 3] = np.nan
+    core.set_sigma(S2)
+    with pytest.raises(EqfError) as e:
+        core.integrate_riccati_fast(random_imu(rng), 0.05, settings.input_gain_diag12(), settings.state_gain_diag8())
+    assert e.value.code == -1  # EQF_E_NONFINITE
+
+
+def test_bad_arguments():
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["euclid"], 4, seed=7)
+    with pytest.raises(EqfError):
+        core.set_sigma(np.eye(5))  # wrong dimension
+    with pytest.raises(EqfError):
+        core.integrate_riccati_accurate(random_imu(rng), 0.0, settings.input_gain_diag12(), settings.state_gain_diag8())  # dt must be > 0
+    with pytest.raises(EqfError):
+        core.remove_landmarks(np.array([9], np.int32))  # index out of range
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0)
+    with pytest.raises(EqfError):
+        core.vision_update(cam, np.concatenate([mid, [999]]).astype(np.int32), np.concatenate([y, [1.0, 2.0]]), 1.0, True, False)  # id not in the state
+    check_sigma(core, orc)  # nothing of the above changed the state
