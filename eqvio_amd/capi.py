@@ -40,6 +40,38 @@ class Camera(C.Structure):
         cam.fx, cam.fy, cam.cx, cam.cy = fx, fy, cx, cy
         return cam
 
+    @staticmethod
+    def radtan(fx, fy, cx, cy, width, height, k1, k2, p1, p2, k3=0.0):
+        """GIFT::StandardCamera (ASLDatasetReader.cpp:90-94): OpenCV order k1 k2 p1 p2 k3."""
+        cam = Camera.pinhole(fx, fy, cx, cy, width, height)
+        cam.model = 1
+        cam.dist[:] = [k1, k2, p1, p2, k3]
+        return cam
+
+    @staticmethod
+    def equidistant(fx, fy, cx, cy, width, height, k1, k2, k3, k4):
+        """GIFT::EquidistantCamera (UZHFPVDatasetReader.cpp:99-102): Kannala-Brandt k1..k4."""
+        cam = Camera.pinhole(fx, fy, cx, cy, width, height)
+        cam.model = 2
+        cam.dist[:] = [k1, k2, k3, k4, 0.0]
+        return cam
+
+    # the product's camera functions on the host (include/eqvio_sim.h)
+    def project(self, p):
+        out = np.zeros(2)
+        _load_sim_protos().eqvio_camera_project(C.byref(self), _dp(_f64(p)), _dp(out))
+        return out
+
+    def undistort(self, y):
+        out = np.zeros(3)
+        _load_sim_protos().eqvio_camera_undistort(C.byref(self), _dp(_f64(y)), _dp(out))
+        return out
+
+    def jacobian(self, p):
+        out = np.zeros(6)
+        _load_sim_protos().eqvio_camera_jacobian(C.byref(self), _dp(_f64(p)), _dp(out))
+        return out.reshape(2, 3)
+
 
 _SETTINGS_DOUBLES = [
     "biasOmegaProcessVariance", "biasAccelProcessVariance", "attitudeProcessVariance", "positionProcessVariance",
@@ -525,6 +557,9 @@ def _load_sim_protos():
         "eqvio_sim_num_points": (C.c_int, [vp]),
         "eqvio_sim_camera": (None, [vp, P(Camera)]),
         "eqvio_sim_camera_offset": (None, [vp, c_double_p]),
+        "eqvio_camera_project": (None, [P(Camera), c_double_p, c_double_p]),
+        "eqvio_camera_undistort": (None, [P(Camera), c_double_p, c_double_p]),
+        "eqvio_camera_jacobian": (None, [P(Camera), c_double_p, c_double_p]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)

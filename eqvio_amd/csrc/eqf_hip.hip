@@ -270,7 +270,14 @@ int join_observer(eqf_ctx* c) {
     return 0;
 }
 
-Cam make_cam(const eqvio_camera* c) { return Cam{c->fx, c->fy, c->cx, c->cy}; }
+Cam make_cam(const eqvio_camera* c) {
+    Cam k{c->fx, c->fy, c->cx, c->cy};
+    k.model = c->model;
+    for (int i = 0; i < 5; ++i)
+        k.d[i] = c->dist[i];
+    return k;
+}
+bool camera_ok(const eqvio_camera* c) { return c->model >= EQVIO_CAMERA_PINHOLE && c->model <= EQVIO_CAMERA_EQUIDISTANT; }
 
 // Sensor-level terms of A and B (EqFStateMatrixA_euclid / EqFInputMatrixB_euclid sensor rows and the per-landmark
 // common factors; coordinateSuite/euclid.cpp:99-233 — identical for the inverse-depth suite, invdepth.cpp:47-63,152-166)
@@ -1027,7 +1034,7 @@ static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, 
 }
 
 int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double* absErr, double* probErr, double* depth2) {
-    if (!c || !cam || M < 0 || (M > 0 && (!ids || !y)) || cam->model != EQVIO_CAMERA_PINHOLE)
+    if (!c || !cam || M < 0 || (M > 0 && (!ids || !y)) || !camera_ok(cam))
         return EQF_E_BAD_ARG;
     const int N = c->N;
     if (N == 0)
@@ -1093,7 +1100,7 @@ static int stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M)
 }
 
 int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEqv, int discreteCorr) {
-    if (!c || !cam || M < 0 || (M > 0 && (!ids || !y)) || cam->model != EQVIO_CAMERA_PINHOLE)
+    if (!c || !cam || M < 0 || (M > 0 && (!ids || !y)) || !camera_ok(cam))
         return EQF_E_BAD_ARG;
     if (M == 0)
         return 0; // VIO_eqf.cpp:108-109

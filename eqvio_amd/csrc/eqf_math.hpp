@@ -246,19 +246,106 @@ HD M6 m6_mul(const M6& A, const M6& B) {
 }
 
 // ---- pinhole camera (GIFT::PinholeCamera contract)
+// ---- camera models (GIFT::PinholeCamera / StandardCamera / EquidistantCamera contracts: projectPoint, undistortPoint =
+// unit bearing of a pixel, projectionJacobian = d projectPoint / d p). model: 0 pinhole, 1 radial-tangential
+// (k1, k2, p1, p2, k3), 2 equidistant / Kannala-Brandt (k1..k4). See include/eqvio_types.h.
 struct Cam {
     double fx, fy, cx, cy;
+    int model = 0;
+    double d[5] = {0, 0, 0, 0, 0};
 };
-HD void cam_project(const Cam& c, V3 p, double& u, double& v) {
-    u = c.fx * p.x / p.z + c.cx;
-    v = c.fy * p.y / p.z + c.cy;
+// distortion of normalised image coordinates (x, y) -> (xd, yd) and its 2x2 Jacobian (row-major j[4])
+HD void cam_distort(const Cam& c, double x, double y, double& xd, double& yd, double* j) {
+    if (c.model == 1) {
+        const double k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3], k3 = c.d[4];
+        const double r2 = x * x + y * y;
+        const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+        const double dr = k1 + r2 * (2.0 * k2 + r2 * 3.0 * k3); // d rad / d r2
+        xd = x * rad + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+        yd = y * rad + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+        j[0] = rad + 2.0 * x * x * dr + 2.0 * p1 * y + 6.0 * p2 * x;
+        j[1] = 2.0 * x * y * dr + 2.0 * p1 * x + 2.0 * p2 * y;
+        j[2] = j[1];
+        j[3] = rad + 2.0 * y * y * dr + 6.0 * p1 * y + 2.0 * p2 * x;
+    } else if (c.model == 2) {
+        const double r = sqrt(x * x + y * y);
+        const double th = atan(r), t2 = th * th;
+        const double thd = th * (1.0 + t2 * (c.d[0] + t2 * (c.d[1] + t2 * (c.d[2] + t2 * c.d[3]))));
+        const double dthd = 1.0 + t2 * (3.0 * c.d[0] + t2 * (5.0 * c.d[1] + t2 * (7.0 * c.d[2] + t2 * 9.0 * c.d[3])));
+        if (r < 1e-8) {
+            xd = x;
+            yd = y;
+            j[0] = j[3] = 1.0;
+            j[1] = j[2] = 0.0;
+        } else {
+            const double sc = thd / r;
+            const double dsc = (dthd / (1.0 + r * r) - sc) / r; // d sc / d r
+            xd = sc * x;
+            yd = sc * y;
+            j[0] = sc + dsc * x * x / r;
+            j[1] = dsc * x * y / r;
+            j[2] = j[1];
+            j[3] = sc + dsc * y * y / r;
+        }
+    } else {
+        xd = x;
+        yd = y;
+        j[0] = j[3] = 1.0;
+        j[1] = j[2] = 0.0;
+    }
 }
-HD V3 cam_undistort(const Cam& c, double u, double v) { return normalized(V3{(u - c.cx) / c.fx, (v - c.cy) / c.fy, 1.0}); }
+HD void cam_project(const Cam& c, V3 p, double& u, double& v) {
+    double xd, yd, j[4];
+    cam_distort(c, p.x / p.z, p.y / p.z, xd, yd, j);
+    u = c.fx * xd + c.cx;
+    v = c.fy * yd + c.cy;
+}
+// pixel -> unit bearing: inverse of the distortion by Newton's method from the distorted coordinates (the map is a small
+// perturbation of the identity on the image), equidistant: the scalar equation theta_d(theta) = |(xd, yd)| instead
+HD V3 cam_undistort(const Cam& c, double u, double v) {
+    const double xd = (u - c.cx) / c.fx, yd = (v - c.cy) / c.fy;
+    if (c.model == 1) {
+        double x = xd, y = yd;
+        for (int it = 0; it < 12; ++it) {
+            double fx, fy, j[4];
+            cam_distort(c, x, y, fx, fy, j);
+            const double ex = fx - xd, ey = fy - yd;
+            const double idet = 1.0 / (j[0] * j[3] - j[1] * j[2]);
+            x -= (j[3] * ex - j[1] * ey) * idet;
+            y -= (j[0] * ey - j[2] * ex) * idet;
+        }
+        return normalized(V3{x, y, 1.0});
+    }
+    if (c.model == 2) {
+        const double thd = sqrt(xd * xd + yd * yd);
+        if (thd < 1e-8)
+            return normalized(V3{xd, yd, 1.0});
+        double th = thd;
+        for (int it = 0; it < 12; ++it) {
+            const double t2 = th * th;
+            const double f = th * (1.0 + t2 * (c.d[0] + t2 * (c.d[1] + t2 * (c.d[2] + t2 * c.d[3])))) - thd;
+            const double df = 1.0 + t2 * (3.0 * c.d[0] + t2 * (5.0 * c.d[1] + t2 * (7.0 * c.d[2] + t2 * 9.0 * c.d[3])));
+            th -= f / df;
+        }
+        const double s = sin(th) / thd;
+        return V3{s * xd, s * yd, cos(th)}; // already unit length
+    }
+    return normalized(V3{xd, yd, 1.0});
+}
+// rows of the projection Jacobian d projectPoint / d p (2x3)
+HD void cam_jac(const Cam& c, V3 p, V3& j0, V3& j1) {
+    const double iz = 1.0 / p.z;
+    const double x = p.x * iz, y = p.y * iz;
+    double xd, yd, j[4];
+    cam_distort(c, x, y, xd, yd, j);
+    // d(x, y)/dp = [[iz, 0, -x iz], [0, iz, -y iz]]
+    j0 = V3{c.fx * j[0] * iz, c.fx * j[1] * iz, -c.fx * (j[0] * x + j[1] * y) * iz};
+    j1 = V3{c.fy * j[2] * iz, c.fy * j[3] * iz, -c.fy * (j[2] * x + j[3] * y) * iz};
+}
 // projection Jacobian J(p) (2x3) times skew(p): rows returned as two V3  (DRho of euclid.cpp:173-178)
 HD void cam_jac_skew(const Cam& c, V3 p, V3& r0, V3& r1) {
-    const double iz = 1.0 / p.z;
-    const V3 j0{c.fx * iz, 0.0, -c.fx * p.x * iz * iz};
-    const V3 j1{0.0, c.fy * iz, -c.fy * p.y * iz * iz};
+    V3 j0, j1;
+    cam_jac(c, p, j0, j1);
     // row * skew(p) = (row x ... ) : (j^T skew(p)) = -(skew(p) j)^T = -(p x j)^T = (j x p)^T
     r0 = cross(j0, p);
     r1 = cross(j1, p);

@@ -93,11 +93,18 @@ struct IMUVelocity {
     IMUVelocity operator*(const double& c) const;
     void pack(double* v13) const;
 };
-// Pinhole camera (GIFT::PinholeCamera contract; the only model of round 1)
+// GIFT::GICamera contract on the three models of include/eqvio_types.h (pinhole, radial-tangential, equidistant)
 struct Camera {
     eqvio_camera c{};
-    void projectPoint(V3 p, double& u, double& v) const { eqf::cam_project(eqf::Cam{c.fx, c.fy, c.cx, c.cy}, p, u, v); }
-    V3 undistortPoint(double u, double v) const { return eqf::cam_undistort(eqf::Cam{c.fx, c.fy, c.cx, c.cy}, u, v); }
+    eqf::Cam model() const {
+        eqf::Cam k{c.fx, c.fy, c.cx, c.cy};
+        k.model = c.model;
+        for (int i = 0; i < 5; ++i)
+            k.d[i] = c.dist[i];
+        return k;
+    }
+    void projectPoint(V3 p, double& u, double& v) const { eqf::cam_project(model(), p, u, v); }
+    V3 undistortPoint(double u, double v) const { return eqf::cam_undistort(model(), u, v); }
 };
 using GICameraPtr = std::shared_ptr<const Camera>;
 struct VisionMeasurement {

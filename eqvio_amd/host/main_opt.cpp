@@ -14,6 +14,7 @@ using namespace eqvio_amd;
 
 static void usage() {
     std::puts("usage: eqvio_opt --imu FILE --features FILE [--format asl|uzhfpv] [--groundtruth FILE] [--dumpMeasurements] [--camera fx fy cx cy width height]\n"
+              "                 [--distortion radtan k1 k2 p1 p2 k3 | --distortion equidistant k1 k2 k3 k4]\n"
               "                 [--cameraOffset qw qx qy qz x y z] [--cameraLag S] [--start S] [--stop S] [--output DIR] [--quiet]\n"
               "                 [--<eqf setting> VALUE ...]   (names of VIOFilter::Settings, e.g. --fastRiccati 1 --coordinateChoice InvDepth)");
 }
@@ -54,6 +55,18 @@ int main(int argc, char** argv) {
                 cam->c.cy = std::atof(val());
                 cam->c.width = std::atoi(val());
                 cam->c.height = std::atoi(val());
+            } else if (a == "--distortion") { // radtan k1 k2 p1 p2 k3 (sensor.yaml distortion_coefficients) | equidistant k1 k2 k3 k4
+                const std::string mdl = val();
+                if (mdl == "radtan") {
+                    cam->c.model = EQVIO_CAMERA_RADTAN;
+                    for (int k = 0; k < 5; ++k)
+                        cam->c.dist[k] = std::atof(val());
+                } else if (mdl == "equidistant") {
+                    cam->c.model = EQVIO_CAMERA_EQUIDISTANT;
+                    for (int k = 0; k < 4; ++k)
+                        cam->c.dist[k] = std::atof(val());
+                } else
+                    throw std::runtime_error("unknown --distortion model " + mdl + " (radtan | equidistant)");
             } else if (a == "--cameraOffset") {
                 double q[7];
                 for (double& v : q)

@@ -100,4 +100,25 @@ void eqvio_sim_camera_offset(const eqvio_sim* s, double* q) {
     const double v[7] = {P.R.w, P.R.x, P.R.y, P.R.z, P.x.x, P.x.y, P.x.z};
     std::memcpy(q, v, sizeof(v));
 }
+void eqvio_camera_project(const eqvio_camera* cam, const double* p3, double* y2) {
+    Camera c;
+    c.c = *cam;
+    c.projectPoint(V3{p3[0], p3[1], p3[2]}, y2[0], y2[1]);
+}
+void eqvio_camera_undistort(const eqvio_camera* cam, const double* y2, double* b3) {
+    Camera c;
+    c.c = *cam;
+    const V3 b = c.undistortPoint(y2[0], y2[1]);
+    b3[0] = b.x;
+    b3[1] = b.y;
+    b3[2] = b.z;
+}
+void eqvio_camera_jacobian(const eqvio_camera* cam, const double* p3, double* J6) {
+    Camera c;
+    c.c = *cam;
+    V3 j0, j1;
+    eqf::cam_jac(c.model(), V3{p3[0], p3[1], p3[2]}, j0, j1);
+    const double v[6] = {j0.x, j0.y, j0.z, j1.x, j1.y, j1.z};
+    std::memcpy(J6, v, sizeof(v));
+}
 }

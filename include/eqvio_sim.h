@@ -45,6 +45,13 @@ int eqvio_sim_num_points(const eqvio_sim* s);
 void eqvio_sim_camera(const eqvio_sim* s, eqvio_camera* cam);    /* generatePinholeCameraSquare */
 void eqvio_sim_camera_offset(const eqvio_sim* s, double* pose7); /* cameraExtrinsics, (qw,qx,qy,qz,x,y,z) */
 
+
+/* The camera-model functions of the product (eqvio_amd/csrc/eqf_math.hpp: the same code the kernels run), callable on the
+ * host: GIFT::GICamera::projectPoint / undistortPoint (unit bearing) / projectionJacobian (2 x 3, row major). */
+void eqvio_camera_project(const eqvio_camera* cam, const double* p3, double* y2);
+void eqvio_camera_undistort(const eqvio_camera* cam, const double* y2, double* bearing3);
+void eqvio_camera_jacobian(const eqvio_camera* cam, const double* p3, double* J6);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,13 +31,19 @@ extern "C" {
 #define EQVIO_IMU_DIM 13
 
 enum { EQVIO_COORD_EUCLIDEAN = 0, EQVIO_COORD_INVDEPTH = 1, EQVIO_COORD_NORMAL = 2 };
-enum { EQVIO_CAMERA_PINHOLE = 0 };
+/* Camera models the reference's dataset readers construct (the classes live in the GIFT submodule, external/GIFT,
+ * which is not vendored in /root/reference: the models are restated from their published definitions):
+ *   PINHOLE      GIFT::PinholeCamera      (SimulationDataServer.cpp:162-176)
+ *   RADTAN       GIFT::StandardCamera     pinhole + radial-tangential, dist = (k1, k2, p1, p2, k3), the OpenCV order of
+ *                                         intrinsics.yaml:8 / sensor.yaml distortion_coefficients (ASLDatasetReader.cpp:90-94)
+ *   EQUIDISTANT  GIFT::EquidistantCamera  Kannala-Brandt, dist = (k1, k2, k3, k4)  (UZHFPVDatasetReader.cpp:99-102) */
+enum { EQVIO_CAMERA_PINHOLE = 0, EQVIO_CAMERA_RADTAN = 1, EQVIO_CAMERA_EQUIDISTANT = 2 };
 
 typedef struct eqvio_camera {
-    int model; /* EQVIO_CAMERA_PINHOLE */
+    int model; /* EQVIO_CAMERA_* */
     int width, height;
     double fx, fy, cx, cy;
-    double dist[5]; /* reserved for the radtan / equidistant models */
+    double dist[5];
 } eqvio_camera;
 
 /* Field names and defaults follow VIOFilter::Settings (VIOFilterSettings.h:59-99). */

@@ -72,6 +72,8 @@ CameraPtr makeCamera(const eqvio_camera* c) {
     cam->cy = c->cy;
     cam->width = c->width;
     cam->height = c->height;
+    for (int i = 0; i < 5; ++i)
+        cam->dist[i] = c->dist[i];
     return cam;
 }
 Settings makeSettings(const eqvio_settings* s) {
@@ -377,6 +379,25 @@ double orc_bench_frame(void* f, const double* imu13_k, const double* dts, int k,
     }
     vf->filterState = saved;
     return total / reps;
+}
+
+// camera model functions (tests/test_cameras.py)
+void orc_cam_project(const eqvio_camera* cam, const double* p3, double* y2) {
+    const Vec2 y = makeCamera(cam)->projectPoint(vec3(p3[0], p3[1], p3[2]));
+    y2[0] = y(0);
+    y2[1] = y(1);
+}
+void orc_cam_undistort(const eqvio_camera* cam, const double* y2, double* b3) {
+    const Vec3 b = makeCamera(cam)->undistortPoint(vec2(y2[0], y2[1]));
+    b3[0] = b(0);
+    b3[1] = b(1);
+    b3[2] = b(2);
+}
+void orc_cam_jacobian(const eqvio_camera* cam, const double* p3, double* J6_rowmajor) {
+    const M<2, 3> J = makeCamera(cam)->projectionJacobian(vec3(p3[0], p3[1], p3[2]));
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c)
+            J6_rowmajor[3 * r + c] = J(r, c);
 }
 
 } // extern "C"

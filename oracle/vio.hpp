@@ -27,24 +27,117 @@ namespace orc {
 constexpr double GRAVITY_CONSTANT = 9.80665; // include/eqvio/mathematical/IMUVelocity.h:26
 
 // ---------------------------------------------------------------- camera (GIFT camera models; source absent)
-// Pinhole restated from the call-site contract: project(p) = (fx x/z + cx, fy y/z + cy),
-// undistortPoint(y) = unit bearing, projectionJacobian(p) = d project / d p.
+// The classes live in the GIFT submodule (external/GIFT, github.com/pvangoor/GIFT, commit not recorded in this snapshot),
+// which is NOT in /root/reference: restated from the call-site contract and the published model
+// definitions. project(p) = K distort(x/z, y/z) + c, undistortPoint(y) = unit bearing, projectionJacobian(p) = d project/d p.
+//   model 0  pinhole                (GIFT::PinholeCamera,     SimulationDataServer.cpp:162-176)
+//   model 1  radial-tangential      (GIFT::StandardCamera,    ASLDatasetReader.cpp:90-94; OpenCV order k1 k2 p1 p2 k3)
+//   model 2  equidistant            (GIFT::EquidistantCamera, UZHFPVDatasetReader.cpp:99-102; Kannala-Brandt k1..k4)
+// PARITY: the inverse (undistortPoint) is a function, not an algorithm: any fully converged iteration agrees to rounding.
+// Here: the classic fixed-point iteration followed by Newton polishing (the product uses Newton from the start).
 struct Camera {
-    int model = 0; // 0 = pinhole
+    int model = 0;
     double fx = 1, fy = 1, cx = 0, cy = 0;
     int width = 0, height = 0;
-    Vec2 projectPoint(const Vec3& p) const { return vec2(fx * p(0) / p(2) + cx, fy * p(1) / p(2) + cy); }
+    double dist[5] = {0, 0, 0, 0, 0};
+    // radial factor and tangential offset of the radtan model at normalised (x, y)
+    void radtanTerms(double x, double y, double& radial, double& tx, double& ty) const {
+        const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+        radial = 1.0 + dist[0] * r2 + dist[1] * r4 + dist[4] * r6;
+        tx = 2.0 * dist[2] * x * y + dist[3] * (r2 + 2.0 * x * x);
+        ty = dist[2] * (r2 + 2.0 * y * y) + 2.0 * dist[3] * x * y;
+    }
+    double kbTheta(double th) const { // theta_d(theta)
+        const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+        return th * (1.0 + dist[0] * t2 + dist[1] * t4 + dist[2] * t6 + dist[3] * t8);
+    }
+    double kbThetaDiff(double th) const {
+        const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+        return 1.0 + 3.0 * dist[0] * t2 + 5.0 * dist[1] * t4 + 7.0 * dist[2] * t6 + 9.0 * dist[3] * t8;
+    }
+    Vec2 distort(const Vec2& xy) const {
+        if (model == 1) {
+            double radial, tx, ty;
+            radtanTerms(xy(0), xy(1), radial, tx, ty);
+            return vec2(xy(0) * radial + tx, xy(1) * radial + ty);
+        }
+        if (model == 2) {
+            const double r = std::sqrt(xy(0) * xy(0) + xy(1) * xy(1));
+            if (r < 1e-8)
+                return xy;
+            return xy * (kbTheta(std::atan(r)) / r);
+        }
+        return xy;
+    }
+    M<2, 2> distortJacobian(const Vec2& xy) const {
+        M<2, 2> J = M<2, 2>::Identity();
+        const double x = xy(0), y = xy(1);
+        if (model == 1) {
+            const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4];
+            const double r2 = x * x + y * y;
+            const double radial = 1.0 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;
+            const double dRadial = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r2 * r2; // d radial / d r2
+            J(0, 0) = radial + x * dRadial * 2.0 * x + 2.0 * p1 * y + p2 * (2.0 * x + 4.0 * x);
+            J(0, 1) = x * dRadial * 2.0 * y + 2.0 * p1 * x + p2 * 2.0 * y;
+            J(1, 0) = y * dRadial * 2.0 * x + p1 * 2.0 * x + 2.0 * p2 * y;
+            J(1, 1) = radial + y * dRadial * 2.0 * y + p1 * (2.0 * y + 4.0 * y) + 2.0 * p2 * x;
+        } else if (model == 2) {
+            const double r = std::sqrt(x * x + y * y);
+            if (r >= 1e-8) {
+                const double th = std::atan(r);
+                const double s = kbTheta(th) / r;
+                const double ds = (kbThetaDiff(th) / (1.0 + r * r) * r - kbTheta(th)) / (r * r); // d s / d r
+                J(0, 0) = s + ds * x * x / r;
+                J(0, 1) = ds * x * y / r;
+                J(1, 0) = J(0, 1);
+                J(1, 1) = s + ds * y * y / r;
+            }
+        }
+        return J;
+    }
+    Vec2 projectPoint(const Vec3& p) const {
+        const Vec2 d = distort(vec2(p(0) / p(2), p(1) / p(2)));
+        return vec2(fx * d(0) + cx, fy * d(1) + cy);
+    }
     Vec3 undistortPoint(const Vec2& y) const {
-        return vec3((y(0) - cx) / fx, (y(1) - cy) / fy, 1.0).normalized();
+        const Vec2 d = vec2((y(0) - cx) / fx, (y(1) - cy) / fy);
+        if (model == 0)
+            return vec3(d(0), d(1), 1.0).normalized();
+        if (model == 2) {
+            const double thd = std::sqrt(d(0) * d(0) + d(1) * d(1));
+            if (thd < 1e-8)
+                return vec3(d(0), d(1), 1.0).normalized();
+            double th = thd;
+            for (int it = 0; it < 30; ++it) // bisection-safe Newton: theta_d is monotone on the image
+                th -= (kbTheta(th) - thd) / kbThetaDiff(th);
+            const double r = std::tan(th);
+            return vec3(d(0) * r / thd, d(1) * r / thd, 1.0).normalized();
+        }
+        Vec2 xy = d;
+        for (int it = 0; it < 20; ++it) { // x <- (x_d - tangential(x)) / radial(x)
+            double radial, tx, ty;
+            radtanTerms(xy(0), xy(1), radial, tx, ty);
+            xy = vec2((d(0) - tx) / radial, (d(1) - ty) / radial);
+        }
+        for (int it = 0; it < 4; ++it) { // Newton polish to rounding
+            const Vec2 e = distort(xy) - d;
+            const M<2, 2> J = distortJacobian(xy);
+            const double det = J(0, 0) * J(1, 1) - J(0, 1) * J(1, 0);
+            xy = vec2(xy(0) - (J(1, 1) * e(0) - J(0, 1) * e(1)) / det, xy(1) - (J(0, 0) * e(1) - J(1, 0) * e(0)) / det);
+        }
+        return vec3(xy(0), xy(1), 1.0).normalized();
     }
     M<2, 3> projectionJacobian(const Vec3& p) const {
-        M<2, 3> J = M<2, 3>::Zero();
         const double iz = 1.0 / p(2);
-        J(0, 0) = fx * iz;
-        J(0, 2) = -fx * p(0) * iz * iz;
-        J(1, 1) = fy * iz;
-        J(1, 2) = -fy * p(1) * iz * iz;
-        return J;
+        M<2, 3> Jn = M<2, 3>::Zero(); // d (x/z, y/z) / d p
+        Jn(0, 0) = iz;
+        Jn(0, 2) = -p(0) * iz * iz;
+        Jn(1, 1) = iz;
+        Jn(1, 2) = -p(1) * iz * iz;
+        M<2, 2> Kf = M<2, 2>::Zero();
+        Kf(0, 0) = fx;
+        Kf(1, 1) = fy;
+        return Kf * distortJacobian(vec2(p(0) * iz, p(1) * iz)) * Jn;
     }
     bool isInDomain(const Vec3& p) const {
         if (p(2) <= 0)

@@ -49,6 +49,9 @@ def load_oracle():
         "orc_filter_last_gamma": (C.c_int, [vp, c_double_p, C.c_int]),
         "orc_eqf_integrate_riccati_fast": (None, [vp, c_double_p, C.c_double]),
         "orc_eqf_integrate_riccati_accurate": (None, [vp, c_double_p, C.c_double]),
+        "orc_cam_project": (None, [P(Camera), c_double_p, c_double_p]),
+        "orc_cam_undistort": (None, [P(Camera), c_double_p, c_double_p]),
+        "orc_cam_jacobian": (None, [P(Camera), c_double_p, c_double_p]),
         "orc_eqf_integrate_riccati_discrete": (None, [vp, c_double_p, C.c_double]),
         "orc_eqf_integrate_observer": (None, [vp, c_double_p, C.c_double, C.c_int]),
         "orc_eqf_vision_update": (None, [vp, C.c_double, P(Camera), c_int_p, c_double_p, C.c_int]),
@@ -229,6 +232,24 @@ class OracleFilter:
     def bench_frame(self, imu13_k, dts, stamp, cam, ids, y, mode, reps):
         imu13_k, dts, ids, y = _f64(imu13_k), _f64(dts), _i32(ids), _f64(y)
         return self.lib.orc_bench_frame(self.h, _dp(imu13_k), _dp(dts), len(dts), stamp, C.byref(cam), _ip(ids), _dp(y), len(ids), mode, reps)
+
+
+def oracle_cam_project(cam, p):
+    out = np.zeros(2)
+    load_oracle().orc_cam_project(C.byref(cam), _dp(_f64(p)), _dp(out))
+    return out
+
+
+def oracle_cam_undistort(cam, y):
+    out = np.zeros(3)
+    load_oracle().orc_cam_undistort(C.byref(cam), _dp(_f64(y)), _dp(out))
+    return out
+
+
+def oracle_cam_jacobian(cam, p):
+    out = np.zeros(6)
+    load_oracle().orc_cam_jacobian(C.byref(cam), _dp(_f64(p)), _dp(out))
+    return out.reshape(2, 3)
 
 
 def se3_log_dist(a7, b7):

@@ -42,8 +42,8 @@ def test_filter_lib_exports_every_declared_symbol(built):
 
     assert sorted(load_filter_lib()._declared) == sorted(names)
     # the simulator's C view lives in the same library (include/eqvio_sim.h)
-    sim_names = [n for n in declared_symbols("eqvio_sim.h") if n.startswith("eqvio_sim_") and n != "eqvio_sim_settings"]
-    assert len(sim_names) >= 11
+    sim_names = [n for n in declared_symbols("eqvio_sim.h") if (n.startswith("eqvio_sim_") and n != "eqvio_sim_settings") or n.startswith("eqvio_camera_")]
+    assert len(sim_names) >= 14
     for n in sim_names:
         assert hasattr(lib, n), f"{n} declared in include/eqvio_sim.h but not exported"
 

@@ -37,6 +37,20 @@ def default_camera():
     return Camera.pinhole(450.0, 450.0, 400.0, 240.0, 800, 480)
 
 
+def euroc_radtan_camera():
+    """EuRoC cam0 with its radial-tangential distortion (reference intrinsics.yaml:7-8)."""
+    return Camera.radtan(458.654, 457.296, 367.215, 248.375, 752, 480, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+
+
+def uzhfpv_equidistant_camera():
+    """UZH-FPV indoor forward snapdragon cam0-like equidistant camera (640x480, f ~ 278; Kannala-Brandt k1..k4)."""
+    return Camera.equidistant(278.66723066149086, 278.48991409740296, 319.75221200593535, 241.96858910358173, 640, 480, -0.013721808247486035, 0.020727425669427896,
+                              -0.012786476702685545, 0.0025242267320687625)
+
+
+CAMERAS = {"pinhole": default_camera, "radtan": euroc_radtan_camera, "equidistant": uzhfpv_equidistant_camera}
+
+
 def euroc_camera():
     """generatePinholeCameraSquare (src/dataserver/SimulationDataServer.cpp:162-176)."""
     return Camera.pinhole(458.654, 457.296, 367.215, 248.375, 752, 480)
@@ -89,7 +103,19 @@ def estimate_landmarks(q0, Q):
 
 
 def project(cam, p):
-    return np.stack([cam.fx * p[:, 0] / p[:, 2] + cam.cx, cam.fy * p[:, 1] / p[:, 2] + cam.cy], axis=1)
+    """Pixels of camera-frame points for any model of include/eqvio_types.h (only used to synthesise measurements)."""
+    x, y = p[:, 0] / p[:, 2], p[:, 1] / p[:, 2]
+    d = list(cam.dist)
+    if cam.model == 1:
+        r2 = x * x + y * y
+        rad = 1 + d[0] * r2 + d[1] * r2**2 + d[4] * r2**3
+        x, y = x * rad + 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x), y * rad + d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y
+    elif cam.model == 2:
+        r = np.sqrt(x * x + y * y)
+        th = np.arctan(r)
+        s = np.where(r > 1e-8, th * (1 + d[0] * th**2 + d[1] * th**4 + d[2] * th**6 + d[3] * th**8) / np.maximum(r, 1e-300), 1.0)
+        x, y = s * x, s * y
+    return np.stack([cam.fx * x + cam.cx, cam.fy * y + cam.cy], axis=1)
 
 
 def synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=None):
