@@ -991,9 +991,10 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
 // Blocked right-looking factorisation of Z (rows x m, leading dimension ldz): one launch per 32-column panel
 // (k_chol_step), preceded by the elimination of the first diagonal tile. Rows >= m of W receive Z[rows >= m] L^-T.
 // nsig > 0: the covariance update Sigma -= W W^T and Gamma = W z ride along in the step kernels (see k_chol_step)
-static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double* W, int nsig = 0, double* Sig = nullptr, double* gamma = nullptr) {
+static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double* W, int nsig = 0, double* Sig = nullptr, double* gamma = nullptr,
+                        bool first_tile_done = false) {
     constexpr int NB = 32;
-    {
+    if (!first_tile_done) { // the vision update's k_build_Z eliminates the first tile itself
         KTimer t(c, KN_CHOL_UPDATE);
         hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, std::min(NB, m), ldz, Z, c->d_Linv, c->d_flags);
         HIPCHK(hipGetLastError());
@@ -1126,16 +1127,17 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     }
     {
         KTimer t(c, KN_BUILD_Z);
-        hipLaunchKernelGGL(k_build_Z, dim3(blocks(n + M + 1, 256), M), dim3(256), 0, c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx, c->sigma(), c->d_C,
-                           c->d_ytil, c->d_Z);
+        // the extra grid row eliminates the first diagonal tile of S (no k_chol_first launch in this chain)
+        hipLaunchKernelGGL(k_build_Z, dim3(blocks(n + M + 1, 256), M + 1), dim3(256), 0, c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx, c->sigma(), c->d_C,
+                           c->d_ytil, c->d_Z, c->d_Linv, c->d_flags);
         HIPCHK(hipGetLastError());
     }
     if (c->opt_fused) {
-        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, n, c->sigma(), c->d_gamma);
+        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, n, c->sigma(), c->d_gamma, true);
         if (rc)
             return rc;
     } else {
-        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W);
+        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true);
         if (rc)
             return rc;
         KTimer t(c, KN_SYRK);

@@ -542,55 +542,6 @@ __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, i
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K8a: build Z = [S ; T ; yTilde^T] from Sigma and the packed C blocks, exploiting the 2x3 block sparsity of C:
-//   T[:, 2j:2j+2] = Sigma[:, l_j:l_j+3] C_j^T          (6 n M flops instead of 2 n^2 m)
-//   S[2i:2i+2, 2j:2j+2] = C_i Sigma[l_i.., l_j..] C_j^T + delta_ij R
-// grid.y = measurement j; grid.x covers "row items": t < n -> row of T, n <= t < n+M -> block row i of S, t == n+M -> y row
-__global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
-                                                 const double* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
-                                                 double* __restrict__ Z) {
-    const int j = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int m = 2 * M;
-    const int lj = 21 + 3 * lmidx[j];
-    double cj[6];
-#pragma unroll
-    for (int e = 0; e < 6; ++e)
-        cj[e] = C[e * Mcap + j];
-    if (t < n) {
-        const double s0 = Sig[t + (size_t)lj * ld], s1 = Sig[t + (size_t)(lj + 1) * ld], s2 = Sig[t + (size_t)(lj + 2) * ld];
-        Z[m + t + (size_t)(2 * j) * ldz] = s0 * cj[0] + s1 * cj[1] + s2 * cj[2];
-        Z[m + t + (size_t)(2 * j + 1) * ldz] = s0 * cj[3] + s1 * cj[4] + s2 * cj[5];
-    } else if (t < n + M) {
-        const int i = t - n;
-        const int li = 21 + 3 * lmidx[i];
-        double ci[6];
-#pragma unroll
-        for (int e = 0; e < 6; ++e)
-            ci[e] = C[e * Mcap + i];
-        double CS[2][3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double s0 = Sig[li + (size_t)(lj + c) * ld], s1 = Sig[li + 1 + (size_t)(lj + c) * ld], s2 = Sig[li + 2 + (size_t)(lj + c) * ld];
-            CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
-            CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                double v = CS[a][0] * cj[3 * bb] + CS[a][1] * cj[3 * bb + 1] + CS[a][2] * cj[3 * bb + 2];
-                if (i == j && a == bb)
-                    v += meas_var;
-                Z[2 * i + a + (size_t)(2 * j + bb) * ldz] = v;
-            }
-    } else if (t == n + M) {
-        Z[m + n + (size_t)(2 * j) * ldz] = ytil[2 * j];
-        Z[m + n + (size_t)(2 * j + 1) * ldz] = ytil[2 * j + 1];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // K8b: blocked right-looking factorisation of Z = [S ; T ; y^T], ONE kernel launch per 32-column panel.
 //
 // Step k (panel = columns [kb, kb+w), c0 = kb + w): workgroup (bi, bj) owns the 32x32 trailing tile rows
@@ -837,6 +788,99 @@ __global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double
     }
     __syncthreads();
     ldl_inverse_tile(sD, 33, w, LinvOut, flags, swork);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K8a: build Z = [S ; T ; yTilde^T] from Sigma and the packed C blocks, exploiting the 2x3 block sparsity of C:
+//   T[:, 2j:2j+2] = Sigma[:, l_j:l_j+3] C_j^T          (6 n M flops instead of 2 n^2 m)
+//   S[2i:2i+2, 2j:2j+2] = C_i Sigma[l_i.., l_j..] C_j^T + delta_ij R
+// grid.y = measurement j; grid.x covers "row items": t < n -> row of T, n <= t < n+M -> block row i of S, t == n+M -> y row
+// With LinvOut != nullptr the grid has one extra row (blockIdx.y == M): its first workgroup recomputes the first 32 x 32
+// tile of S on its own (16 x 16 pairs of 2 x 2 blocks, one per thread) and eliminates it, so that the factorisation chain
+// needs no separate first-tile launch.
+__global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
+                                                 const double* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
+                                                 double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags) {
+    const int m = 2 * M;
+    if ((int)blockIdx.y == M) {
+        if (blockIdx.x != 0)
+            return;
+        __shared__ double sD[32 * 33];
+        __shared__ double swork[LDL_SBUF];
+        const int i = threadIdx.x & 15, jj = threadIdx.x >> 4; // pair (i, jj) of measurements, both < 16
+        double blk[2][2] = {{(i == jj) ? 1.0 : 0.0, 0.0}, {0.0, (i == jj) ? 1.0 : 0.0}};
+        if (i < M && jj < M) {
+            const int li = 21 + 3 * lmidx[i], lj2 = 21 + 3 * lmidx[jj];
+            double ci[6], cj2[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                ci[e] = C[e * Mcap + i];
+                cj2[e] = C[e * Mcap + jj];
+            }
+            double CS[2][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double s0 = Sig[li + (size_t)(lj2 + c) * ld], s1 = Sig[li + 1 + (size_t)(lj2 + c) * ld], s2 = Sig[li + 2 + (size_t)(lj2 + c) * ld];
+                CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
+                CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    double v = CS[a][0] * cj2[3 * bb] + CS[a][1] * cj2[3 * bb + 1] + CS[a][2] * cj2[3 * bb + 2];
+                    if (i == jj && a == bb)
+                        v += meas_var;
+                    blk[a][bb] = v; // identical expression to the S entries written to Z below
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+                sD[2 * i + a + (2 * jj + bb) * 33] = blk[a][bb];
+        __syncthreads();
+        ldl_inverse_tile(sD, 33, min(32, m), LinvOut, flags, swork);
+        return;
+    }
+    const int j = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lj = 21 + 3 * lmidx[j];
+    double cj[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e)
+        cj[e] = C[e * Mcap + j];
+    if (t < n) {
+        const double s0 = Sig[t + (size_t)lj * ld], s1 = Sig[t + (size_t)(lj + 1) * ld], s2 = Sig[t + (size_t)(lj + 2) * ld];
+        Z[m + t + (size_t)(2 * j) * ldz] = s0 * cj[0] + s1 * cj[1] + s2 * cj[2];
+        Z[m + t + (size_t)(2 * j + 1) * ldz] = s0 * cj[3] + s1 * cj[4] + s2 * cj[5];
+    } else if (t < n + M) {
+        const int i = t - n;
+        const int li = 21 + 3 * lmidx[i];
+        double ci[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+            ci[e] = C[e * Mcap + i];
+        double CS[2][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double s0 = Sig[li + (size_t)(lj + c) * ld], s1 = Sig[li + 1 + (size_t)(lj + c) * ld], s2 = Sig[li + 2 + (size_t)(lj + c) * ld];
+            CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
+            CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                double v = CS[a][0] * cj[3 * bb] + CS[a][1] * cj[3 * bb + 1] + CS[a][2] * cj[3 * bb + 2];
+                if (i == j && a == bb)
+                    v += meas_var;
+                Z[2 * i + a + (size_t)(2 * j + bb) * ldz] = v;
+            }
+    } else if (t == n + M) {
+        Z[m + n + (size_t)(2 * j) * ldz] = ytil[2 * j];
+        Z[m + n + (size_t)(2 * j + 1) * ldz] = ytil[2 * j + 1];
+    }
 }
 
 // Sigma fusion (nsig > 0): the workgroups with blockIdx.y >= nyS own the lower 32x32 tiles of Sigma and apply this
