@@ -398,6 +398,7 @@ def load_filter_lib():
         "eqvio_filter_sigma_dim": (C.c_int, [vp]),
         "eqvio_filter_get_sigma": (C.c_int, [vp, c_double_p, C.c_int]),
         "eqvio_filter_compute_nees": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p]),
+        "eqvio_filter_get_feature_predictions": (C.c_int, [vp, P(Camera), C.c_double, c_int_p, c_double_p, C.c_int]),
         "eqvio_filter_core": (vp, [vp]),
         "eqvio_filter_last_timing": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
         "eqvio_filter_run_frames": (C.c_int, [vp, P(Camera), C.c_int, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, c_double_p]),
@@ -493,6 +494,13 @@ class VIOFilter:
         out = C.c_double()
         self._chk(self.lib.eqvio_filter_compute_nees(self.h, _dp(sensor), _ip(ids), _dp(p), len(ids), C.byref(out)))
         return out.value
+
+    def get_feature_predictions(self, cam, stamp):
+        ids, y = np.zeros(self.cap, np.int32), np.zeros(2 * self.cap)
+        k = self.lib.eqvio_filter_get_feature_predictions(self.h, C.byref(cam), stamp, _ip(ids), _dp(y), self.cap)
+        if k < 0:
+            self._chk(-1)
+        return ids[:k].copy(), y[:2 * k].copy()
 
     def core_handle(self):
         return self.lib.eqvio_filter_core(self.h)

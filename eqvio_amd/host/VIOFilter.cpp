@@ -7,6 +7,7 @@
 #include <numeric>
 
 namespace eqvio_amd {
+namespace { constexpr double GRAVITY_CONSTANT_ = 9.80665; } // include/eqvio/mathematical/IMUVelocity.h:26
 
 using namespace eqf;
 
@@ -547,10 +548,50 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
 VIOState VIOFilter::stateEstimate() const { return filterState.stateEstimate(); }
 const VIO_eqf& VIOFilter::viewEqFState() const { return filterState; }
 double VIOFilter::getTime() const { return filterState.currentTime; }
-VisionMeasurement VIOFilter::getFeaturePredictions(const GICameraPtr&, const double&) { // :247-252
-    if (settings->useFeaturePredictions)
-        throw std::runtime_error("VIOFilter::getFeaturePredictions: useFeaturePredictions is not supported by the MI355X path yet");
-    return VisionMeasurement();
+VIOState integrateSystemFunction(const VIOState& state, const IMUVelocity& velocity, const double& dt) { // VIOState.cpp:28-68
+    VIOState ns;
+    const VIOSensorState& s = state.sensor;
+    const V3 gyr = velocity.gyr - V3{s.inputBias[0], s.inputBias[1], s.inputBias[2]}; // v_est = velocity - bias (IMUVelocity.cpp:52-58)
+    const V3 acc = velocity.acc - V3{s.inputBias[3], s.inputBias[4], s.inputBias[5]};
+    const V3 dbg = dt * velocity.gyrBiasVel, dba = dt * velocity.accBiasVel;
+    ns.sensor.inputBias = {s.inputBias[0] + dbg.x, s.inputBias[1] + dbg.y, s.inputBias[2] + dbg.z, s.inputBias[3] + dba.x, s.inputBias[4] + dba.y, s.inputBias[5] + dba.z};
+    const V3 gravity{0, 0, -GRAVITY_CONSTANT_};
+    Pose poseChange;
+    poseChange.R = eqf::so3_exp(dt * gyr);
+    const V3 inertialStep = dt * eqf::q_rot(s.pose.R, s.velocity) + (0.5 * dt * dt) * (eqf::q_rot(s.pose.R, acc) + gravity);
+    poseChange.x = eqf::q_rot(eqf::q_inv(s.pose.R), inertialStep);
+    ns.sensor.pose = eqf::pose_mul(s.pose, poseChange);
+    const V3 inertialVelocityDiff = eqf::q_rot(s.pose.R, acc) + gravity;
+    ns.sensor.velocity = eqf::q_rot(eqf::q_inv(ns.sensor.pose.R), eqf::q_rot(s.pose.R, s.velocity) + dt * inertialVelocityDiff);
+    const Pose cameraPoseChangeInv = eqf::pose_mul(eqf::pose_mul(eqf::pose_inv(s.cameraOffset), eqf::pose_inv(poseChange)), s.cameraOffset);
+    ns.cameraLandmarks.resize(state.cameraLandmarks.size());
+    for (size_t i = 0; i < state.cameraLandmarks.size(); ++i)
+        ns.cameraLandmarks[i] = Landmark{eqf::pose_act(cameraPoseChangeInv, state.cameraLandmarks[i].p), state.cameraLandmarks[i].id};
+    ns.sensor.cameraOffset = s.cameraOffset;
+    return ns;
+}
+VIOState VIO_eqf::predictState(const double& stamp, const std::vector<IMUVelocity>& imuVelocities) const { // VIO_eqf.cpp:139-151
+    VIOState statePrediction = stateEstimate();
+    for (size_t i = 0; i < imuVelocities.size(); ++i) {
+        const double t0 = std::max(imuVelocities.at(i).stamp, this->currentTime);
+        const double t1 = i + 1 < imuVelocities.size() ? std::min(imuVelocities.at(i + 1).stamp, stamp) : stamp;
+        const double dt = std::max(t1 - t0, 0.0);
+        statePrediction = integrateSystemFunction(statePrediction, imuVelocities.at(i), dt);
+    }
+    return statePrediction;
+}
+VisionMeasurement VIOFilter::getFeaturePredictions(const GICameraPtr& camPtr, const double& stamp) { // :247-252
+    VisionMeasurement r;
+    if (settings->useFeaturePredictions) { // measureSystemState(predictState(...)), VIOState.cpp:70-78
+        const VIOState pred = filterState.predictState(stamp, velocityBuffer);
+        for (const Landmark& lm : pred.cameraLandmarks) {
+            double u, v;
+            camPtr->projectPoint(lm.p, u, v);
+            r.camCoordinates[lm.id] = {u, v};
+        }
+        r.cameraPtr = camPtr;
+    }
+    return r;
 }
 void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2) { // :258-278
     std::vector<Landmark> newLandmarks;

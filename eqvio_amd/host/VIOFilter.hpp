@@ -107,6 +107,8 @@ struct Camera {
     V3 undistortPoint(double u, double v) const { return eqf::cam_undistort(model(), u, v); }
 };
 using GICameraPtr = std::shared_ptr<const Camera>;
+// VIOState.cpp:28-68: one step of the VIO dynamics on a state (no covariance), used by predictState
+VIOState integrateSystemFunction(const VIOState& state, const IMUVelocity& velocity, const double& dt);
 struct VisionMeasurement {
     double stamp = 0;
     std::map<int, std::array<double, 2>> camCoordinates; // ascending id == the reference's row order
@@ -162,6 +164,7 @@ struct VIO_eqf {
     void integrateRiccatiStateAccurate(const IMUVelocity& imuVelocity, const double& dt, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8);
     void performVisionUpdate(const VisionMeasurement& measurement, double outputGainVar, const bool& useEquivariantOutput = true, const bool& discreteCorrection = false);
     VIOState stateEstimate() const;
+    VIOState predictState(const double& stamp, const std::vector<IMUVelocity>& imuVelocities) const; // VIO_eqf.cpp:139-151 (host: O(kN))
     double computeNEES(const VIOState& trueState) const; // VIO_eqf.cpp:153-170, factorised on the device
     // per-landmark quantities VIOFilter::removeOutliers / getMedianSceneDepth need, all landmarks at once
     void outlierStats(const VisionMeasurement& measurement, std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2) const;

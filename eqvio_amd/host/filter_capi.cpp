@@ -168,6 +168,23 @@ int eqvio_filter_get_sigma(eqvio_filter* f, double* out, int n) { return eqf_get
 int eqvio_filter_compute_nees(eqvio_filter* f, const double* ts, const int* tids, const double* tp, int nt, double* nees) {
     return guarded(f, [&] { *nees = f->filter->viewEqFState().computeNEES(unpackState(ts, tids, tp, nt)); });
 }
+int eqvio_filter_get_feature_predictions(eqvio_filter* f, const eqvio_camera* cam, double stamp, int* ids, double* y, int cap) {
+    int count = -1;
+    const int rc = guarded(f, [&] {
+        const VisionMeasurement m = f->filter->getFeaturePredictions(makeCamera(cam), stamp);
+        if ((int)m.camCoordinates.size() > cap)
+            throw std::runtime_error("eqvio_filter_get_feature_predictions: capacity");
+        int k = 0;
+        for (const auto& kv : m.camCoordinates) {
+            ids[k] = kv.first;
+            y[2 * k] = kv.second[0];
+            y[2 * k + 1] = kv.second[1];
+            ++k;
+        }
+        count = k;
+    });
+    return rc ? -1 : count;
+}
 eqf_ctx* eqvio_filter_core(eqvio_filter* f) { return f->filter->eqfState().ctx; }
 int eqvio_filter_last_timing(const eqvio_filter* f, double* a, double* b, double* c) {
     if (a)

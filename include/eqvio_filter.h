@@ -44,6 +44,9 @@ int eqvio_filter_sigma_dim(const eqvio_filter* f);
 int eqvio_filter_get_sigma(eqvio_filter* f, double* out_colmajor, int n);
 /* viewEqFState().computeNEES(trueState) (src/main_sim.cpp:148, VIO_eqf.cpp:153-170) */
 int eqvio_filter_compute_nees(eqvio_filter* f, const double* true_sensor, const int* true_ids, const double* true_p, int n_true, double* nees);
+/* getFeaturePredictions(camPtr, stamp) (VIOFilter.cpp:247-252): ids ascending, pixel pairs; returns the count (0 unless
+ * settings.useFeaturePredictions) or -1 */
+int eqvio_filter_get_feature_predictions(eqvio_filter* f, const eqvio_camera* cam, double stamp, int* ids, double* y, int cap);
 /* the device context behind viewEqFState(), for the eqf_* entry points */
 eqf_ctx* eqvio_filter_core(eqvio_filter* f);
 /* loopTimer sections of the last processVisionData (VIOFilter.cpp:196-236), seconds */

@@ -400,4 +400,19 @@ void orc_cam_jacobian(const eqvio_camera* cam, const double* p3, double* J6_rowm
             J6_rowmajor[3 * r + c] = J(r, c);
 }
 
+// getFeaturePredictions (VIOFilter.cpp:247-252)
+int orc_filter_get_feature_predictions(void* f, const eqvio_camera* cam, double stamp, int* ids, double* y, int cap) {
+    const VisionMeasurement m = static_cast<VIOFilter*>(f)->getFeaturePredictions(makeCamera(cam), stamp);
+    if ((int)m.camCoordinates.size() > cap)
+        return -1;
+    int k = 0;
+    for (const auto& kv : m.camCoordinates) {
+        ids[k] = kv.first;
+        y[2 * k] = kv.second(0);
+        y[2 * k + 1] = kv.second(1);
+        ++k;
+    }
+    return k;
+}
+
 } // extern "C"

@@ -49,6 +49,7 @@ def load_oracle():
         "orc_filter_last_gamma": (C.c_int, [vp, c_double_p, C.c_int]),
         "orc_eqf_integrate_riccati_fast": (None, [vp, c_double_p, C.c_double]),
         "orc_eqf_integrate_riccati_accurate": (None, [vp, c_double_p, C.c_double]),
+        "orc_filter_get_feature_predictions": (C.c_int, [vp, P(Camera), C.c_double, c_int_p, c_double_p, C.c_int]),
         "orc_cam_project": (None, [P(Camera), c_double_p, c_double_p]),
         "orc_cam_undistort": (None, [P(Camera), c_double_p, c_double_p]),
         "orc_cam_jacobian": (None, [P(Camera), c_double_p, c_double_p]),
@@ -120,6 +121,12 @@ class OracleFilter:
 
     def get_time(self):
         return self.lib.orc_filter_get_time(self.h)
+
+    def get_feature_predictions(self, cam, stamp):
+        ids, y = np.zeros(self.cap, np.int32), np.zeros(2 * self.cap)
+        k = self.lib.orc_filter_get_feature_predictions(self.h, C.byref(cam), stamp, _ip(ids), _dp(y), self.cap)
+        assert k >= 0
+        return ids[:k].copy(), y[:2 * k].copy()
 
     def set_state(self, sensor, ids, p):
         sensor, ids, p = _f64(sensor), _i32(ids), _f64(p)

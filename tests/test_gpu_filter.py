@@ -143,3 +143,31 @@ def test_discrete_state_matrix_is_refused_loudly():
     flt.process_imu(world.imu(0.0))
     with pytest.raises(RuntimeError):
         flt.process_vision(0.05, world.cam, ids0, y0)
+
+
+def test_feature_predictions_match():
+    """getFeaturePredictions (VIOFilter.cpp:247-252) -> VIO_eqf::predictState (VIO_eqf.cpp:139-151) -> integrateSystemFunction
+    (VIOState.cpp:28-68): the state estimate pushed through the buffered IMU samples up to a stamp, then projected. The
+    prediction is requested between frames (as the tracker front end would, main_opt.cpp:200-203)."""
+    world = SimWorld(seed=9, num_points=800, max_features=25, trajectory="wave", noise_px=0.2)
+    settings = sim_settings(COORD_INVDEPTH, useFeaturePredictions=1)
+    ids0, _ = world.vision(0.0)
+    sensor, ids, p = world.true_state(0.0, ids0)
+    orc = OracleFilter(settings, sensor, ids, p, 0.0)
+    flt = VIOFilter(settings, max_landmarks=64, sensor=sensor, ids=ids, p=p, time=0.0)
+    n_checked = 0
+    for imus, stamp, mid, y in world.frames(12):
+        for s in range(len(imus)):
+            orc.process_imu(imus[s])
+            flt.process_imu(imus[s])
+        # the IMU buffer now reaches the next image stamp: predict the features there, before processing it
+        ig, yg = flt.get_feature_predictions(world.cam, stamp)
+        io, yo = orc.get_feature_predictions(world.cam, stamp)
+        assert np.array_equal(ig, io) and len(ig) > 0
+        np.testing.assert_allclose(yg, yo, rtol=0, atol=1e-7)  # pixels: 1e-9 relative of O(100) px coordinates
+        n_checked += len(ig)
+        orc.process_vision(stamp, world.cam, mid, y)
+        flt.process_vision(stamp, world.cam, mid, y)
+    assert n_checked > 100
+    off = VIOFilter(sim_settings(COORD_INVDEPTH), max_landmarks=64, sensor=sensor, ids=ids, p=p, time=0.0)
+    assert len(off.get_feature_predictions(world.cam, 0.1)[0]) == 0  # disabled by default, like the reference
