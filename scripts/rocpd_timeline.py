@@ -1,0 +1,26 @@
+"""Timeline of one steady-state frame from a rocprofv3 (rocpd sqlite) kernel trace: kernel durations and the gaps
+between consecutive dispatches. Usage: python scripts/rocpd_timeline.py results.db [frame_index_from_end]"""
+import re
+import sqlite3
+import sys
+
+con = sqlite3.connect(sys.argv[1])
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+rows = con.execute(
+    """select d.start, d.end, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start"""
+).fetchall()
+names = [re.sub(r"^_ZN3eqf\d+", "", r[2].split("(")[0]).split("E")[0] if r[2].startswith("_ZN3eqf") else r[2][:24] for r in rows]
+# a frame starts at k_assemble_AB
+starts = [i for i, n in enumerate(names) if n.startswith("k_assemble_AB")]
+a, b = starts[-back - 1], starts[-back]
+t0 = rows[a][0]
+prev_end = None
+busy = 0
+print(f"frame of {b - a} dispatches, {1e-3 * (rows[b][0] - t0):.1f} us from its first kernel to the next frame's first kernel")
+for i in range(a, b):
+    s, e, _ = rows[i]
+    gap = (s - prev_end) if prev_end is not None else 0
+    busy += e - s
+    print(f"{1e-3 * (s - t0):8.1f}  {names[i]:20s} dur {1e-3 * (e - s):6.2f}  gap before {1e-3 * gap:6.2f}")
+    prev_end = max(prev_end or 0, e)
+print(f"kernel time {1e-3 * busy:.1f} us; tail gap to next frame {1e-3 * (rows[b][0] - prev_end):.2f} us")
