@@ -824,15 +824,10 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
     double* Sin = c->d_sigma[c->cur];
     double* Sout = c->d_sigma[1 - c->cur];
     if (!c->opt_dense) {
-        if (N > 0) {
-            KTimer t(c, KN_PROP_G);
-            hipLaunchKernelGGL(k_propagate_G, dim3(blocks(N * 21, 256)), dim3(256), 0, c->stream, N, c->Ncap, c->ld, dt, Sin, c->d_Al, c->d_G);
-            HIPCHK(hipGetLastError());
-        }
-        const int nT = blocks(N, PT), nStrip = blocks(N * 21, 256);
+        const int nT = blocks(N, PT), nStrip = blocks(N, 12);
         KTimer t(c, KN_PROP_MAIN);
-        hipLaunchKernelGGL(k_propagate_main, dim3(nT * nT + nStrip + 1), dim3(256), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, Sin, Sout, c->d_Al, c->d_Bl, c->d_G,
-                           nT, nStrip);
+        hipLaunchKernelGGL(k_propagate_main, dim3(nT * nT + nStrip + 1), dim3(256), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, Sin, Sout, c->d_Al, c->d_Bl, nT,
+                           nStrip);
         HIPCHK(hipGetLastError());
     } else {
         // dense: F materialised, tmp = F Sigma (= (Sigma F^T)^T, Sigma symmetric), Sigma' = tmp F^T + noise

@@ -238,41 +238,20 @@ __global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2a: G_i = (F Sigma)[l_i, 0:21] = dt*A_ls_i Sigma_ss + (I + dt*A_qi) Sigma_{l_i,s}   (3 x 21 per landmark)
-__global__ void __launch_bounds__(256) k_propagate_G(int N, int Ncap, int ld, double dt, const double* __restrict__ Sig, const double* __restrict__ Al,
-                                                     double* __restrict__ G) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= N * 21)
-        return;
-    const int i = t % N, c = t / N;
-    const int l = 21 + 3 * i;
-    const double s0 = Sig[l + (size_t)c * ld], s1 = Sig[l + 1 + (size_t)c * ld], s2 = Sig[l + 2 + (size_t)c * ld];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double acc = 0;
-#pragma unroll
-        for (int e = 0; e < 12; ++e)
-            acc += Al[(r * 15 + e) * Ncap + i] * Sig[al_col(e) + (size_t)c * ld];
-        acc *= dt;
-        const double d0 = dt * Al[(r * 15 + 12) * Ncap + i] + (r == 0 ? 1.0 : 0.0);
-        const double d1 = dt * Al[(r * 15 + 13) * Ncap + i] + (r == 1 ? 1.0 : 0.0);
-        const double d2 = dt * Al[(r * 15 + 14) * Ncap + i] + (r == 2 ? 1.0 : 0.0);
-        acc += d0 * s0 + d1 * s1 + d2 * s2;
-        G[(r * 21 + c) * Ncap + i] = acc;
-    }
-}
-
+// K2: G_i = (F Sigma)[l_i, 0:21] = dt*A_ls_i Sigma_ss + (I + dt*A_qi) Sigma_{l_i,s}   (3 x 21 per landmark) is computed
+// inside the workgroups that need it (the tile's 16 i-landmarks; a strip workgroup's 12 landmarks): it costs the same 63
+// loads per landmark a stored G would, and saves a launch.
 // K2b: Sigma' = F Sigma F^T + dt (B Q B^T + P) in arrow form (integrateRiccatiStateFast, VIO_eqf.cpp:62-72).
 // Block roles by blockIdx.x: [0, nT*nT) landmark-landmark tiles of 16x16 landmarks (one 3x3 block per lane),
 // then strip blocks (landmark-sensor 3x21 blocks and their transposes), then one sensor-sensor block.
 constexpr int PT = 16; // landmarks per tile side
 __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const double* __restrict__ Sig, double* __restrict__ Sout, const double* __restrict__ Al,
-                                                        const double* __restrict__ Bl, const double* __restrict__ G, int nT, int nStrip) {
+                                                        const double* __restrict__ Bl, int nT, int nStrip) {
     const double dt = ra.dt;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 8];
+    __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
     if (b < nT * nT) {
         const int bi = b % nT, bj = b / nT;
         // per-i arrays: G (63), Fls (36), D (9), Bl (9) ; per-j arrays: Ssj (63), Fls (36), D (9), Bl (9). layout [e][PT]
@@ -284,14 +263,18 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
         double* sFj = sSj + 63 * PT;
         double* sDj = sFj + 36 * PT;
         double* sBj = sDj + 9 * PT;
+        double* sSi = sBj + 9 * PT;   // Sigma[k][l_i + c'] at [(k*3 + c') * PT + x]
+        double* sSs = sSi + 63 * PT;  // Sigma_ss[al_col(e)][k] at [e * 21 + k], e < 12
         for (int t = tid; t < 63 * PT; t += 256) {
             const int e = t / PT, x = t % PT;
             const int i = bi * PT + x, j = bj * PT + x;
-            sGi[t] = i < N ? G[e * Ncap + i] : 0.0;
-            // Sigma[k][l_j + c'] with e = k*3 + c'
+            // Sigma[k][l + c'] with e = k*3 + c'
             const int kk = e / 3, cc = e % 3;
+            sSi[t] = i < N ? Sig[kk + (size_t)(21 + 3 * i + cc) * ld] : 0.0;
             sSj[t] = j < N ? Sig[kk + (size_t)(21 + 3 * j + cc) * ld] : 0.0;
         }
+        if (tid < 12 * 21)
+            sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
         for (int t = tid; t < 36 * PT; t += 256) {
             const int e = t / PT, x = t % PT;
             const int r = e / 12, c = e % 12;
@@ -308,6 +291,20 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
             sDj[t] = j < N ? dt * Al[(r * 15 + 12 + c) * Ncap + j] + eye : 0.0;
             sBi[t] = i < N ? Bl[e * Ncap + i] : 0.0;
             sBj[t] = j < N ? Bl[e * Ncap + j] : 0.0;
+        }
+        __syncthreads();
+        // G_i[r][k] = sum_e (dt A_ls_i)[r][e] Sigma_ss[al_col(e)][k] + sum_c' (I + dt A_qi)[r][c'] Sigma[l_i + c'][k]
+        for (int t = tid; t < 63 * PT; t += 256) {
+            const int e = t / PT, x = t % PT;
+            const int r = e / 21, k = e % 21;
+            double g = 0.0;
+#pragma unroll
+            for (int q = 0; q < 12; ++q)
+                g += sFi[(r * 12 + q) * PT + x] * sSs[q * 21 + k];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+                g += sDi[(r * 3 + cc) * PT + x] * sSi[(k * 3 + cc) * PT + x];
+            sGi[t] = g;
         }
         __syncthreads();
         const int ti = tid % PT, tj = tid / PT;
@@ -361,17 +358,41 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
     }
     if (b < nT * nT + nStrip) {
         // landmark-sensor strips: Sigma'[l_i + r][c] = sum_k G_i[r][k] Fss[c][k] + dt sum_q Bl_i[r][q] Qd[q] Bs[c][q]
-        const int t = (b - nT * nT) * 256 + tid;
-        if (t >= N * 21)
+        // 12 landmarks x 21 columns per workgroup; G of the 12 landmarks is built in LDS first.
+        constexpr int SL = 12;
+        double* sG = sm;                  // [lm][r*21 + k]  (SL x 63)
+        double* sSs = sm + SL * 63;       // Sigma_ss[al_col(e)][k] at [e*21 + k]
+        const int i0 = (b - nT * nT) * SL;
+        if (tid < 12 * 21)
+            sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
+        __syncthreads();
+        for (int t = tid; t < SL * 63; t += 256) {
+            const int x = t / 63, e = t % 63;
+            const int r = e / 21, k = e % 21;
+            const int i = i0 + x;
+            double g = 0.0;
+            if (i < N) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q)
+                    g += dt * Al[(r * 15 + q) * Ncap + i] * sSs[q * 21 + k];
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    g += (dt * Al[(r * 15 + 12 + cc) * Ncap + i] + (r == cc ? 1.0 : 0.0)) * Sig[k + (size_t)(21 + 3 * i + cc) * ld];
+            }
+            sG[t] = g;
+        }
+        __syncthreads();
+        const int x = tid / 21, c = tid % 21;
+        const int i = i0 + x;
+        if (tid >= SL * 21 || i >= N)
             return;
-        const int i = t % N, c = t / N;
         const int li = 21 + 3 * i;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             double s = 0;
             for (int k = 0; k < 21; ++k) {
                 const double f = dt * cm->Ass[c * 21 + k] + (k == c ? 1.0 : 0.0);
-                s += G[(r * 21 + k) * Ncap + i] * f;
+                s += sG[x * 63 + r * 21 + k] * f;
             }
             double bq = 0;
 #pragma unroll
