@@ -140,7 +140,7 @@ struct eqf_ctx {
     int lmcur = 0;
     double* d_sigma[2] = {nullptr, nullptr};
     int cur = 0;
-    double *d_Al = nullptr, *d_Bl = nullptr, *d_G = nullptr;
+    double *d_Al = nullptr, *d_Bl = nullptr;
     Common* d_common = nullptr;
     ObsStep* d_steps = nullptr;
     double *d_C = nullptr, *d_ytil = nullptr, *d_y = nullptr;
@@ -431,7 +431,6 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     }
     HIPCHK(hipMalloc(&c->d_Al, sizeof(double) * 45 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_Bl, sizeof(double) * 9 * (size_t)c->Ncap));
-    HIPCHK(hipMalloc(&c->d_G, sizeof(double) * 63 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_common, sizeof(Common)));
     HIPCHK(hipMalloc(&c->d_steps, sizeof(ObsStep) * eqf_ctx::kMaxSteps));
     HIPCHK(hipMalloc(&c->d_C, sizeof(double) * 6 * (size_t)c->Ncap));
@@ -480,7 +479,6 @@ void eqf_destroy(eqf_ctx* c) {
     }
     hipFree(c->d_Al);
     hipFree(c->d_Bl);
-    hipFree(c->d_G);
     hipFree(c->d_common);
     hipFree(c->d_steps);
     hipFree(c->d_C);
