@@ -1,0 +1,86 @@
+"""Production-style robustness of the device path: context churn, several filters sharing one GPU (also from threads),
+and a long free-running sequence against the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+from eqvio_amd.capi import COORD_EUCLIDEAN, COORD_INVDEPTH, EqfCore, VIOFilter
+from oracle_binding import OracleFilter
+from simworld import SimWorld
+from test_gpu_filter import compare, sim_settings
+from util import CHARTS, random_spd, reasonable_state
+
+pytestmark = pytest.mark.gpu
+
+
+def test_context_churn():
+    """Create / use / destroy many contexts: no handle, stream or memory exhaustion, and no state leaks between them."""
+    rng = np.random.default_rng(0)
+    ref = None
+    for k in range(60):
+        N = 8
+        xi0, Xs, ids, q0, Q = reasonable_state(np.random.default_rng(5), N)
+        core = EqfCore(N, CHARTS["invdepth"])
+        core.set_state(xi0, Xs, ids, q0, Q)
+        S = random_spd(np.random.default_rng(6), 21 + 3 * N)
+        core.set_sigma(S)
+        core.integrate_riccati_fast(np.array([0, 0.1, -0.2, 0.3, 0.5, -0.4, 9.8, 0, 0, 0, 0, 0, 0.0]), 0.05, np.full(12, 1e-4), np.full(8, 1e-3))
+        out = core.get_sigma()
+        if ref is None:
+            ref = out
+        assert np.array_equal(out, ref)  # bit-identical every time: deterministic kernels, fresh state
+        core.close()
+
+
+def _run(world, settings, n_frames, out, key):
+    ids0, _ = world.vision(0.0)
+    sensor, ids, p = world.true_state(0.0, ids0)
+    flt = VIOFilter(settings, max_landmarks=64, sensor=sensor, ids=ids, p=p, time=0.0)
+    for imus, stamp, mid, y in world.frames(n_frames):
+        for s in range(len(imus)):
+            flt.process_imu(imus[s])
+        flt.process_vision(stamp, world.cam, mid, y)
+    out[key] = (flt.state_estimate(), flt.get_sigma())
+    flt.close()
+
+
+def test_filters_sharing_a_gpu_do_not_interfere():
+    """Two different filters stepped from two host threads give bit-identical results to the same filters run alone
+    (one eqf_ctx, stream pair and thread-local LoopTimer each; SURVEY.md §8(b) "Threading")."""
+    cfgs = [(dict(seed=21, num_points=900, max_features=24, trajectory="wave", noise_px=0.3), sim_settings(COORD_INVDEPTH)),
+            (dict(seed=22, num_points=700, max_features=18, trajectory="wave", noise_px=0.5), sim_settings(COORD_EUCLIDEAN))]
+    alone, together = {}, {}
+    for k, (w, s) in enumerate(cfgs):
+        _run(SimWorld(**w), s, 25, alone, k)
+    ths = [threading.Thread(target=_run, args=(SimWorld(**w), s, 25, together, k)) for k, (w, s) in enumerate(cfgs)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for k in range(2):
+        (sa, ia, pa), Sa = alone[k]
+        (sb, ib, pb), Sb = together[k]
+        assert np.array_equal(ia, ib) and np.array_equal(sa, sb) and np.array_equal(pa, pb) and np.array_equal(Sa, Sb)
+
+
+def test_long_free_running_sequence_stays_on_the_oracle():
+    """600 frames (30 s) of landmark turnover, free running: still within 1e-8 of the oracle at the end, Sigma SPD."""
+    world = SimWorld(seed=31, num_points=3000, max_features=20, trajectory="wave", noise_px=0.3)
+    settings = sim_settings(COORD_INVDEPTH)
+    ids0, _ = world.vision(0.0)
+    sensor, ids, p = world.true_state(0.0, ids0)
+    orc = OracleFilter(settings, sensor, ids, p, 0.0)
+    flt = VIOFilter(settings, max_landmarks=64, sensor=sensor, ids=ids, p=p, time=0.0)
+    k = 0
+    for imus, stamp, mid, y in world.frames(600):
+        for s in range(len(imus)):
+            orc.process_imu(imus[s])
+            flt.process_imu(imus[s])
+        orc.process_vision(stamp, world.cam, mid, y)
+        flt.process_vision(stamp, world.cam, mid, y)
+        k += 1
+        if k % 100 == 0:
+            compare(flt, orc, tol=1e-8)
+    S = flt.get_sigma()
+    assert np.all(np.isfinite(S)) and np.linalg.eigvalsh(0.5 * (S + S.T)).min() > 0
