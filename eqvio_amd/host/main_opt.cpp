@@ -15,7 +15,7 @@ using namespace eqvio_amd;
 static void usage() {
     std::puts("usage: eqvio_opt --imu FILE --features FILE [--format asl|uzhfpv] [--groundtruth FILE] [--dumpMeasurements] [--camera fx fy cx cy width height]\n"
               "                 [--distortion radtan k1 k2 p1 p2 k3 | --distortion equidistant k1 k2 k3 k4]\n"
-              "                 [--cameraOffset qw qx qy qz x y z] [--cameraLag S] [--start S] [--stop S] [--output DIR] [--quiet]\n"
+              "                 [--cameraOffset qw qx qy qz x y z] [--cameraLag S] [--start S] [--stop S] [--output DIR] [--sigmaFP32] [--quiet]\n"
               "                 [--<eqf setting> VALUE ...]   (names of VIOFilter::Settings, e.g. --fastRiccati 1 --coordinateChoice InvDepth)");
 }
 
@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     cam->c.width = 752;
     cam->c.height = 480;
     double cameraLag = 0, startTime = -1, stopTime = -1;
-    bool quiet = false, dump = false;
+    bool quiet = false, dump = false, sigmaFP32 = false;
     try {
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -77,6 +77,7 @@ int main(int argc, char** argv) {
             else if (a == "--stop") stopTime = std::atof(val());
             else if (a == "--output") outputDir = val();
             else if (a == "--quiet") quiet = true;
+            else if (a == "--sigmaFP32") sigmaFP32 = true;
             else if (a == "--dumpMeasurements") dump = true;
             else if (!parseFilterFlag(a, val, fs)) {
                 usage();
@@ -117,6 +118,8 @@ int main(int argc, char** argv) {
         }
         loopTimer.initialise({"correction", "features", "preprocessing", "propagation", "total", "total vision update", "write output"});
         VIOFilter filter(fs); // main_opt.cpp:150
+        if (sigmaFP32) // BASELINE config 5: Sigma rounded to float on every store (include/eqf_hip.h)
+            eqf_set_option(filter.eqfState().ctx, EQF_OPT_SIGMA_FP32, 1);
         std::unique_ptr<VIOWriter> vioWriter;
         if (!outputDir.empty())
             vioWriter = std::make_unique<VIOWriter>(outputDir);

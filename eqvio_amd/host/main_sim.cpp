@@ -19,7 +19,7 @@ using namespace eqvio_amd;
 static void usage() {
     std::puts("usage: eqvio_sim [--duration S] [--trajectory wave|square|sine|line] [--numPoints N] [--numWalls W] [--wallDistance D]\n"
               "                 [--maxFeatures M] [--seed S] [--imuFreq HZ] [--imageFreq HZ] [--initialNoise] [--inputNoise] [--outputNoise]\n"
-              "                 [--fullState] [--landmarkReset S] [--output DIR] [--writeDataset DIR] [--quiet]\n"
+              "                 [--fullState] [--landmarkReset S] [--output DIR] [--writeDataset DIR] [--sigmaFP32] [--quiet]\n"
               "                 [--<eqf setting> VALUE ...]   (names of VIOFilter::Settings, e.g. --fastRiccati 1 --coordinateChoice InvDepth)");
 }
 
@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
     SimSettings sim;
     sim.duration = 20.0;
     VIOFilter::Settings fs;
-    bool fullState = false, quiet = false;
+    bool fullState = false, quiet = false, sigmaFP32 = false;
     double landmarkResetTime = -1.0;
     std::string outputDir, datasetDir;
     for (int i = 1; i < argc; ++i) {
@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
         else if (a == "--output") outputDir = val();
         else if (a == "--writeDataset") datasetDir = val();
         else if (a == "--quiet") quiet = true;
+        else if (a == "--sigmaFP32") sigmaFP32 = true;
         else if (parseFilterFlag(a, val, fs)) {
         } else {
             usage();
@@ -90,6 +91,8 @@ int main(int argc, char** argv) {
 
     try {
         VIOFilter filter(simDataServer.getInitialCondition(), fs);
+        if (sigmaFP32) // BASELINE config 5: Sigma rounded to float on every store (include/eqf_hip.h)
+            eqf_set_option(filter.eqfState().ctx, EQF_OPT_SIGMA_FP32, 1);
         int imuDataCounter = 0, visionDataCounter = 0;
         double neesSum = 0, neesMax = 0, posErr = 0;
         const auto loopStartTime = std::chrono::steady_clock::now();
