@@ -166,6 +166,7 @@ struct eqf_ctx {
     CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
     int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0;
+    bool sig32 = false; // Sigma stored as float (EQF_OPT_SIGMA_FP32 = 2)
     std::vector<double> last_gamma;
     int n_at_update = 0;
     bool gamma_stale = false; // d_gamma holds a newer Gamma than last_gamma (fetched lazily by eqf_last_gamma)
@@ -529,8 +530,37 @@ void eqf_destroy(eqf_ctx* c) {
     delete c;
 }
 
+// Launch KERNEL<double> or KERNEL<float> according to the storage type of Sigma; Sigma pointer arguments are written (TS*)ptr.
+#define LAUNCH_TS(c, KERNEL, grid, block, stream, ...)                                                        \
+    do {                                                                                                      \
+        if ((c)->sig32) {                                                                                     \
+            using TS = float;                                                                                 \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<TS>), grid, block, 0, stream, __VA_ARGS__);             \
+        } else {                                                                                              \
+            using TS = double;                                                                                \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<TS>), grid, block, 0, stream, __VA_ARGS__);             \
+        }                                                                                                     \
+    } while (0)
+
+// switch the storage type of Sigma: convert the current buffer into the other one and flip
+static int set_sigma_storage(eqf_ctx* c, bool f32) {
+    if (c->sig32 == f32)
+        return 0;
+    const int n = c->n();
+    double* in = c->d_sigma[c->cur];
+    double* out = c->d_sigma[1 - c->cur];
+    if (f32)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convert_sigma<double, float>), dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, in, (float*)out);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convert_sigma<float, double>), dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, (const float*)in, out);
+    HIPCHK(hipGetLastError());
+    c->cur = 1 - c->cur;
+    c->sig32 = f32;
+    return 0;
+}
+
 static int round_sigma(eqf_ctx* c) {
-    if (!c->opt_f32 || c->n() == 0)
+    if (c->opt_f32 != 1 || c->n() == 0) // 2 = real float storage: every store already rounds
         return 0;
     const int n = c->n();
     hipLaunchKernelGGL(k_round_f32, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma());
@@ -543,17 +573,27 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return EQF_E_BAD_ARG;
     switch (option) {
     case EQF_OPT_RICCATI_DENSE:
+        if (value && c->sig32)
+            return EQF_E_UNSUPPORTED;
         c->opt_dense = value;
         return 0;
     case EQF_OPT_CHECK_FINITE:
         c->opt_check = value;
         return 0;
     case EQF_OPT_FUSED_UPDATE:
+        if (value && c->sig32)
+            return EQF_E_UNSUPPORTED;
         c->opt_fused = value;
         return 0;
-    case EQF_OPT_SIGMA_FP32:
+    case EQF_OPT_SIGMA_FP32: {
+        if (value < 0 || value > 2)
+            return EQF_E_BAD_ARG;
+        if (value == 2 && (c->opt_dense || c->opt_fused))
+            return EQF_E_UNSUPPORTED; // the float store exists for the structured fast path only
         c->opt_f32 = value;
-        return round_sigma(c);
+        const int rc = set_sigma_storage(c, value == 2);
+        return rc ? rc : round_sigma(c);
+    }
     case 100:
         c->opt_timing = value;
         timing_reset(c);
@@ -638,7 +678,14 @@ int eqf_set_sigma(eqf_ctx* c, const double* sig, int n) {
     HIPCHK(hipSetDevice(c->device));
     { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(c->h_buf, sig, sizeof(double) * (size_t)n * n);
-    HIPCHK(hipMemcpy2DAsync(c->sigma(), sizeof(double) * c->ld, c->h_buf, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream));
+    if (c->sig32) { // doubles land in the other buffer, the conversion kernel writes the float store
+        double* stage = c->d_sigma[1 - c->cur];
+        HIPCHK(hipMemcpy2DAsync(stage, sizeof(double) * c->ld, c->h_buf, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convert_sigma<double, float>), dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, stage, (float*)c->sigma());
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpy2DAsync(c->sigma(), sizeof(double) * c->ld, c->h_buf, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream));
+    }
     { int _r = round_sigma(c); if (_r) return _r; }
     { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
@@ -650,7 +697,7 @@ int eqf_set_sigma_diag(eqf_ctx* c, const double* diag, int n) {
     { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(c->h_buf, diag, sizeof(double) * n);
     HIPCHK(hipMemcpyAsync(c->d_gamma, c->h_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_set_diag, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->d_gamma, c->sigma());
+    LAUNCH_TS(c, k_set_diag, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->ld, c->d_gamma, (TS*)c->sigma());
     HIPCHK(hipGetLastError());
     { int _r = round_sigma(c); if (_r) return _r; }
     { int _r = sync_ctx(c); if (_r) return _r; }
@@ -662,7 +709,15 @@ int eqf_get_sigma_block(eqf_ctx* c, int r0, int c0, int rows, int cols, double* 
     if (rows == 0 || cols == 0)
         return 0;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpy2DAsync(c->h_buf, sizeof(double) * rows, c->sigma() + r0 + (size_t)c0 * c->ld, sizeof(double) * c->ld, sizeof(double) * rows, cols,
+    const double* src = c->sigma();
+    if (c->sig32) { // widen into the other buffer first
+        const int n = c->n();
+        double* stage = c->d_sigma[1 - c->cur];
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convert_sigma<float, double>), dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, (const float*)c->sigma(), stage);
+        HIPCHK(hipGetLastError());
+        src = stage;
+    }
+    HIPCHK(hipMemcpy2DAsync(c->h_buf, sizeof(double) * rows, src + r0 + (size_t)c0 * c->ld, sizeof(double) * c->ld, sizeof(double) * rows, cols,
                             hipMemcpyDeviceToHost, c->stream));
     { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(out, c->h_buf, sizeof(double) * (size_t)rows * cols);
@@ -732,7 +787,7 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
     HIPCHK(hipGetLastError());
     const int nold = c->n();
     const int nnew = nold + 3 * k;
-    hipLaunchKernelGGL(k_append_sigma, dim3(blocks(nnew, 256), nnew), dim3(256), 0, c->stream, nold, nnew, c->ld, var, c->sigma());
+    LAUNCH_TS(c, k_append_sigma, dim3(blocks(nnew, 256), nnew), dim3(256), c->stream, nold, nnew, c->ld, var, (TS*)c->sigma());
     HIPCHK(hipGetLastError());
     c->ids.insert(c->ids.end(), ids, ids + k);
     c->N += k;
@@ -766,7 +821,7 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
     const int nnew = 21 + 3 * Nnew;
     {
         KTimer t(c, KN_MISC);
-        hipLaunchKernelGGL(k_compact_sigma, dim3(blocks(nnew, 256), nnew), dim3(256), 0, c->stream, nnew, c->ld, c->d_keep, c->d_sigma[c->cur], c->d_sigma[1 - c->cur]);
+        LAUNCH_TS(c, k_compact_sigma, dim3(blocks(nnew, 256), nnew), dim3(256), c->stream, nnew, c->ld, c->d_keep, (const TS*)c->d_sigma[c->cur], (TS*)c->d_sigma[1 - c->cur]);
         HIPCHK(hipGetLastError());
         if (Nnew > 0) {
             double* src = c->d_lm[c->lmcur];
@@ -824,7 +879,7 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
     if (!c->opt_dense) {
         const int nT = blocks(N, PT), nStrip = blocks(N, 12);
         KTimer t(c, KN_PROP_MAIN);
-        hipLaunchKernelGGL(k_propagate_main, dim3(nT * nT + nStrip + 1), dim3(256), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, Sin, Sout, c->d_Al, c->d_Bl, nT,
+        LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1), dim3(256), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout, c->d_Al, c->d_Bl, nT,
                            nStrip);
         HIPCHK(hipGetLastError());
     } else {
@@ -849,7 +904,7 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
     c->cur = 1 - c->cur;
     { int _r = round_sigma(c); if (_r) return _r; }
     if (c->opt_check) {
-        hipLaunchKernelGGL(k_check_finite, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), c->d_flags);
+        LAUNCH_TS(c, k_check_finite, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->ld, (const TS*)c->sigma(), c->d_flags);
         HIPCHK(hipGetLastError());
         rc = read_flags(c);
         if (rc)
@@ -863,6 +918,8 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
 int eqf_integrate_riccati_accurate(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
     if (!c || !imu13 || !Qdiag12 || !Pdiag8 || !(dt > 0.0))
         return EQF_E_BAD_ARG;
+    if (c->sig32)
+        return EQF_E_UNSUPPORTED; // the float store exists for the structured fast path only
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
     if (!c->d_Ebuf) {
@@ -1053,8 +1110,8 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     {
         KTimer t(c, KN_STATS);
         c->busy_meas = true;
-        hipLaunchKernelGGL(k_outlier_stats, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), measof, c->h_y, c->q0(), c->Qq(), c->Qa(),
-                           c->sigma(), c->h_res, 1, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags);
+        LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), measof, c->h_y, c->q0(), c->Qq(), c->Qa(),
+                  (const TS*)c->sigma(), c->h_res, 1, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags);
         HIPCHK(hipGetLastError());
     }
     {
@@ -1121,7 +1178,7 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     {
         KTimer t(c, KN_BUILD_Z);
         // the extra grid row eliminates the first diagonal tile of S (no k_chol_first launch in this chain)
-        hipLaunchKernelGGL(k_build_Z, dim3(blocks(n + M + 1, 256), M + 1), dim3(256), 0, c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx, c->sigma(), c->d_C,
+        LAUNCH_TS(c, k_build_Z, dim3(blocks(n + M + 1, 256), M + 1), dim3(256), c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx, (const TS*)c->sigma(), c->d_C,
                            c->d_ytil, c->d_Z, c->d_Linv, c->d_flags);
         HIPCHK(hipGetLastError());
     }
@@ -1135,7 +1192,7 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
             return rc;
         KTimer t(c, KN_SYRK);
         const int nt = blocks(n, 32);
-        hipLaunchKernelGGL(k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, c->sigma(), nt, c->d_gamma);
+        LAUNCH_TS(c, k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), c->stream, n, m, c->ld, c->ldz, c->d_W, (TS*)c->sigma(), nt, c->d_gamma);
         HIPCHK(hipGetLastError());
     }
     { int _r = round_sigma(c); if (_r) return _r; }
@@ -1146,7 +1203,7 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         HIPCHK(hipGetLastError());
     }
     if (c->opt_check) {
-        hipLaunchKernelGGL(k_check_finite, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), c->d_flags);
+        LAUNCH_TS(c, k_check_finite, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->ld, (const TS*)c->sigma(), c->d_flags);
         HIPCHK(hipGetLastError());
     }
     // The lift kernel wrote Gamma's sensor part, the new estimates / invalid flags (4N) and the status flags straight
@@ -1266,7 +1323,7 @@ int eqf_compute_nees(eqf_ctx* c, const double* ts, const int* tids, const double
     std::memcpy(c->h_buf, eps.data(), sizeof(double) * np);
     HIPCHK(hipMemcpyAsync(c->d_gamma, c->h_buf, sizeof(double) * np, hipMemcpyHostToDevice, c->stream)); // d_gamma as staging (ncap >= np? see below)
     HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(int) * 4, c->stream));
-    hipLaunchKernelGGL(k_build_nees, dim3(blocks(np + 1, 256), np), dim3(256), 0, c->stream, n, np, c->ld, c->ldzn, c->sigma(), c->d_gamma, c->d_Zn);
+    LAUNCH_TS(c, k_build_nees, dim3(blocks(np + 1, 256), np), dim3(256), c->stream, n, np, c->ld, c->ldzn, (const TS*)c->sigma(), c->d_gamma, c->d_Zn);
     HIPCHK(hipGetLastError());
     rc = launch_chain(c, np + 1, np, c->ldzn, c->d_Zn, c->d_Wn);
     if (rc)

@@ -245,8 +245,10 @@ __global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N
 // Block roles by blockIdx.x: [0, nT*nT) landmark-landmark tiles of 16x16 landmarks (one 3x3 block per lane),
 // then strip blocks (landmark-sensor 3x21 blocks and their transposes), then one sensor-sensor block.
 constexpr int PT = 16; // landmarks per tile side
+// TS = storage type of Sigma (double, or float for EQF_OPT_SIGMA_FP32 = 2): loads convert to double, stores round.
+template <typename TS>
 __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
-                                                        const double* __restrict__ Sig, double* __restrict__ Sout, const double* __restrict__ Al,
+                                                        const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
                                                         const double* __restrict__ Bl, int nT, int nStrip) {
     const double dt = ra.dt;
     const int b = blockIdx.x;
@@ -503,9 +505,10 @@ __global__ void __launch_bounds__(64) k_measure(int M, int Mcap, int Ncap, int c
 // stats: out[0..N) absErr, out[N..2N) probErr, out[2N..3N) |q_hat|^2 ; unmeasured -> -1 (meas_of[i] = j or -1)
 // It also emits what k_measure would (C blocks, residuals, index map) for the same measurement, so that the vision
 // update can skip k_measure when the host removes / adds no landmark in between (the common case).
+template <typename TS>
 __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, int chart, Cam cam, const int* __restrict__ meas_of,
                                                       const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
-                                                      const double* __restrict__ Qa, const double* __restrict__ Sig, double* __restrict__ out, int star,
+                                                      const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
                                                       double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -819,8 +822,9 @@ __global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double
 // With LinvOut != nullptr the grid has one extra row (blockIdx.y == M): its first workgroup recomputes the first 32 x 32
 // tile of S on its own (16 x 16 pairs of 2 x 2 blocks, one per thread) and eliminates it, so that the factorisation chain
 // needs no separate first-tile launch.
+template <typename TS>
 __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
-                                                 const double* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
+                                                 const TS* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
                                                  double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags) {
     const int m = 2 * M;
     if ((int)blockIdx.y == M) {
@@ -1191,7 +1195,8 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 // K9: Sigma <- Sigma - W W^T  ( = Sigma - K C Sigma, VIO_eqf.cpp:131 ): lower 32x32 tiles computed (one workgroup
 // each, K = m split over its 4 waves), the strictly-lower ones mirrored so Sigma stays exactly symmetric.
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
-__global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, double* __restrict__ Sig, int nt,
+template <typename TS>
+__global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
                                                   double* __restrict__ gamma) {
     __shared__ double sred[1024 * SYRK_NW];
     int b = blockIdx.x;
@@ -1325,7 +1330,8 @@ __global__ void k_gather_landmarks_aos(int N, int Ncap, const double* __restrict
 }
 // removal of landmarks: new index -> old index map `keep` (length Nnew). Sigma_new = Sigma_old[map, map]
 // (removeRows/removeCols, VIO_eqf.cpp:27-45) written to the other buffer.
-__global__ void __launch_bounds__(256) k_compact_sigma(int nnew, int ld, const int* __restrict__ keep, const double* __restrict__ Sin, double* __restrict__ Sout) {
+template <typename TS>
+__global__ void __launch_bounds__(256) k_compact_sigma(int nnew, int ld, const int* __restrict__ keep, const TS* __restrict__ Sin, TS* __restrict__ Sout) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (r >= nnew)
@@ -1347,7 +1353,8 @@ __global__ void k_compact_landmarks(int Nnew, int Ncap, const int* __restrict__ 
     Qao[i] = Qai[o];
 }
 // append: zero the new strips, put var on the new diagonal (addNewLandmarks, VIO_eqf.cpp:239-244)
-__global__ void __launch_bounds__(256) k_append_sigma(int nold, int nnew, int ld, double var, double* __restrict__ Sig) {
+template <typename TS>
+__global__ void __launch_bounds__(256) k_append_sigma(int nold, int nnew, int ld, double var, TS* __restrict__ Sig) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (r >= nnew || c >= nnew)
@@ -1356,7 +1363,8 @@ __global__ void __launch_bounds__(256) k_append_sigma(int nold, int nnew, int ld
         return;
     Sig[r + (size_t)c * ld] = (r == c) ? var : 0.0;
 }
-__global__ void __launch_bounds__(256) k_set_diag(int n, int ld, const double* __restrict__ diag, double* __restrict__ Sig) {
+template <typename TS>
+__global__ void __launch_bounds__(256) k_set_diag(int n, int ld, const double* __restrict__ diag, TS* __restrict__ Sig) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (r >= n)
@@ -1371,7 +1379,16 @@ __global__ void __launch_bounds__(256) k_round_f32(int n, int ld, double* __rest
     if (r < n)
         Sig[r + (size_t)c * ld] = (double)(float)Sig[r + (size_t)c * ld];
 }
-__global__ void __launch_bounds__(256) k_check_finite(int n, int ld, const double* __restrict__ Sig, int* __restrict__ flags) {
+// storage conversion between the two Sigma buffers (same leading dimension in elements)
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) k_convert_sigma(int n, int ld, const TI* __restrict__ in, TO* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r < n)
+        out[r + (size_t)c * ld] = (TO)in[r + (size_t)c * ld];
+}
+template <typename TS>
+__global__ void __launch_bounds__(256) k_check_finite(int n, int ld, const TS* __restrict__ Sig, int* __restrict__ flags) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (r >= n)
@@ -1712,7 +1729,8 @@ __global__ void __launch_bounds__(256) k_add_noise_dense(int n, int ld, int ldf,
 }
 
 // NEES support: Z = [Sigma (lower, padded to even dimension np with a unit diagonal) ; eps^T] for the factorisation chain
-__global__ void __launch_bounds__(256) k_build_nees(int n, int np, int ld, int ldzn, const double* __restrict__ Sig, const double* __restrict__ eps,
+template <typename TS>
+__global__ void __launch_bounds__(256) k_build_nees(int n, int np, int ld, int ldzn, const TS* __restrict__ Sig, const double* __restrict__ eps,
                                                     double* __restrict__ Z) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;

@@ -118,8 +118,8 @@ int main(int argc, char** argv) {
         }
         loopTimer.initialise({"correction", "features", "preprocessing", "propagation", "total", "total vision update", "write output"});
         VIOFilter filter(fs); // main_opt.cpp:150
-        if (sigmaFP32) // BASELINE config 5: Sigma rounded to float on every store (include/eqf_hip.h)
-            eqf_set_option(filter.eqfState().ctx, EQF_OPT_SIGMA_FP32, 1);
+        if (sigmaFP32) // BASELINE config 5: Sigma stored as float in HBM (include/eqf_hip.h)
+            eqf_set_option(filter.eqfState().ctx, EQF_OPT_SIGMA_FP32, 2);
         std::unique_ptr<VIOWriter> vioWriter;
         if (!outputDir.empty())
             vioWriter = std::make_unique<VIOWriter>(outputDir);

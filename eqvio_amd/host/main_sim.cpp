@@ -91,8 +91,8 @@ int main(int argc, char** argv) {
 
     try {
         VIOFilter filter(simDataServer.getInitialCondition(), fs);
-        if (sigmaFP32) // BASELINE config 5: Sigma rounded to float on every store (include/eqf_hip.h)
-            eqf_set_option(filter.eqfState().ctx, EQF_OPT_SIGMA_FP32, 1);
+        if (sigmaFP32) // BASELINE config 5: Sigma stored as float in HBM (include/eqf_hip.h)
+            eqf_set_option(filter.eqfState().ctx, EQF_OPT_SIGMA_FP32, 2);
         int imuDataCounter = 0, visionDataCounter = 0;
         double neesSum = 0, neesMax = 0, posErr = 0;
         const auto loopStartTime = std::chrono::steady_clock::now();

@@ -40,9 +40,12 @@ enum {
     EQF_OPT_FUSED_UPDATE = 4,  /* 1: Sigma -= W W^T and Gamma = W z ride along in the factorisation step kernels;
                                   0 (default): one split-K SYRK kernel after the chain. Measured: the fused form re-dirties all
                                   of Sigma in every step and the per-kernel write-back costs more than the saved launch. */
-    EQF_OPT_SIGMA_FP32 = 3     /* 1: fp32-Sigma model (BASELINE config 5): Sigma is rounded to the nearest float every time it
-                                  is stored (set, append, propagate, update); all arithmetic stays fp64. Storage itself is
-                                  still 8 bytes per element in this round: this option answers the accuracy question only. */
+    EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
+                                  2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
+                                     path only: dense / accurate Riccati and the fused update return EQF_E_UNSUPPORTED.
+                                  1: numerical model of the same thing on the fp64 store: Sigma rounded to the nearest float after
+                                     every store - bit-identical results to mode 2 (tests/test_gpu_fp32_sigma.py), any mode.
+                                  0: fp64 (default). Switching converts the live Sigma. */
 };
 
 const char* eqf_error_string(int code);

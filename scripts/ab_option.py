@@ -1,5 +1,5 @@
 """A/B of one eqf option on the bench.py workload, same box, alternating runs.
-usage: python scripts/ab_option.py <option id> [N] [steps]"""
+usage: python scripts/ab_option.py <option id>[:valA:valB] [N] [steps]"""
 import os, sys, time, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -7,7 +7,8 @@ import numpy as np
 import bench
 from eqvio_amd.capi import VIOFilter, load_eqf_lib, OPT_TIMING
 
-opt = int(sys.argv[1])
+opt = int(sys.argv[1].split(":")[0])
+VALS = tuple(int(v) for v in sys.argv[1].split(":")[1:]) or (1, 0)  # "3:2:0" = option 3, values 2 and 0
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 600
 lib = load_eqf_lib()
@@ -18,7 +19,7 @@ core = flt.core_handle()
 flt.run_frames(world.cam, *bench.flatten_frames(frames[:200]))
 pos = 200
 for rep in range(4):
-    for val in (1, 0):
+    for val in VALS:
         lib.eqf_set_option(core, opt, val)
         chunk = bench.flatten_frames(frames[pos:pos + steps]); pos += steps
         lib.eqf_synchronize(core)
@@ -29,7 +30,7 @@ for rep in range(4):
         print(f"rep {rep} option {opt}={val}: {steps / el:8.1f} updates/s", flush=True)
 # per-launch spans for both settings
 from eqvio_amd.capi import EqfCore
-for val in (1, 0):
+for val in VALS:
     lib.eqf_set_option(core, opt, val)
     lib.eqf_set_option(core, OPT_TIMING, 1)
     agg = collections.OrderedDict(); seq = []
