@@ -1058,8 +1058,8 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
                     if (i != j)
                         Sig[(j - m) + (size_t)(i - m) * ldsig] = v;
                 }
-            } else if (i < rows && j < m)
-                Z[i + (size_t)j * ldz] = v;
+            } else if (i < rows && j < m && (!next_diag || i >= m))
+                Z[i + (size_t)j * ldz] = v; // (the next diagonal tile itself stays on chip: nobody reads it from Z again)
             if (next_diag)
                 sPJ[16 * ihU + lr + (16 * jhU + lk + 4 * q) * CH_LDP] = v; // keep the updated next-diagonal tile on chip
         }
