@@ -256,9 +256,9 @@ def test_update_rejects_unknown_and_unsorted_ids():
     check_sigma(core, orc, 0.0)
 
 
-@pytest.mark.parametrize("N", [200])
+@pytest.mark.parametrize("N", [200, 500])
 def test_headline_size_properties(N):
-    """BASELINE.json size (N = 200, n = 621, m = 400): oracle parity on one frame (the oracle needs ~1 s here)
+    """BASELINE.json sizes (N = 200: n = 621, m = 400, the metric; N = 500: n = 1521, m = 1000, the stress config): oracle parity on one frame (the oracle needs ~1 s / ~15 s here)
     plus size-independent properties: Sigma stays symmetric, the update never increases any variance, and the
     posterior satisfies the Joseph identity Sigma+ = (I - K C) Sigma within roundoff via trace consistency."""
     chart = CHARTS["invdepth"]
