@@ -2,6 +2,7 @@
 #include "eqf_hip.h"
 #include "eqf_kernels.hpp"
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -167,6 +168,10 @@ struct eqf_ctx {
     // options
     int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0;
     bool sig32 = false; // Sigma stored as float (EQF_OPT_SIGMA_FP32 = 2)
+    int opt_door = 1;   // host doorbell instead of the stream completion signal for the two per-frame waits
+    int* d_door = nullptr; // device counters (one per doorbell)
+    int* h_door = nullptr; // pinned sequence numbers written by the last workgroup
+    unsigned door_seq = 0; // wraps harmlessly: only equality is tested
     std::vector<double> last_gamma;
     int n_at_update = 0;
     bool gamma_stale = false; // d_gamma holds a newer Gamma than last_gamma (fetched lazily by eqf_last_gamma)
@@ -260,6 +265,32 @@ int sync_ctx(eqf_ctx* c) {
     }
     c->busy_common = c->busy_steps = c->busy_meas = false;
     return 0;
+}
+// Wait for the doorbell `which` to show `seq` (written by the last workgroup of the kernel launched with it, after every
+// result store has been fenced at system scope). The stream is polled now and then so that a kernel fault is reported
+// instead of spinning forever; if the stream completes without the bell (cannot happen) the call fails loudly.
+int door_wait(eqf_ctx* c, int which, int seq) {
+    volatile int* bell = reinterpret_cast<volatile int*>(c->h_door) + which;
+    long spins_after_done = 0;
+    for (long it = 1;; ++it) {
+        if (*bell == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            c->busy_common = c->busy_steps = c->busy_meas = false;
+            return 0;
+        }
+        if ((it & 0xfff) == 0 || spins_after_done) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) {
+                if (++spins_after_done > 1000000) {
+                    std::fprintf(stderr, "[eqf_hip] doorbell %d never rang (expected %d, have %d)\n", which, seq, (int)*bell);
+                    return (int)hipErrorUnknown;
+                }
+            } else if (e != hipErrorNotReady) {
+                std::fprintf(stderr, "[eqf_hip] stream error: %s\n", hipGetErrorString(e));
+                return (int)e;
+            }
+        }
+    }
 }
 // make the main stream wait for the observer kernel before anything that reads / writes the landmark arrays
 int join_observer(eqf_ctx* c) {
@@ -459,6 +490,10 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipHostMalloc(&c->h_y, sizeof(double) * 2 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_res, sizeof(double) * (7 * (size_t)c->Ncap + 32)));
     HIPCHK(hipHostMalloc(&c->h_resflags, sizeof(int) * 4));
+    HIPCHK(hipHostMalloc(&c->h_door, sizeof(int) * 4));
+    std::memset(c->h_door, 0, sizeof(int) * 4);
+    HIPCHK(hipMalloc(&c->d_door, sizeof(int) * 4));
+    HIPCHK(hipMemset(c->d_door, 0, sizeof(int) * 4));
     // identity state
     const double s0[23] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     c->xi0 = unpack_sensor(s0);
@@ -520,6 +555,8 @@ void eqf_destroy(eqf_ctx* c) {
     hipHostFree(c->h_y);
     hipHostFree(c->h_res);
     hipHostFree(c->h_resflags);
+    hipHostFree(c->h_door);
+    hipFree(c->d_door);
     hipEventDestroy(c->ev_assembled);
     hipEventDestroy(c->ev_observer);
     hipEventDestroy(c->ev_early);
@@ -579,6 +616,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_CHECK_FINITE:
         c->opt_check = value;
+        return 0;
+    case EQF_OPT_DOORBELL:
+        c->opt_door = value;
         return 0;
     case EQF_OPT_FUSED_UPDATE:
         if (value && c->sig32)
@@ -1107,11 +1147,13 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     rc = join_observer(c);
     if (rc)
         return rc;
+    const bool use_door = c->opt_door && !c->obs_pending;
+    const int door_seq = (int)(++c->door_seq);
     {
         KTimer t(c, KN_STATS);
         c->busy_meas = true;
         LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), measof, c->h_y, c->q0(), c->Qq(), c->Qa(),
-                  (const TS*)c->sigma(), c->h_res, 1, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags);
+                  (const TS*)c->sigma(), c->h_res, 1, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, use_door ? c->d_door : nullptr, c->h_door, door_seq);
         HIPCHK(hipGetLastError());
     }
     {
@@ -1122,7 +1164,7 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         c->meas_star = 1;
         c->meas_ids.assign(ids, ids + M);
     }
-    rc = sync_ctx(c);
+    rc = use_door ? door_wait(c, 0, door_seq) : sync_ctx(c);
     if (rc)
         return rc;
     if (absErr)
@@ -1196,10 +1238,13 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         HIPCHK(hipGetLastError());
     }
     { int _r = round_sigma(c); if (_r) return _r; }
+    const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending; // a later kernel (finite check) or the observer stream need the full wait
+    const int door_seq = (int)(++c->door_seq);
     {
         KTimer t(c, KN_LIFT);
         hipLaunchKernelGGL(k_lift, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),
-                           c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags);
+                           c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags, use_door ? c->d_door + 1 : nullptr, c->h_door + 1,
+                           door_seq);
         HIPCHK(hipGetLastError());
     }
     if (c->opt_check) {
@@ -1209,7 +1254,7 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     // The lift kernel wrote Gamma's sensor part, the new estimates / invalid flags (4N) and the status flags straight
     // into the pinned result packet: one stream synchronisation, no copy kernels. The sensor part of Delta is lifted
     // on the host.
-    rc = sync_ctx(c);
+    rc = use_door ? door_wait(c, 1, door_seq) : sync_ctx(c);
     if (rc)
         return rc;
     c->h_flags[0] = c->h_resflags[0];

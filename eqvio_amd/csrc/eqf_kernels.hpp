@@ -442,6 +442,25 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Host doorbell. The two kernels whose results the host waits for (outlier statistics, innovation lift) write them into
+// the pinned result packet; the LAST workgroup to finish then stores a sequence number next to them. The host polls that
+// word instead of the stream's completion signal and sees the results about 6 us earlier (scripts/ubench/doorbell.hip).
+// Ordering: every workgroup fences its result stores at system scope before its atomic increment; the workgroup that
+// observes all increments fences again and only then writes the sequence number.
+__device__ __forceinline__ void ring_doorbell(int* __restrict__ count, int* __restrict__ host_flag, int seq) {
+    if (!count)
+        return;
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(count, 1) == (int)gridDim.x - 1) {
+            atomicExch(count, 0);
+            __threadfence_system();
+            *reinterpret_cast<volatile int*>(host_flag) = seq;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K3: per measurement j: yHat, yTilde and the 2x3 block of C (measureSystemState VIOState.cpp:70-78,
 // EqFoutputMatrixCiStar euclid.cpp:162-184, invdepth.cpp:255-266, outputMatrixCi EqFMatrices.cpp:84-89).
 // Optionally the outlier statistics of VIOFilter::removeOutliers (VIOFilter.cpp:304-334).
@@ -506,10 +525,10 @@ __global__ void __launch_bounds__(64) k_measure(int M, int Mcap, int Ncap, int c
 // It also emits what k_measure would (C blocks, residuals, index map) for the same measurement, so that the vision
 // update can skip k_measure when the host removes / adds no landmark in between (the common case).
 template <typename TS>
-__global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, int chart, Cam cam, const int* __restrict__ meas_of,
-                                                      const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
-                                                      const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
-                                                      double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags) {
+__device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int chart, const Cam& cam, const int* __restrict__ meas_of,
+                                                   const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
+                                                   const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
+                                                   double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         flags[0] = 0;
@@ -563,6 +582,15 @@ __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, i
     out[i] = sqrt(o.yt[0] * o.yt[0] + o.yt[1] * o.yt[1]);
     out[N + i] = o.yt[0] * t0 + o.yt[1] * t1;
     out[2 * N + i] = norm2(o.qh);
+}
+template <typename TS>
+__global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, int chart, Cam cam, const int* __restrict__ meas_of,
+                                                      const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
+                                                      const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
+                                                      double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags,
+                                                      int* __restrict__ door_count, int* __restrict__ door_host, int door_seq) {
+    outlier_stats_body<TS>(N, Ncap, ld, chart, cam, meas_of, y, q0, Qq, Qa, Sig, out, star, C, ytil, lmidx_dev, flags);
+    ring_doorbell(door_count, door_host, door_seq);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1237,9 +1265,9 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
 // euclid.cpp:36-97, invdepth.cpp:183-253; VIOExp VIOGroup.cpp:273-290; X = Delta * X VIO_eqf.cpp:130).
 // Also writes the new estimates q_hat_i and a flag per landmark with Q_i.a outside (1e-8, 1e8]
 // (removeInvalidLandmarks, VIO_eqf.cpp:213-223) into `est` (4 planes of stride N: qx, qy, qz, invalid).
-__global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
-                                             double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
-                                             const int* __restrict__ flags, int* __restrict__ flags_host) {
+__device__ __forceinline__ void lift_body(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
+                                          double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
+                                          const int* __restrict__ flags, int* __restrict__ flags_host) {
     // est / gamma_host / flags_host point into the pinned host packet: the results reach the host with the stream
     // synchronisation alone, no copy kernels.
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1279,6 +1307,13 @@ __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int dis
     est[N + i] = qh.y;
     est[2 * N + i] = qh.z;
     est[3 * N + i] = (a <= 1e-8 || a > 1e8 || !(a == a)) ? 1.0 : 0.0;
+}
+__global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
+                                             double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
+                                             const int* __restrict__ flags, int* __restrict__ flags_host, int* __restrict__ door_count, int* __restrict__ door_host,
+                                             int door_seq) {
+    lift_body(N, Ncap, chart, discrete, gamma, q0, Qq, Qa, est, gamma_host, flags, flags_host);
+    ring_doorbell(door_count, door_host, door_seq);
 }
 // q_hat_i = Q_i^-1 q0_i for all landmarks (stateGroupAction, VIOGroup.cpp:44-52)
 __global__ void __launch_bounds__(64) k_estimate(int N, int Ncap, const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,

@@ -40,6 +40,9 @@ enum {
     EQF_OPT_FUSED_UPDATE = 4,  /* 1: Sigma -= W W^T and Gamma = W z ride along in the factorisation step kernels;
                                   0 (default): one split-K SYRK kernel after the chain. Measured: the fused form re-dirties all
                                   of Sigma in every step and the per-kernel write-back costs more than the saved launch. */
+    EQF_OPT_DOORBELL = 6,      /* 1 (default): the two per-frame host waits poll a sequence number that the last workgroup of the
+                                  kernel writes into the pinned result packet (~6 us earlier than the stream's completion signal);
+                                  0: wait on the stream */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati and the fused update return EQF_E_UNSUPPORTED.

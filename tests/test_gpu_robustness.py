@@ -84,3 +84,26 @@ def test_long_free_running_sequence_stays_on_the_oracle():
             compare(flt, orc, tol=1e-8)
     S = flt.get_sigma()
     assert np.all(np.isfinite(S)) and np.linalg.eigvalsh(0.5 * (S + S.T)).min() > 0
+
+
+def test_doorbell_and_stream_wait_agree_bitwise():
+    """The two per-frame host waits poll a sequence number written by the last workgroup (EQF_OPT_DOORBELL, default) instead
+    of the stream's completion signal. A stale read of the result packet would change an outlier decision or Gamma: 3000
+    frames must come out bit-identical in both modes (scripts/door_stress.py runs 38 000)."""
+    import bench
+    from eqvio_amd.capi import OPT_DOORBELL, load_eqf_lib
+
+    lib = load_eqf_lib()
+    settings = bench.eurocish_settings()
+    N, nfr = 50, 3000
+    world, frames = bench.build_workload(seed=7, n_frames=nfr + 2, N=N)
+    outs = []
+    for door in (1, 0):
+        flt = bench.make_filter(world, settings, N, 0, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=N, device=0, sensor=se, ids=i, p=p, time=t))
+        lib.eqf_set_option(flt.core_handle(), OPT_DOORBELL, door)
+        assert flt.run_frames(world.cam, *bench.flatten_frames(frames[:nfr])) == nfr
+        outs.append((flt.state_estimate(), flt.get_sigma()))
+        flt.close()
+    (a, ia, pa), Sa = outs[0]
+    (b, ib, pb), Sb = outs[1]
+    assert np.array_equal(a, b) and np.array_equal(pa, pb) and np.array_equal(Sa, Sb) and np.all(np.isfinite(Sa))
