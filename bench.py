@@ -117,8 +117,8 @@ def cpu_baseline(world, frames, settings, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=8000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--landmarks", type=int, default=N_LANDMARKS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

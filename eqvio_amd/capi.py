@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_TIMING = 1, 2, 3, 4, 6, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_TIMING = 1, 2, 3, 4, 6, 7, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -193,6 +193,8 @@ def load_eqf_lib():
         "eqf_integrate_riccati_accurate": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p]),
         "eqf_integrate_observer": (C.c_int, [vp, c_double_p, c_double_p, C.c_int, C.c_int]),
         "eqf_outlier_stats": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+        "eqf_stats_then_update": (C.c_int, [vp, C.POINTER(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p,
+                                  c_double_p, c_int_p]),
         "eqf_vision_update": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_int]),
         "eqf_last_gamma": (C.c_int, [vp, c_double_p, C.c_int]),
         "eqf_compute_nees": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p]),
@@ -326,6 +328,15 @@ class EqfCore:
     def vision_update(self, cam, ids, y, meas_var, use_equivariant=True, discrete=False):
         ids, y = _i32(ids), _f64(y)
         self._chk0(self.lib.eqf_vision_update(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), meas_var, int(use_equivariant), int(discrete)))
+
+    def stats_then_update(self, cam, ids, y, thr_abs, thr_prob, meas_var, use_equivariant=True, discrete=False):
+        """eqf_stats_then_update: returns (updated, absErr, probErr, depth2)."""
+        ids, y = _i32(ids), _f64(y)
+        a, p, d = np.zeros(self.N), np.zeros(self.N), np.zeros(self.N)
+        upd = C.c_int(0)
+        self._chk0(self.lib.eqf_stats_then_update(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), thr_abs, thr_prob, meas_var, int(use_equivariant), int(discrete), _dp(a),
+                                                  _dp(p), _dp(d), C.byref(upd)))
+        return bool(upd.value), a, p, d
 
     def last_gamma(self):
         out = np.zeros(self.n + 64)

@@ -172,6 +172,8 @@ struct eqf_ctx {
     int* d_door = nullptr; // device counters (one per doorbell)
     int* h_door = nullptr; // pinned sequence numbers written by the last workgroup
     unsigned door_seq = 0; // wraps harmlessly: only equality is tested
+    int opt_spec = 1;      // speculative frame tail allowed (eqf_stats_then_update)
+    int* d_spec = nullptr; // device word the statistics kernel sets to the sequence number to cancel a queued tail
     std::vector<double> last_gamma;
     int n_at_update = 0;
     bool gamma_stale = false; // d_gamma holds a newer Gamma than last_gamma (fetched lazily by eqf_last_gamma)
@@ -494,6 +496,8 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     std::memset(c->h_door, 0, sizeof(int) * 4);
     HIPCHK(hipMalloc(&c->d_door, sizeof(int) * 4));
     HIPCHK(hipMemset(c->d_door, 0, sizeof(int) * 4));
+    HIPCHK(hipMalloc(&c->d_spec, sizeof(int) * 4));
+    HIPCHK(hipMemset(c->d_spec, 0, sizeof(int) * 4));
     // identity state
     const double s0[23] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     c->xi0 = unpack_sensor(s0);
@@ -557,6 +561,7 @@ void eqf_destroy(eqf_ctx* c) {
     hipHostFree(c->h_resflags);
     hipHostFree(c->h_door);
     hipFree(c->d_door);
+    hipFree(c->d_spec);
     hipEventDestroy(c->ev_assembled);
     hipEventDestroy(c->ev_observer);
     hipEventDestroy(c->ev_early);
@@ -596,11 +601,11 @@ static int set_sigma_storage(eqf_ctx* c, bool f32) {
     return 0;
 }
 
-static int round_sigma(eqf_ctx* c) {
+static int round_sigma(eqf_ctx* c, const int* spec = nullptr, int spec_seq = 0) {
     if (c->opt_f32 != 1 || c->n() == 0) // 2 = real float storage: every store already rounds
         return 0;
     const int n = c->n();
-    hipLaunchKernelGGL(k_round_f32, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma());
+    hipLaunchKernelGGL(k_round_f32, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), spec, spec_seq);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -616,6 +621,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_CHECK_FINITE:
         c->opt_check = value;
+        return 0;
+    case EQF_OPT_SPECULATIVE:
+        c->opt_spec = value;
         return 0;
     case EQF_OPT_DOORBELL:
         c->opt_door = value;
@@ -1082,7 +1090,7 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
 // (k_chol_step), preceded by the elimination of the first diagonal tile. Rows >= m of W receive Z[rows >= m] L^-T.
 // nsig > 0: the covariance update Sigma -= W W^T and Gamma = W z ride along in the step kernels (see k_chol_step)
 static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double* W, int nsig = 0, double* Sig = nullptr, double* gamma = nullptr,
-                        bool first_tile_done = false) {
+                        bool first_tile_done = false, const int* spec = nullptr, int spec_seq = 0) {
     constexpr int NB = 32;
     if (!first_tile_done) { // the vision update's k_build_Z eliminates the first tile itself
         KTimer t(c, KN_CHOL_UPDATE);
@@ -1101,7 +1109,7 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
         const int nts = blocks(nsig, 32);
         const int nySig = nsig > 0 ? blocks(nts * (nts + 1) / 2, gx) : 0;
         hipLaunchKernelGGL(k_chol_step, dim3(gx, nyS + nySig), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0, nyS, nsig, c->ld,
-                           Sig, gamma);
+                           Sig, gamma, spec, spec_seq);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1153,7 +1161,8 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         KTimer t(c, KN_STATS);
         c->busy_meas = true;
         LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), measof, c->h_y, c->q0(), c->Qq(), c->Qa(),
-                  (const TS*)c->sigma(), c->h_res, 1, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, use_door ? c->d_door : nullptr, c->h_door, door_seq);
+                  (const TS*)c->sigma(), c->h_res, 1, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, use_door ? c->d_door : nullptr, c->h_door, door_seq, 0.0, 0.0,
+                  (int*)nullptr, 0);
         HIPCHK(hipGetLastError());
     }
     {
@@ -1192,71 +1201,50 @@ static int stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M)
     return join_observer(c);
 }
 
-int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEqv, int discreteCorr) {
-    if (!c || !cam || M < 0 || (M > 0 && (!ids || !y)) || !camera_ok(cam))
-        return EQF_E_BAD_ARG;
-    if (M == 0)
-        return 0; // VIO_eqf.cpp:108-109
-    if (M > c->N)
-        return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
-    const bool reuse = c->meas_valid && c->meas_star == (useEqv ? 1 : 0) && (int)c->meas_ids.size() == M && std::equal(ids, ids + M, c->meas_ids.begin()) &&
-                       std::memcmp(c->h_y, y, sizeof(double) * 2 * M) == 0;
-    int rc = 0;
-    if (!reuse) {
-        rc = stage_measurement(c, ids, y, M);
-        if (rc)
-            return rc;
-    }
-    c->meas_valid = false;
+// The device part of the vision update behind the measurement stage: Z, factorisation chain, Sigma update, lift. With
+// spec != nullptr every kernel first compares *spec with spec_seq and returns at once if they match (cancelled tail).
+static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq) {
     const int N = c->N, n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
-    if (!reuse) {
-        KTimer t(c, KN_MEASURE);
-        hipLaunchKernelGGL(k_measure, dim3(blocks(M, 64)), dim3(64), 0, c->stream, M, c->Ncap, c->Ncap, c->chart, make_cam(cam), useEqv, c->h_lmidx, c->h_y, c->q0(), c->Qq(),
-                           c->Qa(), c->d_C, c->d_ytil, c->d_lmidx, c->d_flags);
-        HIPCHK(hipGetLastError());
-    }
+    int rc = 0;
     {
         KTimer t(c, KN_BUILD_Z);
         // the extra grid row eliminates the first diagonal tile of S (no k_chol_first launch in this chain)
         LAUNCH_TS(c, k_build_Z, dim3(blocks(n + M + 1, 256), M + 1), dim3(256), c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx, (const TS*)c->sigma(), c->d_C,
-                           c->d_ytil, c->d_Z, c->d_Linv, c->d_flags);
+                  c->d_ytil, c->d_Z, c->d_Linv, c->d_flags, spec, spec_seq);
         HIPCHK(hipGetLastError());
     }
     if (c->opt_fused) {
-        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, n, c->sigma(), c->d_gamma, true);
+        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, n, c->sigma(), c->d_gamma, true, spec, spec_seq);
         if (rc)
             return rc;
     } else {
-        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true);
+        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq);
         if (rc)
             return rc;
         KTimer t(c, KN_SYRK);
         const int nt = blocks(n, 32);
-        LAUNCH_TS(c, k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), c->stream, n, m, c->ld, c->ldz, c->d_W, (TS*)c->sigma(), nt, c->d_gamma);
+        LAUNCH_TS(c, k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), c->stream, n, m, c->ld, c->ldz, c->d_W, (TS*)c->sigma(), nt, c->d_gamma, spec, spec_seq);
         HIPCHK(hipGetLastError());
     }
-    { int _r = round_sigma(c); if (_r) return _r; }
-    const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending; // a later kernel (finite check) or the observer stream need the full wait
-    const int door_seq = (int)(++c->door_seq);
+    { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }
     {
         KTimer t(c, KN_LIFT);
         hipLaunchKernelGGL(k_lift, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),
                            c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags, use_door ? c->d_door + 1 : nullptr, c->h_door + 1,
-                           door_seq);
+                           door_seq, spec, spec_seq);
         HIPCHK(hipGetLastError());
     }
     if (c->opt_check) {
         LAUNCH_TS(c, k_check_finite, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->ld, (const TS*)c->sigma(), c->d_flags);
         HIPCHK(hipGetLastError());
     }
-    // The lift kernel wrote Gamma's sensor part, the new estimates / invalid flags (4N) and the status flags straight
-    // into the pinned result packet: one stream synchronisation, no copy kernels. The sensor part of Delta is lifted
-    // on the host.
-    rc = use_door ? door_wait(c, 1, door_seq) : sync_ctx(c);
-    if (rc)
-        return rc;
+    return 0;
+}
+// Host part after the wait: the lift kernel wrote Gamma's sensor part, the new estimates / invalid flags (4N) and the status
+// flags straight into the pinned result packet; the sensor part of Delta is lifted here.
+static int finish_update(eqf_ctx* c, int discreteCorr) {
+    const int N = c->N, n = c->n();
     c->h_flags[0] = c->h_resflags[0];
     c->h_flags[1] = c->h_resflags[1];
     c->gamma_stale = true;
@@ -1293,6 +1281,111 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         if (!(g[i] - g[i] == 0.0))
             return EQF_E_NONFINITE;
     return 0;
+}
+
+int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEqv, int discreteCorr) {
+    if (!c || !cam || M < 0 || (M > 0 && (!ids || !y)) || !camera_ok(cam))
+        return EQF_E_BAD_ARG;
+    if (M == 0)
+        return 0; // VIO_eqf.cpp:108-109
+    if (M > c->N)
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const bool reuse = c->meas_valid && c->meas_star == (useEqv ? 1 : 0) && (int)c->meas_ids.size() == M && std::equal(ids, ids + M, c->meas_ids.begin()) &&
+                       std::memcmp(c->h_y, y, sizeof(double) * 2 * M) == 0;
+    int rc = 0;
+    if (!reuse) {
+        rc = stage_measurement(c, ids, y, M);
+        if (rc)
+            return rc;
+    }
+    c->meas_valid = false;
+    if (!reuse) {
+        KTimer t(c, KN_MEASURE);
+        hipLaunchKernelGGL(k_measure, dim3(blocks(M, 64)), dim3(64), 0, c->stream, M, c->Ncap, c->Ncap, c->chart, make_cam(cam), useEqv, c->h_lmidx, c->h_y, c->q0(), c->Qq(),
+                           c->Qa(), c->d_C, c->d_ytil, c->d_lmidx, c->d_flags);
+        HIPCHK(hipGetLastError());
+    }
+    const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending; // a later kernel (finite check) or the observer stream need the full wait
+    const int door_seq = (int)(++c->door_seq);
+    rc = launch_update_tail(c, M, meas_var, discreteCorr, nullptr, 0, use_door, door_seq);
+    if (rc)
+        return rc;
+    rc = use_door ? door_wait(c, 1, door_seq) : sync_ctx(c);
+    if (rc)
+        return rc;
+    return finish_update(c, discreteCorr);
+}
+
+// See include/eqf_hip.h. Statistics and update queued back to back; the statistics kernel cancels the tail on the device if
+// the host has an outlier decision to make.
+int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double thrAbs, double thrProb, double meas_var, int useEqv,
+                          int discreteCorr, double* absErr, double* probErr, double* depth2, int* updated) {
+    if (!c || !cam || !updated || M <= 0 || !ids || !y || !camera_ok(cam))
+        return EQF_E_BAD_ARG;
+    *updated = 0;
+    const int N = c->N;
+    if (N == 0 || M > N)
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->busy_meas) {
+        int r = sync_ctx(c);
+        if (r)
+            return r;
+    }
+    int* lmidx = c->h_lmidx;
+    int* measof = c->h_lmidx + c->Ncap;
+    int rc = map_measurement(c, ids, M, true, lmidx, measof); // every measurement must belong to a landmark of the state
+    if (rc)
+        return rc;
+    std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
+    rc = join_observer(c);
+    if (rc)
+        return rc;
+    // speculation needs the doorbell-free conditions of both waits and the equivariant-output cache of the statistics kernel
+    const bool speculate = c->opt_spec && !c->opt_check && !c->opt_timing && !c->obs_pending;
+    const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
+    const int seq = (int)(++c->door_seq);
+    {
+        KTimer t(c, KN_STATS);
+        c->busy_meas = true;
+        LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), measof, c->h_y, c->q0(), c->Qq(), c->Qa(),
+                  (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, (use_door && !speculate) ? c->d_door : nullptr, c->h_door, seq,
+                  thrAbs, thrProb, speculate ? c->d_spec : (int*)nullptr, seq);
+        HIPCHK(hipGetLastError());
+    }
+    c->meas_valid = true;
+    c->meas_star = useEqv ? 1 : 0;
+    c->meas_ids.assign(ids, ids + M);
+    auto copy_stats = [&]() {
+        if (absErr)
+            std::memcpy(absErr, c->h_res, sizeof(double) * N);
+        if (probErr)
+            std::memcpy(probErr, c->h_res + N, sizeof(double) * N);
+        if (depth2)
+            std::memcpy(depth2, c->h_res + 2 * N, sizeof(double) * N);
+    };
+    if (!speculate) { // plain statistics call: the caller decides and calls eqf_vision_update
+        rc = use_door ? door_wait(c, 0, seq) : sync_ctx(c);
+        if (rc)
+            return rc;
+        copy_stats();
+        return 0;
+    }
+    c->meas_valid = false; // consumed by the tail below (restored if the tail is cancelled)
+    rc = launch_update_tail(c, M, meas_var, discreteCorr, c->d_spec, seq, use_door, seq);
+    if (rc)
+        return rc;
+    rc = use_door ? door_wait(c, 1, seq) : sync_ctx(c);
+    if (rc)
+        return rc;
+    copy_stats();
+    if (c->h_resflags[2]) { // cancelled on the device: nothing was modified, C / residuals of the statistics kernel are still valid
+        c->meas_valid = true;
+        return 0;
+    }
+    *updated = 1;
+    return finish_update(c, discreteCorr);
 }
 
 int eqf_last_gamma(eqf_ctx* c, double* out, int cap) {

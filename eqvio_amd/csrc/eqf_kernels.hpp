@@ -528,7 +528,8 @@ template <typename TS>
 __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int chart, const Cam& cam, const int* __restrict__ meas_of,
                                                    const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
                                                    const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
-                                                   double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags) {
+                                                   double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags,
+                                                   double& abs_err, double& prob_err) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         flags[0] = 0;
@@ -579,8 +580,10 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
     // inverse2 * yt
     const double t0 = (v11 / det) * o.yt[0] + (-v01 / det) * o.yt[1];
     const double t1 = (-v10 / det) * o.yt[0] + (v00 / det) * o.yt[1];
-    out[i] = sqrt(o.yt[0] * o.yt[0] + o.yt[1] * o.yt[1]);
-    out[N + i] = o.yt[0] * t0 + o.yt[1] * t1;
+    abs_err = sqrt(o.yt[0] * o.yt[0] + o.yt[1] * o.yt[1]);
+    prob_err = o.yt[0] * t0 + o.yt[1] * t1;
+    out[i] = abs_err;
+    out[N + i] = prob_err;
     out[2 * N + i] = norm2(o.qh);
 }
 template <typename TS>
@@ -588,8 +591,15 @@ __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, i
                                                       const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
                                                       const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
                                                       double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags,
-                                                      int* __restrict__ door_count, int* __restrict__ door_host, int door_seq) {
-    outlier_stats_body<TS>(N, Ncap, ld, chart, cam, meas_of, y, q0, Qq, Qa, Sig, out, star, C, ytil, lmidx_dev, flags);
+                                                      int* __restrict__ door_count, int* __restrict__ door_host, int door_seq, double thrAbs, double thrProb,
+                                                      int* __restrict__ spec, int spec_seq) {
+    double abs_err = -1.0, prob_err = -1.0; // stay negative for lanes without a measured landmark
+    outlier_stats_body<TS>(N, Ncap, ld, chart, cam, meas_of, y, q0, Qq, Qa, Sig, out, star, C, ytil, lmidx_dev, flags, abs_err, prob_err);
+    // Speculative frame tail (eqf_stats_then_update): the update kernels are already queued behind this one. If any measured
+    // landmark is an outlier candidate (VIOFilter.cpp:316-330: absErr > thrAbs or probErr > thrProb) the host has a decision
+    // to make, so the queued kernels must not run: they compare this word with their sequence number and return at once.
+    if (spec && abs_err >= 0.0 && (abs_err > thrAbs || prob_err > thrProb)) // the comparisons of VIOFilter.cpp:316-330 (NaN: false)
+        *spec = spec_seq;
     ring_doorbell(door_count, door_host, door_seq);
 }
 
@@ -853,7 +863,10 @@ __global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double
 template <typename TS>
 __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
                                                  const TS* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
-                                                 double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags) {
+                                                 double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags, const int* __restrict__ spec,
+                                                 int spec_seq) {
+    if (spec && *spec == spec_seq)
+        return; // cancelled speculative tail
     const int m = 2 * M;
     if ((int)blockIdx.y == M) {
         if (blockIdx.x != 0)
@@ -943,7 +956,9 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
 // complement Sigma - T S^-1 T^T.
 __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
                                                    const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update, int nyS,
-                                                   int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma) {
+                                                   int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq) {
+    if (spec && *spec == spec_seq)
+        return; // cancelled speculative tail
     const int c0 = kb + w;
     int i0, j0, ilim = rows, jlim = m;
     const bool sig = (int)blockIdx.y >= nyS;
@@ -1225,7 +1240,9 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
 template <typename TS>
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
-                                                  double* __restrict__ gamma) {
+                                                  double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq) {
+    if (spec && *spec == spec_seq)
+        return; // cancelled speculative tail
     __shared__ double sred[1024 * SYRK_NW];
     int b = blockIdx.x;
     int bj = 0;
@@ -1311,8 +1328,12 @@ __device__ __forceinline__ void lift_body(int N, int Ncap, int chart, int discre
 __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
                                              double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
                                              const int* __restrict__ flags, int* __restrict__ flags_host, int* __restrict__ door_count, int* __restrict__ door_host,
-                                             int door_seq) {
-    lift_body(N, Ncap, chart, discrete, gamma, q0, Qq, Qa, est, gamma_host, flags, flags_host);
+                                             int door_seq, const int* __restrict__ spec, int spec_seq) {
+    const bool aborted = spec && *spec == spec_seq; // speculative tail cancelled by the statistics kernel
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        flags_host[2] = aborted ? 1 : 0;
+    if (!aborted)
+        lift_body(N, Ncap, chart, discrete, gamma, q0, Qq, Qa, est, gamma_host, flags, flags_host);
     ring_doorbell(door_count, door_host, door_seq);
 }
 // q_hat_i = Q_i^-1 q0_i for all landmarks (stateGroupAction, VIOGroup.cpp:44-52)
@@ -1408,7 +1429,9 @@ __global__ void __launch_bounds__(256) k_set_diag(int n, int ld, const double* _
 }
 // count non-finite entries of Sigma (the reference's assert(!Sigma.hasNaN()))
 // EQF_OPT_SIGMA_FP32: numerical model of an fp32 Sigma store - every element rounded to the nearest float
-__global__ void __launch_bounds__(256) k_round_f32(int n, int ld, double* __restrict__ Sig) {
+__global__ void __launch_bounds__(256) k_round_f32(int n, int ld, double* __restrict__ Sig, const int* __restrict__ spec, int spec_seq) {
+    if (spec && *spec == spec_seq)
+        return;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (r < n)

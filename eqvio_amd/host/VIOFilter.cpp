@@ -326,6 +326,21 @@ void VIO_eqf::outlierStats(const VisionMeasurement& m, std::vector<double>& absE
     flatten(m, ids, y);
     check(eqf_outlier_stats(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), absErr.data(), probErr.data(), depth2.data()), "eqf_outlier_stats");
 }
+bool VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double thrProb, double var, bool useEqv, bool discreteCorrection, std::vector<double>& absErr,
+                              std::vector<double>& probErr, std::vector<double>& depth2) {
+    const int N = numLandmarks();
+    absErr.assign(N, -1.0);
+    probErr.assign(N, -1.0);
+    depth2.assign(N, 0.0);
+    std::vector<int> ids;
+    std::vector<double> y;
+    flatten(m, ids, y);
+    int updated = 0;
+    check(eqf_stats_then_update(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), thrAbs, thrProb, var, useEqv ? 1 : 0, discreteCorrection ? 1 : 0, absErr.data(),
+                                probErr.data(), depth2.data(), &updated),
+          "eqf_stats_then_update");
+    return updated != 0;
+}
 
 // ---------------------------------------------------------------- Settings (VIOFilterSettings.h)
 VIOFilter::Settings::Settings(const eqvio_settings& s) {
@@ -529,7 +544,31 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
         removeOldLandmarks(measurement.getIds());
     VisionMeasurement matchedMeasurement = measurement;
     std::vector<double> depth2;
-    removeOutliers(matchedMeasurement, depth2);
+    // Every measured id already in the state (no landmark to add) and something to update: queue the outlier statistics and
+    // the update back to back (eqf_stats_then_update). If a measured landmark exceeds a threshold the device cancels the
+    // update and the frame continues below exactly as the reference does, with the statistics already in hand.
+    bool haveStats = false;
+    std::vector<double> absErr, probErr;
+    if (!matchedMeasurement.camCoordinates.empty() && filterState.numLandmarks() > 0) {
+        std::vector<int> have = filterState.ids();
+        std::sort(have.begin(), have.end());
+        bool allKnown = true;
+        for (const auto& cc : matchedMeasurement.camCoordinates)
+            allKnown = allKnown && std::binary_search(have.begin(), have.end(), cc.first);
+        if (allKnown) {
+            const bool updated = filterState.statsThenUpdate(matchedMeasurement, settings->outlierThresholdAbs, settings->outlierThresholdProb, settings->constructOutputGainVar(),
+                                                             settings->useEquivariantOutput, settings->useDiscreteInnovationLift, absErr, probErr, depth2);
+            if (updated) {
+                loopTimer.endTiming("preprocessing");
+                loopTimer.startTiming("correction");
+                filterState.removeInvalidLandmarks();
+                loopTimer.endTiming("correction");
+                return;
+            }
+            haveStats = true;
+        }
+    }
+    removeOutliers(matchedMeasurement, depth2, haveStats ? &absErr : nullptr, haveStats ? &probErr : nullptr);
     addNewLandmarks(matchedMeasurement, &depth2);
     loopTimer.endTiming("preprocessing");
 
@@ -623,10 +662,16 @@ void VIOFilter::removeOldLandmarks(const std::vector<int>& measurementIds) { // 
     }
     filterState.removeLandmarksByIndex(lost); // one compaction pass instead of one per landmark
 }
-void VIOFilter::removeOutliers(VisionMeasurement& measurement, std::vector<double>& depth2) { // :304-364
+void VIOFilter::removeOutliers(VisionMeasurement& measurement, std::vector<double>& depth2, const std::vector<double>* absErrIn,
+                               const std::vector<double>* probErrIn) { // :304-364
     const size_t maxOutliers = (size_t)((1.0 - settings->featureRetention) * measurement.camCoordinates.size());
     std::vector<double> absErr, probErr;
-    filterState.outlierStats(measurement, absErr, probErr, depth2);
+    if (absErrIn && probErrIn) { // statistics of a cancelled speculative tail (depth2 filled by the same call)
+        absErr = *absErrIn;
+        probErr = *probErrIn;
+    } else {
+        filterState.outlierStats(measurement, absErr, probErr, depth2);
+    }
     const std::vector<int>& ids = filterState.ids();
     std::vector<int> proposedOutliers;
     std::map<int, double> absoluteOutliers, probabilisticOutliers;

@@ -168,6 +168,10 @@ struct VIO_eqf {
     double computeNEES(const VIOState& trueState) const; // VIO_eqf.cpp:153-170, factorised on the device
     // per-landmark quantities VIOFilter::removeOutliers / getMedianSceneDepth need, all landmarks at once
     void outlierStats(const VisionMeasurement& measurement, std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2) const;
+    // eqf_stats_then_update: the statistics and (unless an outlier candidate cancels it on the device) the update, one host wait.
+    // Returns true when the update was performed.
+    bool statsThenUpdate(const VisionMeasurement& measurement, double thrAbs, double thrProb, double outputGainVar, bool useEquivariantOutput, bool discreteCorrection,
+                         std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2);
 
   private:
     std::vector<int> ids_;
@@ -183,7 +187,8 @@ class VIOFilter {
     bool integrateUpToTime(const double& newTime);
     void addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2);
     void removeOldLandmarks(const std::vector<int>& measurementIds);
-    void removeOutliers(VisionMeasurement& measurement, std::vector<double>& depth2);
+    void removeOutliers(VisionMeasurement& measurement, std::vector<double>& depth2, const std::vector<double>* absErrIn = nullptr,
+                        const std::vector<double>* probErrIn = nullptr);
     double getMedianSceneDepth(const std::vector<double>* depth2) const;
 
   public:

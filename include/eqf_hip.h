@@ -40,6 +40,8 @@ enum {
     EQF_OPT_FUSED_UPDATE = 4,  /* 1: Sigma -= W W^T and Gamma = W z ride along in the factorisation step kernels;
                                   0 (default): one split-K SYRK kernel after the chain. Measured: the fused form re-dirties all
                                   of Sigma in every step and the per-kernel write-back costs more than the saved launch. */
+    EQF_OPT_SPECULATIVE = 7,   /* 1 (default): eqf_stats_then_update queues the update behind the statistics kernel; 0: it only computes
+                                  the statistics */
     EQF_OPT_DOORBELL = 6,      /* 1 (default): the two per-frame host waits poll a sequence number that the last workgroup of the
                                   kernel writes into the pinned result packet (~6 us earlier than the stream's completion signal);
                                   0: wait on the stream */
@@ -111,7 +113,17 @@ int eqf_outlier_stats(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, con
 /* VIO_eqf::performVisionUpdate (VIO_eqf.cpp:105-135): yTilde, C, S = C Sigma C^T + R, K = Sigma C^T S^-1,
  * Gamma = K yTilde, X <- Delta * X, Sigma <- Sigma - K C Sigma; R = meas_var * I
  * (constructOutputGainMatrix, VIOFilterSettings.h:203-206). Every measured id must be a state landmark. */
-int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEquivariantOutput, int discreteCorrection);
+int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEquivariantOutput, int discreteCorrection);/* Speculative frame tail for VIOFilter::processVisionData (VIOFilter.cpp:209-236) when every measurement id is already a
+ * landmark of the state: the outlier statistics of removeOutliers (VIOFilter.cpp:304-334) and performVisionUpdate are
+ * queued back to back with ONE host wait. The statistics kernel compares each measured landmark with the two thresholds
+ * on the device; if any exceeds one (the host then has outliers to rank and remove) it cancels the queued update kernels,
+ * which return at their first instruction: nothing is modified, *updated = 0 and the caller continues exactly as without
+ * speculation (decide with the returned statistics, remove, eqf_vision_update). Otherwise *updated = 1 and the state is
+ * the one eqf_vision_update would have produced (bit-identical). EQF_OPT_SPECULATIVE = 0 turns it into a plain statistics
+ * call (*updated = 0 always). absErr / probErr: -1 for landmarks without a measurement. */
+int eqf_stats_then_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y_px, int M, double thrAbs, double thrProb, double meas_var,
+                          int useEquivariantOutput, int discreteCorrection, double* absErr, double* probErr, double* depth2, int* updated);
+
 /* Gamma of the last update (n doubles) — for parity checks. */
 int eqf_last_gamma(eqf_ctx* ctx, double* out, int cap);
 

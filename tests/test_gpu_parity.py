@@ -303,3 +303,47 @@ def test_compute_nees(chart, N):
     check_sigma(core, orc, 0.0)
     with pytest.raises(EqfError):
         core.compute_nees(true_sensor, true_ids[:1], true_p[:1]) if N > 1 else (_ for _ in ()).throw(EqfError(-3, "n/a"))
+
+
+@pytest.mark.parametrize("chart", list(CHARTS))
+def test_speculative_tail_equals_stats_plus_update(chart):
+    """eqf_stats_then_update: with no outlier candidate the state equals eqf_outlier_stats + eqf_vision_update bit for bit;
+    with a threshold that one landmark exceeds the device cancels the queued update: nothing is modified, the statistics are
+    returned, and the classic calls still work afterwards (oracle parity)."""
+    N = 19
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=77, useDiscreteInnovationLift=0)
+    twin = EqfCore(N, CHARTS[chart])
+    twin.set_state(xi0, Xs, ids, q0, Q)
+    twin.set_sigma(S)
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=rng.permutation(N)[:15])
+    var = settings.measurementNoise**2
+    # classic pair on the twin
+    a0, p0, d0 = twin.outlier_stats(cam, mid, y)
+    twin.vision_update(cam, mid, y, var, True, False)
+    # speculative call, thresholds far away
+    upd, a1, p1, d1 = core.stats_then_update(cam, mid, y, 1e8, 1e8, var, True, False)
+    assert upd
+    assert np.array_equal(a0, a1) and np.array_equal(p0, p1) and np.array_equal(d0, d1)
+    assert np.array_equal(core.get_sigma(), twin.get_sigma())
+    for u, v in zip(core.get_state(), twin.get_state()):
+        assert np.array_equal(u, v)
+    orc.vision_update(cam, mid, y)
+    check_sigma(core, orc)
+    check_state(core, orc)
+    # second frame: a threshold just below the largest probabilistic error cancels the tail on the device
+    mid2, y2 = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=rng.permutation(N)[:12])
+    S_before, st_before = core.get_sigma(), core.get_state()
+    a_ref, p_ref, _ = twin.outlier_stats(cam, mid2, y2)
+    thr = 0.999 * np.max(p_ref)
+    upd, a2, p2, d2 = core.stats_then_update(cam, mid2, y2, 1e8, thr, var, True, False)
+    assert not upd
+    assert np.array_equal(a2, a_ref) and np.array_equal(p2, p_ref)
+    assert np.array_equal(core.get_sigma(), S_before)
+    for u, v in zip(core.get_state(), st_before):
+        assert np.array_equal(u, v)
+    # ... and exactly at the largest error (not exceeded: '>' in VIOFilter.cpp:324) it goes through
+    upd, _, _, _ = core.stats_then_update(cam, mid2, y2, 1e8, np.max(p_ref), var, True, False)
+    assert upd
+    twin.vision_update(cam, mid2, y2, var, True, False)
+    assert np.array_equal(core.get_sigma(), twin.get_sigma())
