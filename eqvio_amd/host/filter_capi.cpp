@@ -201,13 +201,27 @@ int eqvio_filter_run_frames(eqvio_filter* f, const eqvio_camera* cam, int nframe
     const int rc = guarded(f, [&] {
         initTimer();
         const GICameraPtr camPtr = makeCamera(cam);
-        size_t io = 0, mo = 0;
+        // The measurement objects are built before the loop: in the reference they arrive ready-made from the tracker / data
+        // server (main_opt.cpp:196-214); building a 200-entry std::map between two frames would sit on the filter's critical
+        // path here (the device is idle while the host prepares the next frame).
+        std::vector<VisionMeasurement> meas((size_t)nframes);
+        std::vector<IMUVelocity> imus;
+        {
+            size_t io = 0, mo = 0;
+            for (int j = 0; j < nframes; ++j) {
+                for (int s = 0; s < imu_counts[j]; ++s)
+                    imus.push_back(unpackIMU(imu13_all + 13 * (io + s)));
+                io += imu_counts[j];
+                meas[j] = makeMeasurement(stamps[j], camPtr, ids_all + mo, y_all + 2 * mo, meas_counts[j]);
+                mo += meas_counts[j];
+            }
+        }
+        size_t io = 0;
         for (int j = 0; j < nframes; ++j) {
             for (int s = 0; s < imu_counts[j]; ++s)
-                f->filter->processIMUData(unpackIMU(imu13_all + 13 * (io + s)));
+                f->filter->processIMUData(imus[io + s]);
             io += imu_counts[j];
-            f->filter->processVisionData(makeMeasurement(stamps[j], camPtr, ids_all + mo, y_all + 2 * mo, meas_counts[j]));
-            mo += meas_counts[j];
+            f->filter->processVisionData(meas[j]);
             ++done;
         }
         grabTiming(f);
