@@ -193,6 +193,7 @@ def load_eqf_lib():
         "eqf_integrate_riccati_accurate": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p]),
         "eqf_integrate_observer": (C.c_int, [vp, c_double_p, c_double_p, C.c_int, C.c_int]),
         "eqf_outlier_stats": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+        "eqf_propagate_fast": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int]),
         "eqf_stats_then_update": (C.c_int, [vp, C.POINTER(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p,
                                   c_double_p, c_int_p]),
         "eqf_vision_update": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_int]),
@@ -329,6 +330,12 @@ class EqfCore:
         ids, y = _i32(ids), _f64(y)
         self._chk0(self.lib.eqf_vision_update(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), meas_var, int(use_equivariant), int(discrete)))
 
+    def propagate_fast(self, imu13_mean, dt_total, Qdiag12, Pdiag8, imu13_k, dt_k, discrete=True):
+        """eqf_propagate_fast: fast Riccati at the current X + all observer steps, one call."""
+        m, Qd, Pd = _f64(imu13_mean), _f64(Qdiag12), _f64(Pdiag8)
+        imus, dts = _f64(np.atleast_2d(imu13_k)).reshape(-1), _f64(dt_k)
+        self._chk0(self.lib.eqf_propagate_fast(self.h, _dp(m), dt_total, _dp(Qd), _dp(Pd), _dp(imus), _dp(dts), len(dts), int(discrete)))
+
     def stats_then_update(self, cam, ids, y, thr_abs, thr_prob, meas_var, use_equivariant=True, discrete=False):
         """eqf_stats_then_update: returns (updated, absErr, probErr, depth2)."""
         ids, y = _i32(ids), _f64(y)
@@ -336,7 +343,7 @@ class EqfCore:
         upd = C.c_int(0)
         self._chk0(self.lib.eqf_stats_then_update(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), thr_abs, thr_prob, meas_var, int(use_equivariant), int(discrete), _dp(a),
                                                   _dp(p), _dp(d), C.byref(upd)))
-        return bool(upd.value), a, p, d
+        return upd.value, a, p, d  # 1 updated, 0 cancelled on the device, -1 not applicable
 
     def last_gamma(self):
         out = np.zeros(self.n + 64)

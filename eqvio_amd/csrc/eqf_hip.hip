@@ -907,6 +907,7 @@ int eqf_remove_invalid_landmarks(eqf_ctx* c) {
     return rc ? rc : (int)bad.size();
 }
 
+static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8);
 int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
     if (!c || !imu13 || !Qdiag12 || !Pdiag8)
         return EQF_E_BAD_ARG;
@@ -917,6 +918,11 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
     rc = launch_assemble(c);
     if (rc)
         return rc;
+    return riccati_after_assemble(c, dt, Qdiag12, Pdiag8);
+}
+// Sigma' = F Sigma F^T + dt (B Q B^T + P) once A_l / B_l are assembled (arrow form, or the dense GEMM pair)
+static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8) {
+    int rc = 0;
     RiccatiArgs ra;
     ra.dt = dt;
     std::memcpy(ra.Qd, Qdiag12, sizeof(ra.Qd));
@@ -1013,6 +1019,70 @@ int eqf_integrate_riccati_accurate(eqf_ctx* c, const double* imu13, double dt, c
     return round_sigma(c);
 }
 
+// Host half of integrateObserverState for `chunk` consecutive IMU samples: the sensor-level group element Lambda of every
+// step (VIOGroup.cpp:190-271), applied to the host-authoritative X right away, and the per-step terms the landmark kernel needs.
+static void observer_host_steps(eqf_ctx* c, const double* imu13_k, const double* dt_k, int chunk, int discreteLift, ObsSteps& steps_arg) {
+    for (int s = 0; s < chunk; ++s) {
+        const double* imu = imu13_k + 13 * s;
+        const double dt = dt_k[s];
+        // stateEstimate() sensor part and the lift (VIOGroup.cpp:190-271)
+        const SensorState xh = sensor_action(c->X, c->xi0);
+        const V3 gyr = v3(imu[1], imu[2], imu[3]) - xh.bgyr;
+        const V3 acc = v3(imu[4], imu[5], imu[6]) - xh.bacc;
+        const V3 gbv = v3(imu[7], imu[8], imu[9]), abv = v3(imu[10], imu[11], imu[12]);
+        const V3 gdir = q_rot(q_inv(xh.pose.R), v3(0, 0, 1));
+        GroupSensor L;
+        ObsStep& st = steps_arg.s[s];
+        st.discrete = discreteLift ? 1 : 0;
+        st.dt = dt;
+        if (discreteLift) {
+            L.bgyr = dt * gbv;
+            L.bacc = dt * abv;
+            L.A.R = so3_exp(dt * gyr);
+            V3 x = dt * q_rot(xh.pose.R, xh.vel) + (0.5 * dt * dt) * (q_rot(xh.pose.R, acc) + v3(0, 0, -kGravity));
+            L.A.x = q_rot(q_inv(xh.pose.R), x);
+            L.B = pose_mul(pose_mul(pose_inv(xh.cam), L.A), xh.cam);
+            const V3 bodyVelDiff = acc - kGravity * gdir;
+            L.w = xh.vel - (xh.vel + dt * bodyVelDiff);
+            st.Tinv = pose_mul(pose_mul(pose_inv(xh.cam), pose_inv(L.A)), xh.cam);
+            st.omC = v3(0, 0, 0);
+            st.vC = v3(0, 0, 0);
+        } else {
+            // VIOExp(dt * liftVelocity) (VIOGroup.cpp:190-227, 273-290)
+            const V6 U_A{gyr, xh.vel};
+            const V6 U_B = Ad_apply(pose_inv(xh.cam), U_A);
+            const V3 u_w = -acc + kGravity * gdir;
+            L.bgyr = dt * gbv;
+            L.bacc = dt * abv;
+            const M3 V = so3_V(dt * U_A.w);
+            L.A = Pose{so3_exp(dt * U_A.w), V * (dt * U_A.v)};
+            L.w = V * (dt * u_w);
+            L.B = se3_exp(dt * U_B.w, dt * U_B.v);
+            st.Tinv = pose_identity();
+            st.omC = U_B.w;
+            st.vC = U_B.v;
+        }
+        c->X = group_mul(c->X, L);
+    }
+}
+// Device half: the landmark part runs on the second stream. It only has to wait for the last kernel that READS Q on the main
+// stream (k_assemble_AB of a preceding Riccati call: ev_early, else everything queued so far), so it overlaps the Sigma
+// propagation kernels (they touch Sigma / Al / Bl only).
+static int observer_launch(eqf_ctx* c, const ObsSteps& steps_arg, int chunk) {
+    if (c->N == 0)
+        return 0;
+    if (c->obs_pending)
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_observer, 0));
+    if (!c->ev_assembled_early)
+        HIPCHK(hipEventRecord(c->ev_assembled, c->stream)); // everything queued so far on the main stream
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_assembled_early ? c->ev_early : c->ev_assembled, 0));
+    c->ev_assembled_early = false;
+    hipLaunchKernelGGL(k_observer, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream2, steps_arg, c->N, c->Ncap, chunk, c->q0(), c->Qq(), c->Qa());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev_observer, c->stream2));
+    c->obs_pending = true;
+    return 0;
+}
 int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k, int k, int discreteLift) {
     if (!c || k < 0 || (k > 0 && (!imu13_k || !dt_k)))
         return EQF_E_BAD_ARG;
@@ -1025,65 +1095,50 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
     while (done < k) {
         const int chunk = std::min(k - done, eqf_ctx::kMaxSteps);
         ObsSteps steps_arg;
-        for (int s = 0; s < chunk; ++s) {
-            const double* imu = imu13_k + 13 * (done + s);
-            const double dt = dt_k[done + s];
-            // stateEstimate() sensor part and the lift (VIOGroup.cpp:190-271)
-            const SensorState xh = sensor_action(c->X, c->xi0);
-            const V3 gyr = v3(imu[1], imu[2], imu[3]) - xh.bgyr;
-            const V3 acc = v3(imu[4], imu[5], imu[6]) - xh.bacc;
-            const V3 gbv = v3(imu[7], imu[8], imu[9]), abv = v3(imu[10], imu[11], imu[12]);
-            const V3 gdir = q_rot(q_inv(xh.pose.R), v3(0, 0, 1));
-            GroupSensor L;
-            ObsStep& st = steps_arg.s[s];
-            st.discrete = discreteLift ? 1 : 0;
-            st.dt = dt;
-            if (discreteLift) {
-                L.bgyr = dt * gbv;
-                L.bacc = dt * abv;
-                L.A.R = so3_exp(dt * gyr);
-                V3 x = dt * q_rot(xh.pose.R, xh.vel) + (0.5 * dt * dt) * (q_rot(xh.pose.R, acc) + v3(0, 0, -kGravity));
-                L.A.x = q_rot(q_inv(xh.pose.R), x);
-                L.B = pose_mul(pose_mul(pose_inv(xh.cam), L.A), xh.cam);
-                const V3 bodyVelDiff = acc - kGravity * gdir;
-                L.w = xh.vel - (xh.vel + dt * bodyVelDiff);
-                st.Tinv = pose_mul(pose_mul(pose_inv(xh.cam), pose_inv(L.A)), xh.cam);
-                st.omC = v3(0, 0, 0);
-                st.vC = v3(0, 0, 0);
-            } else {
-                // VIOExp(dt * liftVelocity) (VIOGroup.cpp:190-227, 273-290)
-                const V6 U_A{gyr, xh.vel};
-                const V6 U_B = Ad_apply(pose_inv(xh.cam), U_A);
-                const V3 u_w = -acc + kGravity * gdir;
-                L.bgyr = dt * gbv;
-                L.bacc = dt * abv;
-                const M3 V = so3_V(dt * U_A.w);
-                L.A = Pose{so3_exp(dt * U_A.w), V * (dt * U_A.v)};
-                L.w = V * (dt * u_w);
-                L.B = se3_exp(dt * U_B.w, dt * U_B.v);
-                st.Tinv = pose_identity();
-                st.omC = U_B.w;
-                st.vC = U_B.v;
-            }
-            c->X = group_mul(c->X, L);
-        }
-        if (c->N > 0) {
-            // The landmark part runs on the second stream: it only has to wait for the last kernel that READS Q on the
-            // main stream (k_assemble_AB of a preceding Riccati call, ev_assembled), so it overlaps the Sigma
-            // propagation kernels (they touch Sigma / Al / Bl / G only). The steps are read zero-copy from the pinned packet.
-            if (c->obs_pending)
-                HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_observer, 0));
-            HIPCHK(hipEventRecord(c->ev_assembled, c->stream)); // everything queued so far on the main stream
-            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_assembled_early ? c->ev_early : c->ev_assembled, 0));
-            c->ev_assembled_early = false;
-            hipLaunchKernelGGL(k_observer, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream2, steps_arg, c->N, c->Ncap, chunk, c->q0(), c->Qq(), c->Qa());
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(c->ev_observer, c->stream2));
-            c->obs_pending = true;
-        }
+        observer_host_steps(c, imu13_k + 13 * done, dt_k + done, chunk, discreteLift, steps_arg);
+        const int rc = observer_launch(c, steps_arg, chunk);
+        if (rc)
+            return rc;
         done += chunk;
     }
     return 0;
+}
+
+// See include/eqf_hip.h: fast Riccati + all observer steps of one frame, the observer kernel queued AHEAD of the Sigma
+// propagation so that it is never the last thing the outlier statistics wait for.
+int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, const double* Qdiag12, const double* Pdiag8, const double* imu13_k, const double* dt_k,
+                       int k, int discreteLift) {
+    if (!c || !imu13_mean || !Qdiag12 || !Pdiag8 || k < 0 || (k > 0 && (!imu13_k || !dt_k)))
+        return EQF_E_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    // 1. A / B terms at the CURRENT X (before the observer steps move it): integrateRiccatiStateFast uses X as it is
+    int rc = upload_common(c, imu13_mean);
+    if (rc)
+        return rc;
+    // 2. all observer steps on the host (X advances); chunks of kMaxSteps keep the kernel-argument packet small
+    std::vector<ObsSteps> chunks;
+    std::vector<int> counts;
+    for (int done = 0; done < k;) {
+        const int chunk = std::min(k - done, eqf_ctx::kMaxSteps);
+        chunks.emplace_back();
+        observer_host_steps(c, imu13_k + 13 * done, dt_k + done, chunk, discreteLift, chunks.back());
+        counts.push_back(chunk);
+        done += chunk;
+    }
+    if (k > 0) {
+        c->est_valid = false;
+        c->meas_valid = false;
+    }
+    // 3. device: assemble (reads Q), then the observer on stream 2 (writes Q once the assembly has read it), then Sigma
+    rc = launch_assemble(c);
+    if (rc)
+        return rc;
+    for (size_t q = 0; q < chunks.size(); ++q) {
+        rc = observer_launch(c, chunks[q], counts[q]);
+        if (rc)
+            return rc;
+    }
+    return riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8);
 }
 
 // Blocked right-looking factorisation of Z (rows x m, leading dimension ldz): one launch per 32-column panel
@@ -1325,8 +1380,10 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
         return EQF_E_BAD_ARG;
     *updated = 0;
     const int N = c->N;
-    if (N == 0 || M > N)
-        return EQF_E_BAD_ARG;
+    if (N == 0 || M > N) {
+        *updated = -1; // not applicable (a landmark has to be added first)
+        return 0;
+    }
     HIPCHK(hipSetDevice(c->device));
     if (c->busy_meas) {
         int r = sync_ctx(c);
@@ -1335,9 +1392,14 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     }
     int* lmidx = c->h_lmidx;
     int* measof = c->h_lmidx + c->Ncap;
-    int rc = map_measurement(c, ids, M, true, lmidx, measof); // every measurement must belong to a landmark of the state
+    int rc = map_measurement(c, ids, M, false, lmidx, measof);
     if (rc)
         return rc;
+    for (int j = 0; j < M; ++j)
+        if (lmidx[j] < 0) { // a measurement without a landmark: the caller adds landmarks first (VIOFilter.cpp:217), nothing queued
+            *updated = -1;
+            return 0;
+        }
     std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
     rc = join_observer(c);
     if (rc)

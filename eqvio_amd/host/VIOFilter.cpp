@@ -270,6 +270,15 @@ void VIO_eqf::integrateRiccatiStateAccurate(const IMUVelocity& v, const double& 
     v.pack(imu);
     check(eqf_integrate_riccati_accurate(ctx, imu, dt, Qd.data(), Pd8.data()), "integrateRiccatiStateAccurate");
 }
+void VIO_eqf::propagateFast(const IMUVelocity& mean, const double& dtTotal, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8,
+                            const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift) {
+    double m13[13];
+    mean.pack(m13);
+    std::vector<double> all(13 * imus.size());
+    for (size_t i = 0; i < imus.size(); ++i)
+        imus[i].pack(all.data() + 13 * i);
+    check(eqf_propagate_fast(ctx, m13, dtTotal, Qd.data(), Pd8.data(), all.data(), dts.data(), (int)imus.size(), discreteLift ? 1 : 0), "eqf_propagate_fast");
+}
 void VIO_eqf::integrateRiccatiStateFast(const IMUVelocity& imu, const double& dt, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8) { // :62-72
     double v[13];
     imu.pack(v);
@@ -326,7 +335,7 @@ void VIO_eqf::outlierStats(const VisionMeasurement& m, std::vector<double>& absE
     flatten(m, ids, y);
     check(eqf_outlier_stats(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), absErr.data(), probErr.data(), depth2.data()), "eqf_outlier_stats");
 }
-bool VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double thrProb, double var, bool useEqv, bool discreteCorrection, std::vector<double>& absErr,
+int VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double thrProb, double var, bool useEqv, bool discreteCorrection, std::vector<double>& absErr,
                               std::vector<double>& probErr, std::vector<double>& depth2) {
     const int N = numLandmarks();
     absErr.assign(N, -1.0);
@@ -339,7 +348,7 @@ bool VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double 
     check(eqf_stats_then_update(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), thrAbs, thrProb, var, useEqv ? 1 : 0, discreteCorrection ? 1 : 0, absErr.data(),
                                 probErr.data(), depth2.data(), &updated),
           "eqf_stats_then_update");
-    return updated != 0;
+    return updated;
 }
 
 // ---------------------------------------------------------------- Settings (VIOFilterSettings.h)
@@ -511,9 +520,10 @@ bool VIOFilter::integrateUpToTime(const double& newTime) { // :134-192
             accumulatedVelocity = accumulatedVelocity + velocityBuffer.at(i) * dts[i];
         }
         accumulatedVelocity = accumulatedVelocity * (1.0 / accumulatedTime);
-        filterState.integrateRiccatiStateFast(accumulatedVelocity, accumulatedTime, settings->constructInputGainDiag(), settings->constructStateGainDiag8());
-        // The observer steps do not depend on the Riccati state (VIOFilter.cpp:138): all samples in one device call.
-        filterState.integrateObserverStates(velocityBuffer, dts, settings->useDiscreteVelocityLift);
+        // The observer steps do not depend on the Riccati state (VIOFilter.cpp:138): the Riccati step at the current X and all
+        // observer steps go to the device in one call, the observer's landmark kernel queued ahead of the Sigma propagation.
+        filterState.propagateFast(accumulatedVelocity, accumulatedTime, settings->constructInputGainDiag(), settings->constructStateGainDiag8(), velocityBuffer, dts,
+                                  settings->useDiscreteVelocityLift);
     } else {
         if (settings->useDiscreteStateMatrix) // integrateRiccatiStateDiscrete (VIO_eqf.cpp:93-103): SURVEY.md §8 row a7, oracle only
             throw std::runtime_error("VIOFilter: settings.useDiscreteStateMatrix = true is not supported by the MI355X path (EQF_E_UNSUPPORTED)");
@@ -542,32 +552,27 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     loopTimer.startTiming("preprocessing");
     if (settings->removeLostLandmarks)
         removeOldLandmarks(measurement.getIds());
-    VisionMeasurement matchedMeasurement = measurement;
     std::vector<double> depth2;
     // Every measured id already in the state (no landmark to add) and something to update: queue the outlier statistics and
     // the update back to back (eqf_stats_then_update). If a measured landmark exceeds a threshold the device cancels the
-    // update and the frame continues below exactly as the reference does, with the statistics already in hand.
+    // update and the frame continues below exactly as the reference does, with the statistics already in hand; if some id
+    // is unknown nothing is computed (-1). The copy of the measurement the reference makes (VIOFilter.cpp:213) is only
+    // needed when outliers may be erased from it, i.e. on the path below.
     bool haveStats = false;
     std::vector<double> absErr, probErr;
-    if (!matchedMeasurement.camCoordinates.empty() && filterState.numLandmarks() > 0) {
-        std::vector<int> have = filterState.ids();
-        std::sort(have.begin(), have.end());
-        bool allKnown = true;
-        for (const auto& cc : matchedMeasurement.camCoordinates)
-            allKnown = allKnown && std::binary_search(have.begin(), have.end(), cc.first);
-        if (allKnown) {
-            const bool updated = filterState.statsThenUpdate(matchedMeasurement, settings->outlierThresholdAbs, settings->outlierThresholdProb, settings->constructOutputGainVar(),
-                                                             settings->useEquivariantOutput, settings->useDiscreteInnovationLift, absErr, probErr, depth2);
-            if (updated) {
-                loopTimer.endTiming("preprocessing");
-                loopTimer.startTiming("correction");
-                filterState.removeInvalidLandmarks();
-                loopTimer.endTiming("correction");
-                return;
-            }
-            haveStats = true;
+    if (!measurement.camCoordinates.empty() && filterState.numLandmarks() > 0) {
+        const int r = filterState.statsThenUpdate(measurement, settings->outlierThresholdAbs, settings->outlierThresholdProb, settings->constructOutputGainVar(),
+                                                  settings->useEquivariantOutput, settings->useDiscreteInnovationLift, absErr, probErr, depth2);
+        if (r == 1) {
+            loopTimer.endTiming("preprocessing");
+            loopTimer.startTiming("correction");
+            filterState.removeInvalidLandmarks();
+            loopTimer.endTiming("correction");
+            return;
         }
+        haveStats = (r == 0);
     }
+    VisionMeasurement matchedMeasurement = measurement;
     removeOutliers(matchedMeasurement, depth2, haveStats ? &absErr : nullptr, haveStats ? &probErr : nullptr);
     addNewLandmarks(matchedMeasurement, &depth2);
     loopTimer.endTiming("preprocessing");

@@ -161,6 +161,9 @@ struct VIO_eqf {
     void integrateObserverState(const IMUVelocity& imuVelocity, const double& dt, const bool& discreteLift = true);
     void integrateObserverStates(const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift); // batched
     void integrateRiccatiStateFast(const IMUVelocity& imuVelocity, const double& dt, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8);
+    // integrateRiccatiStateFast(mean sample) followed by integrateObserverStates(all samples) in one device call (eqf_propagate_fast)
+    void propagateFast(const IMUVelocity& meanVelocity, const double& dtTotal, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8,
+                       const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift);
     void integrateRiccatiStateAccurate(const IMUVelocity& imuVelocity, const double& dt, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8);
     void performVisionUpdate(const VisionMeasurement& measurement, double outputGainVar, const bool& useEquivariantOutput = true, const bool& discreteCorrection = false);
     VIOState stateEstimate() const;
@@ -169,8 +172,9 @@ struct VIO_eqf {
     // per-landmark quantities VIOFilter::removeOutliers / getMedianSceneDepth need, all landmarks at once
     void outlierStats(const VisionMeasurement& measurement, std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2) const;
     // eqf_stats_then_update: the statistics and (unless an outlier candidate cancels it on the device) the update, one host wait.
-    // Returns true when the update was performed.
-    bool statsThenUpdate(const VisionMeasurement& measurement, double thrAbs, double thrProb, double outputGainVar, bool useEquivariantOutput, bool discreteCorrection,
+    // Returns 1 when the update was performed, 0 when the device cancelled it (statistics valid), -1 when not applicable
+    // (a measurement id is not in the state; nothing computed).
+    int statsThenUpdate(const VisionMeasurement& measurement, double thrAbs, double thrProb, double outputGainVar, bool useEquivariantOutput, bool discreteCorrection,
                          std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2);
 
   private:

@@ -113,14 +113,20 @@ int eqf_outlier_stats(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, con
 /* VIO_eqf::performVisionUpdate (VIO_eqf.cpp:105-135): yTilde, C, S = C Sigma C^T + R, K = Sigma C^T S^-1,
  * Gamma = K yTilde, X <- Delta * X, Sigma <- Sigma - K C Sigma; R = meas_var * I
  * (constructOutputGainMatrix, VIOFilterSettings.h:203-206). Every measured id must be a state landmark. */
-int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEquivariantOutput, int discreteCorrection);/* Speculative frame tail for VIOFilter::processVisionData (VIOFilter.cpp:209-236) when every measurement id is already a
+int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEquivariantOutput, int discreteCorrection);/* VIOFilter::integrateUpToTime, fast-Riccati branch (VIOFilter.cpp:134-192), in one call: integrateRiccatiStateFast with the
+ * mean IMU sample over dt_total (at the current X), then the k observer steps. Same result as eqf_integrate_riccati_fast
+ * followed by eqf_integrate_observer (bit-identical); the difference is the queueing order on the device: the observer's
+ * landmark kernel is launched right behind the assembly kernel, ahead of the Sigma propagation it overlaps with. */
+int eqf_propagate_fast(eqf_ctx* ctx, const double* imu13_mean, double dt_total, const double* Qdiag12, const double* Pdiag8, const double* imu13_k, const double* dt_k,
+                       int k, int discreteLift);
+/* Speculative frame tail for VIOFilter::processVisionData (VIOFilter.cpp:209-236) when every measurement id is already a
  * landmark of the state: the outlier statistics of removeOutliers (VIOFilter.cpp:304-334) and performVisionUpdate are
  * queued back to back with ONE host wait. The statistics kernel compares each measured landmark with the two thresholds
  * on the device; if any exceeds one (the host then has outliers to rank and remove) it cancels the queued update kernels,
  * which return at their first instruction: nothing is modified, *updated = 0 and the caller continues exactly as without
  * speculation (decide with the returned statistics, remove, eqf_vision_update). Otherwise *updated = 1 and the state is
- * the one eqf_vision_update would have produced (bit-identical). EQF_OPT_SPECULATIVE = 0 turns it into a plain statistics
- * call (*updated = 0 always). absErr / probErr: -1 for landmarks without a measurement. */
+ * the one eqf_vision_update would have produced (bit-identical). *updated = -1: not applicable, some measurement id is not in
+ * the state (nothing was computed). EQF_OPT_SPECULATIVE = 0 turns it into a plain statistics call (*updated = 0). absErr / probErr: -1 for landmarks without a measurement. */
 int eqf_stats_then_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y_px, int M, double thrAbs, double thrProb, double meas_var,
                           int useEquivariantOutput, int discreteCorrection, double* absErr, double* probErr, double* depth2, int* updated);
 

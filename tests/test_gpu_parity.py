@@ -323,7 +323,7 @@ def test_speculative_tail_equals_stats_plus_update(chart):
     twin.vision_update(cam, mid, y, var, True, False)
     # speculative call, thresholds far away
     upd, a1, p1, d1 = core.stats_then_update(cam, mid, y, 1e8, 1e8, var, True, False)
-    assert upd
+    assert upd == 1
     assert np.array_equal(a0, a1) and np.array_equal(p0, p1) and np.array_equal(d0, d1)
     assert np.array_equal(core.get_sigma(), twin.get_sigma())
     for u, v in zip(core.get_state(), twin.get_state()):
@@ -337,13 +337,44 @@ def test_speculative_tail_equals_stats_plus_update(chart):
     a_ref, p_ref, _ = twin.outlier_stats(cam, mid2, y2)
     thr = 0.999 * np.max(p_ref)
     upd, a2, p2, d2 = core.stats_then_update(cam, mid2, y2, 1e8, thr, var, True, False)
-    assert not upd
+    assert upd == 0
     assert np.array_equal(a2, a_ref) and np.array_equal(p2, p_ref)
     assert np.array_equal(core.get_sigma(), S_before)
     for u, v in zip(core.get_state(), st_before):
         assert np.array_equal(u, v)
     # ... and exactly at the largest error (not exceeded: '>' in VIOFilter.cpp:324) it goes through
     upd, _, _, _ = core.stats_then_update(cam, mid2, y2, 1e8, np.max(p_ref), var, True, False)
-    assert upd
+    assert upd == 1
+    # an id that is not in the state: not applicable, nothing computed
+    S_now = core.get_sigma()
+    upd, _, _, _ = core.stats_then_update(cam, np.array([10**6], np.int32), np.array([1.0, 2.0]), 1e8, 1e8, var, True, False)
+    assert upd == -1 and np.array_equal(core.get_sigma(), S_now)
     twin.vision_update(cam, mid2, y2, var, True, False)
     assert np.array_equal(core.get_sigma(), twin.get_sigma())
+
+
+@pytest.mark.parametrize("chart", list(CHARTS))
+@pytest.mark.parametrize("k,discrete", [(1, True), (10, True), (30, False)])
+def test_propagate_fast_equals_riccati_plus_observer(chart, k, discrete):
+    """eqf_propagate_fast = integrateRiccatiStateFast at the current X followed by the k observer steps (VIOFilter.cpp:134-192,
+    fast branch); only the queueing order on the device differs. k = 30 needs two kernel-argument chunks."""
+    N = 17
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=91)
+    twin = EqfCore(N, CHARTS[chart])
+    twin.set_state(xi0, Xs, ids, q0, Q)
+    twin.set_sigma(S)
+    imus = np.stack([random_imu(rng, bias_vel=True) for _ in range(k)])
+    dts = rng.uniform(0.002, 0.008, k)
+    mean = (imus * dts[:, None]).sum(0) / dts.sum()
+    Qd, Pd = settings.input_gain_diag12(), settings.state_gain_diag8()
+    twin.integrate_riccati_fast(mean, dts.sum(), Qd, Pd)
+    twin.integrate_observer(imus, dts, discrete)
+    core.propagate_fast(mean, dts.sum(), Qd, Pd, imus, dts, discrete)
+    assert np.array_equal(core.get_sigma(), twin.get_sigma())
+    for u, v in zip(core.get_state(), twin.get_state()):
+        assert np.array_equal(u, v)
+    orc.integrate_riccati_fast(mean, dts.sum())
+    for s_ in range(k):
+        orc.integrate_observer(imus[s_], dts[s_], discrete)
+    check_sigma(core, orc, 1e-12)
+    check_state(core, orc)
