@@ -380,15 +380,19 @@ int upload_common(eqf_ctx* c, const double* imu13) {
     compute_common(c, imu13, *c->h_common); // h_common is host-only now (debug expansion); the kernels get c->ck by value
     return 0;
 }
-int launch_assemble(eqf_ctx* c) {
+// record_early: mark "assembly done" for an observer kernel on the second stream (not needed when the observer rides along
+// in the propagation kernel on this stream)
+int launch_assemble(eqf_ctx* c, bool record_early = true) {
     KTimer t(c, KN_ASSEMBLE);
     int r = join_observer(c);
     if (r)
         return r;
     hipLaunchKernelGGL(k_assemble_AB, dim3(std::max(1, blocks(c->N, 64))), dim3(64), 0, c->stream, c->ck, c->N, c->Ncap, c->chart, c->d_common, c->q0(), c->Qq(),
                        c->Qa(), c->d_Al, c->d_Bl);
-    HIPCHK(hipEventRecord(c->ev_early, c->stream));
-    c->ev_assembled_early = true;
+    if (record_early) {
+        HIPCHK(hipEventRecord(c->ev_early, c->stream));
+        c->ev_assembled_early = true;
+    }
     return (int)hipGetLastError();
 }
 int read_flags(eqf_ctx* c) {
@@ -907,7 +911,7 @@ int eqf_remove_invalid_landmarks(eqf_ctx* c) {
     return rc ? rc : (int)bad.size();
 }
 
-static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8);
+static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs = nullptr, int obs_k = 0);
 int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
     if (!c || !imu13 || !Qdiag12 || !Pdiag8)
         return EQF_E_BAD_ARG;
@@ -921,8 +925,10 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
     return riccati_after_assemble(c, dt, Qdiag12, Pdiag8);
 }
 // Sigma' = F Sigma F^T + dt (B Q B^T + P) once A_l / B_l are assembled (arrow form, or the dense GEMM pair)
-static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8) {
+// obs != nullptr (arrow form only): obs_k observer steps for the landmarks ride along as extra blocks of k_propagate_main
+static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs, int obs_k) {
     int rc = 0;
+    static const ObsSteps kNoSteps{};
     RiccatiArgs ra;
     ra.dt = dt;
     std::memcpy(ra.Qd, Qdiag12, sizeof(ra.Qd));
@@ -932,9 +938,10 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
     double* Sout = c->d_sigma[1 - c->cur];
     if (!c->opt_dense) {
         const int nT = blocks(N, PT), nStrip = blocks(N, 12);
+        const int nObs = (obs && obs_k > 0) ? blocks(N, 256) : 0;
         KTimer t(c, KN_PROP_MAIN);
-        LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1), dim3(256), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout, c->d_Al, c->d_Bl, nT,
-                           nStrip);
+        LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1 + nObs), dim3(256), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout, c->d_Al, c->d_Bl,
+                  nT, nStrip, nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa());
         HIPCHK(hipGetLastError());
     } else {
         // dense: F materialised, tmp = F Sigma (= (Sigma F^T)^T, Sigma symmetric), Sigma' = tmp F^T + noise
@@ -1104,8 +1111,7 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
     return 0;
 }
 
-// See include/eqf_hip.h: fast Riccati + all observer steps of one frame, the observer kernel queued AHEAD of the Sigma
-// propagation so that it is never the last thing the outlier statistics wait for.
+// See include/eqf_hip.h: fast Riccati + all observer steps of one frame, two kernels on one stream.
 int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, const double* Qdiag12, const double* Pdiag8, const double* imu13_k, const double* dt_k,
                        int k, int discreteLift) {
     if (!c || !imu13_mean || !Qdiag12 || !Pdiag8 || k < 0 || (k > 0 && (!imu13_k || !dt_k)))
@@ -1129,16 +1135,22 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
         c->est_valid = false;
         c->meas_valid = false;
     }
-    // 3. device: assemble (reads Q), then the observer on stream 2 (writes Q once the assembly has read it), then Sigma
-    rc = launch_assemble(c);
+    // 3. device. Arrow form: two launches on ONE stream, the first chunk of observer steps riding along as extra blocks of the
+    //    Sigma propagation kernel (it does not touch Q; the assembly before it has read Q, the statistics after it want the new
+    //    Q). Further chunks (k > 24) and the dense mode use the observer kernel, in stream order.
+    rc = launch_assemble(c, false);
     if (rc)
         return rc;
-    for (size_t q = 0; q < chunks.size(); ++q) {
-        rc = observer_launch(c, chunks[q], counts[q]);
-        if (rc)
-            return rc;
+    const bool ride = !c->opt_dense && !chunks.empty() && c->N > 0;
+    rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0);
+    if (rc)
+        return rc;
+    for (size_t q = ride ? 1 : 0; q < chunks.size() && c->N > 0; ++q) {
+        c->ev_assembled_early = false;
+        hipLaunchKernelGGL(k_observer, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, chunks[q], c->N, c->Ncap, counts[q], c->q0(), c->Qq(), c->Qa());
+        HIPCHK(hipGetLastError());
     }
-    return riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8);
+    return 0;
 }
 
 // Blocked right-looking factorisation of Z (rows x m, leading dimension ldz): one launch per 32-column panel

@@ -202,12 +202,9 @@ __global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int
 struct ObsSteps {
     ObsStep s[kObsChunk];
 };
-__global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N, int Ncap, int k, const double* __restrict__ q0,
-                                                 double* __restrict__ Qq, double* __restrict__ Qa) {
-    const ObsStep* steps = steps_arg.s;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
+// landmark i: Q_i <- Q_i * Lambda_1.Q_i * ... * Lambda_k.Q_i for the k steps (one lane per landmark)
+__device__ __forceinline__ void observer_landmark(const ObsStep* __restrict__ steps, int Ncap, int k, int i, const double* __restrict__ q0, double* __restrict__ Qq,
+                                                  double* __restrict__ Qa) {
     const V3 p0 = ld3(q0, Ncap, i);
     Qt q = ldq(Qq, Ncap, i);
     double a = Qa[i];
@@ -236,6 +233,12 @@ __global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N
     Qq[3 * Ncap + i] = q.z;
     Qa[i] = a;
 }
+__global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N, int Ncap, int k, const double* __restrict__ q0,
+                                                 double* __restrict__ Qq, double* __restrict__ Qa) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N)
+        observer_landmark(steps_arg.s, Ncap, k, i, q0, Qq, Qa);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // K2: G_i = (F Sigma)[l_i, 0:21] = dt*A_ls_i Sigma_ss + (I + dt*A_qi) Sigma_{l_i,s}   (3 x 21 per landmark) is computed
@@ -249,10 +252,20 @@ constexpr int PT = 16; // landmarks per tile side
 template <typename TS>
 __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
-                                                        const double* __restrict__ Bl, int nT, int nStrip) {
+                                                        const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
+                                                        const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa) {
     const double dt = ra.dt;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    if (b > nT * nT + nStrip) {
+        // Observer blocks (eqf_propagate_fast): the landmark part of the frame's observer steps rides along with the Sigma
+        // propagation. This kernel touches Sigma / Al / Bl only, the assembly kernel before it has already read Q and the
+        // statistics kernel after it wants the new Q: in-stream order gives all three, no second stream, no events.
+        const int i = (b - (nT * nT + nStrip + 1)) * 256 + tid;
+        if (i < N)
+            observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa);
+        return;
+    }
     __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
     if (b < nT * nT) {
         const int bi = b % nT, bj = b / nT;

@@ -115,8 +115,9 @@ int eqf_outlier_stats(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, con
  * (constructOutputGainMatrix, VIOFilterSettings.h:203-206). Every measured id must be a state landmark. */
 int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEquivariantOutput, int discreteCorrection);/* VIOFilter::integrateUpToTime, fast-Riccati branch (VIOFilter.cpp:134-192), in one call: integrateRiccatiStateFast with the
  * mean IMU sample over dt_total (at the current X), then the k observer steps. Same result as eqf_integrate_riccati_fast
- * followed by eqf_integrate_observer (bit-identical); the difference is the queueing order on the device: the observer's
- * landmark kernel is launched right behind the assembly kernel, ahead of the Sigma propagation it overlaps with. */
+ * followed by eqf_integrate_observer (bit-identical); the difference is on the device: the landmark part of the observer steps
+ * rides along as extra workgroups of the Sigma propagation kernel (which does not touch the landmark arrays), so the whole
+ * propagation is two kernels on one stream, with no second stream and no events. */
 int eqf_propagate_fast(eqf_ctx* ctx, const double* imu13_mean, double dt_total, const double* Qdiag12, const double* Pdiag8, const double* imu13_k, const double* dt_k,
                        int k, int discreteLift);
 /* Speculative frame tail for VIOFilter::processVisionData (VIOFilter.cpp:209-236) when every measurement id is already a
