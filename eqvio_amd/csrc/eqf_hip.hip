@@ -1121,7 +1121,12 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     int rc = upload_common(c, imu13_mean);
     if (rc)
         return rc;
-    // 2. all observer steps on the host (X advances); chunks of kMaxSteps keep the kernel-argument packet small
+    // 2. the assembly kernel goes out first (its terms, c->ck, are fixed now): the host part of the observer steps below then
+    //    overlaps it instead of delaying it
+    rc = launch_assemble(c, false);
+    if (rc)
+        return rc;
+    // 3. all observer steps on the host (X advances); chunks of kMaxSteps keep the kernel-argument packet small
     std::vector<ObsSteps> chunks;
     std::vector<int> counts;
     for (int done = 0; done < k;) {
@@ -1135,12 +1140,9 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
         c->est_valid = false;
         c->meas_valid = false;
     }
-    // 3. device. Arrow form: two launches on ONE stream, the first chunk of observer steps riding along as extra blocks of the
-    //    Sigma propagation kernel (it does not touch Q; the assembly before it has read Q, the statistics after it want the new
-    //    Q). Further chunks (k > 24) and the dense mode use the observer kernel, in stream order.
-    rc = launch_assemble(c, false);
-    if (rc)
-        return rc;
+    // 4. Arrow form: the first chunk of observer steps rides along as extra blocks of the Sigma propagation kernel (it does
+    //    not touch Q; the assembly before it has read Q, the statistics after it want the new Q): two launches on ONE stream.
+    //    Further chunks (k > 24) and the dense mode use the observer kernel, in stream order.
     const bool ride = !c->opt_dense && !chunks.empty() && c->N > 0;
     rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0);
     if (rc)
