@@ -88,6 +88,9 @@ def run_sim(name, fs, sim_kw, augment, oracle_frames):
     if not augment:  # start from the features of the first frame only (main_opt-like: the filter adds landmarks itself)
         ids0, p0 = ids0[:0], p0[:0]
     flt = VIOFilter(fs, max_landmarks=max(sim.numPoints + sim.maxFeatures, 64) if augment else 2 * sim.maxFeatures + 64, sensor=s0, ids=ids0, p=p0, time=0.0)
+    for tok in os.environ.get("EQF_OPTS", "").split(","):  # e.g. EQF_OPTS=7:0,6:0 to switch device options for a diagnosis run
+        if ":" in tok:
+            flt.set_core_option(int(tok.split(":")[0]), int(tok.split(":")[1]))
     orc = OracleFilter(fs, s0, ids0, p0, 0.0) if oracle_frames else None
     # a second oracle in the other dense arithmetic (the first is "as written": LU inverse, K evaluated twice; the second "efficient dense": Cholesky): its distance from the
     # first is the rounding floor this configuration's conditioning allows ANY two fp64 implementations
@@ -102,6 +105,7 @@ def run_sim(name, fs, sim_kw, augment, oracle_frames):
     t_dev = t_orc = 0.0
     worst_state = worst_sigma = 0.0
     nees = []
+    nees_failures = 0
     while srv.next_measurement_type() != srv.NONE:
         if srv.next_measurement_type() == srv.IMU:
             imu = srv.get_imu()
@@ -140,11 +144,16 @@ def run_sim(name, fs, sim_kw, augment, oracle_frames):
         n_lm += flt.sigma_dim()
         if frames % 10 == 0:
             ts2, tids2, tp2 = srv.true_state(flt.get_time())
-            nees.append(flt.compute_nees(ts2, tids2, tp2))
+            try:
+                nees.append(flt.compute_nees(ts2, tids2, tp2))
+            except RuntimeError:
+                # the device factorises Sigma (Cholesky-type): with the template's 0.003 px noise Sigma reaches cond 5e13 and is
+                # SPD only up to rounding; the reference's LU inverse does not notice. Reported, not hidden.
+                nees_failures += 1
     est = flt.state_estimate()[0]
     tru = srv.true_state(flt.get_time())[0]
     out = {"frames": frames, "mean_state_dim": n_lm / max(frames, 1), "device_updates_per_s": frames / t_dev, "final_position_error_m": float(np.linalg.norm(est[10:13] - tru[10:13])),
-           "mean_nees": float(np.mean(nees)) if nees else None}
+           "mean_nees": float(np.mean(nees)) if nees else None, "nees_not_spd": nees_failures}
     if orc:
         k = min(frames, oracle_frames)
         out.update({"oracle_frames": k, "oracle_updates_per_s": k / t_orc, "parity_state_max": worst_state, "parity_sigma_rel_fro_max": worst_sigma,
