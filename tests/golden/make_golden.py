@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle_binding import OracleFilter  # noqa: E402
-from util import CHARTS, euroc_camera, random_imu, random_spd, reasonable_state, settings_for, synth_measurement  # noqa: E402
+from util import CAMERAS, CHARTS, euroc_camera, random_imu, random_spd, reasonable_state, settings_for, synth_measurement  # noqa: E402
 
 CASES = [("euclid", 5, 1), ("invdepth", 5, 2), ("euclid", 20, 3), ("invdepth", 20, 4), ("invdepth", 50, 5)]
 
@@ -61,9 +61,63 @@ def make_case(chart_name, N, seed):
     return out
 
 
+# second family: the non-default branches of the same path (accurate Riccati, continuous observer lift, discrete
+# innovation lift, distorted cameras, outlier statistics, NEES)
+VARIANTS = [("euclid", 8, "radtan", 11), ("invdepth", 8, "equidistant", 12), ("invdepth", 30, "radtan", 13)]
+
+
+def cam_vector(cam):
+    return np.array([cam.model, cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy] + list(cam.dist))
+
+
+def make_variant(chart_name, N, cam_name, seed):
+    rng = np.random.default_rng(seed)
+    chart = CHARTS[chart_name]
+    s = settings_for(chart, fastRiccati=0, useDiscreteInnovationLift=1, useDiscreteVelocityLift=0, measurementNoise=2.0)
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N, shuffle_ids=True)
+    S0 = random_spd(rng, 21 + 3 * N)
+    cam = CAMERAS[cam_name]()
+    imu = random_imu(rng, bias_vel=True)
+    k = 4
+    imus = np.stack([random_imu(rng, stamp=0.005 * i) for i in range(k)])
+    dts = rng.uniform(0.002, 0.006, k)
+    orc = OracleFilter(s)
+    orc.set_eqf(xi0, Xs, ids, q0, Q, S0)
+    out = dict(chart=np.int32(chart), N=np.int32(N), xi0=xi0, Xs=Xs, ids=ids, q0=q0, Q=Q, Sigma0=S0, imu=imu, dt=np.float64(0.02), imus=imus, dts=dts,
+               cam=cam_vector(cam), meas_var=np.float64(s.measurementNoise**2), Qdiag=s.input_gain_diag12(), Pdiag8=s.state_gain_diag8())
+    orc.integrate_riccati_accurate(imu, 0.02)
+    S1 = orc.get_sigma()
+    for i in range(k):
+        orc.integrate_observer(imus[i], dts[i], False)
+    _, Xs1, _, _, Q1 = orc.get_eqf()
+    sub = np.sort(rng.permutation(N)[: N - 2])  # two landmarks unobserved
+    mid, y = synth_measurement(rng, cam, ids, q0, Q1, noise_px=1.5, subset=sub)
+    absE, probE = orc.outlier_stats(cam, mid, y)
+    orc.vision_update(cam, mid, y)
+    S2 = orc.get_sigma()
+    _, Xs2, _, _, Q2 = orc.get_eqf()
+    est_sensor, est_ids, est_p = orc.state_estimate()
+    truth_sensor = est_sensor.copy()
+    truth_sensor[0:6] += rng.normal(size=6) * 1e-3
+    truth_sensor[13:16] += rng.normal(size=3) * 1e-2
+    truth_p = est_p + rng.normal(size=est_p.shape) * 1e-2
+    nees = orc.compute_nees(truth_sensor, est_ids, truth_p)
+    out.update(meas_ids=mid, meas_y=y, Sigma_propagated=S1, Xs_after_observer=Xs1, Q_after_observer=Q1, absErr=absE, probErr=probE, Sigma_updated=S2,
+               Xs_after_update=Xs2, Q_after_update=Q2, Gamma=orc.last_gamma(), truth_sensor=truth_sensor, truth_ids=est_ids, truth_p=truth_p,
+               nees=np.float64(nees))
+    return out
+
+
+def write(path, maker, *a):
+    if os.path.exists(path) and "--force" not in sys.argv:  # the zip container carries timestamps: do not churn the history
+        print(path, "exists (use --force to regenerate)")
+        return
+    np.savez_compressed(path, **maker(*a))
+    print(path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
+    for chart_name, N, cam_name, seed in VARIANTS:
+        write(os.path.join(HERE, f"variant_{chart_name}_N{N}_{cam_name}.npz"), make_variant, chart_name, N, cam_name, seed)
     for chart_name, N, seed in CASES:
-        d = make_case(chart_name, N, seed)
-        path = os.path.join(HERE, f"frame_{chart_name}_N{N}.npz")
-        np.savez_compressed(path, **d)
-        print(path, os.path.getsize(path) // 1024, "KiB")
+        write(os.path.join(HERE, f"frame_{chart_name}_N{N}.npz"), make_case, chart_name, N, seed)
