@@ -166,7 +166,7 @@ struct eqf_ctx {
     static constexpr int kMaxSteps = kObsChunk;
     CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
-    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0;
+    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0, opt_early = 1;
     bool sig32 = false; // Sigma stored as float (EQF_OPT_SIGMA_FP32 = 2)
     int opt_door = 1;   // host doorbell instead of the stream completion signal for the two per-frame waits
     int* d_door = nullptr; // device counters (one per doorbell)
@@ -631,6 +631,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_DOORBELL:
         c->opt_door = value;
+        return 0;
+    case EQF_OPT_EARLY_LIFT:
+        c->opt_early = value;
         return 0;
     case EQF_OPT_FUSED_UPDATE:
         if (value && c->sig32)
@@ -1291,13 +1294,25 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq);
         if (rc)
             return rc;
-        KTimer t(c, KN_SYRK);
         const int nt = blocks(n, 32);
-        LAUNCH_TS(c, k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), c->stream, n, m, c->ld, c->ldz, c->d_W, (TS*)c->sigma(), nt, c->d_gamma, spec, spec_seq);
+        if (c->opt_early) { // Gamma, landmark lift, result packet and doorbell BEFORE the covariance update: the host round trip overlaps with it
+            LiftArgs la;
+            la.N = N, la.Ncap = c->Ncap, la.chart = c->chart, la.discrete = discreteCorr;
+            la.q0 = c->q0(), la.Qq = c->Qq(), la.Qa = c->Qa();
+            la.est = c->h_res + 3 * (size_t)c->Ncap, la.gamma_host = c->h_res + 7 * (size_t)c->Ncap;
+            la.flags = c->d_flags, la.flags_host = c->h_resflags;
+            la.door_count = use_door ? c->d_door + 1 : nullptr, la.door_host = c->h_door + 1, la.door_seq = door_seq;
+            KTimer t(c, KN_LIFT);
+            hipLaunchKernelGGL(k_gamma_lift, dim3(lift_workgroups(N)), dim3(512), 0, c->stream, n, m, c->ldz, c->d_W, c->d_gamma, spec, spec_seq, la);
+            HIPCHK(hipGetLastError());
+        }
+        KTimer t(c, KN_SYRK);
+        LAUNCH_TS(c, k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), c->stream, n, m, c->ld, c->ldz, c->d_W, (TS*)c->sigma(), nt, c->d_gamma, spec, spec_seq,
+                  c->opt_early ? 0 : 1);
         HIPCHK(hipGetLastError());
     }
     { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }
-    {
+    if (c->opt_fused || !c->opt_early) {
         KTimer t(c, KN_LIFT);
         hipLaunchKernelGGL(k_lift, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),
                            c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags, use_door ? c->d_door + 1 : nullptr, c->h_door + 1,
@@ -1342,6 +1357,11 @@ static int finish_update(eqf_ctx* c, int discreteCorr) {
         D.B = se3_exp(cw + UB0.w, cv + UB0.v);
     }
     c->X = group_mul(D, c->X);
+    if (c->opt_check) { // the finite check ran after the result packet was written: fetch its verdict
+        const int r = read_flags(c);
+        if (r)
+            return r;
+    }
     if (c->h_flags[0])
         return EQF_E_NOT_SPD;
     if (c->h_flags[1])

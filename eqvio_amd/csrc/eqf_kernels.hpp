@@ -460,8 +460,12 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
 // word instead of the stream's completion signal and sees the results about 6 us earlier (scripts/ubench/doorbell.hip).
 // Ordering: every workgroup fences its result stores at system scope before its atomic increment; the workgroup that
 // observes all increments fences again and only then writes the sequence number.
-__device__ __forceinline__ void ring_doorbell(int* __restrict__ count, int* __restrict__ host_flag, int seq) {
+// first_wave_only: every store the host will read was issued by the workgroup's first wavefront (then only that wave pays for
+// the system-scope release, which is not cheap when many workgroups execute it at once).
+__device__ __forceinline__ void ring_doorbell(int* __restrict__ count, int* __restrict__ host_flag, int seq, bool first_wave_only = false) {
     if (!count)
+        return;
+    if (first_wave_only && threadIdx.x >= 64)
         return;
     __threadfence_system();
     if (threadIdx.x == 0) {
@@ -1249,11 +1253,105 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 }
 
 // K9: Sigma <- Sigma - W W^T  ( = Sigma - K C Sigma, VIO_eqf.cpp:131 ): lower 32x32 tiles computed (one workgroup
-// each, K = m split over its 4 waves), the strictly-lower ones mirrored so Sigma stays exactly symmetric.
+// each, K = m split over its 8 waves), the strictly-lower ones mirrored so Sigma stays exactly symmetric.
+//
+// With with_gamma = 0 the diagonal tiles skip the Gamma by-product (k_gamma_lift, launched BEFORE this kernel, has done it).
+//
+// K9a: k_gamma_lift finishes the innovation, which needs W and z but not the new Sigma: workgroup 0 computes Gamma[0:21]
+// (sensor rows, two workgroups) and hands it, with the status flags, to the host; workgroup 2 + g computes the Gamma rows of landmarks
+// [4 g, 4 g + 4) and lifts them (K10). The last workgroup rings the host doorbell. Launched between the last factorisation
+// step and the covariance update, it gives the host the frame's results one kernel early: the host round trip (results,
+// filter logic, the next frame's launches) overlaps with Sigma -= W W^T instead of leaving the GPU idle after it.
+__device__ __forceinline__ void lift_landmark(int i, const V3 g, int N, int Ncap, int chart, int discrete, const double* __restrict__ q0, double* __restrict__ Qq,
+                                              double* __restrict__ Qa, double* __restrict__ est);
+struct LiftArgs {
+    int N, Ncap, chart, discrete;
+    const double* q0;
+    double *Qq, *Qa;
+    double *est, *gamma_host; // pinned host packet
+    const int* flags;
+    int* flags_host;          // pinned
+    int *door_count, *door_host;
+    int door_seq;
+};
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
+constexpr int LIFT_LM = 4;    // landmarks per lift workgroup (12 rows of Gamma)
+constexpr int LIFT_ROWS = 3 * LIFT_LM;
+constexpr int LIFT_SEG = 42;  // column segments per row: 12 x 42 = 504 of the 512 threads
+constexpr int LIFT_B = 12;    // columns per thread and batch (one batch covers m <= 504)
+__host__ __device__ __forceinline__ int lift_workgroups(int N) { return 2 + (N + LIFT_LM - 1) / LIFT_LM; } // two for the 21 sensor rows
+__global__ void __launch_bounds__(512) k_gamma_lift(int n, int m, int ldz, const double* __restrict__ Wb, double* __restrict__ gamma, const int* __restrict__ spec,
+                                                     int spec_seq, const LiftArgs la) {
+    __shared__ double sbuf[(LIFT_SEG + 1) * LIFT_ROWS];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const bool aborted = spec && *spec == spec_seq;
+    if (aborted) { // speculative tail cancelled by the statistics kernel: nothing is modified, the host is told
+        if (b == 0 && tid == 0)
+            la.flags_host[2] = 1;
+        ring_doorbell(la.door_count, la.door_host, la.door_seq, true);
+        return;
+    }
+    // rows of Gamma owned by this workgroup: 0..11, 12..20 (sensor), then 12 per group of 4 landmarks
+    const int r0 = (b < 2) ? LIFT_ROWS * b : 21 + LIFT_ROWS * (b - 2);
+    const int nr = (b == 0) ? LIFT_ROWS : (b == 1) ? 21 - LIFT_ROWS : min(LIFT_ROWS, n - r0);
+    const int rr = tid % LIFT_ROWS, seg = tid / LIFT_ROWS;
+    const double* W = Wb + m;
+    const double* z = Wb + m + n;
+    // thread (rr, seg): columns seg, seg + 42, ... in batches of 12 unconditional loads (one L2 round trip for m = 400);
+    // out-of-range columns are clamped for the load and zeroed by a multiplier
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (seg < LIFT_SEG) {
+        const double* Wr = W + r0 + min(rr, nr - 1);
+        for (int p0 = seg; p0 < m; p0 += LIFT_B * LIFT_SEG) {
+            double wv[LIFT_B], zv[LIFT_B];
+#pragma unroll
+            for (int q = 0; q < LIFT_B; ++q) {
+                const int p = p0 + q * LIFT_SEG;
+                const int pc = min(p, m - 1);
+                wv[q] = Wr[(size_t)pc * ldz];
+                zv[q] = p < m ? z[(size_t)pc * ldz] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < LIFT_B; q += 4) {
+                s0 = fma(wv[q], zv[q], s0);
+                s1 = fma(wv[q + 1], zv[q + 1], s1);
+                s2 = fma(wv[q + 2], zv[q + 2], s2);
+                s3 = fma(wv[q + 3], zv[q + 3], s3);
+            }
+        }
+        sbuf[seg * LIFT_ROWS + rr] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    double* sg = sbuf + LIFT_SEG * LIFT_ROWS;
+    if (tid < nr) { // fixed order: deterministic
+        double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < LIFT_SEG; q += 2) {
+            g0 += sbuf[q * LIFT_ROWS + tid];
+            g1 += sbuf[(q + 1) * LIFT_ROWS + tid];
+        }
+        const double g = g0 + g1;
+        sg[tid] = g;
+        gamma[r0 + tid] = g;
+        if (b < 2)
+            la.gamma_host[r0 + tid] = g;
+    }
+    if (b == 0 && tid == 0) {
+        la.flags_host[0] = la.flags[0];
+        la.flags_host[1] = la.flags[1];
+        la.flags_host[2] = 0;
+    }
+    __syncthreads();
+    if (b >= 2 && tid < LIFT_LM) {
+        const int i = LIFT_LM * (b - 2) + tid;
+        if (i < la.N)
+            lift_landmark(i, V3{sg[3 * tid], sg[3 * tid + 1], sg[3 * tid + 2]}, la.N, la.Ncap, la.chart, la.discrete, la.q0, la.Qq, la.Qa, la.est);
+    }
+    ring_doorbell(la.door_count, la.door_host, la.door_seq, true); // all host-visible stores above come from threads < 12
+}
 template <typename TS>
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
-                                                  double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq) {
+                                                  double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma) {
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
     __shared__ double sred[1024 * SYRK_NW];
@@ -1266,14 +1364,14 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
     const int bi = bj + b;
     const int i0 = bi * 32, j0 = bj * 32;
     const double* W = Wb + m;
-    // diagonal tiles also produce Gamma[i0 : i0+32] = W[rows] z  (Gamma = K yTilde = W L^-1 yTilde, VIO_eqf.cpp:119)
+    // with_gamma: the diagonal tiles also produce Gamma[i0 : i0+32] = W[rows] z  (Gamma = K yTilde = W L^-1 yTilde, VIO_eqf.cpp:119)
     double gv = 0.0;
     TileRed t;
-    if (bi == bj)
+    if (bi == bj && with_gamma)
         t = mfma_tile32_splitk<true, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
     else
         t = mfma_tile32_splitk<false, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
-    if (bi == bj && threadIdx.x < 32 && i0 + threadIdx.x < n)
+    if (bi == bj && with_gamma && threadIdx.x < 32 && i0 + threadIdx.x < n)
         gamma[i0 + threadIdx.x] = gv;
     if (threadIdx.x >= 256)
         return;
@@ -1295,22 +1393,9 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
 // euclid.cpp:36-97, invdepth.cpp:183-253; VIOExp VIOGroup.cpp:273-290; X = Delta * X VIO_eqf.cpp:130).
 // Also writes the new estimates q_hat_i and a flag per landmark with Q_i.a outside (1e-8, 1e8]
 // (removeInvalidLandmarks, VIO_eqf.cpp:213-223) into `est` (4 planes of stride N: qx, qy, qz, invalid).
-__device__ __forceinline__ void lift_body(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
-                                          double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
-                                          const int* __restrict__ flags, int* __restrict__ flags_host) {
-    // est / gamma_host / flags_host point into the pinned host packet: the results reach the host with the stream
-    // synchronisation alone, no copy kernels.
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 21)
-        gamma_host[i] = gamma[i];
-    if (i == 0) {
-        flags_host[0] = flags[0];
-        flags_host[1] = flags[1];
-    }
-    if (i >= N)
-        return;
+__device__ __forceinline__ void lift_landmark(int i, const V3 g, int N, int Ncap, int chart, int discrete, const double* __restrict__ q0, double* __restrict__ Qq,
+                                              double* __restrict__ Qa, double* __restrict__ est) {
     const V3 p0 = ld3(q0, Ncap, i);
-    const V3 g{gamma[21 + 3 * i], gamma[21 + 3 * i + 1], gamma[21 + 3 * i + 2]};
     Qt Dq;
     double Da;
     if (discrete) {
@@ -1337,6 +1422,22 @@ __device__ __forceinline__ void lift_body(int N, int Ncap, int chart, int discre
     est[N + i] = qh.y;
     est[2 * N + i] = qh.z;
     est[3 * N + i] = (a <= 1e-8 || a > 1e8 || !(a == a)) ? 1.0 : 0.0;
+}
+__device__ __forceinline__ void lift_body(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
+                                          double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
+                                          const int* __restrict__ flags, int* __restrict__ flags_host) {
+    // est / gamma_host / flags_host point into the pinned host packet: the results reach the host with the stream
+    // synchronisation alone, no copy kernels.
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 21)
+        gamma_host[i] = gamma[i];
+    if (i == 0) {
+        flags_host[0] = flags[0];
+        flags_host[1] = flags[1];
+    }
+    if (i >= N)
+        return;
+    lift_landmark(i, V3{gamma[21 + 3 * i], gamma[21 + 3 * i + 1], gamma[21 + 3 * i + 2]}, N, Ncap, chart, discrete, q0, Qq, Qa, est);
 }
 __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
                                              double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,

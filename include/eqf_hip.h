@@ -45,6 +45,9 @@ enum {
     EQF_OPT_DOORBELL = 6,      /* 1 (default): the two per-frame host waits poll a sequence number that the last workgroup of the
                                   kernel writes into the pinned result packet (~6 us earlier than the stream's completion signal);
                                   0: wait on the stream */
+    EQF_OPT_EARLY_LIFT = 8,    /* 1 (default): the first workgroups of the covariance-update kernel compute Gamma, lift the landmarks and
+                                  ring the doorbell, so the host has the frame's results while Sigma -= W W^T is still running;
+                                  0: Gamma from the diagonal tiles and a separate lift kernel after it */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati and the fused update return EQF_E_UNSUPPORTED.

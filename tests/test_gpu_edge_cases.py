@@ -92,6 +92,26 @@ def test_non_finite_input_is_caught_when_checking_is_on():
     assert e.value.code == -1  # EQF_E_NONFINITE
 
 
+def test_non_finite_sigma_is_caught_after_an_update_when_checking_is_on():
+    """A NaN that the update itself never reads (variance of an unmeasured landmark) survives Sigma -= W W^T: only the
+    finite check (VIO_eqf.cpp:132) can report it."""
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], 5, seed=8)
+    cam = default_camera()
+    order = np.argsort(ids)
+    unmeasured = order[-1]
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=order[:-1])
+    S2 = S.copy()
+    l = 21 + 3 * unmeasured
+    S2[l, l] = np.nan
+    core.set_sigma(S2)
+    core.vision_update(cam, mid, y, 1.0, True, False)  # unchecked: goes through (the reference would only assert in debug builds)
+    core.set_sigma(S2)
+    core.set_option(OPT_CHECK_FINITE, 1)
+    with pytest.raises(EqfError) as e:
+        core.vision_update(cam, mid, y, 1.0, True, False)
+    assert e.value.code == -1  # EQF_E_NONFINITE
+
+
 def test_bad_arguments():
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["euclid"], 4, seed=7)
     with pytest.raises(EqfError):
