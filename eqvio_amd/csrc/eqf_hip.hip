@@ -150,7 +150,7 @@ struct eqf_ctx {
     int* d_expinfo = nullptr;
     double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
     int ldzn = 0;
-    double *d_Z = nullptr, *d_W = nullptr, *d_Linv = nullptr, *d_gamma = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
+    double *d_Z = nullptr, *d_W = nullptr, *d_Linv = nullptr, *d_gamma = nullptr, *d_gpart = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
     int* d_flags = nullptr;
     // pinned host staging
     Common* h_common = nullptr;
@@ -481,6 +481,7 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipMalloc(&c->d_W, sizeof(double) * (size_t)c->ldz * c->mcap));
     HIPCHK(hipMalloc(&c->d_Linv, sizeof(double) * 2048));
     HIPCHK(hipMalloc(&c->d_gamma, sizeof(double) * (c->ncap + 8)));
+    HIPCHK(hipMalloc(&c->d_gpart, sizeof(double) * (GAMMA_G + 1) * (size_t)c->ld));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
@@ -535,6 +536,7 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_W);
     hipFree(c->d_Linv);
     hipFree(c->d_gamma);
+    hipFree(c->d_gpart);
     hipFree(c->d_est);
     hipFree(c->d_stats);
     hipFree(c->d_scratch);
@@ -1162,7 +1164,7 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
 // (k_chol_step), preceded by the elimination of the first diagonal tile. Rows >= m of W receive Z[rows >= m] L^-T.
 // nsig > 0: the covariance update Sigma -= W W^T and Gamma = W z ride along in the step kernels (see k_chol_step)
 static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double* W, int nsig = 0, double* Sig = nullptr, double* gamma = nullptr,
-                        bool first_tile_done = false, const int* spec = nullptr, int spec_seq = 0) {
+                        bool first_tile_done = false, const int* spec = nullptr, int spec_seq = 0, double* gpart = nullptr) {
     constexpr int NB = 32;
     if (!first_tile_done) { // the vision update's k_build_Z eliminates the first tile itself
         KTimer t(c, KN_CHOL_UPDATE);
@@ -1180,8 +1182,10 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
         const int nyS = c0 < m ? blocks(m - c0, 32) : 1;
         const int nts = blocks(nsig, 32);
         const int nySig = nsig > 0 ? blocks(nts * (nts + 1) / 2, gx) : 0;
-        hipLaunchKernelGGL(k_chol_step, dim3(gx, nyS + nySig), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0, nyS, nsig, c->ld,
-                           Sig, gamma, spec, spec_seq);
+        // gpart: the last launch (c0 == m) also produces Gamma = W z as GAMMA_G + 1 partial vectors (extra grid rows + its own panel)
+        double* gp = (gpart && nsig == 0 && c0 >= m) ? gpart : nullptr;
+        hipLaunchKernelGGL(k_chol_step, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
+                           nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1275,6 +1279,14 @@ static int stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M)
 
 // The device part of the vision update behind the measurement stage: Z, factorisation chain, Sigma update, lift. With
 // spec != nullptr every kernel first compares *spec with spec_seq and returns at once if they match (cancelled tail).
+static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, const double* gpart) {
+    KTimer t(c, KN_LIFT);
+    hipLaunchKernelGGL(k_lift, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, c->N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),
+                       c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags, use_door ? c->d_door + 1 : nullptr, c->h_door + 1, door_seq,
+                       spec, spec_seq, gpart, c->ld);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq) {
     const int N = c->N, n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
@@ -1291,21 +1303,15 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         if (rc)
             return rc;
     } else {
-        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq);
+        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
         if (rc)
             return rc;
-        const int nt = blocks(n, 32);
         if (c->opt_early) { // Gamma, landmark lift, result packet and doorbell BEFORE the covariance update: the host round trip overlaps with it
-            LiftArgs la;
-            la.N = N, la.Ncap = c->Ncap, la.chart = c->chart, la.discrete = discreteCorr;
-            la.q0 = c->q0(), la.Qq = c->Qq(), la.Qa = c->Qa();
-            la.est = c->h_res + 3 * (size_t)c->Ncap, la.gamma_host = c->h_res + 7 * (size_t)c->Ncap;
-            la.flags = c->d_flags, la.flags_host = c->h_resflags;
-            la.door_count = use_door ? c->d_door + 1 : nullptr, la.door_host = c->h_door + 1, la.door_seq = door_seq;
-            KTimer t(c, KN_LIFT);
-            hipLaunchKernelGGL(k_gamma_lift, dim3(lift_workgroups(N)), dim3(512), 0, c->stream, n, m, c->ldz, c->d_W, c->d_gamma, spec, spec_seq, la);
-            HIPCHK(hipGetLastError());
+            rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, c->d_gpart);
+            if (rc)
+                return rc;
         }
+        const int nt = blocks(n, 32);
         KTimer t(c, KN_SYRK);
         LAUNCH_TS(c, k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), c->stream, n, m, c->ld, c->ldz, c->d_W, (TS*)c->sigma(), nt, c->d_gamma, spec, spec_seq,
                   c->opt_early ? 0 : 1);
@@ -1313,11 +1319,9 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
     }
     { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }
     if (c->opt_fused || !c->opt_early) {
-        KTimer t(c, KN_LIFT);
-        hipLaunchKernelGGL(k_lift, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),
-                           c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags, use_door ? c->d_door + 1 : nullptr, c->h_door + 1,
-                           door_seq, spec, spec_seq);
-        HIPCHK(hipGetLastError());
+        rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, nullptr);
+        if (rc)
+            return rc;
     }
     if (c->opt_check) {
         LAUNCH_TS(c, k_check_finite, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->ld, (const TS*)c->sigma(), c->d_flags);

@@ -460,12 +460,8 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
 // word instead of the stream's completion signal and sees the results about 6 us earlier (scripts/ubench/doorbell.hip).
 // Ordering: every workgroup fences its result stores at system scope before its atomic increment; the workgroup that
 // observes all increments fences again and only then writes the sequence number.
-// first_wave_only: every store the host will read was issued by the workgroup's first wavefront (then only that wave pays for
-// the system-scope release, which is not cheap when many workgroups execute it at once).
-__device__ __forceinline__ void ring_doorbell(int* __restrict__ count, int* __restrict__ host_flag, int seq, bool first_wave_only = false) {
+__device__ __forceinline__ void ring_doorbell(int* __restrict__ count, int* __restrict__ host_flag, int seq) {
     if (!count)
-        return;
-    if (first_wave_only && threadIdx.x >= 64)
         return;
     __threadfence_system();
     if (threadIdx.x == 0) {
@@ -476,7 +472,6 @@ __device__ __forceinline__ void ring_doorbell(int* __restrict__ count, int* __re
         }
     }
 }
-
 // ---------------------------------------------------------------------------------------------------
 // K3: per measurement j: yHat, yTilde and the 2x3 block of C (measureSystemState VIOState.cpp:70-78,
 // EqFoutputMatrixCiStar euclid.cpp:162-184, invdepth.cpp:255-266, outputMatrixCi EqFMatrices.cpp:84-89).
@@ -971,12 +966,50 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
 // the diagonal-tile elimination; their diagonal tiles also accumulate Gamma += W_k z_k (VIO_eqf.cpp:119). In effect the
 // factorisation runs on [[S, T^T],[T, Sigma]] and stops after the S block: what is left in the corner is the Schur
 // complement Sigma - T S^-1 T^T.
+constexpr int GAMMA_G = 4; // column groups of the Gamma partials computed by the last step launch
 __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
                                                    const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update, int nyS,
-                                                   int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq) {
+                                                   int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq,
+                                                   double* __restrict__ gpart, int ldg) {
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
     const int c0 = kb + w;
+    if (gpart && (int)blockIdx.y >= nyS) {
+        // Gamma partials (last step of the unfused chain only; c0 == m): the W columns [0, kb) were published by the earlier
+        // launches, so Gamma = W z over them can run in the shadow of this step. Grid row nyS + g takes the columns
+        // p = g (mod GAMMA_G); workgroup x takes the 32 rows of W starting at 32 x; its 8 lane groups interleave the columns.
+        // The last panel's share is added by the workgroups that compute it (below); k_lift sums the GAMMA_G + 1 partials.
+        __shared__ double sp[256];
+        const int g = (int)blockIdx.y - nyS;
+        const int r = threadIdx.x & 31, seg = threadIdx.x >> 5;
+        const int n = rows - 1 - m;
+        const int wr = 32 * (int)blockIdx.x + r;
+        const double* Wr = Wout + m + min(wr, n - 1);
+        const double* z = Wout + m + n;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int p0 = g + GAMMA_G * seg; p0 < kb; p0 += 12 * 8 * GAMMA_G) {
+            double wv[12], zv[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const int p = p0 + q * 8 * GAMMA_G;
+                const int pc = min(p, kb - 1);
+                wv[q] = Wr[(size_t)pc * ldz];
+                zv[q] = z[(size_t)pc * ldz] * (p < kb ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < 12; q += 4) {
+                s0 = fma(wv[q], zv[q], s0);
+                s1 = fma(wv[q + 1], zv[q + 1], s1);
+                s2 = fma(wv[q + 2], zv[q + 2], s2);
+                s3 = fma(wv[q + 3], zv[q + 3], s3);
+            }
+        }
+        sp[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (seg == 0 && wr < n) // fixed order: deterministic
+            gpart[(size_t)g * ldg + wr] = ((sp[r] + sp[32 + r]) + (sp[64 + r] + sp[96 + r])) + ((sp[128 + r] + sp[160 + r]) + (sp[192 + r] + sp[224 + r]));
+        return;
+    }
     int i0, j0, ilim = rows, jlim = m;
     const bool sig = (int)blockIdx.y >= nyS;
     if (sig) {
@@ -1030,6 +1063,8 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
             opJ[st] = needJ ? Z[rowJc + (size_t)(kb + pc) * ldz] * (zJ * zp) : 0.0;
         }
     }
+    const bool gam_last = gpart && !update; // this launch also produces the last panel's share of Gamma
+    const double yv = (gam_last && tid < 32) ? Z[(rows - 1) + (size_t)(kb + min(tid, w - 1)) * ldz] : 0.0;
     const int ihU = wave & 1, jhU = wave >> 1;
     double zt[4];
     {
@@ -1043,6 +1078,8 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         sLinv[r + (g + 8 * k) * CH_LDP] = lv[k];
+    if (gam_last && tid < 32)
+        swork[32 + tid] = yv;
     __syncthreads();
     // 2. P = Zpanel * Linv^T : P[i][c] = sum_p Zp[i][p] Linv[c][p]; wave -> 16x16 sub-tile (ih, ch) of P_I and of P_J
     {
@@ -1073,6 +1110,23 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
                 if (c < w)
                     Wout[row + (size_t)(kb + c) * ldz] = sPI[r + c * CH_LDP];
             }
+        }
+    }
+    if (gam_last) {
+        // Gamma share of this panel: z_c = sum_p yTilde[p] Linv[c][p], then P_I z for the 32 rows of this workgroup
+        if (tid < 32) {
+            double z = 0.0;
+            for (int p2 = 0; p2 < w; ++p2)
+                z = fma(swork[32 + p2], sLinv[tid + p2 * CH_LDP], z);
+            swork[tid] = z;
+        }
+        __syncthreads();
+        const int wr = i0 + tid - m;
+        if (tid < 32 && wr >= 0 && wr < rows - 1 - m) {
+            double gsum = 0.0;
+            for (int c = 0; c < w; ++c)
+                gsum = fma(sPI[tid + c * CH_LDP], swork[c], gsum);
+            gpart[(size_t)GAMMA_G * ldg + wr] = gsum;
         }
     }
     if (!update)
@@ -1255,100 +1309,11 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 // K9: Sigma <- Sigma - W W^T  ( = Sigma - K C Sigma, VIO_eqf.cpp:131 ): lower 32x32 tiles computed (one workgroup
 // each, K = m split over its 8 waves), the strictly-lower ones mirrored so Sigma stays exactly symmetric.
 //
-// With with_gamma = 0 the diagonal tiles skip the Gamma by-product (k_gamma_lift, launched BEFORE this kernel, has done it).
-//
-// K9a: k_gamma_lift finishes the innovation, which needs W and z but not the new Sigma: workgroup 0 computes Gamma[0:21]
-// (sensor rows, two workgroups) and hands it, with the status flags, to the host; workgroup 2 + g computes the Gamma rows of landmarks
-// [4 g, 4 g + 4) and lifts them (K10). The last workgroup rings the host doorbell. Launched between the last factorisation
-// step and the covariance update, it gives the host the frame's results one kernel early: the host round trip (results,
-// filter logic, the next frame's launches) overlaps with Sigma -= W W^T instead of leaving the GPU idle after it.
-__device__ __forceinline__ void lift_landmark(int i, const V3 g, int N, int Ncap, int chart, int discrete, const double* __restrict__ q0, double* __restrict__ Qq,
-                                              double* __restrict__ Qa, double* __restrict__ est);
-struct LiftArgs {
-    int N, Ncap, chart, discrete;
-    const double* q0;
-    double *Qq, *Qa;
-    double *est, *gamma_host; // pinned host packet
-    const int* flags;
-    int* flags_host;          // pinned
-    int *door_count, *door_host;
-    int door_seq;
-};
+// With with_gamma = 0 the diagonal tiles skip the Gamma by-product: the factorisation's last launch has produced Gamma as
+// partial vectors and k_lift, launched BEFORE this kernel, has summed them, lifted the landmarks and rung the host doorbell.
+// That order gives the host the frame's results one kernel early: its round trip (results, filter logic, the next frame's
+// launches) overlaps with Sigma -= W W^T instead of leaving the GPU idle after it.
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
-constexpr int LIFT_LM = 4;    // landmarks per lift workgroup (12 rows of Gamma)
-constexpr int LIFT_ROWS = 3 * LIFT_LM;
-constexpr int LIFT_SEG = 42;  // column segments per row: 12 x 42 = 504 of the 512 threads
-constexpr int LIFT_B = 12;    // columns per thread and batch (one batch covers m <= 504)
-__host__ __device__ __forceinline__ int lift_workgroups(int N) { return 2 + (N + LIFT_LM - 1) / LIFT_LM; } // two for the 21 sensor rows
-__global__ void __launch_bounds__(512) k_gamma_lift(int n, int m, int ldz, const double* __restrict__ Wb, double* __restrict__ gamma, const int* __restrict__ spec,
-                                                     int spec_seq, const LiftArgs la) {
-    __shared__ double sbuf[(LIFT_SEG + 1) * LIFT_ROWS];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const bool aborted = spec && *spec == spec_seq;
-    if (aborted) { // speculative tail cancelled by the statistics kernel: nothing is modified, the host is told
-        if (b == 0 && tid == 0)
-            la.flags_host[2] = 1;
-        ring_doorbell(la.door_count, la.door_host, la.door_seq, true);
-        return;
-    }
-    // rows of Gamma owned by this workgroup: 0..11, 12..20 (sensor), then 12 per group of 4 landmarks
-    const int r0 = (b < 2) ? LIFT_ROWS * b : 21 + LIFT_ROWS * (b - 2);
-    const int nr = (b == 0) ? LIFT_ROWS : (b == 1) ? 21 - LIFT_ROWS : min(LIFT_ROWS, n - r0);
-    const int rr = tid % LIFT_ROWS, seg = tid / LIFT_ROWS;
-    const double* W = Wb + m;
-    const double* z = Wb + m + n;
-    // thread (rr, seg): columns seg, seg + 42, ... in batches of 12 unconditional loads (one L2 round trip for m = 400);
-    // out-of-range columns are clamped for the load and zeroed by a multiplier
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (seg < LIFT_SEG) {
-        const double* Wr = W + r0 + min(rr, nr - 1);
-        for (int p0 = seg; p0 < m; p0 += LIFT_B * LIFT_SEG) {
-            double wv[LIFT_B], zv[LIFT_B];
-#pragma unroll
-            for (int q = 0; q < LIFT_B; ++q) {
-                const int p = p0 + q * LIFT_SEG;
-                const int pc = min(p, m - 1);
-                wv[q] = Wr[(size_t)pc * ldz];
-                zv[q] = p < m ? z[(size_t)pc * ldz] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < LIFT_B; q += 4) {
-                s0 = fma(wv[q], zv[q], s0);
-                s1 = fma(wv[q + 1], zv[q + 1], s1);
-                s2 = fma(wv[q + 2], zv[q + 2], s2);
-                s3 = fma(wv[q + 3], zv[q + 3], s3);
-            }
-        }
-        sbuf[seg * LIFT_ROWS + rr] = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-    double* sg = sbuf + LIFT_SEG * LIFT_ROWS;
-    if (tid < nr) { // fixed order: deterministic
-        double g0 = 0.0, g1 = 0.0;
-#pragma unroll
-        for (int q = 0; q < LIFT_SEG; q += 2) {
-            g0 += sbuf[q * LIFT_ROWS + tid];
-            g1 += sbuf[(q + 1) * LIFT_ROWS + tid];
-        }
-        const double g = g0 + g1;
-        sg[tid] = g;
-        gamma[r0 + tid] = g;
-        if (b < 2)
-            la.gamma_host[r0 + tid] = g;
-    }
-    if (b == 0 && tid == 0) {
-        la.flags_host[0] = la.flags[0];
-        la.flags_host[1] = la.flags[1];
-        la.flags_host[2] = 0;
-    }
-    __syncthreads();
-    if (b >= 2 && tid < LIFT_LM) {
-        const int i = LIFT_LM * (b - 2) + tid;
-        if (i < la.N)
-            lift_landmark(i, V3{sg[3 * tid], sg[3 * tid + 1], sg[3 * tid + 2]}, la.N, la.Ncap, la.chart, la.discrete, la.q0, la.Qq, la.Qa, la.est);
-    }
-    ring_doorbell(la.door_count, la.door_host, la.door_seq, true); // all host-visible stores above come from threads < 12
-}
 template <typename TS>
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
                                                   double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma) {
@@ -1423,31 +1388,41 @@ __device__ __forceinline__ void lift_landmark(int i, const V3 g, int N, int Ncap
     est[2 * N + i] = qh.z;
     est[3 * N + i] = (a <= 1e-8 || a > 1e8 || !(a == a)) ? 1.0 : 0.0;
 }
-__device__ __forceinline__ void lift_body(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
+__device__ __forceinline__ void lift_body(int N, int Ncap, int chart, int discrete, double* __restrict__ gamma, const double* __restrict__ q0,
                                           double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
-                                          const int* __restrict__ flags, int* __restrict__ flags_host) {
+                                          const int* __restrict__ flags, int* __restrict__ flags_host, const double* __restrict__ gpart, int ldg) {
     // est / gamma_host / flags_host point into the pinned host packet: the results reach the host with the stream
     // synchronisation alone, no copy kernels.
+    // gpart != nullptr: Gamma arrives as GAMMA_G + 1 partial vectors (k_chol_step's last launch) and is summed here, in a fixed order
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    auto gam = [&](int row) {
+        if (!gpart)
+            return gamma[row];
+        double v = ((gpart[row] + gpart[(size_t)ldg + row]) + (gpart[2 * (size_t)ldg + row] + gpart[3 * (size_t)ldg + row])) + gpart[4 * (size_t)ldg + row];
+        gamma[row] = v;
+        return v;
+    };
+    static_assert(GAMMA_G == 4, "partial sum order above");
     if (i < 21)
-        gamma_host[i] = gamma[i];
+        gamma_host[i] = gam(i);
     if (i == 0) {
         flags_host[0] = flags[0];
         flags_host[1] = flags[1];
     }
     if (i >= N)
         return;
-    lift_landmark(i, V3{gamma[21 + 3 * i], gamma[21 + 3 * i + 1], gamma[21 + 3 * i + 2]}, N, Ncap, chart, discrete, q0, Qq, Qa, est);
+    const double g0 = gam(21 + 3 * i), g1 = gam(21 + 3 * i + 1), g2 = gam(21 + 3 * i + 2);
+    lift_landmark(i, V3{g0, g1, g2}, N, Ncap, chart, discrete, q0, Qq, Qa, est);
 }
-__global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, const double* __restrict__ gamma, const double* __restrict__ q0,
+__global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, double* __restrict__ gamma, const double* __restrict__ q0,
                                              double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
                                              const int* __restrict__ flags, int* __restrict__ flags_host, int* __restrict__ door_count, int* __restrict__ door_host,
-                                             int door_seq, const int* __restrict__ spec, int spec_seq) {
+                                             int door_seq, const int* __restrict__ spec, int spec_seq, const double* __restrict__ gpart, int ldg) {
     const bool aborted = spec && *spec == spec_seq; // speculative tail cancelled by the statistics kernel
     if (blockIdx.x == 0 && threadIdx.x == 0)
         flags_host[2] = aborted ? 1 : 0;
     if (!aborted)
-        lift_body(N, Ncap, chart, discrete, gamma, q0, Qq, Qa, est, gamma_host, flags, flags_host);
+        lift_body(N, Ncap, chart, discrete, gamma, q0, Qq, Qa, est, gamma_host, flags, flags_host, gpart, ldg);
     ring_doorbell(door_count, door_host, door_seq);
 }
 // q_hat_i = Q_i^-1 q0_i for all landmarks (stateGroupAction, VIOGroup.cpp:44-52)
