@@ -161,6 +161,7 @@ struct eqf_ctx {
     int* h_flags = nullptr;
     int* h_lmidx = nullptr;  // pinned measurement packet: lmidx[Ncap], measof[Ncap]
     double* h_y = nullptr;   //   y[2 Ncap]
+    double* h_ylm = nullptr; //   the same measurement by landmark: u[Ncap] | v[Ncap] | measurement index or -1 [Ncap]
     double* h_res = nullptr; // pinned result packet: stats[3 Ncap] | est[4 Ncap] | gamma[32]
     int* h_resflags = nullptr;
     static constexpr int kMaxSteps = kObsChunk;
@@ -495,6 +496,7 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 4));
     HIPCHK(hipHostMalloc(&c->h_lmidx, sizeof(int) * 2 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_y, sizeof(double) * 2 * (size_t)c->Ncap));
+    HIPCHK(hipHostMalloc(&c->h_ylm, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_res, sizeof(double) * (7 * (size_t)c->Ncap + 32)));
     HIPCHK(hipHostMalloc(&c->h_resflags, sizeof(int) * 4));
     HIPCHK(hipHostMalloc(&c->h_door, sizeof(int) * 4));
@@ -563,6 +565,7 @@ void eqf_destroy(eqf_ctx* c) {
     hipHostFree(c->h_flags);
     hipHostFree(c->h_lmidx);
     hipHostFree(c->h_y);
+    hipHostFree(c->h_ylm);
     hipHostFree(c->h_res);
     hipHostFree(c->h_resflags);
     hipHostFree(c->h_door);
@@ -1191,6 +1194,17 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
     return 0;
 }
 
+// the statistics kernel's input: the measurement by landmark in the pinned packet
+static const double* pack_by_landmark(eqf_ctx* c, const int* measof, const double* y) {
+    const size_t Ncap = (size_t)c->Ncap;
+    for (int i = 0; i < c->N; ++i) {
+        const int j = measof[i];
+        c->h_ylm[i] = j >= 0 ? y[2 * j] : 0.0;
+        c->h_ylm[Ncap + i] = j >= 0 ? y[2 * j + 1] : 0.0;
+        c->h_ylm[2 * Ncap + i] = (double)j;
+    }
+    return c->h_ylm;
+}
 // map ascending measurement ids to state indices; returns 0 or EQF_E_BAD_ARG
 static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, int* lmidx, int* measof) {
     for (int i = 0; i < c->N; ++i)
@@ -1236,7 +1250,7 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     {
         KTimer t(c, KN_STATS);
         c->busy_meas = true;
-        LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), measof, c->h_y, c->q0(), c->Qq(), c->Qa(),
+        LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
                   (const TS*)c->sigma(), c->h_res, 1, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, use_door ? c->d_door : nullptr, c->h_door, door_seq, 0.0, 0.0,
                   (int*)nullptr, 0);
         HIPCHK(hipGetLastError());
@@ -1449,7 +1463,7 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     {
         KTimer t(c, KN_STATS);
         c->busy_meas = true;
-        LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), measof, c->h_y, c->q0(), c->Qq(), c->Qa(),
+        LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
                   (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, (use_door && !speculate) ? c->d_door : nullptr, c->h_door, seq,
                   thrAbs, thrProb, speculate ? c->d_spec : (int*)nullptr, seq);
         HIPCHK(hipGetLastError());

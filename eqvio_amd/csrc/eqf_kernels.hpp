@@ -533,12 +533,12 @@ __global__ void __launch_bounds__(64) k_measure(int M, int Mcap, int Ncap, int c
     ytil[2 * j] = o.yt[0];
     ytil[2 * j + 1] = o.yt[1];
 }
-// stats: out[0..N) absErr, out[N..2N) probErr, out[2N..3N) |q_hat|^2 ; unmeasured -> -1 (meas_of[i] = j or -1)
+// stats: out[0..N) absErr, out[N..2N) probErr, out[2N..3N) |q_hat|^2 ; unmeasured -> -1
 // It also emits what k_measure would (C blocks, residuals, index map) for the same measurement, so that the vision
 // update can skip k_measure when the host removes / adds no landmark in between (the common case).
 template <typename TS>
-__device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int chart, const Cam& cam, const int* __restrict__ meas_of,
-                                                   const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
+__device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int chart, const Cam& cam, const double* __restrict__ ylm,
+                                                   const double* __restrict__ q0, const double* __restrict__ Qq,
                                                    const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
                                                    double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags,
                                                    double& abs_err, double& prob_err) {
@@ -549,10 +549,13 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
     }
     if (i >= N)
         return;
+    // ylm: the measurement sorted by LANDMARK in the pinned host packet (planes u, v, measurement index or -1): three independent
+    // coalesced zero-copy loads, one PCIe round trip (an index followed by y[index] would be two)
+    const double yu = ylm[i], yv = ylm[Ncap + i];
+    const int j = (int)ylm[2 * Ncap + i];
     const V3 p0 = ld3(q0, Ncap, i);
     const Qt q = ldq(Qq, Ncap, i);
     const double a = Qa[i];
-    const int j = meas_of[i];
     if (j < 0) {
         const V3 qh = (1.0 / a) * q_rot(q_inv(q), p0);
         out[i] = -1.0;
@@ -560,9 +563,9 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
         out[2 * N + i] = norm2(qh);
         return;
     }
-    const MeasOut o = measure_one(chart, cam, p0, q, a, y[2 * j], y[2 * j + 1], false);
+    const MeasOut o = measure_one(chart, cam, p0, q, a, yu, yv, false);
     {
-        const MeasOut os = star ? measure_one(chart, cam, p0, q, a, y[2 * j], y[2 * j + 1], true) : o;
+        const MeasOut os = star ? measure_one(chart, cam, p0, q, a, yu, yv, true) : o;
 #pragma unroll
         for (int e = 0; e < 6; ++e)
             C[e * Ncap + j] = os.c[e];
@@ -599,14 +602,14 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
     out[2 * N + i] = norm2(o.qh);
 }
 template <typename TS>
-__global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, int chart, Cam cam, const int* __restrict__ meas_of,
-                                                      const double* __restrict__ y, const double* __restrict__ q0, const double* __restrict__ Qq,
+__global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, int chart, Cam cam, const double* __restrict__ ylm,
+                                                      const double* __restrict__ q0, const double* __restrict__ Qq,
                                                       const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
                                                       double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags,
                                                       int* __restrict__ door_count, int* __restrict__ door_host, int door_seq, double thrAbs, double thrProb,
                                                       int* __restrict__ spec, int spec_seq) {
     double abs_err = -1.0, prob_err = -1.0; // stay negative for lanes without a measured landmark
-    outlier_stats_body<TS>(N, Ncap, ld, chart, cam, meas_of, y, q0, Qq, Qa, Sig, out, star, C, ytil, lmidx_dev, flags, abs_err, prob_err);
+    outlier_stats_body<TS>(N, Ncap, ld, chart, cam, ylm, q0, Qq, Qa, Sig, out, star, C, ytil, lmidx_dev, flags, abs_err, prob_err);
     // Speculative frame tail (eqf_stats_then_update): the update kernels are already queued behind this one. If any measured
     // landmark is an outlier candidate (VIOFilter.cpp:316-330: absErr > thrAbs or probErr > thrProb) the host has a decision
     // to make, so the queued kernels must not run: they compare this word with their sequence number and return at once.
