@@ -194,6 +194,7 @@ def load_eqf_lib():
         "eqf_integrate_observer": (C.c_int, [vp, c_double_p, c_double_p, C.c_int, C.c_int]),
         "eqf_outlier_stats": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]),
         "eqf_propagate_fast": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int]),
+        "eqf_stage_measurement": (C.c_int, [vp, c_int_p, c_double_p, C.c_int]),
         "eqf_stats_then_update": (C.c_int, [vp, C.POINTER(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p,
                                   c_double_p, c_int_p]),
         "eqf_vision_update": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_int]),
@@ -335,6 +336,11 @@ class EqfCore:
         m, Qd, Pd = _f64(imu13_mean), _f64(Qdiag12), _f64(Pdiag8)
         imus, dts = _f64(np.atleast_2d(imu13_k)).reshape(-1), _f64(dt_k)
         self._chk0(self.lib.eqf_propagate_fast(self.h, _dp(m), dt_total, _dp(Qd), _dp(Pd), _dp(imus), _dp(dts), len(dts), int(discrete)))
+
+    def stage_measurement(self, ids, y):
+        """eqf_stage_measurement: hint ahead of the propagation call of the same frame."""
+        ids, y = _i32(ids), _f64(y)
+        self._chk0(self.lib.eqf_stage_measurement(self.h, _ip(ids), _dp(y), len(ids)))
 
     def stats_then_update(self, cam, ids, y, thr_abs, thr_prob, meas_var, use_equivariant=True, discrete=False):
         """eqf_stats_then_update: returns (updated, absErr, probErr, depth2)."""

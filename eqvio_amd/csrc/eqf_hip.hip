@@ -162,6 +162,14 @@ struct eqf_ctx {
     int* h_lmidx = nullptr;  // pinned measurement packet: lmidx[Ncap], measof[Ncap]
     double* h_y = nullptr;   //   y[2 Ncap]
     double* h_ylm = nullptr; //   the same measurement by landmark: u[Ncap] | v[Ncap] | measurement index or -1 [Ncap]
+    // eqf_stage_measurement: HBM copies of the three arrays above, made by a block of the propagation kernel
+    double* d_meas = nullptr; //   y[2 Ncap] | ylm[3 Ncap]
+    int* d_meas_idx = nullptr;
+    bool stage_pending = false, staged_valid = false;
+    int staged_M = 0;
+    unsigned lm_gen = 0, staged_gen = 0; // lm_gen counts changes of the landmark set (indices in a staged measurement go stale)
+    std::vector<int> staged_ids;
+    std::vector<double> staged_y;
     double* h_res = nullptr; // pinned result packet: stats[3 Ncap] | est[4 Ncap] | gamma[32]
     int* h_resflags = nullptr;
     static constexpr int kMaxSteps = kObsChunk;
@@ -497,6 +505,8 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipHostMalloc(&c->h_lmidx, sizeof(int) * 2 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_y, sizeof(double) * 2 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_ylm, sizeof(double) * 3 * (size_t)c->Ncap));
+    HIPCHK(hipMalloc(&c->d_meas, sizeof(double) * 5 * (size_t)c->Ncap));
+    HIPCHK(hipMalloc(&c->d_meas_idx, sizeof(int) * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_res, sizeof(double) * (7 * (size_t)c->Ncap + 32)));
     HIPCHK(hipHostMalloc(&c->h_resflags, sizeof(int) * 4));
     HIPCHK(hipHostMalloc(&c->h_door, sizeof(int) * 4));
@@ -566,6 +576,8 @@ void eqf_destroy(eqf_ctx* c) {
     hipHostFree(c->h_lmidx);
     hipHostFree(c->h_y);
     hipHostFree(c->h_ylm);
+    hipFree(c->d_meas);
+    hipFree(c->d_meas_idx);
     hipHostFree(c->h_res);
     hipHostFree(c->h_resflags);
     hipHostFree(c->h_door);
@@ -691,6 +703,7 @@ int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, 
     c->X = unpack_group(X_sensor);
     c->ids.assign(ids, ids + N);
     c->N = N;
+    ++c->lm_gen;
     if (N > 0) {
         std::memcpy(c->h_buf, q0, sizeof(double) * 3 * N);
         std::memcpy(c->h_buf + 3 * N, Q, sizeof(double) * 5 * N);
@@ -851,6 +864,7 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
     HIPCHK(hipGetLastError());
     c->ids.insert(c->ids.end(), ids, ids + k);
     c->N += k;
+    ++c->lm_gen;
     c->est_valid = false;
     c->meas_valid = false;
     return round_sigma(c);
@@ -895,6 +909,7 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
     c->lmcur = 1 - c->lmcur;
     c->ids = newids;
     c->N = Nnew;
+    ++c->lm_gen;
     c->est_valid = false;
     c->meas_valid = false;
     return 0;
@@ -947,9 +962,18 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
     if (!c->opt_dense) {
         const int nT = blocks(N, PT), nStrip = blocks(N, 12);
         const int nObs = (obs && obs_k > 0) ? blocks(N, 256) : 0;
+        StageArgs sg{};
+        if (c->stage_pending) { // one more block copies the staged measurement from the pinned packet to HBM
+            sg.M = c->staged_M;
+            sg.y_h = c->h_y, sg.ylm_h = c->h_ylm, sg.idx_h = c->h_lmidx;
+            sg.y_d = c->d_meas, sg.ylm_d = c->d_meas + 2 * (size_t)c->Ncap, sg.idx_d = c->d_meas_idx;
+            c->stage_pending = false;
+            c->staged_valid = true;
+            c->busy_meas = true;
+        }
         KTimer t(c, KN_PROP_MAIN);
-        LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1 + nObs), dim3(256), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout, c->d_Al, c->d_Bl,
-                  nT, nStrip, nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa());
+        LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1 + nObs + (sg.M ? 1 : 0)), dim3(256), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout,
+                  c->d_Al, c->d_Bl, nT, nStrip, nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg);
         HIPCHK(hipGetLastError());
     } else {
         // dense: F materialised, tmp = F Sigma (= (Sigma F^T)^T, Sigma symmetric), Sigma' = tmp F^T + noise
@@ -1231,6 +1255,7 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     if (M > c->Ncap)
         return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
+    c->staged_valid = c->stage_pending = false; // the pinned measurement packet is about to be rewritten
     if (c->busy_meas) {
         int r = sync_ctx(c);
         if (r)
@@ -1281,6 +1306,7 @@ static int stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M)
         if (r)
             return r;
     }
+    c->staged_valid = c->stage_pending = false; // the pinned measurement packet is about to be rewritten
     int* lmidx = c->h_lmidx;
     int* measof = c->h_lmidx + c->Ncap;
     int rc = map_measurement(c, ids, M, true, lmidx, measof);
@@ -1301,15 +1327,20 @@ static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_s
     HIPCHK(hipGetLastError());
     return 0;
 }
-static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq) {
-    const int N = c->N, n = c->n(), m = 2 * M;
+static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq,
+                              const MeasFuse* fuse = nullptr) {
+    const int n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
     int rc = 0;
     {
         KTimer t(c, KN_BUILD_Z);
-        // the extra grid row eliminates the first diagonal tile of S (no k_chol_first launch in this chain)
-        LAUNCH_TS(c, k_build_Z, dim3(blocks(n + M + 1, 256), M + 1), dim3(256), c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx, (const TS*)c->sigma(), c->d_C,
-                  c->d_ytil, c->d_Z, c->d_Linv, c->d_flags, spec, spec_seq);
+        // one extra grid row eliminates the first diagonal tile of S (no k_chol_first launch in this chain); with measurement fusion
+        // the kernel also evaluates C itself, one more grid row computes the outlier statistics and decides about the tail
+        MeasFuse mf{};
+        if (fuse)
+            mf = *fuse;
+        LAUNCH_TS(c, k_build_Z, dim3(blocks(n + M + 1, 256), blocks(M, BZ_JB) + 1 + (mf.enabled ? 1 : 0)), dim3(256), c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx,
+                  (const TS*)c->sigma(), c->d_C, c->d_ytil, c->d_Z, c->d_Linv, c->d_flags, mf.enabled ? (const int*)nullptr : spec, spec_seq, mf);
         HIPCHK(hipGetLastError());
     }
     if (c->opt_fused) {
@@ -1424,6 +1455,37 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     return finish_update(c, discreteCorr);
 }
 
+// See include/eqf_hip.h. Optional hint ahead of the propagation call of the same frame.
+int eqf_stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M) {
+    if (!c || M < 0 || (M > 0 && (!ids || !y)))
+        return EQF_E_BAD_ARG;
+    c->stage_pending = c->staged_valid = false;
+    if (M == 0 || c->N == 0 || M > c->N)
+        return 0;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->busy_meas) {
+        int r = sync_ctx(c);
+        if (r)
+            return r;
+    }
+    int* lmidx = c->h_lmidx;
+    int* measof = c->h_lmidx + c->Ncap;
+    const int rc = map_measurement(c, ids, M, false, lmidx, measof);
+    if (rc)
+        return rc;
+    for (int j = 0; j < M; ++j)
+        if (lmidx[j] < 0)
+            return 0; // an id without a landmark: nothing staged, the update call takes its ordinary route
+    std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
+    pack_by_landmark(c, measof, y);
+    c->staged_ids.assign(ids, ids + M);
+    c->staged_y.assign(y, y + 2 * M);
+    c->staged_M = M;
+    c->staged_gen = c->lm_gen;
+    c->stage_pending = true;
+    return 0;
+}
+
 // See include/eqf_hip.h. Statistics and update queued back to back; the statistics kernel cancels the tail on the device if
 // the host has an outlier decision to make.
 int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double thrAbs, double thrProb, double meas_var, int useEqv,
@@ -1437,40 +1499,36 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
         return 0;
     }
     HIPCHK(hipSetDevice(c->device));
-    if (c->busy_meas) {
-        int r = sync_ctx(c);
-        if (r)
-            return r;
-    }
-    int* lmidx = c->h_lmidx;
-    int* measof = c->h_lmidx + c->Ncap;
-    int rc = map_measurement(c, ids, M, false, lmidx, measof);
-    if (rc)
-        return rc;
-    for (int j = 0; j < M; ++j)
-        if (lmidx[j] < 0) { // a measurement without a landmark: the caller adds landmarks first (VIOFilter.cpp:217), nothing queued
-            *updated = -1;
-            return 0;
-        }
-    std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
-    rc = join_observer(c);
-    if (rc)
-        return rc;
     // speculation needs the doorbell-free conditions of both waits and the equivariant-output cache of the statistics kernel
     const bool speculate = c->opt_spec && !c->opt_check && !c->opt_timing && !c->obs_pending;
     const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
-    const int seq = (int)(++c->door_seq);
-    {
-        KTimer t(c, KN_STATS);
-        c->busy_meas = true;
-        LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
-                  (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, (use_door && !speculate) ? c->d_door : nullptr, c->h_door, seq,
-                  thrAbs, thrProb, speculate ? c->d_spec : (int*)nullptr, seq);
-        HIPCHK(hipGetLastError());
+    // staged by eqf_stage_measurement and copied to HBM by the propagation kernel: same measurement, same landmark set?
+    const bool staged = speculate && c->staged_valid && c->staged_gen == c->lm_gen && c->staged_M == M && std::equal(ids, ids + M, c->staged_ids.begin()) &&
+                        std::memcmp(c->staged_y.data(), y, sizeof(double) * 2 * M) == 0;
+    c->staged_valid = c->stage_pending = false;
+    int* lmidx = c->h_lmidx;
+    int* measof = c->h_lmidx + c->Ncap;
+    int rc = 0;
+    if (!staged) {
+        if (c->busy_meas) {
+            int r = sync_ctx(c);
+            if (r)
+                return r;
+        }
+        rc = map_measurement(c, ids, M, false, lmidx, measof);
+        if (rc)
+            return rc;
+        for (int j = 0; j < M; ++j)
+            if (lmidx[j] < 0) { // a measurement without a landmark: the caller adds landmarks first (VIOFilter.cpp:217), nothing queued
+                *updated = -1;
+                return 0;
+            }
+        std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
     }
-    c->meas_valid = true;
-    c->meas_star = useEqv ? 1 : 0;
-    c->meas_ids.assign(ids, ids + M);
+    rc = join_observer(c);
+    if (rc)
+        return rc;
+    const int seq = (int)(++c->door_seq);
     auto copy_stats = [&]() {
         if (absErr)
             std::memcpy(absErr, c->h_res, sizeof(double) * N);
@@ -1479,15 +1537,41 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
         if (depth2)
             std::memcpy(depth2, c->h_res + 2 * N, sizeof(double) * N);
     };
+    c->meas_star = useEqv ? 1 : 0;
+    c->meas_ids.assign(ids, ids + M);
+    c->busy_meas = true;
     if (!speculate) { // plain statistics call: the caller decides and calls eqf_vision_update
+        {
+            KTimer t(c, KN_STATS);
+            LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(),
+                      c->Qa(), (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, use_door ? c->d_door : nullptr, c->h_door, seq, thrAbs,
+                      thrProb, (int*)nullptr, seq);
+            HIPCHK(hipGetLastError());
+        }
+        c->meas_valid = true;
         rc = use_door ? door_wait(c, 0, seq) : sync_ctx(c);
         if (rc)
             return rc;
         copy_stats();
         return 0;
     }
+    // Speculative tail: measurement, statistics and Z in ONE kernel (k_build_Z with measurement fusion), then the factorisation,
+    // the lift and the covariance update, all queued at once. An outlier candidate cancels everything behind the first kernel.
+    MeasFuse mf{};
+    mf.enabled = 1;
+    mf.N = N, mf.Ncap = c->Ncap, mf.chart = c->chart, mf.star = useEqv ? 1 : 0;
+    mf.cam = make_cam(cam);
+    if (staged)
+        mf.y = c->d_meas, mf.lmidx = c->d_meas_idx, mf.ylm = c->d_meas + 2 * (size_t)c->Ncap;
+    else
+        mf.y = c->h_y, mf.lmidx = lmidx, mf.ylm = pack_by_landmark(c, measof, y);
+    mf.q0 = c->q0(), mf.Qq = c->Qq(), mf.Qa = c->Qa();
+    mf.out = c->h_res;
+    mf.C = c->d_C, mf.ytil = c->d_ytil, mf.lmidx_dev = c->d_lmidx;
+    mf.thrAbs = thrAbs, mf.thrProb = thrProb;
+    mf.spec_w = c->d_spec, mf.spec_seq = seq;
     c->meas_valid = false; // consumed by the tail below (restored if the tail is cancelled)
-    rc = launch_update_tail(c, M, meas_var, discreteCorr, c->d_spec, seq, use_door, seq);
+    rc = launch_update_tail(c, M, meas_var, discreteCorr, c->d_spec, seq, use_door, seq, &mf);
     if (rc)
         return rc;
     rc = use_door ? door_wait(c, 1, seq) : sync_ctx(c);

@@ -248,15 +248,35 @@ __global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N
 // Block roles by blockIdx.x: [0, nT*nT) landmark-landmark tiles of 16x16 landmarks (one 3x3 block per lane),
 // then strip blocks (landmark-sensor 3x21 blocks and their transposes), then one sensor-sensor block.
 constexpr int PT = 16; // landmarks per tile side
+struct StageArgs {
+    int M; // 0: nothing to stage
+    const double *y_h, *ylm_h; // pinned host packet
+    const int* idx_h;
+    double *y_d, *ylm_d;       // HBM copies
+    int* idx_d;
+};
 // TS = storage type of Sigma (double, or float for EQF_OPT_SIGMA_FP32 = 2): loads convert to double, stores round.
 template <typename TS>
 __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
                                                         const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
-                                                        const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa) {
+                                                        const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg) {
     const double dt = ra.dt;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    if (b > nT * nT + nStrip + nObs) {
+        // Staging block (eqf_stage_measurement): the coming frame's measurement moves from the pinned host packet to HBM while Sigma
+        // is being propagated, so that the update's first kernel finds it next to the state instead of across PCIe.
+        for (int t = tid; t < 2 * sg.M; t += 256)
+            sg.y_d[t] = sg.y_h[t];
+        for (int t = tid; t < sg.M; t += 256)
+            sg.idx_d[t] = sg.idx_h[t];
+        for (int t = tid; t < 3 * N; t += 256) {
+            const int pl = t / N, i = t - pl * N;
+            sg.ylm_d[pl * Ncap + i] = sg.ylm_h[pl * Ncap + i];
+        }
+        return;
+    }
     if (b > nT * nT + nStrip) {
         // Observer blocks (eqf_propagate_fast): the landmark part of the frame's observer steps rides along with the Sigma
         // propagation. This kernel touches Sigma / Al / Bl only, the assembly kernel before it has already read Q and the
@@ -541,9 +561,10 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
                                                    const double* __restrict__ q0, const double* __restrict__ Qq,
                                                    const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
                                                    double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags,
-                                                   double& abs_err, double& prob_err) {
+                                                   double& abs_err, double& prob_err, bool emit = true) {
+    // emit: also reset the status flags and write C / yTilde / the index map (false inside k_build_Z, which does both itself)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
+    if (emit && i == 0) {
         flags[0] = 0;
         flags[1] = 0;
     }
@@ -564,7 +585,7 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
         return;
     }
     const MeasOut o = measure_one(chart, cam, p0, q, a, yu, yv, false);
-    {
+    if (emit) {
         const MeasOut os = star ? measure_one(chart, cam, p0, q, a, yu, yv, true) : o;
 #pragma unroll
         for (int e = 0; e < 6; ++e)
@@ -871,37 +892,102 @@ __global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double
 // K8a: build Z = [S ; T ; yTilde^T] from Sigma and the packed C blocks, exploiting the 2x3 block sparsity of C:
 //   T[:, 2j:2j+2] = Sigma[:, l_j:l_j+3] C_j^T          (6 n M flops instead of 2 n^2 m)
 //   S[2i:2i+2, 2j:2j+2] = C_i Sigma[l_i.., l_j..] C_j^T + delta_ij R
-// grid.y = measurement j; grid.x covers "row items": t < n -> row of T, n <= t < n+M -> block row i of S, t == n+M -> y row
-// With LinvOut != nullptr the grid has one extra row (blockIdx.y == M): its first workgroup recomputes the first 32 x 32
+// grid.y - 1 (- 2 with fusion) = group of BZ_JB measurements; grid.x covers "row items": t < n -> row of T, n <= t < n+M -> block row i of S, t == n+M -> y row
+// Grid row 0: its first workgroup recomputes the first 32 x 32
 // tile of S on its own (16 x 16 pairs of 2 x 2 blocks, one per thread) and eliminates it, so that the factorisation chain
 // needs no separate first-tile launch.
+//
+// Measurement fusion (mf.enabled, eqf_stats_then_update): there is no k_measure / k_outlier_stats launch in front of this kernel.
+//  * Every thread that needs a block C_i evaluates it itself from the measurement in the pinned host packet (measure_one: the
+//    same function, inputs and therefore bits wherever it is evaluated); the workgroups with blockIdx.x == 0 store C_j, yTilde_j
+//    and the index map for later reuse (eqf_vision_update after a cancelled tail, debugging).
+//  * Grid row 1 computes the per-landmark outlier statistics (VIOFilter.cpp:304-334), writes them
+//    to the host packet and, if any landmark is an outlier candidate, stores spec_seq into *spec_w: this kernel only writes
+//    scratch (Z, C), the kernels behind it compare that word and return at once.
+constexpr int BZ_JB = 4; // measurements per workgroup of k_build_Z
+struct MeasFuse {
+    int enabled;
+    int N, Ncap, chart, star;
+    Cam cam;
+    const double* y;     // pinned: y[2 j], y[2 j + 1]
+    const int* lmidx;    // pinned: landmark index of measurement j
+    const double* ylm;   // pinned: the measurement by landmark (statistics row)
+    const double *q0, *Qq, *Qa;
+    double* out;         // pinned: statistics (3 N)
+    double *C, *ytil;    // device, for reuse
+    int* lmidx_dev;
+    double thrAbs, thrProb;
+    int* spec_w;
+    int spec_seq;
+};
+__device__ __forceinline__ MeasOut measure_j(const MeasFuse& mf, int j, int& i_out) {
+    const int i = mf.lmidx[j];
+    i_out = i;
+    return measure_one(mf.chart, mf.cam, ld3(mf.q0, mf.Ncap, i), ldq(mf.Qq, mf.Ncap, i), mf.Qa[i], mf.y[2 * j], mf.y[2 * j + 1], mf.star != 0);
+}
 template <typename TS>
 __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
                                                  const TS* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
                                                  double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags, const int* __restrict__ spec,
-                                                 int spec_seq) {
+                                                 int spec_seq, const MeasFuse mf) {
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
     const int m = 2 * M;
-    if ((int)blockIdx.y == M) {
+    // grid rows: 0 = first tile, 1 = statistics (with fusion), then one per measurement. The two special rows have the longest
+    // dependent chains (evaluation + 32 x 32 elimination; evaluation + stores to the host), so they are dispatched first.
+    const int row0 = mf.enabled ? 2 : 1;
+    if (mf.enabled && (int)blockIdx.y == 1) {
+        // outlier statistics, one lane per landmark
+        if ((int)(blockIdx.x * blockDim.x) >= mf.N)
+            return;
+        double abs_err = -1.0, prob_err = -1.0;
+        outlier_stats_body<TS>(mf.N, mf.Ncap, ld, mf.chart, mf.cam, mf.ylm, mf.q0, mf.Qq, mf.Qa, Sig, mf.out, 0, nullptr, nullptr, nullptr, nullptr, abs_err, prob_err, false);
+        if (mf.spec_w && abs_err >= 0.0 && (abs_err > mf.thrAbs || prob_err > mf.thrProb)) // the comparisons of VIOFilter.cpp:316-330 (NaN: false)
+            *mf.spec_w = mf.spec_seq;
+        return;
+    }
+    if ((int)blockIdx.y == 0) {
         if (blockIdx.x != 0)
             return;
         __shared__ double sD[32 * 33];
         __shared__ double swork[LDL_SBUF];
+        __shared__ double sC16[16 * 6];
         const int i = threadIdx.x & 15, jj = threadIdx.x >> 4; // pair (i, jj) of measurements, both < 16
+        double sv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // Sigma[l_i.., l_jj..], requested before the C blocks are evaluated
+        if (i < M && jj < M) {
+            const int li = 21 + 3 * (mf.enabled ? mf.lmidx[i] : lmidx[i]), lj2 = 21 + 3 * (mf.enabled ? mf.lmidx[jj] : lmidx[jj]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    sv[3 * c + r] = Sig[li + r + (size_t)(lj2 + c) * ld];
+        }
+        if (mf.enabled) {
+            if (threadIdx.x == 0) { // this launch's only writer of the status flags
+                flags[0] = 0;
+                flags[1] = 0;
+            }
+            if (jj == 0 && i < M) {
+                int lidx;
+                const MeasOut o = measure_j(mf, i, lidx);
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+                    sC16[i * 6 + e] = o.c[e];
+            }
+            __syncthreads();
+        }
         double blk[2][2] = {{(i == jj) ? 1.0 : 0.0, 0.0}, {0.0, (i == jj) ? 1.0 : 0.0}};
         if (i < M && jj < M) {
-            const int li = 21 + 3 * lmidx[i], lj2 = 21 + 3 * lmidx[jj];
             double ci[6], cj2[6];
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
-                ci[e] = C[e * Mcap + i];
-                cj2[e] = C[e * Mcap + jj];
+                ci[e] = mf.enabled ? sC16[i * 6 + e] : C[e * Mcap + i];
+                cj2[e] = mf.enabled ? sC16[jj * 6 + e] : C[e * Mcap + jj];
             }
             double CS[2][3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const double s0 = Sig[li + (size_t)(lj2 + c) * ld], s1 = Sig[li + 1 + (size_t)(lj2 + c) * ld], s2 = Sig[li + 2 + (size_t)(lj2 + c) * ld];
+                const double s0 = sv[3 * c], s1 = sv[3 * c + 1], s2 = sv[3 * c + 2];
                 CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
                 CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
             }
@@ -924,43 +1010,115 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
         ldl_inverse_tile(sD, 33, min(32, m), LinvOut, flags, swork);
         return;
     }
-    const int j = blockIdx.y;
+    // BZ_JB measurements per workgroup: with fusion one wavefront evaluates their C blocks in BZ_JB lanes at once, and a thread of
+    // a block row of S evaluates its own C_i once for all of them (an evaluation costs a few thousand issue cycles per WAVE,
+    // however few lanes are active: one measurement per workgroup would make the kernel VALU-bound on redundant evaluations)
+    const int j0 = BZ_JB * ((int)blockIdx.y - row0);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lj = 21 + 3 * lmidx[j];
-    double cj[6];
+    __shared__ double sCj[BZ_JB][8];
+    const bool trow = t < n, srow = t >= n && t < n + M;
+    // index map first and the Sigma operands right behind it: those loads are in flight while the C blocks are being evaluated
+    int lj[BZ_JB];
 #pragma unroll
-    for (int e = 0; e < 6; ++e)
-        cj[e] = C[e * Mcap + j];
-    if (t < n) {
-        const double s0 = Sig[t + (size_t)lj * ld], s1 = Sig[t + (size_t)(lj + 1) * ld], s2 = Sig[t + (size_t)(lj + 2) * ld];
-        Z[m + t + (size_t)(2 * j) * ldz] = s0 * cj[0] + s1 * cj[1] + s2 * cj[2];
-        Z[m + t + (size_t)(2 * j + 1) * ldz] = s0 * cj[3] + s1 * cj[4] + s2 * cj[5];
-    } else if (t < n + M) {
-        const int i = t - n;
-        const int li = 21 + 3 * lmidx[i];
-        double ci[6];
+    for (int q = 0; q < BZ_JB; ++q) {
+        const int jc = min(j0 + q, M - 1);
+        lj[q] = 21 + 3 * (mf.enabled ? mf.lmidx[jc] : lmidx[jc]);
+    }
+    int li = 0;
+    double sv[BZ_JB][9];
+    if (trow) {
+#pragma unroll
+        for (int q = 0; q < BZ_JB; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                sv[q][c] = Sig[t + (size_t)(lj[q] + c) * ld];
+    } else if (srow) {
+        li = 21 + 3 * (mf.enabled ? mf.lmidx[t - n] : lmidx[t - n]);
+#pragma unroll
+        for (int q = 0; q < BZ_JB; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    sv[q][3 * c + r] = Sig[li + r + (size_t)(lj[q] + c) * ld];
+    }
+    if (mf.enabled) {
+        if (threadIdx.x < BZ_JB && j0 + (int)threadIdx.x < M) {
+            const int j = j0 + threadIdx.x;
+            int lidx;
+            const MeasOut o = measure_j(mf, j, lidx);
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                sCj[threadIdx.x][e] = o.c[e];
+            sCj[threadIdx.x][6] = o.yt[0];
+            sCj[threadIdx.x][7] = o.yt[1];
+            if (blockIdx.x == 0) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+                    mf.C[e * Mcap + j] = o.c[e];
+                mf.ytil[2 * j] = o.yt[0];
+                mf.ytil[2 * j + 1] = o.yt[1];
+                mf.lmidx_dev[j] = lidx;
+            }
+        }
+    } else if (threadIdx.x < BZ_JB && j0 + (int)threadIdx.x < M) {
+        const int j = j0 + threadIdx.x;
 #pragma unroll
         for (int e = 0; e < 6; ++e)
-            ci[e] = C[e * Mcap + i];
-        double CS[2][3];
+            sCj[threadIdx.x][e] = C[e * Mcap + j];
+        sCj[threadIdx.x][6] = ytil[2 * j];
+        sCj[threadIdx.x][7] = ytil[2 * j + 1];
+    }
+    // a block row of S needs its own C_i as well: evaluated by the thread that uses it (before the barrier: the evaluations overlap)
+    double ci[6] = {0, 0, 0, 0, 0, 0};
+    if (srow) {
+        if (mf.enabled) {
+            int lidx;
+            const MeasOut o = measure_j(mf, t - n, lidx);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double s0 = Sig[li + (size_t)(lj + c) * ld], s1 = Sig[li + 1 + (size_t)(lj + c) * ld], s2 = Sig[li + 2 + (size_t)(lj + c) * ld];
-            CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
-            CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
+            for (int e = 0; e < 6; ++e)
+                ci[e] = o.c[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                ci[e] = C[e * Mcap + (t - n)];
         }
+    }
+    __syncthreads();
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+    for (int q = 0; q < BZ_JB; ++q) {
+        const int j = j0 + q;
+        if (j >= M)
+            break;
+        double cj[6];
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                double v = CS[a][0] * cj[3 * bb] + CS[a][1] * cj[3 * bb + 1] + CS[a][2] * cj[3 * bb + 2];
-                if (i == j && a == bb)
-                    v += meas_var;
-                Z[2 * i + a + (size_t)(2 * j + bb) * ldz] = v;
+        for (int e = 0; e < 6; ++e)
+            cj[e] = sCj[q][e];
+        if (trow) {
+            Z[m + t + (size_t)(2 * j) * ldz] = sv[q][0] * cj[0] + sv[q][1] * cj[1] + sv[q][2] * cj[2];
+            Z[m + t + (size_t)(2 * j + 1) * ldz] = sv[q][0] * cj[3] + sv[q][1] * cj[4] + sv[q][2] * cj[5];
+        } else if (srow) {
+            const int i = t - n;
+            double CS[2][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double s0 = sv[q][3 * c], s1 = sv[q][3 * c + 1], s2 = sv[q][3 * c + 2];
+                CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
+                CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
             }
-    } else if (t == n + M) {
-        Z[m + n + (size_t)(2 * j) * ldz] = ytil[2 * j];
-        Z[m + n + (size_t)(2 * j + 1) * ldz] = ytil[2 * j + 1];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    double v = CS[a][0] * cj[3 * bb] + CS[a][1] * cj[3 * bb + 1] + CS[a][2] * cj[3 * bb + 2];
+                    if (i == j && a == bb)
+                        v += meas_var;
+                    Z[2 * i + a + (size_t)(2 * j + bb) * ldz] = v;
+                }
+        } else if (t == n + M) {
+            Z[m + n + (size_t)(2 * j) * ldz] = sCj[q][6];
+            Z[m + n + (size_t)(2 * j + 1) * ldz] = sCj[q][7];
+        }
     }
 }
 

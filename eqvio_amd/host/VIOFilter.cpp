@@ -335,6 +335,14 @@ void VIO_eqf::outlierStats(const VisionMeasurement& m, std::vector<double>& absE
     flatten(m, ids, y);
     check(eqf_outlier_stats(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), absErr.data(), probErr.data(), depth2.data()), "eqf_outlier_stats");
 }
+void VIO_eqf::stageMeasurement(const VisionMeasurement& m) {
+    if (m.camCoordinates.empty() || numLandmarks() == 0)
+        return;
+    std::vector<int> ids;
+    std::vector<double> y;
+    flatten(m, ids, y);
+    check(eqf_stage_measurement(ctx, ids.data(), y.data(), (int)ids.size()), "eqf_stage_measurement");
+}
 int VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double thrProb, double var, bool useEqv, bool discreteCorrection, std::vector<double>& absErr,
                               std::vector<double>& probErr, std::vector<double>& depth2) {
     const int N = numLandmarks();
@@ -544,6 +552,10 @@ bool VIOFilter::integrateUpToTime(const double& newTime) { // :134-192
 }
 void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :194-241
     loopTimer.startTiming("propagation");
+    // The measurement is in hand before the propagation (VIOFilter.cpp:194-196): hand it to the device now, so that it travels to
+    // HBM inside the propagation kernel instead of across PCIe in the update's first kernel (a hint: ignored if an id is unknown).
+    if (initialisedFlag && settings->fastRiccati)
+        filterState.stageMeasurement(measurement);
     const bool integrationFlag = integrateUpToTime(measurement.stamp);
     if (!integrationFlag || !initialisedFlag)
         return;

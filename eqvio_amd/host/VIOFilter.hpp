@@ -174,6 +174,7 @@ struct VIO_eqf {
     // eqf_stats_then_update: the statistics and (unless an outlier candidate cancels it on the device) the update, one host wait.
     // Returns 1 when the update was performed, 0 when the device cancelled it (statistics valid), -1 when not applicable
     // (a measurement id is not in the state; nothing computed).
+    void stageMeasurement(const VisionMeasurement& measurement); // eqf_stage_measurement: hint ahead of the propagation of the same frame
     int statsThenUpdate(const VisionMeasurement& measurement, double thrAbs, double thrProb, double outputGainVar, bool useEquivariantOutput, bool discreteCorrection,
                          std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2);
 

@@ -123,6 +123,14 @@ int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, con
  * propagation is two kernels on one stream, with no second stream and no events. */
 int eqf_propagate_fast(eqf_ctx* ctx, const double* imu13_mean, double dt_total, const double* Qdiag12, const double* Pdiag8, const double* imu13_k, const double* dt_k,
                        int k, int discreteLift);
+/* Optional hint, to be called BEFORE the propagation call of the same frame (eqf_propagate_fast / eqf_integrate_riccati_fast)
+ * with the measurement that eqf_stats_then_update will receive (VIOFilter::processVisionData has it in hand before it propagates,
+ * VIOFilter.cpp:194-196). If every id is in the state, the measurement is written to the pinned packet and one extra block of the
+ * propagation kernel copies it to HBM, so that the update's first kernel does not fetch it across PCIe. eqf_stats_then_update
+ * uses the staged copy only if ids, y and the landmark set are unchanged; otherwise (or without this call) it behaves as before.
+ * Never an error for unknown ids (nothing is staged). */
+int eqf_stage_measurement(eqf_ctx* ctx, const int* ids, const double* y_px, int M);
+
 /* Speculative frame tail for VIOFilter::processVisionData (VIOFilter.cpp:209-236) when every measurement id is already a
  * landmark of the state: the outlier statistics of removeOutliers (VIOFilter.cpp:304-334) and performVisionUpdate are
  * queued back to back with ONE host wait. The statistics kernel compares each measured landmark with the two thresholds

@@ -378,3 +378,68 @@ def test_propagate_fast_equals_riccati_plus_observer(chart, k, discrete):
         orc.integrate_observer(imus[s_], dts[s_], discrete)
     check_sigma(core, orc, 1e-12)
     check_state(core, orc)
+
+
+@pytest.mark.parametrize("chart", list(CHARTS))
+def test_staged_measurement_is_bit_identical_and_falls_back_when_stale(chart):
+    """eqf_stage_measurement before the propagation: eqf_stats_then_update then reads the measurement from HBM (copied by a block of
+    the propagation kernel) and must produce exactly what it produces without the hint; a hint that no longer matches (other
+    pixels, other ids, landmark set changed in between) is ignored."""
+    N = 21
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=91, useDiscreteInnovationLift=0)
+    twin = EqfCore(N, CHARTS[chart])
+    twin.set_state(xi0, Xs, ids, q0, Q)
+    twin.set_sigma(S)
+    cam = default_camera()
+    var = settings.measurementNoise**2
+    Qd, Pd = settings.input_gain_diag12(), settings.state_gain_diag8()
+    k = 5
+    imus = np.stack([random_imu(rng, stamp=0.005 * i) for i in range(k)])
+    dts = rng.uniform(0.002, 0.006, k)
+    mean = imus.mean(axis=0)
+
+    def frame(c, hint_ids, hint_y, mid, y):
+        if hint_ids is not None:
+            c.stage_measurement(hint_ids, hint_y)
+        c.propagate_fast(mean, float(dts.sum()), Qd, Pd, imus, dts, True)
+        return c.stats_then_update(cam, mid, y, 1e8, 1e8, var, True, False)
+
+    def same(a, b):
+        assert np.array_equal(a.get_sigma(), b.get_sigma())
+        for u, v in zip(a.get_state(), b.get_state()):
+            assert np.array_equal(u, v)
+
+    # 1. matching hint
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=rng.permutation(N)[:17])
+    r0 = frame(core, mid, y, mid, y)
+    r1 = frame(twin, None, None, mid, y)
+    assert r0[0] == 1 and r1[0] == 1
+    for u, v in zip(r0[1:], r1[1:]):
+        assert np.array_equal(u, v)
+    same(core, twin)
+    # 2. hint with other pixels / other ids: ignored
+    mid2, y2 = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=rng.permutation(N)[:15])
+    frame(core, mid2, y2 + 0.5, mid2, y2)
+    frame(twin, None, None, mid2, y2)
+    same(core, twin)
+    frame(core, mid, y, mid2, y2)
+    frame(twin, None, None, mid2, y2)
+    same(core, twin)
+    # 3. landmark set changed between hint and update (indices shift): ignored
+    order = np.argsort(ids)
+    gone = int(order[0])
+    keep = np.array([i for i in ids if i != ids[gone]], np.int32)
+    mid3, y3 = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0)
+    sel = np.isin(mid3, keep)
+    mid3k, y3k = mid3[sel], y3.reshape(-1, 2)[sel].reshape(-1)
+    core.stage_measurement(mid3k, y3k)
+    core.propagate_fast(mean, float(dts.sum()), Qd, Pd, imus, dts, True)
+    twin.propagate_fast(mean, float(dts.sum()), Qd, Pd, imus, dts, True)
+    core.remove_landmarks(np.array([gone], np.int32))
+    twin.remove_landmarks(np.array([gone], np.int32))
+    a = core.stats_then_update(cam, mid3k, y3k, 1e8, 1e8, var, True, False)
+    b = twin.stats_then_update(cam, mid3k, y3k, 1e8, 1e8, var, True, False)
+    assert a[0] == 1 and b[0] == 1
+    same(core, twin)
+    # 4. a hint with an id that is not in the state is not an error and stages nothing
+    core.stage_measurement(np.array([999999], np.int32), np.array([1.0, 2.0]))
