@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 9, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -195,6 +195,8 @@ def load_eqf_lib():
         "eqf_outlier_stats": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]),
         "eqf_propagate_fast": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int]),
         "eqf_stage_measurement": (C.c_int, [vp, c_int_p, c_double_p, C.c_int]),
+        "eqf_trace_read": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong), C.POINTER(C.c_uint)]),
+        "eqf_host_wait_stats": (C.c_int, [vp, C.POINTER(C.c_long), c_double_p, C.c_int]),
         "eqf_stats_then_update": (C.c_int, [vp, C.POINTER(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p,
                                   c_double_p, c_int_p]),
         "eqf_vision_update": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_int]),

@@ -3,6 +3,7 @@
 #include "eqf_kernels.hpp"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -165,11 +166,20 @@ struct eqf_ctx {
     // eqf_stage_measurement: HBM copies of the three arrays above, made by a block of the propagation kernel
     double* d_meas = nullptr; //   y[2 Ncap] | ylm[3 Ncap]
     int* d_meas_idx = nullptr;
-    bool stage_pending = false, staged_valid = false;
+    bool stage_requested = false, stage_pending = false, staged_valid = false;
     int staged_M = 0;
     unsigned lm_gen = 0, staged_gen = 0; // lm_gen counts changes of the landmark set (indices in a staged measurement go stale)
     std::vector<int> staged_ids;
     std::vector<double> staged_y;
+    std::vector<std::pair<int, int>> lookup; // sorted (id, index), valid for lookup_gen == lm_gen
+    unsigned lookup_gen = ~0u;
+    // host-side wait statistics (eqf_host_wait_stats): doorbell waits and the time spent spinning in them
+    // EQF_OPT_TRACE: device-side frame timeline (ring of TR_FRAMES frames x TR_SLOTS stamps, 100 MHz device wall clock)
+    trace_t* d_trace = nullptr;
+    unsigned trace_frame = 0;
+    std::vector<long long> h_trace; // host steady_clock stamps (ns), TR_FRAMES x TR_HOST
+    long wait_calls = 0, launch_calls = 0;
+    double wait_seconds = 0.0, launch_seconds = 0.0;
     double* h_res = nullptr; // pinned result packet: stats[3 Ncap] | est[4 Ncap] | gamma[32]
     int* h_resflags = nullptr;
     static constexpr int kMaxSteps = kObsChunk;
@@ -223,11 +233,21 @@ hipEvent_t get_event(eqf_ctx* c) {
     }
     return c->evpool[c->evused++];
 }
+constexpr int TR_FRAMES = 64, TR_SLOTS = 48;
+enum { TR_ASSEMBLE = 0, TR_PROPAGATE = 1, TR_BUILD_Z = 2, TR_STEP0 = 3, TR_LIFT = 40, TR_SYRK = 42 }; // TR_LIFT + 1, TR_SYRK + 1: end times
+constexpr int TR_HOST = 8;
+enum { TH_DOOR = 0, TH_PROP_ENTRY = 1, TH_ASSEMBLE_OUT = 2, TH_PROP_OUT = 3, TH_TAIL_ENTRY = 4, TH_BUILD_Z_OUT = 5, TH_TAIL_OUT = 6 };
+void host_stamp(eqf_ctx* c, int k) {
+    if (c->d_trace)
+        c->h_trace[(size_t)(c->trace_frame % TR_FRAMES) * TR_HOST + k] = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+trace_t* trace_slot(eqf_ctx* c, int slot) { return c->d_trace ? c->d_trace + (size_t)(c->trace_frame % TR_FRAMES) * TR_SLOTS + slot : nullptr; }
 struct KTimer {
     eqf_ctx* c;
     int which;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    KTimer(eqf_ctx* ctx, int w) : c(ctx), which(w) {
+    std::chrono::steady_clock::time_point h0;
+    KTimer(eqf_ctx* ctx, int w) : c(ctx), which(w), h0(std::chrono::steady_clock::now()) {
         if (c->opt_timing) {
             e0 = get_event(c);
             e1 = get_event(c);
@@ -239,6 +259,8 @@ struct KTimer {
             hipEventRecord(e1, c->stream);
             c->tev.push_back({which, {e0, e1}});
         }
+        ++c->launch_calls; // host-side cost of the launch calls (eqf_host_wait_stats)
+        c->launch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
     }
 };
 void timing_reset(eqf_ctx* c) {
@@ -283,10 +305,15 @@ int sync_ctx(eqf_ctx* c) {
 int door_wait(eqf_ctx* c, int which, int seq) {
     volatile int* bell = reinterpret_cast<volatile int*>(c->h_door) + which;
     long spins_after_done = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     for (long it = 1;; ++it) {
         if (*bell == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
             c->busy_common = c->busy_steps = c->busy_meas = false;
+            ++c->wait_calls;
+            c->wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (which == 1)
+                host_stamp(c, TH_DOOR);
             return 0;
         }
         if ((it & 0xfff) == 0 || spins_after_done) {
@@ -397,7 +424,7 @@ int launch_assemble(eqf_ctx* c, bool record_early = true) {
     if (r)
         return r;
     hipLaunchKernelGGL(k_assemble_AB, dim3(std::max(1, blocks(c->N, 64))), dim3(64), 0, c->stream, c->ck, c->N, c->Ncap, c->chart, c->d_common, c->q0(), c->Qq(),
-                       c->Qa(), c->d_Al, c->d_Bl);
+                       c->Qa(), c->d_Al, c->d_Bl, trace_slot(c, TR_ASSEMBLE));
     if (record_early) {
         HIPCHK(hipEventRecord(c->ev_early, c->stream));
         c->ev_assembled_early = true;
@@ -409,11 +436,18 @@ int read_flags(eqf_ctx* c) {
     { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
 }
-int index_of(const eqf_ctx* c, int id) {
-    for (int i = 0; i < c->N; ++i)
-        if (c->ids[i] == id)
-            return i;
-    return -1;
+// id -> state index. The filter looks up every measured id every frame: a sorted (id, index) table, rebuilt only when the
+// landmark set changes, makes that O(M log N) instead of O(M N).
+int index_of(eqf_ctx* c, int id) {
+    if (c->lookup_gen != c->lm_gen || (int)c->lookup.size() != c->N) {
+        c->lookup.resize(c->N);
+        for (int i = 0; i < c->N; ++i)
+            c->lookup[i] = {c->ids[i], i};
+        std::sort(c->lookup.begin(), c->lookup.end());
+        c->lookup_gen = c->lm_gen;
+    }
+    const auto it = std::lower_bound(c->lookup.begin(), c->lookup.end(), std::make_pair(id, -1));
+    return (it != c->lookup.end() && it->first == id) ? it->second : -1;
 }
 
 } // namespace
@@ -549,6 +583,8 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_Linv);
     hipFree(c->d_gamma);
     hipFree(c->d_gpart);
+    if (c->d_trace)
+        hipFree(c->d_trace);
     hipFree(c->d_est);
     hipFree(c->d_stats);
     hipFree(c->d_scratch);
@@ -652,6 +688,18 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case EQF_OPT_EARLY_LIFT:
         c->opt_early = value;
         return 0;
+    case EQF_OPT_TRACE: {
+        { int _r = sync_ctx(c); if (_r) return _r; }
+        if (value && !c->d_trace) {
+            HIPCHK(hipMalloc(&c->d_trace, sizeof(trace_t) * TR_FRAMES * TR_SLOTS));
+            HIPCHK(hipMemset(c->d_trace, 0, sizeof(trace_t) * TR_FRAMES * TR_SLOTS));
+            c->h_trace.assign((size_t)TR_FRAMES * TR_HOST, 0);
+        } else if (!value && c->d_trace) {
+            hipFree(c->d_trace);
+            c->d_trace = nullptr;
+        }
+        return 0;
+    }
     case EQF_OPT_FUSED_UPDATE:
         if (value && c->sig32)
             return EQF_E_UNSUPPORTED;
@@ -973,7 +1021,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
         }
         KTimer t(c, KN_PROP_MAIN);
         LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1 + nObs + (sg.M ? 1 : 0)), dim3(256), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout,
-                  c->d_Al, c->d_Bl, nT, nStrip, nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg);
+                  c->d_Al, c->d_Bl, nT, nStrip, nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE));
         HIPCHK(hipGetLastError());
     } else {
         // dense: F materialised, tmp = F Sigma (= (Sigma F^T)^T, Sigma symmetric), Sigma' = tmp F^T + noise
@@ -1144,11 +1192,14 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
 }
 
 // See include/eqf_hip.h: fast Riccati + all observer steps of one frame, two kernels on one stream.
+static int stage_prepare(eqf_ctx* c);
 int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, const double* Qdiag12, const double* Pdiag8, const double* imu13_k, const double* dt_k,
                        int k, int discreteLift) {
     if (!c || !imu13_mean || !Qdiag12 || !Pdiag8 || k < 0 || (k > 0 && (!imu13_k || !dt_k)))
         return EQF_E_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
+    ++c->trace_frame; // EQF_OPT_TRACE: a frame starts here
+    host_stamp(c, TH_PROP_ENTRY);
     // 1. A / B terms at the CURRENT X (before the observer steps move it): integrateRiccatiStateFast uses X as it is
     int rc = upload_common(c, imu13_mean);
     if (rc)
@@ -1156,6 +1207,10 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     // 2. the assembly kernel goes out first (its terms, c->ck, are fixed now): the host part of the observer steps below then
     //    overlaps it instead of delaying it
     rc = launch_assemble(c, false);
+    if (rc)
+        return rc;
+    host_stamp(c, TH_ASSEMBLE_OUT);
+    rc = stage_prepare(c);
     if (rc)
         return rc;
     // 3. all observer steps on the host (X advances); chunks of kMaxSteps keep the kernel-argument packet small
@@ -1179,6 +1234,7 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0);
     if (rc)
         return rc;
+    host_stamp(c, TH_PROP_OUT);
     for (size_t q = ride ? 1 : 0; q < chunks.size() && c->N > 0; ++q) {
         c->ev_assembled_early = false;
         hipLaunchKernelGGL(k_observer, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, chunks[q], c->N, c->Ncap, counts[q], c->q0(), c->Qq(), c->Qa());
@@ -1212,7 +1268,7 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
         // gpart: the last launch (c0 == m) also produces Gamma = W z as GAMMA_G + 1 partial vectors (extra grid rows + its own panel)
         double* gp = (gpart && nsig == 0 && c0 >= m) ? gpart : nullptr;
         hipLaunchKernelGGL(k_chol_step, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
-                           nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld);
+                           nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld, (gpart || nsig) && step < 32 ? trace_slot(c, TR_STEP0 + step) : nullptr);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1255,7 +1311,7 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     if (M > c->Ncap)
         return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
-    c->staged_valid = c->stage_pending = false; // the pinned measurement packet is about to be rewritten
+    c->staged_valid = c->stage_pending = c->stage_requested = false; // the pinned measurement packet is about to be rewritten
     if (c->busy_meas) {
         int r = sync_ctx(c);
         if (r)
@@ -1306,7 +1362,7 @@ static int stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M)
         if (r)
             return r;
     }
-    c->staged_valid = c->stage_pending = false; // the pinned measurement packet is about to be rewritten
+    c->staged_valid = c->stage_pending = c->stage_requested = false; // the pinned measurement packet is about to be rewritten
     int* lmidx = c->h_lmidx;
     int* measof = c->h_lmidx + c->Ncap;
     int rc = map_measurement(c, ids, M, true, lmidx, measof);
@@ -1323,7 +1379,7 @@ static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_s
     KTimer t(c, KN_LIFT);
     hipLaunchKernelGGL(k_lift, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, c->N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),
                        c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags, use_door ? c->d_door + 1 : nullptr, c->h_door + 1, door_seq,
-                       spec, spec_seq, gpart, c->ld);
+                       spec, spec_seq, gpart, c->ld, trace_slot(c, TR_LIFT));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1340,9 +1396,10 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         if (fuse)
             mf = *fuse;
         LAUNCH_TS(c, k_build_Z, dim3(blocks(n + M + 1, 256), blocks(M, BZ_JB) + 1 + (mf.enabled ? 1 : 0)), dim3(256), c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx,
-                  (const TS*)c->sigma(), c->d_C, c->d_ytil, c->d_Z, c->d_Linv, c->d_flags, mf.enabled ? (const int*)nullptr : spec, spec_seq, mf);
+                  (const TS*)c->sigma(), c->d_C, c->d_ytil, c->d_Z, c->d_Linv, c->d_flags, mf.enabled ? (const int*)nullptr : spec, spec_seq, mf, trace_slot(c, TR_BUILD_Z));
         HIPCHK(hipGetLastError());
     }
+    host_stamp(c, TH_BUILD_Z_OUT);
     if (c->opt_fused) {
         rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, n, c->sigma(), c->d_gamma, true, spec, spec_seq);
         if (rc)
@@ -1359,7 +1416,7 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         const int nt = blocks(n, 32);
         KTimer t(c, KN_SYRK);
         LAUNCH_TS(c, k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), c->stream, n, m, c->ld, c->ldz, c->d_W, (TS*)c->sigma(), nt, c->d_gamma, spec, spec_seq,
-                  c->opt_early ? 0 : 1);
+                  c->opt_early ? 0 : 1, trace_slot(c, TR_SYRK));
         HIPCHK(hipGetLastError());
     }
     { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }
@@ -1459,10 +1516,25 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
 int eqf_stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M) {
     if (!c || M < 0 || (M > 0 && (!ids || !y)))
         return EQF_E_BAD_ARG;
-    c->stage_pending = c->staged_valid = false;
+    c->stage_requested = c->stage_pending = c->staged_valid = false;
     if (M == 0 || c->N == 0 || M > c->N)
         return 0;
-    HIPCHK(hipSetDevice(c->device));
+    // only a copy here: this call sits between the previous frame's results and this frame's first launch, where every host
+    // microsecond is GPU idle time. The id lookup and the packing run in eqf_propagate_fast, behind the first launch.
+    c->staged_ids.assign(ids, ids + M);
+    c->staged_y.assign(y, y + 2 * M);
+    c->staged_M = M;
+    c->stage_requested = true;
+    return 0;
+}
+// second half of eqf_stage_measurement (called with at least one kernel of the frame already queued)
+static int stage_prepare(eqf_ctx* c) {
+    if (!c->stage_requested)
+        return 0;
+    c->stage_requested = false;
+    const int M = c->staged_M;
+    if (c->N == 0 || M > c->N)
+        return 0;
     if (c->busy_meas) {
         int r = sync_ctx(c);
         if (r)
@@ -1470,17 +1542,14 @@ int eqf_stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M) {
     }
     int* lmidx = c->h_lmidx;
     int* measof = c->h_lmidx + c->Ncap;
-    const int rc = map_measurement(c, ids, M, false, lmidx, measof);
+    const int rc = map_measurement(c, c->staged_ids.data(), M, false, lmidx, measof);
     if (rc)
-        return rc;
+        return 0; // ids not ascending: the update call will report it
     for (int j = 0; j < M; ++j)
         if (lmidx[j] < 0)
             return 0; // an id without a landmark: nothing staged, the update call takes its ordinary route
-    std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
-    pack_by_landmark(c, measof, y);
-    c->staged_ids.assign(ids, ids + M);
-    c->staged_y.assign(y, y + 2 * M);
-    c->staged_M = M;
+    std::memcpy(c->h_y, c->staged_y.data(), sizeof(double) * 2 * M);
+    pack_by_landmark(c, measof, c->staged_y.data());
     c->staged_gen = c->lm_gen;
     c->stage_pending = true;
     return 0;
@@ -1499,13 +1568,14 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
         return 0;
     }
     HIPCHK(hipSetDevice(c->device));
+    host_stamp(c, TH_TAIL_ENTRY);
     // speculation needs the doorbell-free conditions of both waits and the equivariant-output cache of the statistics kernel
     const bool speculate = c->opt_spec && !c->opt_check && !c->opt_timing && !c->obs_pending;
     const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
     // staged by eqf_stage_measurement and copied to HBM by the propagation kernel: same measurement, same landmark set?
     const bool staged = speculate && c->staged_valid && c->staged_gen == c->lm_gen && c->staged_M == M && std::equal(ids, ids + M, c->staged_ids.begin()) &&
                         std::memcmp(c->staged_y.data(), y, sizeof(double) * 2 * M) == 0;
-    c->staged_valid = c->stage_pending = false;
+    c->staged_valid = c->stage_pending = c->stage_requested = false;
     int* lmidx = c->h_lmidx;
     int* measof = c->h_lmidx + c->Ncap;
     int rc = 0;
@@ -1574,6 +1644,7 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     rc = launch_update_tail(c, M, meas_var, discreteCorr, c->d_spec, seq, use_door, seq, &mf);
     if (rc)
         return rc;
+    host_stamp(c, TH_TAIL_OUT);
     rc = use_door ? door_wait(c, 1, seq) : sync_ctx(c);
     if (rc)
         return rc;
@@ -1774,6 +1845,32 @@ int eqf_mfma_f64_peak(eqf_ctx* c, double* tflops) {
     hipEventDestroy(e1);
     hipFree(d_out);
     *tflops = best;
+    return 0;
+}
+
+int eqf_trace_read(eqf_ctx* c, unsigned long long* device_ticks, long long* host_ns, unsigned* last_frame) {
+    if (!c || !device_ticks || !host_ns || !last_frame)
+        return EQF_E_BAD_ARG;
+    if (!c->d_trace)
+        return EQF_E_UNSUPPORTED;
+    { int _r = sync_ctx(c); if (_r) return _r; }
+    HIPCHK(hipMemcpy(device_ticks, c->d_trace, sizeof(trace_t) * TR_FRAMES * TR_SLOTS, hipMemcpyDeviceToHost));
+    std::memcpy(host_ns, c->h_trace.data(), sizeof(long long) * TR_FRAMES * TR_HOST);
+    *last_frame = c->trace_frame;
+    return 0;
+}
+
+int eqf_host_wait_stats(eqf_ctx* c, long* calls, double* seconds, int reset) {
+    if (!c || !calls || !seconds)
+        return EQF_E_BAD_ARG;
+    calls[0] = c->wait_calls;
+    seconds[0] = c->wait_seconds;
+    calls[1] = c->launch_calls;
+    seconds[1] = c->launch_seconds;
+    if (reset) {
+        c->wait_calls = c->launch_calls = 0;
+        c->wait_seconds = c->launch_seconds = 0.0;
+    }
     return 0;
 }
 

@@ -67,6 +67,19 @@ __device__ __forceinline__ void st_plane9(double* base, int stride, int i, int p
     base[(plane0 + 8) * stride + i] = A.a22;
 }
 
+// EQF_OPT_TRACE: the first thread of a launch stamps the device wall clock (100 MHz) into its slot of a per-frame ring; kernels
+// whose end matters keep the latest finishing time of their workgroups next to it. tr == nullptr (the default) costs one
+// uniform branch.
+typedef unsigned long long trace_t;
+__device__ __forceinline__ void trace_start(trace_t* tr) {
+    if (tr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *tr = wall_clock64();
+}
+__device__ __forceinline__ void trace_end(trace_t* tr) {
+    if (tr && threadIdx.x == 0)
+        atomicMax(tr + 1, (trace_t)wall_clock64());
+}
+
 // column index in A of packed column e (0..11) of the landmark-sensor block
 __host__ __device__ __forceinline__ int al_col(int e) { return e < 3 ? e : (e < 6 ? 12 + (e - 3) : 15 + (e - 6)); }
 
@@ -75,7 +88,8 @@ __host__ __device__ __forceinline__ int al_col(int e) { return e < 3 ? e : (e < 
 // One lane per landmark; the sensor-level terms are staged in LDS once per workgroup.
 __global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int Ncap, int chart, Common* __restrict__ cmdev,
                                                     const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
-                                                    double* __restrict__ Al, double* __restrict__ Bl) {
+                                                    double* __restrict__ Al, double* __restrict__ Bl, trace_t* tr) {
+    trace_start(tr);
     // The sensor-level terms arrive as a kernel argument. Workgroup 0 expands the sensor blocks A_ss (21x21) and
     // B_s (21x12) into HBM for the propagate kernels (block layout of euclid.cpp:103-109, 186-233).
     __shared__ double s_cm[9 + 9 + 9 + 36 + 3];
@@ -260,7 +274,9 @@ template <typename TS>
 __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
                                                         const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
-                                                        const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg) {
+                                                        const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
+                                                        trace_t* tr) {
+    trace_start(tr);
     const double dt = ra.dt;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -929,7 +945,8 @@ template <typename TS>
 __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
                                                  const TS* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
                                                  double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags, const int* __restrict__ spec,
-                                                 int spec_seq, const MeasFuse mf) {
+                                                 int spec_seq, const MeasFuse mf, trace_t* tr) {
+    trace_start(tr);
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
     const int m = 2 * M;
@@ -1131,7 +1148,8 @@ constexpr int GAMMA_G = 4; // column groups of the Gamma partials computed by th
 __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
                                                    const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update, int nyS,
                                                    int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq,
-                                                   double* __restrict__ gpart, int ldg) {
+                                                   double* __restrict__ gpart, int ldg, trace_t* tr) {
+    trace_start(tr);
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
     const int c0 = kb + w;
@@ -1477,7 +1495,8 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
 template <typename TS>
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
-                                                  double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma) {
+                                                  double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma, trace_t* tr) {
+    trace_start(tr);
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
     __shared__ double sred[1024 * SYRK_NW];
@@ -1512,6 +1531,7 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
                 Sig[j + (size_t)i * ld] = v;
         }
     }
+    trace_end(tr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1578,13 +1598,15 @@ __device__ __forceinline__ void lift_body(int N, int Ncap, int chart, int discre
 __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, double* __restrict__ gamma, const double* __restrict__ q0,
                                              double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
                                              const int* __restrict__ flags, int* __restrict__ flags_host, int* __restrict__ door_count, int* __restrict__ door_host,
-                                             int door_seq, const int* __restrict__ spec, int spec_seq, const double* __restrict__ gpart, int ldg) {
+                                             int door_seq, const int* __restrict__ spec, int spec_seq, const double* __restrict__ gpart, int ldg, trace_t* tr) {
+    trace_start(tr);
     const bool aborted = spec && *spec == spec_seq; // speculative tail cancelled by the statistics kernel
     if (blockIdx.x == 0 && threadIdx.x == 0)
         flags_host[2] = aborted ? 1 : 0;
     if (!aborted)
         lift_body(N, Ncap, chart, discrete, gamma, q0, Qq, Qa, est, gamma_host, flags, flags_host, gpart, ldg);
     ring_doorbell(door_count, door_host, door_seq);
+    trace_end(tr);
 }
 // q_hat_i = Q_i^-1 q0_i for all landmarks (stateGroupAction, VIOGroup.cpp:44-52)
 __global__ void __launch_bounds__(64) k_estimate(int N, int Ncap, const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
