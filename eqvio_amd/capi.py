@@ -428,6 +428,7 @@ def load_filter_lib():
         "eqvio_filter_core": (vp, [vp]),
         "eqvio_filter_last_timing": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
         "eqvio_filter_run_frames": (C.c_int, [vp, P(Camera), C.c_int, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, c_double_p]),
+        "eqvio_filter_run_prepared": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -547,6 +548,14 @@ class VIOFilter:
         self.lib.eqvio_filter_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c))
         return {"propagation": a.value, "preprocessing": b.value, "correction": c.value}
 
+    def run_prepared(self, frames, first=0, count=None):
+        """eqvio_filter_run_prepared on a PreparedFrames object: no container construction inside the call."""
+        count = len(frames) - first if count is None else count
+        done = self.lib.eqvio_filter_run_prepared(self.h, frames.h, first, count)
+        if done < 0:
+            self._chk(-1)
+        return done
+
     def run_frames(self, cam, imu_counts, imu13_all, stamps, meas_counts, ids_all, y_all):
         imu_counts, imu13_all, stamps = _i32(imu_counts), _f64(imu13_all), _f64(stamps)
         meas_counts, ids_all, y_all = _i32(meas_counts), _i32(ids_all), _f64(y_all)
@@ -554,6 +563,39 @@ class VIOFilter:
         if done < 0:
             self._chk(-1)
         return done
+
+
+class PreparedFrames:
+    """eqvio_frames (include/eqvio_filter.h): IMU samples and VisionMeasurement objects built once from flat arrays."""
+
+    def __init__(self, cam, imu_counts, imu13_all, stamps, meas_counts, ids_all, y_all):
+        lib = load_filter_lib()
+        lib.eqvio_frames_create.restype = C.c_void_p
+        lib.eqvio_frames_create.argtypes = [C.POINTER(Camera), C.c_int, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, c_double_p]
+        lib.eqvio_frames_destroy.restype = None
+        lib.eqvio_frames_destroy.argtypes = [C.c_void_p]
+        lib.eqvio_frames_count.restype = C.c_int
+        lib.eqvio_frames_count.argtypes = [C.c_void_p]
+        imu_counts, imu13_all, stamps = _i32(imu_counts), _f64(imu13_all), _f64(stamps)
+        meas_counts, ids_all, y_all = _i32(meas_counts), _i32(ids_all), _f64(y_all)
+        self.lib = lib
+        self.h = lib.eqvio_frames_create(C.byref(cam), len(stamps), _ip(imu_counts), _dp(imu13_all), _dp(stamps), _ip(meas_counts), _ip(ids_all), _dp(y_all))
+        if not self.h:
+            raise RuntimeError("eqvio_frames_create failed")
+
+    def __len__(self):
+        return self.lib.eqvio_frames_count(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.eqvio_frames_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---------------------------------------------------------------------------------------------------------

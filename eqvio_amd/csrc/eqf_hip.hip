@@ -233,7 +233,7 @@ hipEvent_t get_event(eqf_ctx* c) {
     }
     return c->evpool[c->evused++];
 }
-constexpr int TR_FRAMES = 64, TR_SLOTS = 48;
+constexpr int TR_FRAMES = 1024, TR_SLOTS = 48;
 enum { TR_ASSEMBLE = 0, TR_PROPAGATE = 1, TR_BUILD_Z = 2, TR_STEP0 = 3, TR_LIFT = 40, TR_SYRK = 42 }; // TR_LIFT + 1, TR_SYRK + 1: end times
 constexpr int TR_HOST = 8;
 enum { TH_DOOR = 0, TH_PROP_ENTRY = 1, TH_ASSEMBLE_OUT = 2, TH_PROP_OUT = 3, TH_TAIL_ENTRY = 4, TH_BUILD_Z_OUT = 5, TH_TAIL_OUT = 6 };

@@ -195,38 +195,63 @@ int eqvio_filter_last_timing(const eqvio_filter* f, double* a, double* b, double
         *c = f->t_corr;
     return 0;
 }
-int eqvio_filter_run_frames(eqvio_filter* f, const eqvio_camera* cam, int nframes, const int* imu_counts, const double* imu13_all, const double* stamps,
-                            const int* meas_counts, const int* ids_all, const double* y_all) {
+// Prepared replay: the IMU samples and the VisionMeasurement objects (a std::map per frame, as the reference's tracker / data
+// server hands them to the filter, main_opt.cpp:196-214) are built once, outside any timed region.
+struct eqvio_frames {
+    GICameraPtr camPtr;
+    std::vector<VisionMeasurement> meas;
+    std::vector<IMUVelocity> imus;
+    std::vector<size_t> imuBegin; // nframes + 1 offsets into imus
+};
+eqvio_frames* eqvio_frames_create(const eqvio_camera* cam, int nframes, const int* imu_counts, const double* imu13_all, const double* stamps, const int* meas_counts,
+                                  const int* ids_all, const double* y_all) {
+    if (!cam || nframes < 0 || (nframes > 0 && (!imu_counts || !stamps || !meas_counts)))
+        return nullptr;
+    try {
+        auto* fr = new eqvio_frames;
+        fr->camPtr = makeCamera(cam);
+        fr->meas.resize((size_t)nframes);
+        fr->imuBegin.assign(1, 0);
+        size_t io = 0, mo = 0;
+        for (int j = 0; j < nframes; ++j) {
+            for (int s = 0; s < imu_counts[j]; ++s)
+                fr->imus.push_back(unpackIMU(imu13_all + 13 * (io + s)));
+            io += imu_counts[j];
+            fr->imuBegin.push_back(io);
+            fr->meas[j] = makeMeasurement(stamps[j], fr->camPtr, ids_all + mo, y_all + 2 * mo, meas_counts[j]);
+            mo += meas_counts[j];
+        }
+        return fr;
+    } catch (...) {
+        return nullptr;
+    }
+}
+void eqvio_frames_destroy(eqvio_frames* fr) { delete fr; }
+int eqvio_frames_count(const eqvio_frames* fr) { return fr ? (int)fr->meas.size() : -1; }
+int eqvio_filter_run_prepared(eqvio_filter* f, const eqvio_frames* fr, int first, int count) {
+    if (!fr || first < 0 || count < 0 || (size_t)first + (size_t)count > fr->meas.size())
+        return -1;
     int done = 0;
     const int rc = guarded(f, [&] {
         initTimer();
-        const GICameraPtr camPtr = makeCamera(cam);
-        // The measurement objects are built before the loop: in the reference they arrive ready-made from the tracker / data
-        // server (main_opt.cpp:196-214); building a 200-entry std::map between two frames would sit on the filter's critical
-        // path here (the device is idle while the host prepares the next frame).
-        std::vector<VisionMeasurement> meas((size_t)nframes);
-        std::vector<IMUVelocity> imus;
-        {
-            size_t io = 0, mo = 0;
-            for (int j = 0; j < nframes; ++j) {
-                for (int s = 0; s < imu_counts[j]; ++s)
-                    imus.push_back(unpackIMU(imu13_all + 13 * (io + s)));
-                io += imu_counts[j];
-                meas[j] = makeMeasurement(stamps[j], camPtr, ids_all + mo, y_all + 2 * mo, meas_counts[j]);
-                mo += meas_counts[j];
-            }
-        }
-        size_t io = 0;
-        for (int j = 0; j < nframes; ++j) {
-            for (int s = 0; s < imu_counts[j]; ++s)
-                f->filter->processIMUData(imus[io + s]);
-            io += imu_counts[j];
-            f->filter->processVisionData(meas[j]);
+        for (int j = first; j < first + count; ++j) {
+            for (size_t s = fr->imuBegin[j]; s < fr->imuBegin[j + 1]; ++s)
+                f->filter->processIMUData(fr->imus[s]);
+            f->filter->processVisionData(fr->meas[j]);
             ++done;
         }
         grabTiming(f);
     });
     return rc ? -1 : done;
+}
+int eqvio_filter_run_frames(eqvio_filter* f, const eqvio_camera* cam, int nframes, const int* imu_counts, const double* imu13_all, const double* stamps,
+                            const int* meas_counts, const int* ids_all, const double* y_all) {
+    eqvio_frames* fr = eqvio_frames_create(cam, nframes, imu_counts, imu13_all, stamps, meas_counts, ids_all, y_all);
+    if (!fr)
+        return -1;
+    const int done = eqvio_filter_run_prepared(f, fr, 0, nframes);
+    eqvio_frames_destroy(fr);
+    return done;
 }
 
 } // extern "C"

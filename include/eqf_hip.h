@@ -164,12 +164,12 @@ int eqf_mfma_f64_peak(eqf_ctx* ctx, double* tflops);
 /* per-kernel timing of the last frame's launches on the context's stream (HIP events); fills up to cap
  * (name index, microseconds) pairs; see eqf_kernel_name. Enabled with eqf_set_option(ctx, 100, 1). */
 int eqf_last_kernel_times(eqf_ctx* ctx, int* which, float* usec, int cap);
-/* EQF_OPT_TRACE = 1: device-side timeline of the last 64 frames, no profiler and no events involved.
- * device_ticks[64][48] (100 MHz device wall clock; 0 = not stamped): slot 0 k_assemble_AB start, 1 k_propagate_main start, 2 k_build_Z start,
+/* EQF_OPT_TRACE = 1: device-side timeline of the last 1024 frames, no profiler and no events involved.
+ * device_ticks[1024][48] (100 MHz device wall clock; 0 = not stamped): slot 0 k_assemble_AB start, 1 k_propagate_main start, 2 k_build_Z start,
  * 3 + s start of factorisation step s (s < 32), 40 / 41 k_lift start / last workgroup done (= doorbell), 42 / 43 k_syrk_sub start /
- * last workgroup done. host_ns[64][8] (steady_clock): 0 doorbell seen, 1 eqf_propagate_fast entered, 2 assembly launch returned,
+ * last workgroup done. host_ns[1024][8] (steady_clock): 0 doorbell seen, 1 eqf_propagate_fast entered, 2 assembly launch returned,
  * 3 propagation launch returned, 4 eqf_stats_then_update entered, 5 k_build_Z launch returned, 6 last launch of the tail returned.
- * Row = frame number mod 64; *last_frame = number of the newest frame. The doorbell (slot 41 / host 0) ties the two clocks together. */
+ * Row = frame number mod 1024; *last_frame = number of the newest frame. The doorbell (slot 41 / host 0) ties the two clocks together. */
 int eqf_trace_read(eqf_ctx* ctx, unsigned long long* device_ticks, long long* host_ns, unsigned* last_frame);
 /* Host-side view of the frame since the last reset: calls[0] / seconds[0] = doorbell waits and the wall time the host spent spinning
  * in them; calls[1] / seconds[1] = kernel launch calls and the wall time spent inside them. (frame period - wait time per frame) is

@@ -52,7 +52,19 @@ eqf_ctx* eqvio_filter_core(eqvio_filter* f);
 /* loopTimer sections of the last processVisionData (VIOFilter.cpp:196-236), seconds */
 int eqvio_filter_last_timing(const eqvio_filter* f, double* propagation, double* preprocessing, double* correction);
 
-/* Replay helper for benchmarks: for each frame j, feed imu_counts[j] IMU samples (processIMUData) then one vision
+/* Prepared replay. eqvio_frames_create builds, once, what the reference's tracker / data server hands to the filter: the IMU
+ * samples and one VisionMeasurement (a std::map of pixel coordinates) per frame, from arrays concatenated over frames (frame j:
+ * imu_counts[j] IMU samples of 13 doubles, then meas_counts[j] features at stamps[j]). eqvio_filter_run_prepared feeds frames
+ * [first, first + count) to processIMUData / processVisionData and returns the number of frames processed or -1: it is what a
+ * benchmark times, with the construction of the input containers outside the timed region. */
+typedef struct eqvio_frames eqvio_frames;
+eqvio_frames* eqvio_frames_create(const eqvio_camera* cam, int nframes, const int* imu_counts, const double* imu13_all, const double* stamps, const int* meas_counts,
+                                  const int* ids_all, const double* y_all);
+void eqvio_frames_destroy(eqvio_frames* frames);
+int eqvio_frames_count(const eqvio_frames* frames);
+int eqvio_filter_run_prepared(eqvio_filter* f, const eqvio_frames* frames, int first, int count);
+
+/* Replay helper (create + run + destroy in one call): for each frame j, feed imu_counts[j] IMU samples (processIMUData) then one vision
  * measurement of meas_counts[j] features at stamps[j] (processVisionData). Arrays are concatenated over frames.
  * Returns the number of frames processed or -1. */
 int eqvio_filter_run_frames(eqvio_filter* f, const eqvio_camera* cam, int nframes, const int* imu_counts, const double* imu13_all, const double* stamps,

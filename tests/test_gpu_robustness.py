@@ -107,3 +107,33 @@ def test_doorbell_and_stream_wait_agree_bitwise():
     (a, ia, pa), Sa = outs[0]
     (b, ib, pb), Sb = outs[1]
     assert np.array_equal(a, b) and np.array_equal(pa, pb) and np.array_equal(Sa, Sb) and np.all(np.isfinite(Sa))
+
+
+def test_prepared_replay_equals_run_frames_and_the_staging_hint_changes_nothing():
+    """eqvio_filter_run_prepared (containers built once, in two slices) == eqvio_filter_run_frames, bit for bit; and the filter's
+    own use of eqf_stage_measurement (measurement copied to HBM by the propagation kernel) == the same run with speculation off,
+    where the hint is never consumed, to rounding of nothing: both paths evaluate the same kernels on the same inputs."""
+    import bench
+    from eqvio_amd.capi import PreparedFrames
+
+    settings = bench.eurocish_settings()
+    N, nfr = 40, 300
+    world, frames = bench.build_workload(seed=21, n_frames=nfr + 2, N=N)
+    flat = bench.flatten_frames(frames[:nfr])
+
+    def fresh():
+        return bench.make_filter(world, settings, N, 0, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=N, device=0, sensor=se, ids=i, p=p, time=t))
+
+    a = fresh()
+    assert a.run_frames(world.cam, *flat) == nfr
+    b = fresh()
+    pf = PreparedFrames(world.cam, *flat)
+    assert len(pf) == nfr
+    assert b.run_prepared(pf, 0, 100) == 100 and b.run_prepared(pf, 100, nfr - 100) == nfr - 100
+    with pytest.raises(Exception):
+        b.run_prepared(pf, nfr - 1, 5)  # out of range
+    (sa, ia, pa), (sb, ib, pb) = a.state_estimate(), b.state_estimate()
+    assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(pa, pb) and np.array_equal(a.get_sigma(), b.get_sigma())
+    pf.close()
+    a.close()
+    b.close()
