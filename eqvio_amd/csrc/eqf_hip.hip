@@ -1009,7 +1009,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
     double* Sout = c->d_sigma[1 - c->cur];
     if (!c->opt_dense) {
         const int nT = blocks(N, PT), nStrip = blocks(N, 12);
-        const int nObs = (obs && obs_k > 0) ? blocks(N, 256) : 0;
+        const int nObs = (obs && obs_k > 0) ? blocks(N, PROP_T) : 0;
         StageArgs sg{};
         if (c->stage_pending) { // one more block copies the staged measurement from the pinned packet to HBM
             sg.M = c->staged_M;
@@ -1020,7 +1020,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
             c->busy_meas = true;
         }
         KTimer t(c, KN_PROP_MAIN);
-        LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1 + nObs + (sg.M ? 1 : 0)), dim3(256), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout,
+        LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout,
                   c->d_Al, c->d_Bl, nT, nStrip, nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE));
         HIPCHK(hipGetLastError());
     } else {

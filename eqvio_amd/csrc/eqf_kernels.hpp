@@ -80,6 +80,23 @@ __device__ __forceinline__ void trace_end(trace_t* tr) {
         atomicMax(tr + 1, (trace_t)wall_clock64());
 }
 
+// full-precision reciprocal from v_rcp_f64 + two Newton steps (shorter dependent chain than an IEEE division)
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+
+// full-precision 1/sqrt from v_rsq_f64 + two Newton steps (an IEEE sqrt followed by a division is ~10x longer a chain)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
 // column index in A of packed column e (0..11) of the landmark-sensor block
 __host__ __device__ __forceinline__ int al_col(int e) { return e < 3 ? e : (e < 6 ? 12 + (e - 3) : 15 + (e - 6)); }
 
@@ -217,29 +234,59 @@ struct ObsSteps {
     ObsStep s[kObsChunk];
 };
 // landmark i: Q_i <- Q_i * Lambda_1.Q_i * ... * Lambda_k.Q_i for the k steps (one lane per landmark)
+// The k steps of a landmark are a serial chain, and with 10-25 IMU samples per frame that chain is as long as the whole Sigma
+// propagation it rides along with. The discrete lift is therefore written for a short dependent chain: one reciprocal square
+// root gives 1 / (|p1| |q_hat|) for both normalisations and the scale ratio, a second one the half-angle factor; the
+// re-normalisation of the unit quaternion uses 1/sqrt(x) = 1.5 - 0.5 x (exact to O((x-1)^2), |x - 1| < 1e-9 here); 1/a is carried
+// along instead of divided out each step. Algebraically this is SO3::SO3FromVectors(p1.normalized(), q_hat.normalized()) and
+// |q_hat| / |p1| of VIOGroup.cpp:254-262; the antiparallel special case keeps the general routine.
 __device__ __forceinline__ void observer_landmark(const ObsStep* __restrict__ steps, int Ncap, int k, int i, const double* __restrict__ q0, double* __restrict__ Qq,
                                                   double* __restrict__ Qa) {
     const V3 p0 = ld3(q0, Ncap, i);
     Qt q = ldq(Qq, Ncap, i);
     double a = Qa[i];
+    double inva = 1.0 / a;
     for (int s = 0; s < k; ++s) {
         const ObsStep st = steps[s];
-        const V3 ph = (1.0 / a) * q_rot(q_inv(q), p0); // current estimate q_hat_i
+        const V3 ph = inva * q_rot(q_inv(q), p0); // current estimate q_hat_i
         Qt Lq;
-        double La;
+        double La, invLa;
         if (st.discrete) {
             const V3 p1 = pose_act(st.Tinv, ph);
-            Lq = so3_from_vectors(normalized(p1), normalized(ph));
-            La = norm(ph) / norm(p1);
+            const double nh2 = norm2(ph), n12 = norm2(p1);
+            const double r = fast_rsqrt(nh2 * n12);
+            const double c = dot(p1, ph) * r;
+            if (c < -1.0 + 1e-12) {
+                Lq = so3_from_vectors(normalized(p1), normalized(ph));
+            } else {
+                const V3 ax = r * cross(p1, ph);
+                const double t = (1.0 + c) * 2.0;
+                const double is = fast_rsqrt(t);
+                const Qt L{0.5 * (t * is), ax.x * is, ax.y * is, ax.z * is};
+                const double kk = 1.5 - 0.5 * (L.w * L.w + L.x * L.x + L.y * L.y + L.z * L.z);
+                Lq = Qt{L.w * kk, L.x * kk, L.y * kk, L.z * kk};
+            }
+            La = nh2 * r;
+            invLa = n12 * r;
         } else {
             const double ip2 = 1.0 / norm2(ph);
             const V3 Wr = st.omC + ip2 * cross(ph, st.vC);
             const double Ws = ip2 * dot(ph, st.vC);
             Lq = so3_exp(st.dt * Wr);
             La = exp(st.dt * Ws);
+            invLa = 1.0 / La;
         }
-        q = q_mul(q, Lq);
+        if (st.discrete) {
+            // product of two quaternions that are unit to a few ulp: the re-normalisation of q_mul without its sqrt and division
+            const Qt m{q.w * Lq.w - q.x * Lq.x - q.y * Lq.y - q.z * Lq.z, q.w * Lq.x + q.x * Lq.w + q.y * Lq.z - q.z * Lq.y,
+                       q.w * Lq.y + q.y * Lq.w + q.z * Lq.x - q.x * Lq.z, q.w * Lq.z + q.z * Lq.w + q.x * Lq.y - q.y * Lq.x};
+            const double km = 1.5 - 0.5 * (m.w * m.w + m.x * m.x + m.y * m.y + m.z * m.z);
+            q = Qt{m.w * km, m.x * km, m.y * km, m.z * km};
+        } else {
+            q = q_mul(q, Lq);
+        }
         a = a * La;
+        inva = inva * invLa;
     }
     Qq[i] = q.w;
     Qq[Ncap + i] = q.x;
@@ -262,6 +309,7 @@ __global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N
 // Block roles by blockIdx.x: [0, nT*nT) landmark-landmark tiles of 16x16 landmarks (one 3x3 block per lane),
 // then strip blocks (landmark-sensor 3x21 blocks and their transposes), then one sensor-sensor block.
 constexpr int PT = 16; // landmarks per tile side
+constexpr int PROP_T = 3 * PT * PT; // threads per workgroup of k_propagate_main: one per (row of a 3x3 block, landmark pair)
 struct StageArgs {
     int M; // 0: nothing to stage
     const double *y_h, *ylm_h; // pinned host packet
@@ -271,7 +319,7 @@ struct StageArgs {
 };
 // TS = storage type of Sigma (double, or float for EQF_OPT_SIGMA_FP32 = 2): loads convert to double, stores round.
 template <typename TS>
-__global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
+__global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
                                                         const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
                                                         const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
@@ -283,11 +331,11 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
     if (b > nT * nT + nStrip + nObs) {
         // Staging block (eqf_stage_measurement): the coming frame's measurement moves from the pinned host packet to HBM while Sigma
         // is being propagated, so that the update's first kernel finds it next to the state instead of across PCIe.
-        for (int t = tid; t < 2 * sg.M; t += 256)
+        for (int t = tid; t < 2 * sg.M; t += PROP_T)
             sg.y_d[t] = sg.y_h[t];
-        for (int t = tid; t < sg.M; t += 256)
+        for (int t = tid; t < sg.M; t += PROP_T)
             sg.idx_d[t] = sg.idx_h[t];
-        for (int t = tid; t < 3 * N; t += 256) {
+        for (int t = tid; t < 3 * N; t += PROP_T) {
             const int pl = t / N, i = t - pl * N;
             sg.ylm_d[pl * Ncap + i] = sg.ylm_h[pl * Ncap + i];
         }
@@ -297,7 +345,7 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
         // Observer blocks (eqf_propagate_fast): the landmark part of the frame's observer steps rides along with the Sigma
         // propagation. This kernel touches Sigma / Al / Bl only, the assembly kernel before it has already read Q and the
         // statistics kernel after it wants the new Q: in-stream order gives all three, no second stream, no events.
-        const int i = (b - (nT * nT + nStrip + 1)) * 256 + tid;
+        const int i = (b - (nT * nT + nStrip + 1)) * PROP_T + tid;
         if (i < N)
             observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa);
         return;
@@ -316,7 +364,7 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
         double* sBj = sDj + 9 * PT;
         double* sSi = sBj + 9 * PT;   // Sigma[k][l_i + c'] at [(k*3 + c') * PT + x]
         double* sSs = sSi + 63 * PT;  // Sigma_ss[al_col(e)][k] at [e * 21 + k], e < 12
-        for (int t = tid; t < 63 * PT; t += 256) {
+        for (int t = tid; t < 63 * PT; t += PROP_T) {
             const int e = t / PT, x = t % PT;
             const int i = bi * PT + x, j = bj * PT + x;
             // Sigma[k][l + c'] with e = k*3 + c'
@@ -326,14 +374,14 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
         }
         if (tid < 12 * 21)
             sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
-        for (int t = tid; t < 36 * PT; t += 256) {
+        for (int t = tid; t < 36 * PT; t += PROP_T) {
             const int e = t / PT, x = t % PT;
             const int r = e / 12, c = e % 12;
             const int i = bi * PT + x, j = bj * PT + x;
             sFi[t] = i < N ? dt * Al[(r * 15 + c) * Ncap + i] : 0.0;
             sFj[t] = j < N ? dt * Al[(r * 15 + c) * Ncap + j] : 0.0;
         }
-        for (int t = tid; t < 9 * PT; t += 256) {
+        for (int t = tid; t < 9 * PT; t += PROP_T) {
             const int e = t / PT, x = t % PT;
             const int r = e / 3, c = e % 3;
             const int i = bi * PT + x, j = bj * PT + x;
@@ -345,7 +393,7 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
         }
         __syncthreads();
         // G_i[r][k] = sum_e (dt A_ls_i)[r][e] Sigma_ss[al_col(e)][k] + sum_c' (I + dt A_qi)[r][c'] Sigma[l_i + c'][k]
-        for (int t = tid; t < 63 * PT; t += 256) {
+        for (int t = tid; t < 63 * PT; t += PROP_T) {
             const int e = t / PT, x = t % PT;
             const int r = e / 21, k = e % 21;
             double g = 0.0;
@@ -358,7 +406,10 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
             sGi[t] = g;
         }
         __syncthreads();
-        const int ti = tid % PT, tj = tid / PT;
+        // lane = (output row r, landmark pair (ti, tj)): three lanes share a 3x3 block, each produces one row of it. The
+        // per-element sums run in the same order as a one-lane-per-block version would (results are bit-identical to it).
+        const int r = tid / (PT * PT), tp = tid % (PT * PT);
+        const int ti = tp % PT, tj = tp / PT;
         const int i = bi * PT + ti, j = bj * PT + tj;
         if (i >= N || j >= N)
             return;
@@ -370,41 +421,37 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 Sij[k][c] = Sig[li + k + (size_t)(lj + c) * ld];
-        // E = Fls_i Sigma_sj + D_i Sigma_ij
-        double E[3][3];
+        // E[r][:] = (Fls_i Sigma_sj + D_i Sigma_ij)[r][:]
+        double E[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double s = 0;
+            for (int e = 0; e < 12; ++e)
+                s += sFi[(r * 12 + e) * PT + ti] * sSj[(al_col(e) * 3 + c) * PT + tj];
 #pragma unroll
-                for (int e = 0; e < 12; ++e)
-                    s += sFi[(r * 12 + e) * PT + ti] * sSj[(al_col(e) * 3 + c) * PT + tj];
+            for (int k = 0; k < 3; ++k)
+                s += sDi[(r * 3 + k) * PT + ti] * Sij[k][c];
+            E[c] = s;
+        }
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    s += sDi[(r * 3 + k) * PT + ti] * Sij[k][c];
-                E[r][c] = s;
-            }
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int e = 0; e < 12; ++e)
+                s += sGi[(r * 21 + al_col(e)) * PT + ti] * sFj[(c * 12 + e) * PT + tj];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double s = 0;
+            for (int k = 0; k < 3; ++k)
+                s += E[k] * sDj[(c * 3 + k) * PT + tj];
+            double bq = 0;
 #pragma unroll
-                for (int e = 0; e < 12; ++e)
-                    s += sGi[(r * 21 + al_col(e)) * PT + ti] * sFj[(c * 12 + e) * PT + tj];
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    s += E[r][k] * sDj[(c * 3 + k) * PT + tj];
-                double bq = 0;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    bq += sBi[(r * 3 + q) * PT + ti] * ra.Qd[q] * sBj[(c * 3 + q) * PT + tj];
-                s += dt * bq;
-                if (i == j && r == c)
-                    s += dt * ra.Pd[7];
-                Sout[li + r + (size_t)(lj + c) * ld] = s;
-            }
+            for (int q = 0; q < 3; ++q)
+                bq += sBi[(r * 3 + q) * PT + ti] * ra.Qd[q] * sBj[(c * 3 + q) * PT + tj];
+            s += dt * bq;
+            if (i == j && r == c)
+                s += dt * ra.Pd[7];
+            Sout[li + r + (size_t)(lj + c) * ld] = s;
+        }
         return;
     }
     if (b < nT * nT + nStrip) {
@@ -417,7 +464,7 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
         if (tid < 12 * 21)
             sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
         __syncthreads();
-        for (int t = tid; t < SL * 63; t += 256) {
+        for (int t = tid; t < SL * 63; t += PROP_T) {
             const int x = t / 63, e = t % 63;
             const int r = e / 21, k = e % 21;
             const int i = i0 + x;
@@ -460,13 +507,13 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
         double* sF = sm;        // 441
         double* sS = sm + 441;  // 441
         double* sT = sm + 882;  // 441  (F Sigma_ss)
-        for (int t = tid; t < 441; t += 256) {
+        for (int t = tid; t < 441; t += PROP_T) {
             const int r = t / 21, c = t % 21;
             sF[t] = dt * cm->Ass[t] + (r == c ? 1.0 : 0.0);
             sS[t] = Sig[r + (size_t)c * ld];
         }
         __syncthreads();
-        for (int t = tid; t < 441; t += 256) {
+        for (int t = tid; t < 441; t += PROP_T) {
             const int r = t / 21, c = t % 21;
             double s = 0;
             for (int k = 0; k < 21; ++k)
@@ -474,7 +521,7 @@ __global__ void __launch_bounds__(256) k_propagate_main(int N, int Ncap, int ld,
             sT[t] = s;
         }
         __syncthreads();
-        for (int t = tid; t < 441; t += 256) {
+        for (int t = tid; t < 441; t += PROP_T) {
             const int r = t / 21, c = t % 21;
             double s = 0;
             for (int k = 0; k < 21; ++k)
@@ -675,23 +722,6 @@ __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, i
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int CH_LDP = 48; // MFMA operand tiles in LDS: k and k+1 columns 32 dwords apart -> conflict-free ds_read_b64
 
-// full-precision reciprocal from v_rcp_f64 + two Newton steps (shorter dependent chain than an IEEE division)
-__device__ __forceinline__ double fast_rcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-d, r, 1.0);
-    return fma(r, e, r);
-}
-
-// full-precision 1/sqrt from v_rsq_f64 + two Newton steps (an IEEE sqrt followed by a division is ~10x longer a chain)
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double h = 0.5 * x;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
-}
 // ---- inverse Cholesky factor of a 32x32 SPD tile, blocked 16 + 16 -----------------------------------------------
 // D = [[D11, .],[D21, D22]]:  L11^-1 by a 16x16 elimination;  L21 = D21 L11^-T (MFMA);  S22 = D22 - L21 L21^T (MFMA);
 // L22^-1 by a second 16x16 elimination;  L^-1 = [[L11^-1, 0], [-L22^-1 L21 L11^-1, L22^-1]] (two MFMA products).
