@@ -246,8 +246,10 @@ __device__ __forceinline__ void observer_landmark(const ObsStep* __restrict__ st
     Qt q = ldq(Qq, Ncap, i);
     double a = Qa[i];
     double inva = 1.0 / a;
+    ObsStep nxt = steps[0];
     for (int s = 0; s < k; ++s) {
-        const ObsStep st = steps[s];
+        const ObsStep st = nxt;
+        nxt = steps[min(s + 1, k - 1)]; // the next step's terms (scalar loads from the argument segment) arrive during this step
         const V3 ph = inva * q_rot(q_inv(q), p0); // current estimate q_hat_i
         Qt Lq;
         double La, invLa;
