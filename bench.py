@@ -314,12 +314,12 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
     # same bench command; bench.py cannot run the profiler on itself)
     traffic, traffic_note = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")))["kernels"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")))["kernels"]
         kn = [k_ for k_ in fam[dom][0] if k_ in pmc and launches.get(k_, 0) > 0]
         if kn:
             tot_l = sum(launches[k_] for k_ in kn)
             traffic = 1024.0 * sum((pmc[k_]["fetch_kib_per_launch"] + pmc[k_]["write_kib_per_launch"]) * launches[k_] for k_ in kn) / tot_l
-            traffic_note = "bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r01_v5_pmc_*.csv (N=200)"
+            traffic_note = "bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r01_v8_pmc_*.csv (N=200)"
     except Exception:
         pass
     return {
@@ -336,7 +336,7 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
         "algorithmic_flops_per_launch": fam[dom][1] / max(dom_launches, 1.0),
         "measured_mfma_f64_issue_ceiling_tflops": tpeak.value,
         "per_kernel_us_per_frame": {k_: round(v, 2) for k_, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
-        "note": "durations from hipEvents on the filter's own stream around each launch, over %d frames of the same workload right after the timed region" % k,
+        "note": "hipEvent spans on the filter's own stream over %d frames of the same workload right after the timed region; the factorisation chain is ONE span over its back-to-back launches divided by their number (launch boundaries included, no events between the steps), the other kernels one span each" % k,
     }
 
 

@@ -204,6 +204,7 @@ struct eqf_ctx {
     std::vector<int> meas_ids;
     // timing
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> tev;
+    std::vector<int> tev_n; // launches inside each span
     std::vector<hipEvent_t> evpool;
     size_t evused = 0;
 
@@ -247,7 +248,8 @@ struct KTimer {
     int which;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::chrono::steady_clock::time_point h0;
-    KTimer(eqf_ctx* ctx, int w) : c(ctx), which(w), h0(std::chrono::steady_clock::now()) {
+    int nlaunch; // launches inside the span: reported as that many entries of span / nlaunch each (no events BETWEEN them)
+    KTimer(eqf_ctx* ctx, int w, int n = 1) : c(ctx), which(w), h0(std::chrono::steady_clock::now()), nlaunch(n) {
         if (c->opt_timing) {
             e0 = get_event(c);
             e1 = get_event(c);
@@ -258,13 +260,16 @@ struct KTimer {
         if (c->opt_timing) {
             hipEventRecord(e1, c->stream);
             c->tev.push_back({which, {e0, e1}});
+            c->tev_n.push_back(nlaunch);
         }
+        c->launch_calls += nlaunch - 1;
         ++c->launch_calls; // host-side cost of the launch calls (eqf_host_wait_stats)
         c->launch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
     }
 };
 void timing_reset(eqf_ctx* c) {
     c->tev.clear();
+    c->tev_n.clear();
     c->evused = 0;
 }
 
@@ -1255,12 +1260,12 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
         HIPCHK(hipGetLastError());
     }
     int step = 0;
+    KTimer t(c, KN_CHOL_PANEL, blocks(m, NB)); // one event pair around the whole chain: events between the steps would stretch it
     for (int kb = 0; kb < m; kb += NB, ++step) {
         const int w = std::min(NB, m - kb);
         const int c0 = kb + w;
         double* Lin = c->d_Linv + 1024 * (step & 1);
         double* Lout = c->d_Linv + 1024 * ((step + 1) & 1);
-        KTimer t(c, KN_CHOL_PANEL);
         const int gx = blocks(rows - c0, 32);
         const int nyS = c0 < m ? blocks(m - c0, 32) : 1;
         const int nts = blocks(nsig, 32);
@@ -1570,7 +1575,7 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     HIPCHK(hipSetDevice(c->device));
     host_stamp(c, TH_TAIL_ENTRY);
     // speculation needs the doorbell-free conditions of both waits and the equivariant-output cache of the statistics kernel
-    const bool speculate = c->opt_spec && !c->opt_check && !c->opt_timing && !c->obs_pending;
+    const bool speculate = c->opt_spec && !c->opt_check && !c->obs_pending;
     const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
     // staged by eqf_stage_measurement and copied to HBM by the propagation kernel: same measurement, same landmark set?
     const bool staged = speculate && c->staged_valid && c->staged_gen == c->lm_gen && c->staged_M == M && std::equal(ids, ids + M, c->staged_ids.begin()) &&
@@ -1879,14 +1884,16 @@ int eqf_last_kernel_times(eqf_ctx* c, int* which, float* usec, int cap) {
         return EQF_E_BAD_ARG;
     { int _r = sync_ctx(c); if (_r) return _r; }
     int cnt = 0;
-    for (auto& t : c->tev) {
-        if (cnt >= cap)
-            break;
+    for (size_t q = 0; q < c->tev.size(); ++q) {
+        auto& t = c->tev[q];
         float ms = 0;
         hipEventElapsedTime(&ms, t.second.first, t.second.second);
-        which[cnt] = t.first;
-        usec[cnt] = ms * 1000.0f;
-        ++cnt;
+        const int nl = std::max(1, c->tev_n[q]);
+        for (int r = 0; r < nl && cnt < cap; ++r) { // a span over nl back-to-back launches: nl entries of span / nl
+            which[cnt] = t.first;
+            usec[cnt] = ms * 1000.0f / nl;
+            ++cnt;
+        }
     }
     timing_reset(c);
     return cnt;

@@ -101,6 +101,8 @@ VIOSensorState unpackSensor(const double* d) {
 void flatten(const VisionMeasurement& m, std::vector<int>& ids, std::vector<double>& y) {
     ids.clear();
     y.clear();
+    ids.reserve(m.camCoordinates.size());
+    y.reserve(2 * m.camCoordinates.size());
     for (const auto& kv : m.camCoordinates) {
         ids.push_back(kv.first);
         y.push_back(kv.second[0]);
