@@ -1,6 +1,7 @@
 """SURVEY.md §8(d) measurement configs 1, 2, 3, 5 on one MI355X (config 4 is `bench.py --gpus N`).
 Each simulated config drives the device filter main_sim-style from the C++ SimulationDataServer; a bounded prefix of the
-same run goes through the CPU oracle in lockstep for parity and the CPU time. Prints one JSON object."""
+same run goes through the CPU oracle in lockstep for parity and the CPU time. Prints one JSON object.
+It lives under tests/ because it uses the oracle (as the checker), which only tests/, smoke() and bench.py's cpu_baseline may do."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
