@@ -185,7 +185,7 @@ struct eqf_ctx {
     static constexpr int kMaxSteps = kObsChunk;
     CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
-    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0, opt_early = 1;
+    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0, opt_early = 1, opt_two_phase = 700;
     bool sig32 = false; // Sigma stored as float (EQF_OPT_SIGMA_FP32 = 2)
     int opt_door = 1;   // host doorbell instead of the stream completion signal for the two per-frame waits
     int* d_door = nullptr; // device counters (one per doorbell)
@@ -692,6 +692,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_EARLY_LIFT:
         c->opt_early = value;
+        return 0;
+    case EQF_OPT_TWO_PHASE:
+        c->opt_two_phase = value;
         return 0;
     case EQF_OPT_TRACE: {
         { int _r = sync_ctx(c); if (_r) return _r; }
@@ -1272,8 +1275,17 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
         const int nySig = nsig > 0 ? blocks(nts * (nts + 1) / 2, gx) : 0;
         // gpart: the last launch (c0 == m) also produces Gamma = W z as GAMMA_G + 1 partial vectors (extra grid rows + its own panel)
         double* gp = (gpart && nsig == 0 && c0 >= m) ? gpart : nullptr;
+        // Two-phase step where the trailing matrix is large (N = 500: the first ~15 steps): P for every block row once, by its own
+        // launch, instead of twice per trailing tile. Below the threshold the extra launch boundary costs more than it saves.
+        const long trailing_tiles = (long)nyS * (nyS + 1) / 2 + (long)(gx - nyS) * nyS; // lower tiles of the S part + the T / y rows
+        const bool two_phase = nsig == 0 && c0 < m && c->opt_two_phase > 0 && trailing_tiles >= c->opt_two_phase;
+        if (two_phase) {
+            hipLaunchKernelGGL(k_chol_panel, dim3(gx), dim3(256), 0, c->stream, rows, kb, w, ldz, Z, W, Lin, spec, spec_seq);
+            HIPCHK(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_chol_step, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
-                           nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld, (gpart || nsig) && step < 32 ? trace_slot(c, TR_STEP0 + step) : nullptr);
+                           nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld, (gpart || nsig) && step < 32 ? trace_slot(c, TR_STEP0 + step) : nullptr,
+                           two_phase ? (const double*)W : (const double*)nullptr);
         HIPCHK(hipGetLastError());
     }
     return 0;

@@ -1176,11 +1176,71 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
 // the diagonal-tile elimination; their diagonal tiles also accumulate Gamma += W_k z_k (VIO_eqf.cpp:119). In effect the
 // factorisation runs on [[S, T^T],[T, Sigma]] and stops after the S block: what is left in the corner is the Schur
 // complement Sigma - T S^-1 T^T.
+// First half of a two-phase step: P_I = Z[I, panel] L^-T for every block row I >= c0, ONE workgroup per block row, stored in the
+// panel's columns of Wout (rows >= m of it are the final W / z rows anyway; the rows < m are scratch). Same operand layout and
+// MFMA order as the in-step evaluation: the values are bit-identical to it.
+__global__ void __launch_bounds__(256) k_chol_panel(int rows, int kb, int w, int ldz, const double* __restrict__ Z, double* __restrict__ Wout,
+                                                    const double* __restrict__ LinvIn, const int* __restrict__ spec, int spec_seq) {
+    if (spec && *spec == spec_seq)
+        return; // cancelled speculative tail
+    const int c0 = kb + w;
+    const int i0 = c0 + blockIdx.x * 32;
+    __shared__ double sLinv[32 * CH_LDP];
+    __shared__ double sPI[32 * CH_LDP];
+    const int tid = threadIdx.x;
+    const int r = tid & 31, g = tid >> 5;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    double lv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        lv[k] = LinvIn[r + 32 * (g + 8 * k)];
+    const int ihP = wave & 1;
+    double opI[8];
+    {
+        const int rowI = i0 + 16 * ihP + lr;
+        const int rowIc = min(rowI, rows - 1);
+        const double zI = rowI < rows ? 1.0 : 0.0;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int p = 4 * st + lk;
+            const int pc = min(p, w - 1);
+            const double zp = p < w ? 1.0 : 0.0;
+            opI[st] = Z[rowIc + (size_t)(kb + pc) * ldz] * (zI * zp);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        sLinv[r + (g + 8 * k) * CH_LDP] = lv[k];
+    __syncthreads();
+    {
+        const int ch = wave >> 1;
+        d4 accI = {0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const double b = sLinv[16 * ch + lr + (4 * st + lk) * CH_LDP];
+            accI = __builtin_amdgcn_mfma_f64_16x16x4f64(b, opI[st], accI, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            sPI[16 * ihP + lr + (16 * ch + lk + 4 * q) * CH_LDP] = accI[q];
+    }
+    __syncthreads();
+    const int row = i0 + r;
+    if (row < rows) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = g + 8 * k;
+            if (c < w)
+                Wout[row + (size_t)(kb + c) * ldz] = sPI[r + c * CH_LDP];
+        }
+    }
+}
 constexpr int GAMMA_G = 4; // column groups of the Gamma partials computed by the last step launch
 __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
                                                    const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update, int nyS,
                                                    int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq,
-                                                   double* __restrict__ gpart, int ldg, trace_t* tr) {
+                                                   double* __restrict__ gpart, int ldg, trace_t* tr, const double* __restrict__ Ppre) {
     trace_start(tr);
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
@@ -1255,13 +1315,31 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     const bool needJ = update && !diag_tile;
     // 0. issue every global load up front: L^-1, the panel rows of I and J in MFMA operand layout
     //    (Zp[row][p], p = 4 st + lk) and the output tile
-    double lv[4];
+    // Two-phase steps (Ppre != nullptr, k_chol_panel ran just before): P_I and P_J come ready-made from Ppre instead of being
+    // recomputed by every workgroup of a block row / column (two thirds of a trailing tile's work at N = 500).
+    const bool pre = Ppre && !sig;
+    double lv[4] = {0, 0, 0, 0};
+    if (!pre) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        lv[k] = LinvIn[r + 32 * (g + 8 * k)];
+        for (int k = 0; k < 4; ++k)
+            lv[k] = LinvIn[r + 32 * (g + 8 * k)];
+    }
     const int ihP = wave & 1;
     double opI[8], opJ[8];
-    {
+    double ppI[4] = {0, 0, 0, 0}, ppJ[4] = {0, 0, 0, 0};
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = g + 8 * k;
+            const int cc = min(c, w - 1);
+            const double zc = c < w ? 1.0 : 0.0;
+            ppI[k] = Ppre[min(i0 + r, ilim - 1) + (size_t)(kb + cc) * ldz] * ((i0 + r < ilim) ? zc : 0.0);
+            ppJ[k] = (update && i0 != j0) ? Ppre[min(j0 + r, jlim - 1) + (size_t)(kb + cc) * ldz] * ((j0 + r < jlim) ? zc : 0.0) : 0.0;
+        }
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+            opI[st] = opJ[st] = 0.0;
+    } else {
         const int rowI = i0 + 16 * ihP + lr, rowJ = j0 + 16 * ihP + lr;
         const int rowIc = min(rowI, ilim - 1), rowJc = min(rowJ, jlim - 1);
         const double zI = rowI < ilim ? 1.0 : 0.0, zJ = (needJ && rowJ < jlim) ? 1.0 : 0.0;
@@ -1293,7 +1371,14 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
         swork[32 + tid] = yv;
     __syncthreads();
     // 2. P = Zpanel * Linv^T : P[i][c] = sum_p Zp[i][p] Linv[c][p]; wave -> 16x16 sub-tile (ih, ch) of P_I and of P_J
-    {
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sPI[r + (g + 8 * k) * CH_LDP] = ppI[k];
+            if (needJ)
+                sPJ[r + (g + 8 * k) * CH_LDP] = ppJ[k];
+        }
+    } else {
         const int ch = wave >> 1;
         d4 accI = {0, 0, 0, 0}, accJ = {0, 0, 0, 0};
 #pragma unroll
@@ -1311,8 +1396,8 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
         }
     }
     __syncthreads();
-    // 4. final W / z rows of this panel
-    if (!sig && blockIdx.y == 0) {
+    // 4. final W / z rows of this panel (k_chol_panel has stored them in two-phase steps)
+    if (!sig && !pre && blockIdx.y == 0) {
         const int row = i0 + r;
         if (row < rows && row >= m) {
 #pragma unroll

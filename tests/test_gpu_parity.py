@@ -443,3 +443,29 @@ def test_staged_measurement_is_bit_identical_and_falls_back_when_stale(chart):
     same(core, twin)
     # 4. a hint with an id that is not in the state is not an error and stages nothing
     core.stage_measurement(np.array([999999], np.int32), np.array([1.0, 2.0]))
+
+
+def test_two_phase_factorisation_steps_are_bit_identical():
+    """EQF_OPT_TWO_PHASE: steps with a large trailing matrix evaluate P = Z[:, panel] L^-T once per block row in a launch of its
+    own (k_chol_panel) instead of inside every trailing tile. Same operand layout and MFMA order: the update must not change by a
+    bit, whatever the threshold (1 = every step, 0 = never), here at a size where the default would not switch it on."""
+    from eqvio_amd.capi import OPT_TWO_PHASE
+
+    N = 60
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=5, useDiscreteInnovationLift=0)
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=rng.permutation(N)[:51])
+    outs = []
+    for thr in (0, 1, 40):
+        c = EqfCore(N, CHARTS["invdepth"])
+        c.set_state(xi0, Xs, ids, q0, Q)
+        c.set_sigma(S)
+        c.set_option(OPT_TWO_PHASE, thr)
+        c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+        outs.append((c.get_sigma(), c.get_state(), c.last_gamma()))
+    for S1, st1, g1 in outs[1:]:
+        assert np.array_equal(S1, outs[0][0]) and np.array_equal(g1, outs[0][2])
+        for u, v in zip(st1, outs[0][1]):
+            assert np.array_equal(u, v)
+    orc.vision_update(cam, mid, y)
+    assert rel_fro(outs[1][0], orc.get_sigma()) <= 1e-9
