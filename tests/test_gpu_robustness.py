@@ -137,3 +137,49 @@ def test_prepared_replay_equals_run_frames_and_the_staging_hint_changes_nothing(
     pf.close()
     a.close()
     b.close()
+
+
+def test_trace_and_host_statistics():
+    """EQF_OPT_TRACE / eqf_trace_read and eqf_host_wait_stats (diagnostics): the stamps of a frame are ordered the way the kernels
+    run (assembly < propagation < Z < steps < lift < covariance update), the doorbell wait is counted once per frame, and switching
+    the trace on does not change a bit of the result."""
+    import ctypes as C
+
+    import bench
+    from eqvio_amd.capi import OPT_TRACE, PreparedFrames, load_eqf_lib
+
+    lib = load_eqf_lib()
+    settings = bench.eurocish_settings()
+    N, nfr = 40, 60
+    world, frames = bench.build_workload(seed=33, n_frames=nfr + 2, N=N)
+    pf = PreparedFrames(world.cam, *bench.flatten_frames(frames[:nfr]))
+    outs = []
+    for trace in (0, 1):
+        flt = bench.make_filter(world, settings, N, 0, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=N, device=0, sensor=se, ids=i, p=p, time=t))
+        core = flt.core_handle()
+        assert lib.eqf_set_option(core, OPT_TRACE, trace) == 0
+        calls, secs = (C.c_long * 2)(), (C.c_double * 2)()
+        assert lib.eqf_host_wait_stats(core, calls, secs, 1) == 0
+        assert flt.run_prepared(pf) == nfr
+        assert lib.eqf_host_wait_stats(core, calls, secs, 0) == 0
+        assert calls[0] == nfr and secs[0] > 0.0 and calls[1] >= 5 * nfr and secs[1] > 0.0
+        dev = np.zeros((1024, 48), np.uint64)
+        host = np.zeros((1024, 8), np.int64)
+        last = C.c_uint()
+        rc = lib.eqf_trace_read(core, dev.ctypes.data_as(C.POINTER(C.c_ulonglong)), host.ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(last))
+        if trace:
+            assert rc == 0 and last.value >= nfr
+            d = dev[(last.value - 1) % 1024].astype(np.int64)
+            nsteps = int(np.count_nonzero(d[3:35]))
+            assert nsteps == (2 * N + 31) // 32
+            order = [d[0], d[1], d[2]] + list(d[3 : 3 + nsteps]) + [d[40], d[41], d[42], d[43]]
+            assert all(b > a for a, b in zip(order, order[1:])), order
+            h = host[(last.value - 1) % 1024]
+            assert h[1] < h[2] < h[3] < h[4] < h[5] < h[6]
+        else:
+            assert rc != 0  # not enabled
+        outs.append((flt.state_estimate(), flt.get_sigma()))
+        flt.close()
+    (a, ia, pa), Sa = outs[0]
+    (b, ib, pb), Sb = outs[1]
+    assert np.array_equal(a, b) and np.array_equal(pa, pb) and np.array_equal(Sa, Sb)
