@@ -940,26 +940,27 @@ __global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double
 // K8a: build Z = [S ; T ; yTilde^T] from Sigma and the packed C blocks, exploiting the 2x3 block sparsity of C:
 //   T[:, 2j:2j+2] = Sigma[:, l_j:l_j+3] C_j^T          (6 n M flops instead of 2 n^2 m)
 //   S[2i:2i+2, 2j:2j+2] = C_i Sigma[l_i.., l_j..] C_j^T + delta_ij R
-// grid.y - 1 (- 2 with fusion) = group of BZ_JB measurements; grid.x covers "row items": t < n -> row of T, n <= t < n+M -> block row i of S, t == n+M -> y row
-// Grid row 0: its first workgroup recomputes the first 32 x 32
-// tile of S on its own (16 x 16 pairs of 2 x 2 blocks, one per thread) and eliminates it, so that the factorisation chain
-// needs no separate first-tile launch.
+// Grid: x covers "row items" (t < n -> row of T, n <= t < n+M -> block row i of S, t == n+M -> the yTilde row); y = 0 is the
+// first-tile row, y = 1 the statistics row (with fusion only), every further y a group of BZ_JB measurements.
+// Grid row 0: its first workgroup recomputes the first 32 x 32 tile of S on its own (16 x 16 pairs of 2 x 2 blocks, one per
+// thread) and eliminates it, so that the factorisation chain needs no separate first-tile launch.
 //
 // Measurement fusion (mf.enabled, eqf_stats_then_update): there is no k_measure / k_outlier_stats launch in front of this kernel.
-//  * Every thread that needs a block C_i evaluates it itself from the measurement in the pinned host packet (measure_one: the
-//    same function, inputs and therefore bits wherever it is evaluated); the workgroups with blockIdx.x == 0 store C_j, yTilde_j
-//    and the index map for later reuse (eqf_vision_update after a cancelled tail, debugging).
-//  * Grid row 1 computes the per-landmark outlier statistics (VIOFilter.cpp:304-334), writes them
-//    to the host packet and, if any landmark is an outlier candidate, stores spec_seq into *spec_w: this kernel only writes
-//    scratch (Z, C), the kernels behind it compare that word and return at once.
+//  * Every thread that needs a block C_i evaluates it itself (measure_one: the same function and inputs, therefore the same
+//    bits, wherever it is evaluated) from the measurement in HBM (eqf_stage_measurement) or in the pinned host packet; the
+//    workgroups with blockIdx.x == 0 store C_j, yTilde_j and the index map for later reuse (eqf_vision_update after a cancelled
+//    tail, debugging).
+//  * Grid row 1 computes the per-landmark outlier statistics (VIOFilter.cpp:304-334), writes them to the host packet and, if any
+//    landmark is an outlier candidate, stores spec_seq into *spec_w: this kernel only writes scratch (Z, C), the kernels behind
+//    it compare that word and return at once.
 constexpr int BZ_JB = 4; // measurements per workgroup of k_build_Z
 struct MeasFuse {
     int enabled;
     int N, Ncap, chart, star;
     Cam cam;
-    const double* y;     // pinned: y[2 j], y[2 j + 1]
-    const int* lmidx;    // pinned: landmark index of measurement j
-    const double* ylm;   // pinned: the measurement by landmark (statistics row)
+    const double* y;     // y[2 j], y[2 j + 1]        } staged copies in HBM, or the pinned host packet
+    const int* lmidx;    // landmark index of measurement j
+    const double* ylm;   // the measurement by landmark (statistics row)
     const double *q0, *Qq, *Qa;
     double* out;         // pinned: statistics (3 N)
     double *C, *ytil;    // device, for reuse
