@@ -185,7 +185,7 @@ struct eqf_ctx {
     static constexpr int kMaxSteps = kObsChunk;
     CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
-    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0, opt_early = 1, opt_two_phase = 700;
+    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0, opt_early = 1, opt_two_phase = 700, opt_fuse_asm = 1;
     bool sig32 = false; // Sigma stored as float (EQF_OPT_SIGMA_FP32 = 2)
     int opt_door = 1;   // host doorbell instead of the stream completion signal for the two per-frame waits
     int* d_door = nullptr; // device counters (one per doorbell)
@@ -693,6 +693,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case EQF_OPT_EARLY_LIFT:
         c->opt_early = value;
         return 0;
+    case EQF_OPT_FUSED_ASSEMBLY:
+        c->opt_fuse_asm = value;
+        return 0;
     case EQF_OPT_TWO_PHASE:
         c->opt_two_phase = value;
         return 0;
@@ -990,7 +993,7 @@ int eqf_remove_invalid_landmarks(eqf_ctx* c) {
     return rc ? rc : (int)bad.size();
 }
 
-static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs = nullptr, int obs_k = 0);
+static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs = nullptr, int obs_k = 0, bool fused = false);
 int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
     if (!c || !imu13 || !Qdiag12 || !Pdiag8)
         return EQF_E_BAD_ARG;
@@ -1005,7 +1008,7 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
 }
 // Sigma' = F Sigma F^T + dt (B Q B^T + P) once A_l / B_l are assembled (arrow form, or the dense GEMM pair)
 // obs != nullptr (arrow form only): obs_k observer steps for the landmarks ride along as extra blocks of k_propagate_main
-static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs, int obs_k) {
+static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs, int obs_k, bool fused) {
     int rc = 0;
     static const ObsSteps kNoSteps{};
     RiccatiArgs ra;
@@ -1027,10 +1030,22 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
             c->staged_valid = true;
             c->busy_meas = true;
         }
+        // fused assembly (eqf_propagate_fast): every workgroup assembles the rows of A / B it needs from the current Q and c->ck; the
+        // observer blocks then write the other landmark buffer, which becomes the current one
+        FuseArgs fa{};
+        if (fused) {
+            fa.on = 1;
+            fa.chart = c->chart;
+            double* other = c->d_lm[1 - c->lmcur];
+            fa.q0o = other, fa.Qqo = other + 3 * (size_t)c->Ncap, fa.Qao = other + 7 * (size_t)c->Ncap;
+            fa.ck = c->ck;
+        }
         KTimer t(c, KN_PROP_MAIN);
         LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout,
-                  c->d_Al, c->d_Bl, nT, nStrip, nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE));
+                  c->d_Al, c->d_Bl, nT, nStrip, nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa);
         HIPCHK(hipGetLastError());
+        if (fused && nObs)
+            c->lmcur = 1 - c->lmcur;
     } else {
         // dense: F materialised, tmp = F Sigma (= (Sigma F^T)^T, Sigma symmetric), Sigma' = tmp F^T + noise
         const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
@@ -1214,7 +1229,9 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
         return rc;
     // 2. the assembly kernel goes out first (its terms, c->ck, are fixed now): the host part of the observer steps below then
     //    overlaps it instead of delaying it
-    rc = launch_assemble(c, false);
+    // (with fused assembly there is no such launch: the propagation kernel assembles what it needs itself)
+    const bool fuse = c->opt_fuse_asm && !c->opt_dense;
+    rc = fuse ? join_observer(c) : launch_assemble(c, false);
     if (rc)
         return rc;
     host_stamp(c, TH_ASSEMBLE_OUT);
@@ -1239,7 +1256,7 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     //    not touch Q; the assembly before it has read Q, the statistics after it want the new Q): two launches on ONE stream.
     //    Further chunks (k > 24) and the dense mode use the observer kernel, in stream order.
     const bool ride = !c->opt_dense && !chunks.empty() && c->N > 0;
-    rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0);
+    rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0, fuse);
     if (rc)
         return rc;
     host_stamp(c, TH_PROP_OUT);

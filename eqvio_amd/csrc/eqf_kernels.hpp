@@ -38,7 +38,7 @@ struct CommonK {
     double G[9];     // -g skew(R_0^T e3)
     double adT[36];  // ad(Ad_{T0^-1} Ad_A U_I)
 };
-constexpr int kObsChunk = 24; // observer steps per launch (kernel-argument budget)
+constexpr int kObsChunk = 20; // observer steps per launch (kernel-argument budget: they share 4 KB with the CommonK terms)
 struct RiccatiArgs {
     double dt;
     double Qd[12];
@@ -103,65 +103,50 @@ __host__ __device__ __forceinline__ int al_col(int e) { return e < 3 ? e : (e < 
 // ---------------------------------------------------------------------------------------------------
 // K1: per-landmark rows of A and B (EqFStateMatrixA / EqFInputMatrixB, euclid.cpp:99-233, invdepth.cpp:36-181)
 // One lane per landmark; the sensor-level terms are staged in LDS once per workgroup.
-__global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int Ncap, int chart, Common* __restrict__ cmdev,
-                                                    const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
-                                                    double* __restrict__ Al, double* __restrict__ Bl, trace_t* tr) {
-    trace_start(tr);
-    // The sensor-level terms arrive as a kernel argument. Workgroup 0 expands the sensor blocks A_ss (21x21) and
-    // B_s (21x12) into HBM for the propagate kernels (block layout of euclid.cpp:103-109, 186-233).
-    __shared__ double s_cm[9 + 9 + 9 + 36 + 3];
-    for (int t = threadIdx.x; t < 66; t += blockDim.x)
-        s_cm[t] = ck.lm[t];
-    {
-        const int gt = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
-        for (int t = gt; t < 252; t += gs) {
-            const int r = t / 12, c = t % 12;
-            double v = 0.0;
-            if (r < 6)
-                v = (c == 6 + r) ? 1.0 : 0.0;
-            else if (r < 9 && c < 3)
-                v = ck.RA[(r - 6) * 3 + c];
-            else if (r >= 9 && r < 12 && c < 3)
-                v = ck.SxRA[(r - 9) * 3 + c];
-            else if (r >= 12 && r < 15 && c < 3)
-                v = ck.RAsv[(r - 12) * 3 + c];
-            else if (r >= 12 && r < 15 && c >= 3 && c < 6)
-                v = ck.RA[(r - 12) * 3 + (c - 3)];
-            cmdev->Bs[t] = v;
-        }
-        for (int t = gt; t < 441; t += gs) {
-            const int r = t / 21, c = t % 21;
-            double v = 0.0;
-            if (c < 6) { // -B[:, 0:6]
-                if (r >= 6 && r < 9 && c < 3)
-                    v = -ck.RA[(r - 6) * 3 + c];
-                else if (r >= 9 && r < 12 && c < 3)
-                    v = -ck.SxRA[(r - 9) * 3 + c];
-                else if (r >= 12 && r < 15 && c < 3)
-                    v = -ck.RAsv[(r - 12) * 3 + c];
-                else if (r >= 12 && r < 15 && c >= 3)
-                    v = -ck.RA[(r - 12) * 3 + (c - 3)];
-            } else if (r >= 9 && r < 12 && c == r + 3) {
-                v = 1.0;
-            } else if (r >= 12 && r < 15 && c >= 6 && c < 9) {
-                v = ck.G[(r - 12) * 3 + (c - 6)];
-            } else if (r >= 15 && c >= 15) {
-                v = ck.adT[(r - 15) * 6 + (c - 15)];
-            }
-            cmdev->Ass[t] = v;
-        }
+// entries of the sensor blocks B_s (21 x 12, row-major) and A_ss (21 x 21) from the compact terms (block layout of
+// euclid.cpp:103-109, 186-233)
+__device__ __forceinline__ double sensor_Bs_entry(const CommonK& ck, int t) {
+    const int r = t / 12, c = t % 12;
+    double v = 0.0;
+    if (r < 6)
+        v = (c == 6 + r) ? 1.0 : 0.0;
+    else if (r < 9 && c < 3)
+        v = ck.RA[(r - 6) * 3 + c];
+    else if (r >= 9 && r < 12 && c < 3)
+        v = ck.SxRA[(r - 9) * 3 + c];
+    else if (r >= 12 && r < 15 && c < 3)
+        v = ck.RAsv[(r - 12) * 3 + c];
+    else if (r >= 12 && r < 15 && c >= 3 && c < 6)
+        v = ck.RA[(r - 12) * 3 + (c - 3)];
+    return v;
+}
+__device__ __forceinline__ double sensor_Ass_entry(const CommonK& ck, int t) {
+    const int r = t / 21, c = t % 21;
+    double v = 0.0;
+    if (c < 6) { // -B[:, 0:6]
+        if (r >= 6 && r < 9 && c < 3)
+            v = -ck.RA[(r - 6) * 3 + c];
+        else if (r >= 9 && r < 12 && c < 3)
+            v = -ck.SxRA[(r - 9) * 3 + c];
+        else if (r >= 12 && r < 15 && c < 3)
+            v = -ck.RAsv[(r - 12) * 3 + c];
+        else if (r >= 12 && r < 15 && c >= 3)
+            v = -ck.RA[(r - 12) * 3 + (c - 3)];
+    } else if (r >= 9 && r < 12 && c == r + 3) {
+        v = 1.0;
+    } else if (r >= 12 && r < 15 && c >= 6 && c < 9) {
+        v = ck.G[(r - 12) * 3 + (c - 6)];
+    } else if (r >= 15 && c >= 15) {
+        v = ck.adT[(r - 15) * 6 + (c - 15)];
     }
-    __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
+    return v;
+}
+// The rows of A and B of ONE landmark: al[r * 15 + c] (packed columns: 0:3 | 12:15 | 15:21 | own 3x3) and bl[9].
+// s_cm: the 66 per-landmark factors (Mv, RTic, RTicSx, CT, vC) in LDS.
+__device__ __forceinline__ void assemble_landmark(const double* __restrict__ s_cm, int chart, const V3 p0, const Qt q, const double a, double (&al)[45], double (&bl)[9]) {
     const M3 Mv = ldm3(s_cm), RTic = ldm3(s_cm + 9), RTicSx = ldm3(s_cm + 18);
     const double* CT = s_cm + 27;
     const V3 vC{s_cm[63], s_cm[64], s_cm[65]};
-
-    const V3 p0 = ld3(q0, Ncap, i);
-    const Qt q = ldq(Qq, Ncap, i);
-    const double a = Qa[i];
     const M3 RQ = q_mat(q);
     const M3 Qhat = a * RQ;
     const V3 qh = (1.0 / a) * (transpose(RQ) * p0); // Q^-1 * q0
@@ -208,7 +193,6 @@ __global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int
                 Ac[r][c] = Ac2[r][c];
         A_q = e2i * A_q * i2e;
     }
-    // Al planes: row r, packed col c -> plane r*15 + c
     const M3 A_b = (-1.0) * Bblk;
     const double ab[9] = {A_b.a00, A_b.a01, A_b.a02, A_b.a10, A_b.a11, A_b.a12, A_b.a20, A_b.a21, A_b.a22};
     const double av[9] = {A_v.a00, A_v.a01, A_v.a02, A_v.a10, A_v.a11, A_v.a12, A_v.a20, A_v.a21, A_v.a22};
@@ -217,15 +201,44 @@ __global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            Al[(r * 15 + c) * Ncap + i] = ab[r * 3 + c];
-            Al[(r * 15 + 3 + c) * Ncap + i] = av[r * 3 + c];
-            Al[(r * 15 + 12 + c) * Ncap + i] = aq[r * 3 + c];
+            al[r * 15 + c] = ab[r * 3 + c];
+            al[r * 15 + 3 + c] = av[r * 3 + c];
+            al[r * 15 + 12 + c] = aq[r * 3 + c];
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c)
-            Al[(r * 15 + 6 + c) * Ncap + i] = Ac[r][c];
+            al[r * 15 + 6 + c] = Ac[r][c];
     }
-    st_plane9(Bl, Ncap, i, 0, Bblk);
+    bl[0] = Bblk.a00, bl[1] = Bblk.a01, bl[2] = Bblk.a02, bl[3] = Bblk.a10, bl[4] = Bblk.a11, bl[5] = Bblk.a12, bl[6] = Bblk.a20, bl[7] = Bblk.a21, bl[8] = Bblk.a22;
+}
+__global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int Ncap, int chart, Common* __restrict__ cmdev,
+                                                    const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
+                                                    double* __restrict__ Al, double* __restrict__ Bl, trace_t* tr) {
+    trace_start(tr);
+    // The sensor-level terms arrive as a kernel argument. The grid expands the sensor blocks A_ss (21x21) and
+    // B_s (21x12) into HBM for the propagate kernels.
+    __shared__ double s_cm[9 + 9 + 9 + 36 + 3];
+    for (int t = threadIdx.x; t < 66; t += blockDim.x)
+        s_cm[t] = ck.lm[t];
+    {
+        const int gt = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+        for (int t = gt; t < 252; t += gs)
+            cmdev->Bs[t] = sensor_Bs_entry(ck, t);
+        for (int t = gt; t < 441; t += gs)
+            cmdev->Ass[t] = sensor_Ass_entry(ck, t);
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    double al[45], bl[9];
+    assemble_landmark(s_cm, chart, ld3(q0, Ncap, i), ldq(Qq, Ncap, i), Qa[i], al, bl);
+#pragma unroll
+    for (int e = 0; e < 45; ++e)
+        Al[e * Ncap + i] = al[e];
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+        Bl[e * Ncap + i] = bl[e];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -240,11 +253,13 @@ struct ObsSteps {
 // re-normalisation of the unit quaternion uses 1/sqrt(x) = 1.5 - 0.5 x (exact to O((x-1)^2), |x - 1| < 1e-9 here); 1/a is carried
 // along instead of divided out each step. Algebraically this is SO3::SO3FromVectors(p1.normalized(), q_hat.normalized()) and
 // |q_hat| / |p1| of VIOGroup.cpp:254-262; the antiparallel special case keeps the general routine.
-__device__ __forceinline__ void observer_landmark(const ObsStep* __restrict__ steps, int Ncap, int k, int i, const double* __restrict__ q0, double* __restrict__ Qq,
-                                                  double* __restrict__ Qa) {
+__device__ __forceinline__ void observer_landmark(const ObsStep* __restrict__ steps, int Ncap, int k, int i, const double* __restrict__ q0, const double* __restrict__ QqIn,
+                                                  const double* __restrict__ QaIn, double* __restrict__ Qq, double* __restrict__ Qa) {
+    // QqIn / QaIn == Qq / Qa: in place; otherwise the result goes to the other landmark buffer (fused assembly: the tiles of the
+    // same launch still read the old Q)
     const V3 p0 = ld3(q0, Ncap, i);
-    Qt q = ldq(Qq, Ncap, i);
-    double a = Qa[i];
+    Qt q = ldq(QqIn, Ncap, i);
+    double a = QaIn[i];
     double inva = 1.0 / a;
     ObsStep nxt = steps[0];
     for (int s = 0; s < k; ++s) {
@@ -300,7 +315,7 @@ __global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N
                                                  double* __restrict__ Qq, double* __restrict__ Qa) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N)
-        observer_landmark(steps_arg.s, Ncap, k, i, q0, Qq, Qa);
+        observer_landmark(steps_arg.s, Ncap, k, i, q0, Qq, Qa, Qq, Qa);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -312,6 +327,14 @@ __global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N
 // then strip blocks (landmark-sensor 3x21 blocks and their transposes), then one sensor-sensor block.
 constexpr int PT = 16; // landmarks per tile side
 constexpr int PROP_T = 3 * PT * PT; // threads per workgroup of k_propagate_main: one per (row of a 3x3 block, landmark pair)
+// Fused assembly (eqf_propagate_fast): no k_assemble_AB launch in front of the propagation. Every workgroup evaluates the rows
+// of A and B of the landmarks it needs itself (one lane per landmark, results straight into LDS), the sensor blocks come from
+// the compact terms in the argument segment.
+struct FuseArgs {
+    int on, chart;
+    double *q0o, *Qqo, *Qao; // the OTHER landmark buffer: target of the observer blocks
+    CommonK ck;
+};
 struct StageArgs {
     int M; // 0: nothing to stage
     const double *y_h, *ylm_h; // pinned host packet
@@ -325,7 +348,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
                                                         const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
                                                         const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
-                                                        trace_t* tr) {
+                                                        trace_t* tr, const FuseArgs fa) {
     trace_start(tr);
     const double dt = ra.dt;
     const int b = blockIdx.x;
@@ -347,12 +370,28 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         // Observer blocks (eqf_propagate_fast): the landmark part of the frame's observer steps rides along with the Sigma
         // propagation. This kernel touches Sigma / Al / Bl only, the assembly kernel before it has already read Q and the
         // statistics kernel after it wants the new Q: in-stream order gives all three, no second stream, no events.
+        // With fused assembly the tiles of THIS launch read Q, so the observer blocks write the other landmark buffer (the host
+        // flips to it after the launch).
         const int i = (b - (nT * nT + nStrip + 1)) * PROP_T + tid;
-        if (i < N)
-            observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa);
+        if (i < N) {
+            if (fa.on) {
+                fa.q0o[i] = q0[i];
+                fa.q0o[Ncap + i] = q0[Ncap + i];
+                fa.q0o[2 * Ncap + i] = q0[2 * Ncap + i];
+                observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, fa.Qqo, fa.Qao);
+            } else {
+                observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, Qq, Qa);
+            }
+        }
         return;
     }
     __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
+    __shared__ double s_cm[66];
+    if (fa.on) {
+        for (int t = tid; t < 66; t += PROP_T)
+            s_cm[t] = fa.ck.lm[t];
+        __syncthreads();
+    }
     if (b < nT * nT) {
         const int bi = b % nT, bj = b / nT;
         // per-i arrays: G (63), Fls (36), D (9), Bl (9) ; per-j arrays: Ssj (63), Fls (36), D (9), Bl (9). layout [e][PT]
@@ -376,22 +415,56 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         }
         if (tid < 12 * 21)
             sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
-        for (int t = tid; t < 36 * PT; t += PROP_T) {
-            const int e = t / PT, x = t % PT;
-            const int r = e / 12, c = e % 12;
-            const int i = bi * PT + x, j = bj * PT + x;
-            sFi[t] = i < N ? dt * Al[(r * 15 + c) * Ncap + i] : 0.0;
-            sFj[t] = j < N ? dt * Al[(r * 15 + c) * Ncap + j] : 0.0;
-        }
-        for (int t = tid; t < 9 * PT; t += PROP_T) {
-            const int e = t / PT, x = t % PT;
-            const int r = e / 3, c = e % 3;
-            const int i = bi * PT + x, j = bj * PT + x;
-            const double eye = (r == c) ? 1.0 : 0.0;
-            sDi[t] = i < N ? dt * Al[(r * 15 + 12 + c) * Ncap + i] + eye : 0.0;
-            sDj[t] = j < N ? dt * Al[(r * 15 + 12 + c) * Ncap + j] + eye : 0.0;
-            sBi[t] = i < N ? Bl[e * Ncap + i] : 0.0;
-            sBj[t] = j < N ? Bl[e * Ncap + j] : 0.0;
+        if (fa.on) {
+            // lanes 0..PT-1 assemble the i-landmarks, lanes PT..2PT-1 the j-landmarks (the other threads are loading Sigma meanwhile)
+            if (tid < 2 * PT) {
+                const bool isj = tid >= PT;
+                const int x = tid % PT;
+                const int l = (isj ? bj : bi) * PT + x;
+                double* dF = isj ? sFj : sFi;
+                double* dD = isj ? sDj : sDi;
+                double* dB = isj ? sBj : sBi;
+                double al[45], bl[9];
+                if (l < N) {
+                    assemble_landmark(s_cm, fa.chart, ld3(q0, Ncap, l), ldq(Qq, Ncap, l), Qa[l], al, bl);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 45; ++e)
+                        al[e] = 0.0;
+#pragma unroll
+                    for (int e = 0; e < 9; ++e)
+                        bl[e] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 12; ++c)
+                        dF[(r * 12 + c) * PT + x] = l < N ? dt * al[r * 15 + c] : 0.0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        dD[(r * 3 + c) * PT + x] = l < N ? dt * al[r * 15 + 12 + c] + ((r == c) ? 1.0 : 0.0) : 0.0;
+                        dB[(r * 3 + c) * PT + x] = bl[r * 3 + c];
+                    }
+                }
+            }
+        } else {
+            for (int t = tid; t < 36 * PT; t += PROP_T) {
+                const int e = t / PT, x = t % PT;
+                const int r = e / 12, c = e % 12;
+                const int i = bi * PT + x, j = bj * PT + x;
+                sFi[t] = i < N ? dt * Al[(r * 15 + c) * Ncap + i] : 0.0;
+                sFj[t] = j < N ? dt * Al[(r * 15 + c) * Ncap + j] : 0.0;
+            }
+            for (int t = tid; t < 9 * PT; t += PROP_T) {
+                const int e = t / PT, x = t % PT;
+                const int r = e / 3, c = e % 3;
+                const int i = bi * PT + x, j = bj * PT + x;
+                const double eye = (r == c) ? 1.0 : 0.0;
+                sDi[t] = i < N ? dt * Al[(r * 15 + 12 + c) * Ncap + i] + eye : 0.0;
+                sDj[t] = j < N ? dt * Al[(r * 15 + 12 + c) * Ncap + j] + eye : 0.0;
+                sBi[t] = i < N ? Bl[e * Ncap + i] : 0.0;
+                sBj[t] = j < N ? Bl[e * Ncap + j] : 0.0;
+            }
         }
         __syncthreads();
         // G_i[r][k] = sum_e (dt A_ls_i)[r][e] Sigma_ss[al_col(e)][k] + sum_c' (I + dt A_qi)[r][c'] Sigma[l_i + c'][k]
@@ -462,9 +535,33 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         constexpr int SL = 12;
         double* sG = sm;                  // [lm][r*21 + k]  (SL x 63)
         double* sSs = sm + SL * 63;       // Sigma_ss[al_col(e)][k] at [e*21 + k]
+        double* sAl = sSs + 252;          // fused assembly: rows of A of the SL landmarks [lm][45] ...
+        double* sBl = sAl + SL * 45;      // ... rows of B [lm][9] ...
+        double* sAss = sBl + SL * 9;      // ... and the sensor blocks A_ss (441), B_s (252)
+        double* sBs = sAss + 441;
         const int i0 = (b - nT * nT) * SL;
         if (tid < 12 * 21)
             sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
+        if (fa.on) {
+            // lanes 256.. assemble the landmarks (the first 252 are loading Sigma_ss), everyone expands the sensor blocks
+            if (tid >= 256 && tid < 256 + SL) {
+                const int x = tid - 256, l = i0 + x;
+                double al[45], bl[9];
+                if (l < N) {
+                    assemble_landmark(s_cm, fa.chart, ld3(q0, Ncap, l), ldq(Qq, Ncap, l), Qa[l], al, bl);
+#pragma unroll
+                    for (int e = 0; e < 45; ++e)
+                        sAl[x * 45 + e] = al[e];
+#pragma unroll
+                    for (int e = 0; e < 9; ++e)
+                        sBl[x * 9 + e] = bl[e];
+                }
+            }
+            for (int t = tid; t < 441; t += PROP_T)
+                sAss[t] = sensor_Ass_entry(fa.ck, t);
+            for (int t = tid; t < 252; t += PROP_T)
+                sBs[t] = sensor_Bs_entry(fa.ck, t);
+        }
         __syncthreads();
         for (int t = tid; t < SL * 63; t += PROP_T) {
             const int x = t / 63, e = t % 63;
@@ -474,10 +571,10 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             if (i < N) {
 #pragma unroll
                 for (int q = 0; q < 12; ++q)
-                    g += dt * Al[(r * 15 + q) * Ncap + i] * sSs[q * 21 + k];
+                    g += dt * (fa.on ? sAl[x * 45 + r * 15 + q] : Al[(r * 15 + q) * Ncap + i]) * sSs[q * 21 + k];
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc)
-                    g += (dt * Al[(r * 15 + 12 + cc) * Ncap + i] + (r == cc ? 1.0 : 0.0)) * Sig[k + (size_t)(21 + 3 * i + cc) * ld];
+                    g += (dt * (fa.on ? sAl[x * 45 + r * 15 + 12 + cc] : Al[(r * 15 + 12 + cc) * Ncap + i]) + (r == cc ? 1.0 : 0.0)) * Sig[k + (size_t)(21 + 3 * i + cc) * ld];
             }
             sG[t] = g;
         }
@@ -491,13 +588,13 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         for (int r = 0; r < 3; ++r) {
             double s = 0;
             for (int k = 0; k < 21; ++k) {
-                const double f = dt * cm->Ass[c * 21 + k] + (k == c ? 1.0 : 0.0);
+                const double f = dt * (fa.on ? sAss[c * 21 + k] : cm->Ass[c * 21 + k]) + (k == c ? 1.0 : 0.0);
                 s += sG[x * 63 + r * 21 + k] * f;
             }
             double bq = 0;
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                bq += Bl[(r * 3 + q) * Ncap + i] * ra.Qd[q] * cm->Bs[c * 12 + q];
+                bq += (fa.on ? sBl[x * 9 + r * 3 + q] : Bl[(r * 3 + q) * Ncap + i]) * ra.Qd[q] * (fa.on ? sBs[c * 12 + q] : cm->Bs[c * 12 + q]);
             s += dt * bq;
             Sout[li + r + (size_t)c * ld] = s;
             Sout[c + (size_t)(li + r) * ld] = s;
@@ -509,11 +606,14 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         double* sF = sm;        // 441
         double* sS = sm + 441;  // 441
         double* sT = sm + 882;  // 441  (F Sigma_ss)
+        double* sBs = sm + 1323; // 252 (fused assembly: B_s expanded from the compact terms)
         for (int t = tid; t < 441; t += PROP_T) {
             const int r = t / 21, c = t % 21;
-            sF[t] = dt * cm->Ass[t] + (r == c ? 1.0 : 0.0);
+            sF[t] = dt * (fa.on ? sensor_Ass_entry(fa.ck, t) : cm->Ass[t]) + (r == c ? 1.0 : 0.0);
             sS[t] = Sig[r + (size_t)c * ld];
         }
+        for (int t = tid; t < 252; t += PROP_T)
+            sBs[t] = fa.on ? sensor_Bs_entry(fa.ck, t) : cm->Bs[t];
         __syncthreads();
         for (int t = tid; t < 441; t += PROP_T) {
             const int r = t / 21, c = t % 21;
@@ -530,7 +630,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                 s += sT[r * 21 + k] * sF[c * 21 + k];
             double bq = 0;
             for (int q = 0; q < 12; ++q)
-                bq += cm->Bs[r * 12 + q] * ra.Qd[q] * cm->Bs[c * 12 + q];
+                bq += sBs[r * 12 + q] * ra.Qd[q] * sBs[c * 12 + q];
             s += dt * bq;
             if (r == c)
                 s += dt * ra.Pd[r / 3];

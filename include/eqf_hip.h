@@ -51,6 +51,8 @@ enum {
     EQF_OPT_TRACE = 9,         /* 1: the frame's kernels stamp the device wall clock (100 MHz) into a ring (eqf_trace_read); 0 (default): off */
     EQF_OPT_TWO_PHASE = 10,    /* factorisation steps whose trailing matrix has at least this many 32x32 tiles run in two launches (P for every
                                   block row once, then the tile updates); default 700 (N = 500: the first 19 of 32 steps, +9 %; never at N = 200); 0: never */
+    EQF_OPT_FUSED_ASSEMBLY = 11, /* 1 (default): eqf_propagate_fast has no assembly launch: the propagation kernel's workgroups evaluate the rows of
+                                  A and B they need themselves and its observer blocks write the second landmark buffer; 0: k_assemble_AB first */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati and the fused update return EQF_E_UNSUPPORTED.

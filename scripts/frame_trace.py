@@ -27,6 +27,8 @@ while pos + CH <= 300 + nfr:
     for back in range(CH - 2, 1, -1):  # complete frames only: f and f + 1 both in the ring, not across a read
         f = last.value - back
         d0, d1, h0, h1 = dev[f % R].astype(np.float64) * TICK, dev[(f + 1) % R].astype(np.float64) * TICK, host[f % R] * 1e-3, host[(f + 1) % R] * 1e-3
+        if d0[0] == 0:  # fused assembly (the default): no assembly kernel, the frame starts with the propagation kernel
+            d0[0], d1[0] = d0[1], d1[1]
         if d0[0] == 0 or d1[0] == 0 or d0[41] == 0:
             continue
         nsteps = int(np.count_nonzero(d0[3:35]))
