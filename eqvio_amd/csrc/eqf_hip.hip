@@ -138,7 +138,7 @@ struct eqf_ctx {
     SensorState xi0;
     GroupSensor X;
     // device
-    double* d_lm[2] = {nullptr, nullptr}; // each: q0 (3 planes), Qq (4 planes), Qa (1 plane) = 8*Ncap
+    double* d_lm[2] = {nullptr, nullptr}; // each: q0 (3 planes), Qq (4 planes), Qa (1 plane), chart constants of q0 (27 planes) = 35*Ncap
     int lmcur = 0;
     double* d_sigma[2] = {nullptr, nullptr};
     int cur = 0;
@@ -512,8 +512,8 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     for (int b = 0; b < 2; ++b) {
         HIPCHK(hipMalloc(&c->d_sigma[b], sig_bytes));
         HIPCHK(hipMemsetAsync(c->d_sigma[b], 0, sig_bytes, c->stream));
-        HIPCHK(hipMalloc(&c->d_lm[b], sizeof(double) * 8 * (size_t)c->Ncap));
-        HIPCHK(hipMemsetAsync(c->d_lm[b], 0, sizeof(double) * 8 * (size_t)c->Ncap, c->stream));
+        HIPCHK(hipMalloc(&c->d_lm[b], sizeof(double) * (LM_PLANES + CC_PLANES) * (size_t)c->Ncap));
+        HIPCHK(hipMemsetAsync(c->d_lm[b], 0, sizeof(double) * (LM_PLANES + CC_PLANES) * (size_t)c->Ncap, c->stream));
     }
     HIPCHK(hipMalloc(&c->d_Al, sizeof(double) * 45 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_Bl, sizeof(double) * 9 * (size_t)c->Ncap));

@@ -97,6 +97,16 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     y = y * fma(-h * y, y, 1.5);
     return y;
 }
+// Chart constants of a landmark's origin point q0_i (InvDepth chart): conv_euc2ind, conv_ind2euc, ind2euc_r0 (invdepth.cpp:65-81,
+// 201-207) cost a dozen square roots / divisions and a rotation from two vectors, and q0_i changes only when a landmark is added.
+// They are stored once (k_scatter_landmarks) as 27 more SoA planes behind q0 | Qq | Qa in the same landmark buffer, so every
+// kernel that has the q0 pointer finds them at a fixed offset.
+constexpr int LM_PLANES = 8, CC_E2I = 0, CC_I2E = 9, CC_R0 = 18, CC_PLANES = 27;
+__device__ __forceinline__ M3 ld_cc(const double* __restrict__ q0, int Ncap, int i, int which) {
+    const double* b = q0 + (size_t)(LM_PLANES + which) * Ncap + i;
+    return M3{b[0], b[Ncap], b[2 * (size_t)Ncap], b[3 * (size_t)Ncap], b[4 * (size_t)Ncap], b[5 * (size_t)Ncap], b[6 * (size_t)Ncap], b[7 * (size_t)Ncap], b[8 * (size_t)Ncap]};
+}
+
 // column index in A of packed column e (0..11) of the landmark-sensor block
 __host__ __device__ __forceinline__ int al_col(int e) { return e < 3 ? e : (e < 6 ? 12 + (e - 3) : 15 + (e - 6)); }
 
@@ -143,7 +153,8 @@ __device__ __forceinline__ double sensor_Ass_entry(const CommonK& ck, int t) {
 }
 // The rows of A and B of ONE landmark: al[r * 15 + c] (packed columns: 0:3 | 12:15 | 15:21 | own 3x3) and bl[9].
 // s_cm: the 66 per-landmark factors (Mv, RTic, RTicSx, CT, vC) in LDS.
-__device__ __forceinline__ void assemble_landmark(const double* __restrict__ s_cm, int chart, const V3 p0, const Qt q, const double a, double (&al)[45], double (&bl)[9]) {
+__device__ __forceinline__ void assemble_landmark(const double* __restrict__ s_cm, int chart, const V3 p0, const Qt q, const double a, const M3& e2i, const M3& i2e,
+                                                  double (&al)[45], double (&bl)[9]) {
     const M3 Mv = ldm3(s_cm), RTic = ldm3(s_cm + 9), RTicSx = ldm3(s_cm + 18);
     const double* CT = s_cm + 27;
     const V3 vC{s_cm[63], s_cm[64], s_cm[65]};
@@ -174,9 +185,7 @@ __device__ __forceinline__ void assemble_landmark(const double* __restrict__ s_c
     const M3 QhatInv = (1.0 / a) * transpose(RQ);
     M3 A_q = (-1.0 / norm2(qh)) * (Qhat * inner * QhatInv);
 
-    if (chart == EQVIO_COORD_INVDEPTH) {
-        const M3 e2i = conv_euc2ind(p0);
-        const M3 i2e = conv_ind2euc(p0);
+    if (chart == EQVIO_COORD_INVDEPTH) { // e2i = conv_euc2ind(p0), i2e = conv_ind2euc(p0): stored chart constants
         Bblk = e2i * Bblk;
         A_v = e2i * A_v;
         const double e[3][3] = {{e2i.a00, e2i.a01, e2i.a02}, {e2i.a10, e2i.a11, e2i.a12}, {e2i.a20, e2i.a21, e2i.a22}};
@@ -232,7 +241,8 @@ __global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int
     if (i >= N)
         return;
     double al[45], bl[9];
-    assemble_landmark(s_cm, chart, ld3(q0, Ncap, i), ldq(Qq, Ncap, i), Qa[i], al, bl);
+    const bool ind = chart == EQVIO_COORD_INVDEPTH;
+    assemble_landmark(s_cm, chart, ld3(q0, Ncap, i), ldq(Qq, Ncap, i), Qa[i], ind ? ld_cc(q0, Ncap, i, CC_E2I) : M3{}, ind ? ld_cc(q0, Ncap, i, CC_I2E) : M3{}, al, bl);
 #pragma unroll
     for (int e = 0; e < 45; ++e)
         Al[e * Ncap + i] = al[e];
@@ -378,6 +388,9 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                 fa.q0o[i] = q0[i];
                 fa.q0o[Ncap + i] = q0[Ncap + i];
                 fa.q0o[2 * Ncap + i] = q0[2 * Ncap + i];
+#pragma unroll
+                for (int c = LM_PLANES; c < LM_PLANES + CC_PLANES; ++c)
+                    fa.q0o[(size_t)c * Ncap + i] = q0[(size_t)c * Ncap + i];
                 observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, fa.Qqo, fa.Qao);
             } else {
                 observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, Qq, Qa);
@@ -426,7 +439,9 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                 double* dB = isj ? sBj : sBi;
                 double al[45], bl[9];
                 if (l < N) {
-                    assemble_landmark(s_cm, fa.chart, ld3(q0, Ncap, l), ldq(Qq, Ncap, l), Qa[l], al, bl);
+                    const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
+                    assemble_landmark(s_cm, fa.chart, ld3(q0, Ncap, l), ldq(Qq, Ncap, l), Qa[l], ind ? ld_cc(q0, Ncap, l, CC_E2I) : M3{}, ind ? ld_cc(q0, Ncap, l, CC_I2E) : M3{}, al,
+                                      bl);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 45; ++e)
@@ -548,7 +563,9 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                 const int x = tid - 256, l = i0 + x;
                 double al[45], bl[9];
                 if (l < N) {
-                    assemble_landmark(s_cm, fa.chart, ld3(q0, Ncap, l), ldq(Qq, Ncap, l), Qa[l], al, bl);
+                    const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
+                    assemble_landmark(s_cm, fa.chart, ld3(q0, Ncap, l), ldq(Qq, Ncap, l), Qa[l], ind ? ld_cc(q0, Ncap, l, CC_E2I) : M3{}, ind ? ld_cc(q0, Ncap, l, CC_I2E) : M3{}, al,
+                                      bl);
 #pragma unroll
                     for (int e = 0; e < 45; ++e)
                         sAl[x * 45 + e] = al[e];
@@ -666,7 +683,7 @@ struct MeasOut {
     double yt[2];
     V3 qh;
 };
-__device__ __forceinline__ MeasOut measure_one(int chart, const Cam& cam, V3 p0, Qt q, double a, double yu, double yv, bool star) {
+__device__ __forceinline__ MeasOut measure_one(int chart, const Cam& cam, V3 p0, Qt q, double a, double yu, double yv, bool star, const M3& r0m) {
     MeasOut o;
     const M3 RQ = q_mat(q);
     const V3 qh = (1.0 / a) * (transpose(RQ) * p0);
@@ -684,8 +701,8 @@ __device__ __forceinline__ MeasOut measure_one(int chart, const Cam& cam, V3 p0,
     const double iq2 = 1.0 / norm2(p0);
     V3 c0 = iq2 * cross(p0, RQ * g0);
     V3 c1 = iq2 * cross(p0, RQ * g1);
-    if (chart == EQVIO_COORD_INVDEPTH) {
-        const M3 Mt = transpose(ind2euc_r0(p0));
+    if (chart == EQVIO_COORD_INVDEPTH) { // r0m = ind2euc_r0(p0): stored chart constant
+        const M3 Mt = transpose(r0m);
         c0 = Mt * c0;
         c1 = Mt * c1;
     }
@@ -711,7 +728,8 @@ __global__ void __launch_bounds__(64) k_measure(int M, int Mcap, int Ncap, int c
         return;
     const int i = lmidx[j];
     lmidx_dev[j] = i;
-    const MeasOut o = measure_one(chart, cam, ld3(q0, Ncap, i), ldq(Qq, Ncap, i), Qa[i], y[2 * j], y[2 * j + 1], star != 0);
+    const MeasOut o = measure_one(chart, cam, ld3(q0, Ncap, i), ldq(Qq, Ncap, i), Qa[i], y[2 * j], y[2 * j + 1], star != 0,
+                                  chart == EQVIO_COORD_INVDEPTH ? ld_cc(q0, Ncap, i, CC_R0) : M3{});
 #pragma unroll
     for (int e = 0; e < 6; ++e)
         C[e * Mcap + j] = o.c[e];
@@ -749,9 +767,10 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
         out[2 * N + i] = norm2(qh);
         return;
     }
-    const MeasOut o = measure_one(chart, cam, p0, q, a, yu, yv, false);
+    const M3 r0m = chart == EQVIO_COORD_INVDEPTH ? ld_cc(q0, Ncap, i, CC_R0) : M3{};
+    const MeasOut o = measure_one(chart, cam, p0, q, a, yu, yv, false, r0m);
     if (emit) {
-        const MeasOut os = star ? measure_one(chart, cam, p0, q, a, yu, yv, true) : o;
+        const MeasOut os = star ? measure_one(chart, cam, p0, q, a, yu, yv, true, r0m) : o;
 #pragma unroll
         for (int e = 0; e < 6; ++e)
             C[e * Ncap + j] = os.c[e];
@@ -1072,7 +1091,8 @@ struct MeasFuse {
 __device__ __forceinline__ MeasOut measure_j(const MeasFuse& mf, int j, int& i_out) {
     const int i = mf.lmidx[j];
     i_out = i;
-    return measure_one(mf.chart, mf.cam, ld3(mf.q0, mf.Ncap, i), ldq(mf.Qq, mf.Ncap, i), mf.Qa[i], mf.y[2 * j], mf.y[2 * j + 1], mf.star != 0);
+    return measure_one(mf.chart, mf.cam, ld3(mf.q0, mf.Ncap, i), ldq(mf.Qq, mf.Ncap, i), mf.Qa[i], mf.y[2 * j], mf.y[2 * j + 1], mf.star != 0,
+                       mf.chart == EQVIO_COORD_INVDEPTH ? ld_cc(mf.q0, mf.Ncap, i, CC_R0) : M3{});
 }
 template <typename TS>
 __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
@@ -1767,7 +1787,7 @@ __device__ __forceinline__ void lift_landmark(int i, const V3 g, int N, int Ncap
         Dq = so3_from_vectors(normalized(q1), normalized(p0));
         Da = norm(p0) / norm(q1);
     } else {
-        const V3 ge = (chart == EQVIO_COORD_INVDEPTH) ? ind2euc_r0(p0) * g : g;
+        const V3 ge = (chart == EQVIO_COORD_INVDEPTH) ? ld_cc(q0, Ncap, i, CC_R0) * g : g; // ind2euc_r0(p0): stored chart constant
         const double iq2 = 1.0 / norm2(p0);
         const V3 Wr = (-iq2) * cross(p0, ge);
         const double Ws = -iq2 * dot(p0, ge);
@@ -1851,6 +1871,13 @@ __global__ void k_scatter_landmarks(int k, int dst0, int Ncap, const double* __r
     const int i = dst0 + t;
     for (int c = 0; c < 3; ++c)
         q0[c * Ncap + i] = p_aos[3 * t + c];
+    { // chart constants of the new origin point (ld_cc): the only place they are computed
+        const V3 p{p_aos[3 * t], p_aos[3 * t + 1], p_aos[3 * t + 2]};
+        double* cc = q0 + (size_t)LM_PLANES * Ncap;
+        st_plane9(cc, Ncap, i, CC_E2I, conv_euc2ind(p));
+        st_plane9(cc, Ncap, i, CC_I2E, conv_ind2euc(p));
+        st_plane9(cc, Ncap, i, CC_R0, ind2euc_r0(p));
+    }
     if (Q_aos) {
         for (int c = 0; c < 4; ++c)
             Qq[c * Ncap + i] = Q_aos[5 * t + c];
@@ -1897,6 +1924,8 @@ __global__ void k_compact_landmarks(int Nnew, int Ncap, const int* __restrict__ 
     for (int c = 0; c < 4; ++c)
         Qqo[c * Ncap + i] = Qqi[c * Ncap + o];
     Qao[i] = Qai[o];
+    for (int c = LM_PLANES; c < LM_PLANES + CC_PLANES; ++c) // chart constants travel with their landmark
+        q0o[(size_t)c * Ncap + i] = q0i[(size_t)c * Ncap + o];
 }
 // append: zero the new strips, put var on the new diagonal (addNewLandmarks, VIO_eqf.cpp:239-244)
 template <typename TS>
