@@ -138,8 +138,12 @@ struct eqf_ctx {
     SensorState xi0;
     GroupSensor X;
     // device
-    double* d_lm[2] = {nullptr, nullptr}; // each: q0 (3 planes), Qq (4 planes), Qa (1 plane), chart constants of q0 (27 planes) = 35*Ncap
-    int lmcur = 0;
+    // Landmark arrays, SoA planes of stride Ncap. Static part: q0 (3 planes) + the chart constants of q0 (27 planes); it changes only
+    // when landmarks are added / removed. Dynamic part: Qq (4 planes) + Qa (1 plane). Both double-buffered: compaction is out of place
+    // and flips both, the observer blocks of a fused propagation write the other DYNAMIC buffer and flip only that one.
+    double* d_st[2] = {nullptr, nullptr};
+    double* d_lm[2] = {nullptr, nullptr};
+    int stcur = 0, lmcur = 0;
     double* d_sigma[2] = {nullptr, nullptr};
     int cur = 0;
     double *d_Al = nullptr, *d_Bl = nullptr;
@@ -208,9 +212,9 @@ struct eqf_ctx {
     std::vector<hipEvent_t> evpool;
     size_t evused = 0;
 
-    double* q0() { return d_lm[lmcur]; }
-    double* Qq() { return d_lm[lmcur] + 3 * (size_t)Ncap; }
-    double* Qa() { return d_lm[lmcur] + 7 * (size_t)Ncap; }
+    double* q0() { return d_st[stcur]; }
+    double* Qq() { return d_lm[lmcur]; }
+    double* Qa() { return d_lm[lmcur] + 4 * (size_t)Ncap; }
     double* sigma() { return d_sigma[cur]; }
     int n() const { return 21 + 3 * N; }
 };
@@ -512,8 +516,10 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     for (int b = 0; b < 2; ++b) {
         HIPCHK(hipMalloc(&c->d_sigma[b], sig_bytes));
         HIPCHK(hipMemsetAsync(c->d_sigma[b], 0, sig_bytes, c->stream));
-        HIPCHK(hipMalloc(&c->d_lm[b], sizeof(double) * (LM_PLANES + CC_PLANES) * (size_t)c->Ncap));
-        HIPCHK(hipMemsetAsync(c->d_lm[b], 0, sizeof(double) * (LM_PLANES + CC_PLANES) * (size_t)c->Ncap, c->stream));
+        HIPCHK(hipMalloc(&c->d_st[b], sizeof(double) * (CC_OFF + CC_PLANES) * (size_t)c->Ncap));
+        HIPCHK(hipMemsetAsync(c->d_st[b], 0, sizeof(double) * (CC_OFF + CC_PLANES) * (size_t)c->Ncap, c->stream));
+        HIPCHK(hipMalloc(&c->d_lm[b], sizeof(double) * 5 * (size_t)c->Ncap));
+        HIPCHK(hipMemsetAsync(c->d_lm[b], 0, sizeof(double) * 5 * (size_t)c->Ncap, c->stream));
     }
     HIPCHK(hipMalloc(&c->d_Al, sizeof(double) * 45 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_Bl, sizeof(double) * 9 * (size_t)c->Ncap));
@@ -572,6 +578,7 @@ void eqf_destroy(eqf_ctx* c) {
     for (int b = 0; b < 2; ++b) {
         hipFree(c->d_sigma[b]);
         hipFree(c->d_lm[b]);
+        hipFree(c->d_st[b]);
     }
     hipFree(c->d_Al);
     hipFree(c->d_Bl);
@@ -959,13 +966,14 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
         if (Nnew > 0) {
             double* src = c->d_lm[c->lmcur];
             double* dst = c->d_lm[1 - c->lmcur];
-            hipLaunchKernelGGL(k_compact_landmarks, dim3(blocks(Nnew, 64)), dim3(64), 0, c->stream, Nnew, c->Ncap, c->d_keep, src, src + 3 * (size_t)c->Ncap,
-                               src + 7 * (size_t)c->Ncap, dst, dst + 3 * (size_t)c->Ncap, dst + 7 * (size_t)c->Ncap);
+            hipLaunchKernelGGL(k_compact_landmarks, dim3(blocks(Nnew, 64)), dim3(64), 0, c->stream, Nnew, c->Ncap, c->d_keep, c->d_st[c->stcur], src, src + 4 * (size_t)c->Ncap,
+                               c->d_st[1 - c->stcur], dst, dst + 4 * (size_t)c->Ncap);
             HIPCHK(hipGetLastError());
         }
     }
     c->cur = 1 - c->cur;
     c->lmcur = 1 - c->lmcur;
+    c->stcur = 1 - c->stcur;
     c->ids = newids;
     c->N = Nnew;
     ++c->lm_gen;
@@ -1019,7 +1027,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
     double* Sin = c->d_sigma[c->cur];
     double* Sout = c->d_sigma[1 - c->cur];
     if (!c->opt_dense) {
-        const int nT = blocks(N, PT), nStrip = blocks(N, 12);
+        const int nT = blocks(N, PT), nStrip = 0; // the landmark-sensor strips are written by the tile workgroups of column 0
         const int nObs = (obs && obs_k > 0) ? blocks(N, PROP_T) : 0;
         StageArgs sg{};
         if (c->stage_pending) { // one more block copies the staged measurement from the pinned packet to HBM
@@ -1037,7 +1045,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
             fa.on = 1;
             fa.chart = c->chart;
             double* other = c->d_lm[1 - c->lmcur];
-            fa.q0o = other, fa.Qqo = other + 3 * (size_t)c->Ncap, fa.Qao = other + 7 * (size_t)c->Ncap;
+            fa.Qqo = other, fa.Qao = other + 4 * (size_t)c->Ncap;
             fa.ck = c->ck;
         }
         KTimer t(c, KN_PROP_MAIN);
@@ -1300,7 +1308,12 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
             hipLaunchKernelGGL(k_chol_panel, dim3(gx), dim3(256), 0, c->stream, rows, kb, w, ldz, Z, W, Lin, spec, spec_seq);
             HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_chol_step, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
+        if (two_phase)
+            hipLaunchKernelGGL(k_chol_step<true>, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
+                           nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld, (gpart || nsig) && step < 32 ? trace_slot(c, TR_STEP0 + step) : nullptr,
+                           two_phase ? (const double*)W : (const double*)nullptr);
+        else
+            hipLaunchKernelGGL(k_chol_step<false>, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
                            nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld, (gpart || nsig) && step < 32 ? trace_slot(c, TR_STEP0 + step) : nullptr,
                            two_phase ? (const double*)W : (const double*)nullptr);
         HIPCHK(hipGetLastError());

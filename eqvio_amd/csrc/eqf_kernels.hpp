@@ -99,11 +99,11 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 // Chart constants of a landmark's origin point q0_i (InvDepth chart): conv_euc2ind, conv_ind2euc, ind2euc_r0 (invdepth.cpp:65-81,
 // 201-207) cost a dozen square roots / divisions and a rotation from two vectors, and q0_i changes only when a landmark is added.
-// They are stored once (k_scatter_landmarks) as 27 more SoA planes behind q0 | Qq | Qa in the same landmark buffer, so every
-// kernel that has the q0 pointer finds them at a fixed offset.
-constexpr int LM_PLANES = 8, CC_E2I = 0, CC_I2E = 9, CC_R0 = 18, CC_PLANES = 27;
+// They are stored once (k_scatter_landmarks) as 27 more SoA planes behind the 3 planes of q0 (the static half of the landmark
+// arrays), so every kernel that has the q0 pointer finds them at a fixed offset.
+constexpr int CC_OFF = 3, CC_E2I = 0, CC_I2E = 9, CC_R0 = 18, CC_PLANES = 27;
 __device__ __forceinline__ M3 ld_cc(const double* __restrict__ q0, int Ncap, int i, int which) {
-    const double* b = q0 + (size_t)(LM_PLANES + which) * Ncap + i;
+    const double* b = q0 + (size_t)(CC_OFF + which) * Ncap + i;
     return M3{b[0], b[Ncap], b[2 * (size_t)Ncap], b[3 * (size_t)Ncap], b[4 * (size_t)Ncap], b[5 * (size_t)Ncap], b[6 * (size_t)Ncap], b[7 * (size_t)Ncap], b[8 * (size_t)Ncap]};
 }
 
@@ -342,7 +342,7 @@ constexpr int PROP_T = 3 * PT * PT; // threads per workgroup of k_propagate_main
 // the compact terms in the argument segment.
 struct FuseArgs {
     int on, chart;
-    double *q0o, *Qqo, *Qao; // the OTHER landmark buffer: target of the observer blocks
+    double *Qqo, *Qao; // the OTHER dynamic landmark buffer: target of the observer blocks
     CommonK ck;
 };
 struct StageArgs {
@@ -380,17 +380,11 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         // Observer blocks (eqf_propagate_fast): the landmark part of the frame's observer steps rides along with the Sigma
         // propagation. This kernel touches Sigma / Al / Bl only, the assembly kernel before it has already read Q and the
         // statistics kernel after it wants the new Q: in-stream order gives all three, no second stream, no events.
-        // With fused assembly the tiles of THIS launch read Q, so the observer blocks write the other landmark buffer (the host
-        // flips to it after the launch).
+        // With fused assembly the tiles of THIS launch read Q, so the observer blocks write the other (Qq, Qa) buffer (the host
+        // flips to it after the launch; q0 and its chart constants live in a buffer of their own and stay where they are).
         const int i = (b - (nT * nT + nStrip + 1)) * PROP_T + tid;
         if (i < N) {
             if (fa.on) {
-                fa.q0o[i] = q0[i];
-                fa.q0o[Ncap + i] = q0[Ncap + i];
-                fa.q0o[2 * Ncap + i] = q0[2 * Ncap + i];
-#pragma unroll
-                for (int c = LM_PLANES; c < LM_PLANES + CC_PLANES; ++c)
-                    fa.q0o[(size_t)c * Ncap + i] = q0[(size_t)c * Ncap + i];
                 observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, fa.Qqo, fa.Qao);
             } else {
                 observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, Qq, Qa);
@@ -399,6 +393,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         return;
     }
     __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
+    __shared__ double sSens[21 * 33]; // per strip column of this workgroup: row c of A_ss (21) | row c of B_s (12)
     __shared__ double s_cm[66];
     if (fa.on) {
         for (int t = tid; t < 66; t += PROP_T)
@@ -428,6 +423,13 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         }
         if (tid < 12 * 21)
             sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
+        // the strip columns this workgroup writes (below): c = bj, bj + nT, ... ; their rows of the sensor blocks go to LDS
+        const int ncol = bj < 21 ? (21 - bj + nT - 1) / nT : 0;
+        for (int t = PROP_T - 1 - tid; t < ncol * 33; t += PROP_T) { // taken from the top of the workgroup: the first lanes assemble
+            const int m_ = t / 33, e = t % 33;
+            const int c = bj + nT * m_;
+            sSens[t] = e < 21 ? (fa.on ? sensor_Ass_entry(fa.ck, c * 21 + e) : cm->Ass[c * 21 + e]) : (fa.on ? sensor_Bs_entry(fa.ck, c * 12 + (e - 21)) : cm->Bs[c * 12 + (e - 21)]);
+        }
         if (fa.on) {
             // lanes 0..PT-1 assemble the i-landmarks, lanes PT..2PT-1 the j-landmarks (the other threads are loading Sigma meanwhile)
             if (tid < 2 * PT) {
@@ -496,6 +498,31 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             sGi[t] = g;
         }
         __syncthreads();
+        {
+            // Landmark-sensor strips of the PT i-landmarks: Sigma'[l_i + r][c] = sum_k G_i[r][k] Fss[c][k] + dt sum_q Bl_i[r][q] Qd[q] Bs[c][q].
+            // G_i is in LDS here anyway; the nT workgroups of this block row share the 21 columns (c = bj, bj + nT, ...), at most a few
+            // outputs per workgroup. Same sums, in the same order, as a separate strip pass would evaluate.
+            for (int t = tid; t < PT * 3 * ncol; t += PROP_T) {
+                const int x = t % PT, rc = t / PT;
+                const int r = rc % 3, m_ = rc / 3, c = bj + nT * m_;
+                const int i = bi * PT + x;
+                if (i < N) {
+                    double sacc = 0;
+                    for (int k = 0; k < 21; ++k) {
+                        const double f = dt * sSens[m_ * 33 + k] + (k == c ? 1.0 : 0.0);
+                        sacc += sGi[(r * 21 + k) * PT + x] * f;
+                    }
+                    double bq = 0;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        bq += sBi[(r * 3 + q) * PT + x] * ra.Qd[q] * sSens[m_ * 33 + 21 + q];
+                    sacc += dt * bq;
+                    const int li = 21 + 3 * i;
+                    Sout[li + r + (size_t)c * ld] = sacc;
+                    Sout[c + (size_t)(li + r) * ld] = sacc;
+                }
+            }
+        }
         // lane = (output row r, landmark pair (ti, tj)): three lanes share a 3x3 block, each produces one row of it. The
         // per-element sums run in the same order as a one-lane-per-block version would (results are bit-identical to it).
         const int r = tid / (PT * PT), tp = tid % (PT * PT);
@@ -1358,6 +1385,7 @@ __global__ void __launch_bounds__(256) k_chol_panel(int rows, int kb, int w, int
     }
 }
 constexpr int GAMMA_G = 4; // column groups of the Gamma partials computed by the last step launch
+template <bool PRE> // PRE: second half of a two-phase step (P comes ready-made from Ppre); a template so that the ordinary step carries none of it
 __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
                                                    const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update, int nyS,
                                                    int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq,
@@ -1438,7 +1466,7 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     //    (Zp[row][p], p = 4 st + lk) and the output tile
     // Two-phase steps (Ppre != nullptr, k_chol_panel ran just before): P_I and P_J come ready-made from Ppre instead of being
     // recomputed by every workgroup of a block row / column (two thirds of a trailing tile's work at N = 500).
-    const bool pre = Ppre && !sig;
+    const bool pre = PRE && !sig;
     double lv[4] = {0, 0, 0, 0};
     if (!pre) {
 #pragma unroll
@@ -1873,7 +1901,7 @@ __global__ void k_scatter_landmarks(int k, int dst0, int Ncap, const double* __r
         q0[c * Ncap + i] = p_aos[3 * t + c];
     { // chart constants of the new origin point (ld_cc): the only place they are computed
         const V3 p{p_aos[3 * t], p_aos[3 * t + 1], p_aos[3 * t + 2]};
-        double* cc = q0 + (size_t)LM_PLANES * Ncap;
+        double* cc = q0 + (size_t)CC_OFF * Ncap;
         st_plane9(cc, Ncap, i, CC_E2I, conv_euc2ind(p));
         st_plane9(cc, Ncap, i, CC_I2E, conv_ind2euc(p));
         st_plane9(cc, Ncap, i, CC_R0, ind2euc_r0(p));
@@ -1924,7 +1952,7 @@ __global__ void k_compact_landmarks(int Nnew, int Ncap, const int* __restrict__ 
     for (int c = 0; c < 4; ++c)
         Qqo[c * Ncap + i] = Qqi[c * Ncap + o];
     Qao[i] = Qai[o];
-    for (int c = LM_PLANES; c < LM_PLANES + CC_PLANES; ++c) // chart constants travel with their landmark
+    for (int c = CC_OFF; c < CC_OFF + CC_PLANES; ++c) // chart constants travel with their landmark
         q0o[(size_t)c * Ncap + i] = q0i[(size_t)c * Ncap + o];
 }
 // append: zero the new strips, put var on the new diagonal (addNewLandmarks, VIO_eqf.cpp:239-244)
