@@ -1308,14 +1308,21 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
             hipLaunchKernelGGL(k_chol_panel, dim3(gx), dim3(256), 0, c->stream, rows, kb, w, ldz, Z, W, Lin, spec, spec_seq);
             HIPCHK(hipGetLastError());
         }
-        if (two_phase)
-            hipLaunchKernelGGL(k_chol_step<true>, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
+        {
+            auto launch = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
                            nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld, (gpart || nsig) && step < 32 ? trace_slot(c, TR_STEP0 + step) : nullptr,
                            two_phase ? (const double*)W : (const double*)nullptr);
-        else
-            hipLaunchKernelGGL(k_chol_step<false>, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
-                           nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld, (gpart || nsig) && step < 32 ? trace_slot(c, TR_STEP0 + step) : nullptr,
-                           two_phase ? (const double*)W : (const double*)nullptr);
+            };
+            if (two_phase)
+                launch(k_chol_step<true, false, false>);
+            else if (nsig > 0)
+                launch(k_chol_step<false, true, false>);
+            else if (gp)
+                launch(k_chol_step<false, false, true>);
+            else
+                launch(k_chol_step<false, false, false>);
+        }
         HIPCHK(hipGetLastError());
     }
     return 0;

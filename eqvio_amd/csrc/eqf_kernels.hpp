@@ -1385,7 +1385,10 @@ __global__ void __launch_bounds__(256) k_chol_panel(int rows, int kb, int w, int
     }
 }
 constexpr int GAMMA_G = 4; // column groups of the Gamma partials computed by the last step launch
-template <bool PRE> // PRE: second half of a two-phase step (P comes ready-made from Ppre); a template so that the ordinary step carries none of it
+// Template flags, so that the ordinary step (12 of 13 launches at N = 200) carries none of the optional code: PRE = second half of a
+// two-phase step (P ready-made in Ppre); SIGF = the fused covariance update rides along (nsig > 0); GAM = last launch of the
+// unfused chain, produces the Gamma partials (gpart).
+template <bool PRE, bool SIGF, bool GAM>
 __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
                                                    const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update, int nyS,
                                                    int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq,
@@ -1394,7 +1397,7 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
     const int c0 = kb + w;
-    if (gpart && (int)blockIdx.y >= nyS) {
+    if (GAM && (int)blockIdx.y >= nyS) {
         // Gamma partials (last step of the unfused chain only; c0 == m): the W columns [0, kb) were published by the earlier
         // launches, so Gamma = W z over them can run in the shadow of this step. Grid row nyS + g takes the columns
         // p = g (mod GAMMA_G); workgroup x takes the 32 rows of W starting at 32 x; its 8 lane groups interleave the columns.
@@ -1431,7 +1434,7 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
         return;
     }
     int i0, j0, ilim = rows, jlim = m;
-    const bool sig = (int)blockIdx.y >= nyS;
+    const bool sig = SIGF && (int)blockIdx.y >= nyS;
     if (sig) {
         const int nt = (nsig + 31) >> 5;
         int L = ((int)blockIdx.y - nyS) * (int)gridDim.x + (int)blockIdx.x;
@@ -1501,7 +1504,7 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
             opJ[st] = needJ ? Z[rowJc + (size_t)(kb + pc) * ldz] * (zJ * zp) : 0.0;
         }
     }
-    const bool gam_last = gpart && !update; // this launch also produces the last panel's share of Gamma
+    const bool gam_last = GAM && !update; // this launch also produces the last panel's share of Gamma
     const double yv = (gam_last && tid < 32) ? Z[(rows - 1) + (size_t)(kb + min(tid, w - 1)) * ldz] : 0.0;
     const int ihU = wave & 1, jhU = wave >> 1;
     double zt[4];
