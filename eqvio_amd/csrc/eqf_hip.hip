@@ -1449,8 +1449,21 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         MeasFuse mf{};
         if (fuse)
             mf = *fuse;
-        LAUNCH_TS(c, k_build_Z, dim3(blocks(n + M + 1, 256), blocks(M, BZ_JB) + 1 + (mf.enabled ? 1 : 0)), dim3(256), c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx,
-                  (const TS*)c->sigma(), c->d_C, c->d_ytil, c->d_Z, c->d_Linv, c->d_flags, mf.enabled ? (const int*)nullptr : spec, spec_seq, mf, trace_slot(c, TR_BUILD_Z));
+        auto launch = [&](auto kern, auto* sig) {
+            hipLaunchKernelGGL(kern, dim3(blocks(n + M + 1, 256), blocks(M, BZ_JB) + 1 + (mf.enabled ? 1 : 0)), dim3(256), 0, c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx, sig,
+                               c->d_C, c->d_ytil, c->d_Z, c->d_Linv, c->d_flags, mf.enabled ? (const int*)nullptr : spec, spec_seq, mf, trace_slot(c, TR_BUILD_Z));
+        };
+        if (c->sig32) {
+            if (mf.enabled)
+                launch(k_build_Z<float, true>, (const float*)c->sigma());
+            else
+                launch(k_build_Z<float, false>, (const float*)c->sigma());
+        } else {
+            if (mf.enabled)
+                launch(k_build_Z<double, true>, (const double*)c->sigma());
+            else
+                launch(k_build_Z<double, false>, (const double*)c->sigma());
+        }
         HIPCHK(hipGetLastError());
     }
     host_stamp(c, TH_BUILD_Z_OUT);
@@ -1469,8 +1482,21 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         }
         const int nt = blocks(n, 32);
         KTimer t(c, KN_SYRK);
-        LAUNCH_TS(c, k_syrk_sub, dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), c->stream, n, m, c->ld, c->ldz, c->d_W, (TS*)c->sigma(), nt, c->d_gamma, spec, spec_seq,
-                  c->opt_early ? 0 : 1, trace_slot(c, TR_SYRK));
+        if (c->opt_early) {
+            if (c->sig32)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<float, false>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (float*)c->sigma(), nt,
+                                   c->d_gamma, spec, spec_seq, 0, trace_slot(c, TR_SYRK));
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<double, false>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(), nt,
+                                   c->d_gamma, spec, spec_seq, 0, trace_slot(c, TR_SYRK));
+        } else {
+            if (c->sig32)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<float, true>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (float*)c->sigma(), nt,
+                                   c->d_gamma, spec, spec_seq, 1, trace_slot(c, TR_SYRK));
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<double, true>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(), nt,
+                                   c->d_gamma, spec, spec_seq, 1, trace_slot(c, TR_SYRK));
+        }
         HIPCHK(hipGetLastError());
     }
     { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }

@@ -1121,7 +1121,7 @@ __device__ __forceinline__ MeasOut measure_j(const MeasFuse& mf, int j, int& i_o
     return measure_one(mf.chart, mf.cam, ld3(mf.q0, mf.Ncap, i), ldq(mf.Qq, mf.Ncap, i), mf.Qa[i], mf.y[2 * j], mf.y[2 * j + 1], mf.star != 0,
                        mf.chart == EQVIO_COORD_INVDEPTH ? ld_cc(mf.q0, mf.Ncap, i, CC_R0) : M3{});
 }
-template <typename TS>
+template <typename TS, bool FUSE> // FUSE: measurement fusion (FUSE); a template so that neither variant carries the other's code
 __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
                                                  const TS* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
                                                  double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags, const int* __restrict__ spec,
@@ -1132,8 +1132,8 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
     const int m = 2 * M;
     // grid rows: 0 = first tile, 1 = statistics (with fusion), then one per measurement. The two special rows have the longest
     // dependent chains (evaluation + 32 x 32 elimination; evaluation + stores to the host), so they are dispatched first.
-    const int row0 = mf.enabled ? 2 : 1;
-    if (mf.enabled && (int)blockIdx.y == 1) {
+    const int row0 = FUSE ? 2 : 1;
+    if (FUSE && (int)blockIdx.y == 1) {
         // outlier statistics, one lane per landmark
         if ((int)(blockIdx.x * blockDim.x) >= mf.N)
             return;
@@ -1152,14 +1152,14 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
         const int i = threadIdx.x & 15, jj = threadIdx.x >> 4; // pair (i, jj) of measurements, both < 16
         double sv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // Sigma[l_i.., l_jj..], requested before the C blocks are evaluated
         if (i < M && jj < M) {
-            const int li = 21 + 3 * (mf.enabled ? mf.lmidx[i] : lmidx[i]), lj2 = 21 + 3 * (mf.enabled ? mf.lmidx[jj] : lmidx[jj]);
+            const int li = 21 + 3 * (FUSE ? mf.lmidx[i] : lmidx[i]), lj2 = 21 + 3 * (FUSE ? mf.lmidx[jj] : lmidx[jj]);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
                     sv[3 * c + r] = Sig[li + r + (size_t)(lj2 + c) * ld];
         }
-        if (mf.enabled) {
+        if (FUSE) {
             if (threadIdx.x == 0) { // this launch's only writer of the status flags
                 flags[0] = 0;
                 flags[1] = 0;
@@ -1178,8 +1178,8 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
             double ci[6], cj2[6];
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
-                ci[e] = mf.enabled ? sC16[i * 6 + e] : C[e * Mcap + i];
-                cj2[e] = mf.enabled ? sC16[jj * 6 + e] : C[e * Mcap + jj];
+                ci[e] = FUSE ? sC16[i * 6 + e] : C[e * Mcap + i];
+                cj2[e] = FUSE ? sC16[jj * 6 + e] : C[e * Mcap + jj];
             }
             double CS[2][3];
 #pragma unroll
@@ -1219,7 +1219,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
 #pragma unroll
     for (int q = 0; q < BZ_JB; ++q) {
         const int jc = min(j0 + q, M - 1);
-        lj[q] = 21 + 3 * (mf.enabled ? mf.lmidx[jc] : lmidx[jc]);
+        lj[q] = 21 + 3 * (FUSE ? mf.lmidx[jc] : lmidx[jc]);
     }
     int li = 0;
     double sv[BZ_JB][9];
@@ -1230,7 +1230,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
             for (int c = 0; c < 3; ++c)
                 sv[q][c] = Sig[t + (size_t)(lj[q] + c) * ld];
     } else if (srow) {
-        li = 21 + 3 * (mf.enabled ? mf.lmidx[t - n] : lmidx[t - n]);
+        li = 21 + 3 * (FUSE ? mf.lmidx[t - n] : lmidx[t - n]);
 #pragma unroll
         for (int q = 0; q < BZ_JB; ++q)
 #pragma unroll
@@ -1239,7 +1239,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
                 for (int r = 0; r < 3; ++r)
                     sv[q][3 * c + r] = Sig[li + r + (size_t)(lj[q] + c) * ld];
     }
-    if (mf.enabled) {
+    if (FUSE) {
         if (threadIdx.x < BZ_JB && j0 + (int)threadIdx.x < M) {
             const int j = j0 + threadIdx.x;
             int lidx;
@@ -1269,7 +1269,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
     // a block row of S needs its own C_i as well: evaluated by the thread that uses it (before the barrier: the evaluations overlap)
     double ci[6] = {0, 0, 0, 0, 0, 0};
     if (srow) {
-        if (mf.enabled) {
+        if (FUSE) {
             int lidx;
             const MeasOut o = measure_j(mf, t - n, lidx);
 #pragma unroll
@@ -1762,7 +1762,7 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 // That order gives the host the frame's results one kernel early: its round trip (results, filter logic, the next frame's
 // launches) overlaps with Sigma -= W W^T instead of leaving the GPU idle after it.
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
-template <typename TS>
+template <typename TS, bool WITH_GAMMA>
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
                                                   double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma, trace_t* tr) {
     trace_start(tr);
@@ -1781,11 +1781,11 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
     // with_gamma: the diagonal tiles also produce Gamma[i0 : i0+32] = W[rows] z  (Gamma = K yTilde = W L^-1 yTilde, VIO_eqf.cpp:119)
     double gv = 0.0;
     TileRed t;
-    if (bi == bj && with_gamma)
+    if (WITH_GAMMA && bi == bj)
         t = mfma_tile32_splitk<true, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
     else
         t = mfma_tile32_splitk<false, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
-    if (bi == bj && with_gamma && threadIdx.x < 32 && i0 + threadIdx.x < n)
+    if (WITH_GAMMA && bi == bj && threadIdx.x < 32 && i0 + threadIdx.x < n)
         gamma[i0 + threadIdx.x] = gv;
     if (threadIdx.x >= 256)
         return;
