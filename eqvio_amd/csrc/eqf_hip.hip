@@ -1049,8 +1049,21 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
             fa.ck = c->ck;
         }
         KTimer t(c, KN_PROP_MAIN);
-        LAUNCH_TS(c, k_propagate_main, dim3(nT * nT + nStrip + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), c->stream, N, c->Ncap, c->ld, ra, c->d_common, (const TS*)Sin, (TS*)Sout,
-                  c->d_Al, c->d_Bl, nT, nStrip, nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa);
+        auto launch = [&](auto kern, auto* sin, auto* sout) {
+            hipLaunchKernelGGL(kern, dim3(nT * nT + nStrip + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, sin, sout, c->d_Al, c->d_Bl, nT, nStrip,
+                               nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa);
+        };
+        if (c->sig32) {
+            if (fused)
+                launch(k_propagate_main<float, true>, (const float*)Sin, (float*)Sout);
+            else
+                launch(k_propagate_main<float, false>, (const float*)Sin, (float*)Sout);
+        } else {
+            if (fused)
+                launch(k_propagate_main<double, true>, (const double*)Sin, (double*)Sout);
+            else
+                launch(k_propagate_main<double, false>, (const double*)Sin, (double*)Sout);
+        }
         HIPCHK(hipGetLastError());
         if (fused && nObs)
             c->lmcur = 1 - c->lmcur;

@@ -353,7 +353,7 @@ struct StageArgs {
     int* idx_d;
 };
 // TS = storage type of Sigma (double, or float for EQF_OPT_SIGMA_FP32 = 2): loads convert to double, stores round.
-template <typename TS>
+template <typename TS, bool FUSED> // FUSED: fused assembly (FUSED)
 __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
                                                         const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         // flips to it after the launch; q0 and its chart constants live in a buffer of their own and stay where they are).
         const int i = (b - (nT * nT + nStrip + 1)) * PROP_T + tid;
         if (i < N) {
-            if (fa.on) {
+            if (FUSED) {
                 observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, fa.Qqo, fa.Qao);
             } else {
                 observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, Qq, Qa);
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
     __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
     __shared__ double sSens[21 * 33]; // per strip column of this workgroup: row c of A_ss (21) | row c of B_s (12)
     __shared__ double s_cm[66];
-    if (fa.on) {
+    if (FUSED) {
         for (int t = tid; t < 66; t += PROP_T)
             s_cm[t] = fa.ck.lm[t];
         __syncthreads();
@@ -428,9 +428,9 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         for (int t = PROP_T - 1 - tid; t < ncol * 33; t += PROP_T) { // taken from the top of the workgroup: the first lanes assemble
             const int m_ = t / 33, e = t % 33;
             const int c = bj + nT * m_;
-            sSens[t] = e < 21 ? (fa.on ? sensor_Ass_entry(fa.ck, c * 21 + e) : cm->Ass[c * 21 + e]) : (fa.on ? sensor_Bs_entry(fa.ck, c * 12 + (e - 21)) : cm->Bs[c * 12 + (e - 21)]);
+            sSens[t] = e < 21 ? (FUSED ? sensor_Ass_entry(fa.ck, c * 21 + e) : cm->Ass[c * 21 + e]) : (FUSED ? sensor_Bs_entry(fa.ck, c * 12 + (e - 21)) : cm->Bs[c * 12 + (e - 21)]);
         }
-        if (fa.on) {
+        if (FUSED) {
             // lanes 0..PT-1 assemble the i-landmarks, lanes PT..2PT-1 the j-landmarks (the other threads are loading Sigma meanwhile)
             if (tid < 2 * PT) {
                 const bool isj = tid >= PT;
@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         const int i0 = (b - nT * nT) * SL;
         if (tid < 12 * 21)
             sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
-        if (fa.on) {
+        if (FUSED) {
             // lanes 256.. assemble the landmarks (the first 252 are loading Sigma_ss), everyone expands the sensor blocks
             if (tid >= 256 && tid < 256 + SL) {
                 const int x = tid - 256, l = i0 + x;
@@ -615,10 +615,10 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             if (i < N) {
 #pragma unroll
                 for (int q = 0; q < 12; ++q)
-                    g += dt * (fa.on ? sAl[x * 45 + r * 15 + q] : Al[(r * 15 + q) * Ncap + i]) * sSs[q * 21 + k];
+                    g += dt * (FUSED ? sAl[x * 45 + r * 15 + q] : Al[(r * 15 + q) * Ncap + i]) * sSs[q * 21 + k];
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc)
-                    g += (dt * (fa.on ? sAl[x * 45 + r * 15 + 12 + cc] : Al[(r * 15 + 12 + cc) * Ncap + i]) + (r == cc ? 1.0 : 0.0)) * Sig[k + (size_t)(21 + 3 * i + cc) * ld];
+                    g += (dt * (FUSED ? sAl[x * 45 + r * 15 + 12 + cc] : Al[(r * 15 + 12 + cc) * Ncap + i]) + (r == cc ? 1.0 : 0.0)) * Sig[k + (size_t)(21 + 3 * i + cc) * ld];
             }
             sG[t] = g;
         }
@@ -632,13 +632,13 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         for (int r = 0; r < 3; ++r) {
             double s = 0;
             for (int k = 0; k < 21; ++k) {
-                const double f = dt * (fa.on ? sAss[c * 21 + k] : cm->Ass[c * 21 + k]) + (k == c ? 1.0 : 0.0);
+                const double f = dt * (FUSED ? sAss[c * 21 + k] : cm->Ass[c * 21 + k]) + (k == c ? 1.0 : 0.0);
                 s += sG[x * 63 + r * 21 + k] * f;
             }
             double bq = 0;
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                bq += (fa.on ? sBl[x * 9 + r * 3 + q] : Bl[(r * 3 + q) * Ncap + i]) * ra.Qd[q] * (fa.on ? sBs[c * 12 + q] : cm->Bs[c * 12 + q]);
+                bq += (FUSED ? sBl[x * 9 + r * 3 + q] : Bl[(r * 3 + q) * Ncap + i]) * ra.Qd[q] * (FUSED ? sBs[c * 12 + q] : cm->Bs[c * 12 + q]);
             s += dt * bq;
             Sout[li + r + (size_t)c * ld] = s;
             Sout[c + (size_t)(li + r) * ld] = s;
@@ -653,11 +653,11 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         double* sBs = sm + 1323; // 252 (fused assembly: B_s expanded from the compact terms)
         for (int t = tid; t < 441; t += PROP_T) {
             const int r = t / 21, c = t % 21;
-            sF[t] = dt * (fa.on ? sensor_Ass_entry(fa.ck, t) : cm->Ass[t]) + (r == c ? 1.0 : 0.0);
+            sF[t] = dt * (FUSED ? sensor_Ass_entry(fa.ck, t) : cm->Ass[t]) + (r == c ? 1.0 : 0.0);
             sS[t] = Sig[r + (size_t)c * ld];
         }
         for (int t = tid; t < 252; t += PROP_T)
-            sBs[t] = fa.on ? sensor_Bs_entry(fa.ck, t) : cm->Bs[t];
+            sBs[t] = FUSED ? sensor_Bs_entry(fa.ck, t) : cm->Bs[t];
         __syncthreads();
         for (int t = tid; t < 441; t += PROP_T) {
             const int r = t / 21, c = t % 21;
