@@ -571,80 +571,6 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         }
         return;
     }
-    if (b < nT * nT + nStrip) {
-        // landmark-sensor strips: Sigma'[l_i + r][c] = sum_k G_i[r][k] Fss[c][k] + dt sum_q Bl_i[r][q] Qd[q] Bs[c][q]
-        // 12 landmarks x 21 columns per workgroup; G of the 12 landmarks is built in LDS first.
-        constexpr int SL = 12;
-        double* sG = sm;                  // [lm][r*21 + k]  (SL x 63)
-        double* sSs = sm + SL * 63;       // Sigma_ss[al_col(e)][k] at [e*21 + k]
-        double* sAl = sSs + 252;          // fused assembly: rows of A of the SL landmarks [lm][45] ...
-        double* sBl = sAl + SL * 45;      // ... rows of B [lm][9] ...
-        double* sAss = sBl + SL * 9;      // ... and the sensor blocks A_ss (441), B_s (252)
-        double* sBs = sAss + 441;
-        const int i0 = (b - nT * nT) * SL;
-        if (tid < 12 * 21)
-            sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
-        if (FUSED) {
-            // lanes 256.. assemble the landmarks (the first 252 are loading Sigma_ss), everyone expands the sensor blocks
-            if (tid >= 256 && tid < 256 + SL) {
-                const int x = tid - 256, l = i0 + x;
-                double al[45], bl[9];
-                if (l < N) {
-                    const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
-                    assemble_landmark(s_cm, fa.chart, ld3(q0, Ncap, l), ldq(Qq, Ncap, l), Qa[l], ind ? ld_cc(q0, Ncap, l, CC_E2I) : M3{}, ind ? ld_cc(q0, Ncap, l, CC_I2E) : M3{}, al,
-                                      bl);
-#pragma unroll
-                    for (int e = 0; e < 45; ++e)
-                        sAl[x * 45 + e] = al[e];
-#pragma unroll
-                    for (int e = 0; e < 9; ++e)
-                        sBl[x * 9 + e] = bl[e];
-                }
-            }
-            for (int t = tid; t < 441; t += PROP_T)
-                sAss[t] = sensor_Ass_entry(fa.ck, t);
-            for (int t = tid; t < 252; t += PROP_T)
-                sBs[t] = sensor_Bs_entry(fa.ck, t);
-        }
-        __syncthreads();
-        for (int t = tid; t < SL * 63; t += PROP_T) {
-            const int x = t / 63, e = t % 63;
-            const int r = e / 21, k = e % 21;
-            const int i = i0 + x;
-            double g = 0.0;
-            if (i < N) {
-#pragma unroll
-                for (int q = 0; q < 12; ++q)
-                    g += dt * (FUSED ? sAl[x * 45 + r * 15 + q] : Al[(r * 15 + q) * Ncap + i]) * sSs[q * 21 + k];
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc)
-                    g += (dt * (FUSED ? sAl[x * 45 + r * 15 + 12 + cc] : Al[(r * 15 + 12 + cc) * Ncap + i]) + (r == cc ? 1.0 : 0.0)) * Sig[k + (size_t)(21 + 3 * i + cc) * ld];
-            }
-            sG[t] = g;
-        }
-        __syncthreads();
-        const int x = tid / 21, c = tid % 21;
-        const int i = i0 + x;
-        if (tid >= SL * 21 || i >= N)
-            return;
-        const int li = 21 + 3 * i;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            double s = 0;
-            for (int k = 0; k < 21; ++k) {
-                const double f = dt * (FUSED ? sAss[c * 21 + k] : cm->Ass[c * 21 + k]) + (k == c ? 1.0 : 0.0);
-                s += sG[x * 63 + r * 21 + k] * f;
-            }
-            double bq = 0;
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                bq += (FUSED ? sBl[x * 9 + r * 3 + q] : Bl[(r * 3 + q) * Ncap + i]) * ra.Qd[q] * (FUSED ? sBs[c * 12 + q] : cm->Bs[c * 12 + q]);
-            s += dt * bq;
-            Sout[li + r + (size_t)c * ld] = s;
-            Sout[c + (size_t)(li + r) * ld] = s;
-        }
-        return;
-    }
     // sensor-sensor block
     {
         double* sF = sm;        // 441
