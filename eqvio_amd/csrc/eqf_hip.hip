@@ -175,6 +175,10 @@ struct eqf_ctx {
     unsigned lm_gen = 0, staged_gen = 0; // lm_gen counts changes of the landmark set (indices in a staged measurement go stale)
     std::vector<int> staged_ids;
     std::vector<double> staged_y;
+    std::vector<int> map_ids; // ids of the mapping that sits in h_lmidx (map_measurement), valid for map_gen == lm_gen
+    unsigned map_gen = ~0u;
+    int map_N = -1;
+    bool map_all = false;
     std::vector<std::pair<int, int>> lookup; // sorted (id, index), valid for lookup_gen == lm_gen
     unsigned lookup_gen = ~0u;
     // host-side wait statistics (eqf_host_wait_stats): doorbell waits and the time spent spinning in them
@@ -1354,8 +1358,15 @@ static const double* pack_by_landmark(eqf_ctx* c, const int* measof, const doubl
 }
 // map ascending measurement ids to state indices; returns 0 or EQF_E_BAD_ARG
 static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, int* lmidx, int* measof) {
+    // Consecutive frames usually measure the same ids: the previous mapping (still in the pinned packet, which only this function
+    // writes) is reused when ids and landmark set are unchanged.
+    if (c->map_gen == c->lm_gen && c->map_N == c->N && (int)c->map_ids.size() == M && lmidx == c->h_lmidx && (M == 0 || std::memcmp(ids, c->map_ids.data(), sizeof(int) * M) == 0) &&
+        (!require_all || c->map_all))
+        return 0;
+    c->map_gen = c->lm_gen - 1; // invalid until this call succeeds
     for (int i = 0; i < c->N; ++i)
         measof[i] = -1;
+    bool all = true;
     for (int j = 0; j < M; ++j) {
         if (j > 0 && ids[j] <= ids[j - 1])
             return EQF_E_BAD_ARG; // must be strictly ascending (std::map order)
@@ -1365,6 +1376,14 @@ static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, 
             measof[i] = j;
         else if (require_all)
             return EQF_E_BAD_ARG;
+        else
+            all = false;
+    }
+    if (lmidx == c->h_lmidx) {
+        c->map_ids.assign(ids, ids + M);
+        c->map_gen = c->lm_gen;
+        c->map_N = c->N;
+        c->map_all = all;
     }
     return 0;
 }
