@@ -354,26 +354,29 @@ def test_speculative_tail_equals_stats_plus_update(chart):
 
 
 @pytest.mark.parametrize("chart", list(CHARTS))
-@pytest.mark.parametrize("k,discrete", [(1, True), (10, True), (30, False)])
+@pytest.mark.parametrize("k,discrete", [(1, True), (10, True), (30, False), (45, True), (0, True)])
 def test_propagate_fast_equals_riccati_plus_observer(chart, k, discrete):
     """eqf_propagate_fast = integrateRiccatiStateFast at the current X followed by the k observer steps (VIOFilter.cpp:134-192,
-    fast branch); only the queueing order on the device differs. k = 30 needs two kernel-argument chunks."""
+    fast branch); only the queueing order on the device differs (assembly inside the propagation kernel, observer blocks writing the
+    second landmark buffer). k = 30 / 45 need two / three kernel-argument chunks of 20 steps; k = 0: no observer blocks at all."""
     N = 17
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=91)
     twin = EqfCore(N, CHARTS[chart])
     twin.set_state(xi0, Xs, ids, q0, Q)
     twin.set_sigma(S)
-    imus = np.stack([random_imu(rng, bias_vel=True) for _ in range(k)])
+    imus = np.stack([random_imu(rng, bias_vel=True) for _ in range(k)]) if k else np.zeros((0, 13))
     dts = rng.uniform(0.002, 0.008, k)
-    mean = (imus * dts[:, None]).sum(0) / dts.sum()
+    mean = (imus * dts[:, None]).sum(0) / dts.sum() if k else random_imu(rng, bias_vel=True)
+    dt_total = float(dts.sum()) if k else 0.05
     Qd, Pd = settings.input_gain_diag12(), settings.state_gain_diag8()
-    twin.integrate_riccati_fast(mean, dts.sum(), Qd, Pd)
-    twin.integrate_observer(imus, dts, discrete)
-    core.propagate_fast(mean, dts.sum(), Qd, Pd, imus, dts, discrete)
+    twin.integrate_riccati_fast(mean, dt_total, Qd, Pd)
+    if k:
+        twin.integrate_observer(imus, dts, discrete)
+    core.propagate_fast(mean, dt_total, Qd, Pd, imus, dts, discrete)
     assert np.array_equal(core.get_sigma(), twin.get_sigma())
     for u, v in zip(core.get_state(), twin.get_state()):
         assert np.array_equal(u, v)
-    orc.integrate_riccati_fast(mean, dts.sum())
+    orc.integrate_riccati_fast(mean, dt_total)
     for s_ in range(k):
         orc.integrate_observer(imus[s_], dts[s_], discrete)
     check_sigma(core, orc, 1e-12)
