@@ -121,11 +121,14 @@ int eqf_outlier_stats(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, con
 /* VIO_eqf::performVisionUpdate (VIO_eqf.cpp:105-135): yTilde, C, S = C Sigma C^T + R, K = Sigma C^T S^-1,
  * Gamma = K yTilde, X <- Delta * X, Sigma <- Sigma - K C Sigma; R = meas_var * I
  * (constructOutputGainMatrix, VIOFilterSettings.h:203-206). Every measured id must be a state landmark. */
-int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEquivariantOutput, int discreteCorrection);/* VIOFilter::integrateUpToTime, fast-Riccati branch (VIOFilter.cpp:134-192), in one call: integrateRiccatiStateFast with the
+int eqf_vision_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double meas_var, int useEquivariantOutput, int discreteCorrection);
+
+/* VIOFilter::integrateUpToTime, fast-Riccati branch (VIOFilter.cpp:134-192), in one call: integrateRiccatiStateFast with the
  * mean IMU sample over dt_total (at the current X), then the k observer steps. Same result as eqf_integrate_riccati_fast
- * followed by eqf_integrate_observer (bit-identical); the difference is on the device: the landmark part of the observer steps
- * rides along as extra workgroups of the Sigma propagation kernel (which does not touch the landmark arrays), so the whole
- * propagation is two kernels on one stream, with no second stream and no events. */
+ * followed by eqf_integrate_observer (bit-identical); the difference is on the device: the rows of A and B are assembled by the
+ * workgroups of the Sigma propagation kernel that need them, and the landmark part of the observer steps rides along as extra
+ * workgroups of the same launch (writing a second landmark buffer), so the whole propagation is ONE kernel on one stream, with
+ * no second stream and no events (EQF_OPT_FUSED_ASSEMBLY = 0: a separate assembly kernel in front of it). */
 int eqf_propagate_fast(eqf_ctx* ctx, const double* imu13_mean, double dt_total, const double* Qdiag12, const double* Pdiag8, const double* imu13_k, const double* dt_k,
                        int k, int discreteLift);
 /* Optional hint, to be called BEFORE the propagation call of the same frame (eqf_propagate_fast / eqf_integrate_riccati_fast)
