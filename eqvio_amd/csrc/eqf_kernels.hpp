@@ -153,72 +153,90 @@ __device__ __forceinline__ double sensor_Ass_entry(const CommonK& ck, int t) {
 }
 // The rows of A and B of ONE landmark: al[r * 15 + c] (packed columns: 0:3 | 12:15 | 15:21 | own 3x3) and bl[9].
 // s_cm: the 66 per-landmark factors (Mv, RTic, RTicSx, CT, vC) in LDS.
+// PART = -1: everything. PART = 0 / 1 / 2: only the columns 0:6 of the row block and bl / the columns 6:12 / the own 3x3 block
+// (columns 12:15): the three parts share a short prefix (R_Q, Q_hat, q_hat) and are otherwise independent, so three lanes in
+// three different wavefronts assemble one landmark in a third of the time (the unused results are dead code in each instance).
+template <int PART>
 __device__ __forceinline__ void assemble_landmark(const double* __restrict__ s_cm, int chart, const V3 p0, const Qt q, const double a, const M3& e2i, const M3& i2e,
                                                   double (&al)[45], double (&bl)[9]) {
+    constexpr bool P0 = PART < 0 || PART == 0, P1 = PART < 0 || PART == 1, P2 = PART < 0 || PART == 2;
     const M3 Mv = ldm3(s_cm), RTic = ldm3(s_cm + 9), RTicSx = ldm3(s_cm + 18);
     const double* CT = s_cm + 27;
     const V3 vC{s_cm[63], s_cm[64], s_cm[65]};
     const M3 RQ = q_mat(q);
     const M3 Qhat = a * RQ;
     const V3 qh = (1.0 / a) * (transpose(RQ) * p0); // Q^-1 * q0
-
-    M3 Bblk = Qhat * (skew(qh) * RTic + RTicSx);
-    M3 A_v = (-1.0) * (Qhat * Mv);
-    // [skew(q0) R_Q, -a R_Q] * CT  (3x6 * 6x6)
-    const M3 T0 = skew(p0) * RQ;
-    const M3 T1 = (-a) * RQ;
-    const double t[3][6] = {{T0.a00, T0.a01, T0.a02, T1.a00, T1.a01, T1.a02},
-                            {T0.a10, T0.a11, T0.a12, T1.a10, T1.a11, T1.a12},
-                            {T0.a20, T0.a21, T0.a22, T1.a20, T1.a21, T1.a22}};
-    double Ac[3][6];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            double s = 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                s += t[r][k] * CT[k * 6 + c];
-            Ac[r][c] = s;
+    const bool ind = chart == EQVIO_COORD_INVDEPTH; // e2i = conv_euc2ind(p0), i2e = conv_ind2euc(p0): stored chart constants
+    if (P0) {
+        M3 Bblk = Qhat * (skew(qh) * RTic + RTicSx);
+        M3 A_v = (-1.0) * (Qhat * Mv);
+        if (ind) {
+            Bblk = e2i * Bblk;
+            A_v = e2i * A_v;
         }
-    const M3 inner = skew(qh) * skew(vC) - 2.0 * outer(vC, qh) + outer(qh, vC);
-    const M3 QhatInv = (1.0 / a) * transpose(RQ);
-    M3 A_q = (-1.0 / norm2(qh)) * (Qhat * inner * QhatInv);
-
-    if (chart == EQVIO_COORD_INVDEPTH) { // e2i = conv_euc2ind(p0), i2e = conv_ind2euc(p0): stored chart constants
-        Bblk = e2i * Bblk;
-        A_v = e2i * A_v;
-        const double e[3][3] = {{e2i.a00, e2i.a01, e2i.a02}, {e2i.a10, e2i.a11, e2i.a12}, {e2i.a20, e2i.a21, e2i.a22}};
-        double Ac2[3][6];
+        const M3 A_b = (-1.0) * Bblk;
+        const double ab[9] = {A_b.a00, A_b.a01, A_b.a02, A_b.a10, A_b.a11, A_b.a12, A_b.a20, A_b.a21, A_b.a22};
+        const double av[9] = {A_v.a00, A_v.a01, A_v.a02, A_v.a10, A_v.a11, A_v.a12, A_v.a20, A_v.a21, A_v.a22};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                al[r * 15 + c] = ab[r * 3 + c];
+                al[r * 15 + 3 + c] = av[r * 3 + c];
+            }
+        bl[0] = Bblk.a00, bl[1] = Bblk.a01, bl[2] = Bblk.a02, bl[3] = Bblk.a10, bl[4] = Bblk.a11, bl[5] = Bblk.a12, bl[6] = Bblk.a20, bl[7] = Bblk.a21, bl[8] = Bblk.a22;
+    }
+    if (P1) {
+        // [skew(q0) R_Q, -a R_Q] * CT  (3x6 * 6x6)
+        const M3 T0 = skew(p0) * RQ;
+        const M3 T1 = (-a) * RQ;
+        const double t[3][6] = {{T0.a00, T0.a01, T0.a02, T1.a00, T1.a01, T1.a02},
+                                {T0.a10, T0.a11, T0.a12, T1.a10, T1.a11, T1.a12},
+                                {T0.a20, T0.a21, T0.a22, T1.a20, T1.a21, T1.a22}};
+        double Ac[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    s += t[r][k] * CT[k * 6 + c];
+                Ac[r][c] = s;
+            }
+        if (ind) {
+            const double e[3][3] = {{e2i.a00, e2i.a01, e2i.a02}, {e2i.a10, e2i.a11, e2i.a12}, {e2i.a20, e2i.a21, e2i.a22}};
+            double Ac2[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    Ac2[r][c] = e[r][0] * Ac[0][c] + e[r][1] * Ac[1][c] + e[r][2] * Ac[2][c];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    Ac[r][c] = Ac2[r][c];
+        }
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 6; ++c)
-                Ac2[r][c] = e[r][0] * Ac[0][c] + e[r][1] * Ac[1][c] + e[r][2] * Ac[2][c];
+                al[r * 15 + 6 + c] = Ac[r][c];
+    }
+    if (P2) {
+        const M3 inner = skew(qh) * skew(vC) - 2.0 * outer(vC, qh) + outer(qh, vC);
+        const M3 QhatInv = (1.0 / a) * transpose(RQ);
+        M3 A_q = (-1.0 / norm2(qh)) * (Qhat * inner * QhatInv);
+        if (ind)
+            A_q = e2i * A_q * i2e;
+        const double aq[9] = {A_q.a00, A_q.a01, A_q.a02, A_q.a10, A_q.a11, A_q.a12, A_q.a20, A_q.a21, A_q.a22};
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
-                Ac[r][c] = Ac2[r][c];
-        A_q = e2i * A_q * i2e;
+            for (int c = 0; c < 3; ++c)
+                al[r * 15 + 12 + c] = aq[r * 3 + c];
     }
-    const M3 A_b = (-1.0) * Bblk;
-    const double ab[9] = {A_b.a00, A_b.a01, A_b.a02, A_b.a10, A_b.a11, A_b.a12, A_b.a20, A_b.a21, A_b.a22};
-    const double av[9] = {A_v.a00, A_v.a01, A_v.a02, A_v.a10, A_v.a11, A_v.a12, A_v.a20, A_v.a21, A_v.a22};
-    const double aq[9] = {A_q.a00, A_q.a01, A_q.a02, A_q.a10, A_q.a11, A_q.a12, A_q.a20, A_q.a21, A_q.a22};
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            al[r * 15 + c] = ab[r * 3 + c];
-            al[r * 15 + 3 + c] = av[r * 3 + c];
-            al[r * 15 + 12 + c] = aq[r * 3 + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-            al[r * 15 + 6 + c] = Ac[r][c];
-    }
-    bl[0] = Bblk.a00, bl[1] = Bblk.a01, bl[2] = Bblk.a02, bl[3] = Bblk.a10, bl[4] = Bblk.a11, bl[5] = Bblk.a12, bl[6] = Bblk.a20, bl[7] = Bblk.a21, bl[8] = Bblk.a22;
 }
 __global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int Ncap, int chart, Common* __restrict__ cmdev,
                                                     const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
@@ -242,7 +260,7 @@ __global__ void __launch_bounds__(64) k_assemble_AB(const CommonK ck, int N, int
         return;
     double al[45], bl[9];
     const bool ind = chart == EQVIO_COORD_INVDEPTH;
-    assemble_landmark(s_cm, chart, ld3(q0, Ncap, i), ldq(Qq, Ncap, i), Qa[i], ind ? ld_cc(q0, Ncap, i, CC_E2I) : M3{}, ind ? ld_cc(q0, Ncap, i, CC_I2E) : M3{}, al, bl);
+    assemble_landmark<-1>(s_cm, chart, ld3(q0, Ncap, i), ldq(Qq, Ncap, i), Qa[i], ind ? ld_cc(q0, Ncap, i, CC_E2I) : M3{}, ind ? ld_cc(q0, Ncap, i, CC_I2E) : M3{}, al, bl);
 #pragma unroll
     for (int e = 0; e < 45; ++e)
         Al[e * Ncap + i] = al[e];
@@ -431,37 +449,58 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             sSens[t] = e < 21 ? (FUSED ? sensor_Ass_entry(fa.ck, c * 21 + e) : cm->Ass[c * 21 + e]) : (FUSED ? sensor_Bs_entry(fa.ck, c * 12 + (e - 21)) : cm->Bs[c * 12 + (e - 21)]);
         }
         if (FUSED) {
-            // lanes 0..PT-1 assemble the i-landmarks, lanes PT..2PT-1 the j-landmarks (the other threads are loading Sigma meanwhile)
-            if (tid < 2 * PT) {
-                const bool isj = tid >= PT;
-                const int x = tid % PT;
+            // Three wavefronts assemble: lanes 0..2PT-1 of waves 0, 1, 2 take part 0, 1, 2 (assemble_landmark) of the PT i-landmarks and
+            // the PT j-landmarks; the other threads are loading Sigma meanwhile.
+            const int part = tid >> 6, lane_ = tid & 63;
+            if (part < 3 && lane_ < 2 * PT) {
+                const bool isj = lane_ >= PT;
+                const int x = lane_ % PT;
                 const int l = (isj ? bj : bi) * PT + x;
                 double* dF = isj ? sFj : sFi;
                 double* dD = isj ? sDj : sDi;
                 double* dB = isj ? sBj : sBi;
                 double al[45], bl[9];
-                if (l < N) {
-                    const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
-                    assemble_landmark(s_cm, fa.chart, ld3(q0, Ncap, l), ldq(Qq, Ncap, l), Qa[l], ind ? ld_cc(q0, Ncap, l, CC_E2I) : M3{}, ind ? ld_cc(q0, Ncap, l, CC_I2E) : M3{}, al,
-                                      bl);
-                } else {
 #pragma unroll
-                    for (int e = 0; e < 45; ++e)
-                        al[e] = 0.0;
+                for (int e = 0; e < 45; ++e)
+                    al[e] = 0.0;
 #pragma unroll
-                    for (int e = 0; e < 9; ++e)
-                        bl[e] = 0.0;
-                }
+                for (int e = 0; e < 9; ++e)
+                    bl[e] = 0.0;
+                const bool in = l < N;
+                const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
+                const int lc = in ? l : 0;
+                const V3 p0_ = ld3(q0, Ncap, lc);
+                const Qt q_ = ldq(Qq, Ncap, lc);
+                const double a_ = Qa[lc];
+                const M3 e2i = ind ? ld_cc(q0, Ncap, lc, CC_E2I) : M3{};
+                if (part == 0) {
+                    if (in)
+                        assemble_landmark<0>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+                    for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                    for (int c = 0; c < 12; ++c)
-                        dF[(r * 12 + c) * PT + x] = l < N ? dt * al[r * 15 + c] : 0.0;
+                        for (int c = 0; c < 6; ++c)
+                            dF[(r * 12 + c) * PT + x] = in ? dt * al[r * 15 + c] : 0.0;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        dD[(r * 3 + c) * PT + x] = l < N ? dt * al[r * 15 + 12 + c] + ((r == c) ? 1.0 : 0.0) : 0.0;
-                        dB[(r * 3 + c) * PT + x] = bl[r * 3 + c];
+                        for (int c = 0; c < 3; ++c)
+                            dB[(r * 3 + c) * PT + x] = bl[r * 3 + c];
                     }
+                } else if (part == 1) {
+                    if (in)
+                        assemble_landmark<1>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 6; c < 12; ++c)
+                            dF[(r * 12 + c) * PT + x] = in ? dt * al[r * 15 + c] : 0.0;
+                } else {
+                    if (in)
+                        assemble_landmark<2>(s_cm, fa.chart, p0_, q_, a_, e2i, ind ? ld_cc(q0, Ncap, lc, CC_I2E) : M3{}, al, bl);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            dD[(r * 3 + c) * PT + x] = in ? dt * al[r * 15 + 12 + c] + ((r == c) ? 1.0 : 0.0) : 0.0;
                 }
             }
         } else {
