@@ -1773,9 +1773,24 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
 // euclid.cpp:36-97, invdepth.cpp:183-253; VIOExp VIOGroup.cpp:273-290; X = Delta * X VIO_eqf.cpp:130).
 // Also writes the new estimates q_hat_i and a flag per landmark with Q_i.a outside (1e-8, 1e8]
 // (removeInvalidLandmarks, VIO_eqf.cpp:213-223) into `est` (4 planes of stride N: qx, qy, qz, invalid).
-__device__ __forceinline__ void lift_landmark(int i, const V3 g, int N, int Ncap, int chart, int discrete, const double* __restrict__ q0, double* __restrict__ Qq,
-                                              double* __restrict__ Qa, double* __restrict__ est) {
-    const V3 p0 = ld3(q0, Ncap, i);
+// what the lift of landmark i reads besides Gamma, requested up front (one memory round trip for everything)
+struct LiftIn {
+    V3 p0;
+    Qt q;
+    double a;
+    M3 r0m;
+};
+__device__ __forceinline__ LiftIn lift_load(int i, int Ncap, int chart, int discrete, const double* q0, const double* Qq, const double* Qa) {
+    LiftIn in;
+    in.p0 = ld3(q0, Ncap, i);
+    in.q = ldq(Qq, Ncap, i);
+    in.a = Qa[i];
+    in.r0m = (chart == EQVIO_COORD_INVDEPTH && !discrete) ? ld_cc(q0, Ncap, i, CC_R0) : M3{}; // ind2euc_r0(p0): stored chart constant
+    return in;
+}
+__device__ __forceinline__ void lift_landmark(int i, const V3 g, const LiftIn& in, int N, int Ncap, int chart, int discrete, double* __restrict__ Qq, double* __restrict__ Qa,
+                                              double* __restrict__ est) {
+    const V3 p0 = in.p0;
     Qt Dq;
     double Da;
     if (discrete) {
@@ -1783,15 +1798,15 @@ __device__ __forceinline__ void lift_landmark(int i, const V3 g, int N, int Ncap
         Dq = so3_from_vectors(normalized(q1), normalized(p0));
         Da = norm(p0) / norm(q1);
     } else {
-        const V3 ge = (chart == EQVIO_COORD_INVDEPTH) ? ld_cc(q0, Ncap, i, CC_R0) * g : g; // ind2euc_r0(p0): stored chart constant
+        const V3 ge = (chart == EQVIO_COORD_INVDEPTH) ? in.r0m * g : g;
         const double iq2 = 1.0 / norm2(p0);
         const V3 Wr = (-iq2) * cross(p0, ge);
         const double Ws = -iq2 * dot(p0, ge);
         Dq = so3_exp(Wr);
         Da = exp(Ws);
     }
-    const Qt q = q_mul(Dq, ldq(Qq, Ncap, i));
-    const double a = Da * Qa[i];
+    const Qt q = q_mul(Dq, in.q);
+    const double a = Da * in.a;
     Qq[i] = q.w;
     Qq[Ncap + i] = q.x;
     Qq[2 * Ncap + i] = q.y;
@@ -1803,42 +1818,51 @@ __device__ __forceinline__ void lift_landmark(int i, const V3 g, int N, int Ncap
     est[2 * N + i] = qh.z;
     est[3 * N + i] = (a <= 1e-8 || a > 1e8 || !(a == a)) ? 1.0 : 0.0;
 }
-__device__ __forceinline__ void lift_body(int N, int Ncap, int chart, int discrete, double* __restrict__ gamma, const double* __restrict__ q0,
-                                          double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
-                                          const int* __restrict__ flags, int* __restrict__ flags_host, const double* __restrict__ gpart, int ldg) {
-    // est / gamma_host / flags_host point into the pinned host packet: the results reach the host with the stream
-    // synchronisation alone, no copy kernels.
-    // gpart != nullptr: Gamma arrives as GAMMA_G + 1 partial vectors (k_chol_step's last launch) and is summed here, in a fixed order
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    auto gam = [&](int row) {
-        if (!gpart)
-            return gamma[row];
-        double v = ((gpart[row] + gpart[(size_t)ldg + row]) + (gpart[2 * (size_t)ldg + row] + gpart[3 * (size_t)ldg + row])) + gpart[4 * (size_t)ldg + row];
-        gamma[row] = v;
-        return v;
-    };
-    static_assert(GAMMA_G == 4, "partial sum order above");
-    if (i < 21)
-        gamma_host[i] = gam(i);
-    if (i == 0) {
-        flags_host[0] = flags[0];
-        flags_host[1] = flags[1];
-    }
-    if (i >= N)
-        return;
-    const double g0 = gam(21 + 3 * i), g1 = gam(21 + 3 * i + 1), g2 = gam(21 + 3 * i + 2);
-    lift_landmark(i, V3{g0, g1, g2}, N, Ncap, chart, discrete, q0, Qq, Qa, est);
+// Gamma row: direct, or the fixed-order sum of the GAMMA_G + 1 partial vectors of k_chol_step's last launch
+__device__ __forceinline__ double gamma_row(const double* __restrict__ gamma, const double* __restrict__ gpart, int ldg, int row) {
+    static_assert(GAMMA_G == 4, "partial sum order below");
+    if (!gpart)
+        return gamma[row];
+    return ((gpart[row] + gpart[(size_t)ldg + row]) + (gpart[2 * (size_t)ldg + row] + gpart[3 * (size_t)ldg + row])) + gpart[4 * (size_t)ldg + row];
 }
 __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, double* __restrict__ gamma, const double* __restrict__ q0,
                                              double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
                                              const int* __restrict__ flags, int* __restrict__ flags_host, int* __restrict__ door_count, int* __restrict__ door_host,
                                              int door_seq, const int* __restrict__ spec, int spec_seq, const double* __restrict__ gpart, int ldg, trace_t* tr) {
     trace_start(tr);
-    const bool aborted = spec && *spec == spec_seq; // speculative tail cancelled by the statistics kernel
+    // est / gamma_host / flags_host point into the pinned host packet: the results reach the host without copy kernels.
+    // Every load this kernel needs is requested before the first result is used (Gamma partials, landmark state, chart constant, status
+    // words, cancellation word): one memory round trip instead of three on the path to the doorbell.
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool lm = i < N;
+    const int ic = lm ? i : 0;
+    const double gs = gamma_row(gamma, gpart, ldg, i < 21 ? i : 0);
+    const double g0 = gamma_row(gamma, gpart, ldg, 21 + 3 * ic), g1 = gamma_row(gamma, gpart, ldg, 21 + 3 * ic + 1), g2 = gamma_row(gamma, gpart, ldg, 21 + 3 * ic + 2);
+    const LiftIn in = lift_load(ic, Ncap, chart, discrete, q0, Qq, Qa);
+    const int f0 = flags[0], f1 = flags[1];
+    const int specv = spec ? __hip_atomic_load(spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const bool aborted = spec && specv == spec_seq; // speculative tail cancelled by the statistics kernel
     if (blockIdx.x == 0 && threadIdx.x == 0)
         flags_host[2] = aborted ? 1 : 0;
-    if (!aborted)
-        lift_body(N, Ncap, chart, discrete, gamma, q0, Qq, Qa, est, gamma_host, flags, flags_host, gpart, ldg);
+    if (!aborted) {
+        if (i < 21) {
+            gamma_host[i] = gs;
+            if (gpart)
+                gamma[i] = gs;
+        }
+        if (i == 0) {
+            flags_host[0] = f0;
+            flags_host[1] = f1;
+        }
+        if (lm) {
+            if (gpart) {
+                gamma[21 + 3 * i] = g0;
+                gamma[21 + 3 * i + 1] = g1;
+                gamma[21 + 3 * i + 2] = g2;
+            }
+            lift_landmark(i, V3{g0, g1, g2}, in, N, Ncap, chart, discrete, Qq, Qa, est);
+        }
+    }
     ring_doorbell(door_count, door_host, door_seq);
     trace_end(tr);
 }
