@@ -314,12 +314,12 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
     # same bench command; bench.py cannot run the profiler on itself)
     traffic, traffic_note = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v10_pmc_traffic.json")))["kernels"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v11_pmc_traffic.json")))["kernels"]
         kn = [k_ for k_ in fam[dom][0] if k_ in pmc and launches.get(k_, 0) > 0]
         if kn:
             tot_l = sum(launches[k_] for k_ in kn)
             traffic = 1024.0 * sum((pmc[k_]["fetch_kib_per_launch"] + pmc[k_]["write_kib_per_launch"]) * launches[k_] for k_ in kn) / tot_l
-            traffic_note = "bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r01_v10_pmc_*.csv (N=200)"
+            traffic_note = "bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r01_v11_pmc_*.csv (N=200)"
     except Exception:
         pass
     return {
