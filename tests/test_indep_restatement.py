@@ -127,4 +127,4 @@ def test_continuous_innovation_lift_and_fast_riccati_default_path():
         orc.vision_update(cam, mid, y)
         _, Xs2, _, _, Q2 = orc.get_eqf()
         Xf, Qf = r.group_to_flat(X)
-        assert rel_fro(S, orc.get_sigma()) <= 1e-11 and _xerr(Xf, Xs2) <= 1e-11 and _qerr(Qf, Q2) <= 1e-10  # Q follows Gamma (conditioning of S)
+        assert rel_fro(S, orc.get_sigma()) <= 1e-10 and _xerr(Xf, Xs2) <= 1e-9 and _qerr(Qf, Q2) <= 1e-9  # free running: the state follows Gamma = K y~ (conditioning of S)
