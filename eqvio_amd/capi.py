@@ -202,6 +202,7 @@ def load_eqf_lib():
         "eqf_vision_update": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_int]),
         "eqf_last_gamma": (C.c_int, [vp, c_double_p, C.c_int]),
         "eqf_compute_nees": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p]),
+        "eqf_nees_lu_fallbacks": (C.c_int, [vp, C.POINTER(C.c_long)]),
         "eqf_debug_matrices_AB": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
         "eqf_debug_matrix_C": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p]),
         "eqf_mfma_f64_peak": (C.c_int, [vp, c_double_p]),
@@ -364,6 +365,11 @@ class EqfCore:
         sensor, ids, p = _f64(sensor), _i32(ids), _f64(p)
         out = C.c_double()
         self._chk0(self.lib.eqf_compute_nees(self.h, _dp(sensor), _ip(ids), _dp(p), len(ids), C.byref(out)))
+        return out.value
+
+    def nees_lu_fallbacks(self):
+        out = C.c_long()
+        self._chk0(self.lib.eqf_nees_lu_fallbacks(self.h, C.byref(out)))
         return out.value
 
     def debug_matrices_AB(self, imu13):

@@ -154,6 +154,8 @@ struct eqf_ctx {
     double *d_Ebuf = nullptr, *d_Yl = nullptr, *d_Fl = nullptr, *d_PhiB = nullptr; // accurate Riccati (lazily allocated)
     int* d_expinfo = nullptr;
     double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
+    int* d_perm = nullptr;                   // 2 x (ncap + 2) row permutations of the NEES elimination fallback
+    long nees_lu_fallbacks = 0;              // computeNEES calls answered by the partial-pivot elimination (Sigma not numerically SPD)
     int ldzn = 0;
     double *d_Z = nullptr, *d_W = nullptr, *d_Linv = nullptr, *d_gamma = nullptr, *d_gpart = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
     int* d_flags = nullptr;
@@ -444,6 +446,18 @@ int launch_assemble(eqf_ctx* c, bool record_early = true) {
     }
     return (int)hipGetLastError();
 }
+// d_gamma doubles as a staging buffer (eqf_set_sigma_diag, eqf_compute_nees): if it still holds a Gamma that eqf_last_gamma has not
+// fetched yet, fetch it first.
+int keep_last_gamma(eqf_ctx* c) {
+    if (!c->gamma_stale)
+        return 0;
+    const int ng = c->n_at_update;
+    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_gamma, sizeof(double) * ng, hipMemcpyDeviceToHost, c->stream));
+    { int _r = sync_ctx(c); if (_r) return _r; }
+    c->last_gamma.assign(c->h_buf, c->h_buf + ng);
+    c->gamma_stale = false;
+    return 0;
+}
 int read_flags(eqf_ctx* c) {
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     { int _r = sync_ctx(c); if (_r) return _r; }
@@ -616,6 +630,8 @@ void eqf_destroy(eqf_ctx* c) {
         hipFree(c->d_Zn);
     if (c->d_Wn)
         hipFree(c->d_Wn);
+    if (c->d_perm)
+        hipFree(c->d_perm);
     if (c->d_F)
         hipFree(c->d_F);
     if (c->d_tmp)
@@ -838,6 +854,7 @@ int eqf_set_sigma_diag(eqf_ctx* c, const double* diag, int n) {
         return EQF_E_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
     { int _r = sync_ctx(c); if (_r) return _r; }
+    { int _r = keep_last_gamma(c); if (_r) return _r; }
     std::memcpy(c->h_buf, diag, sizeof(double) * n);
     HIPCHK(hipMemcpyAsync(c->d_gamma, c->h_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     LAUNCH_TS(c, k_set_diag, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->ld, c->d_gamma, (TS*)c->sigma());
@@ -1772,13 +1789,7 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
 int eqf_last_gamma(eqf_ctx* c, double* out, int cap) {
     if (!c || !out)
         return EQF_E_BAD_ARG;
-    if (c->gamma_stale) {
-        const int n = c->n_at_update;
-        HIPCHK(hipMemcpyAsync(c->h_buf, c->d_gamma, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-        { int _r = sync_ctx(c); if (_r) return _r; }
-        c->last_gamma.assign(c->h_buf, c->h_buf + n);
-        c->gamma_stale = false;
-    }
+    { int _r = keep_last_gamma(c); if (_r) return _r; }
     if ((int)c->last_gamma.size() > cap)
         return EQF_E_CAPACITY;
     std::memcpy(out, c->last_gamma.data(), sizeof(double) * c->last_gamma.size());
@@ -1837,7 +1848,9 @@ int eqf_compute_nees(eqf_ctx* c, const double* ts, const int* tids, const double
         c->ldzn = pick_ld(npcap + 1);
         HIPCHK(hipMalloc(&c->d_Zn, sizeof(double) * (size_t)c->ldzn * npcap));
         HIPCHK(hipMalloc(&c->d_Wn, sizeof(double) * (size_t)c->ldzn * npcap));
+        HIPCHK(hipMalloc(&c->d_perm, sizeof(int) * 2 * (size_t)(c->ncap + 2)));
     }
+    { int _r = keep_last_gamma(c); if (_r) return _r; } // d_gamma serves as the staging buffer of eps below
     { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(c->h_buf, eps.data(), sizeof(double) * np);
     HIPCHK(hipMemcpyAsync(c->d_gamma, c->h_buf, sizeof(double) * np, hipMemcpyHostToDevice, c->stream)); // d_gamma as staging (ncap >= np? see below)
@@ -1853,9 +1866,31 @@ int eqf_compute_nees(eqf_ctx* c, const double* ts, const int* tids, const double
     rc = read_flags(c);
     if (rc)
         return rc;
-    if (c->h_flags[0])
-        return EQF_E_NOT_SPD;
+    if (c->h_flags[0]) {
+        // Sigma is positive definite only up to rounding. The reference inverts it by partial-pivot LU and returns a number regardless
+        // (VIO_eqf.cpp:166-168): Gaussian elimination with partial pivoting on [Sigma | eps], on the device (k_ge_step, one launch per pivot)
+        ++c->nees_lu_fallbacks;
+        std::memcpy(c->h_buf, eps.data(), sizeof(double) * np);
+        HIPCHK(hipMemcpyAsync(c->d_gamma, c->h_buf, sizeof(double) * np, hipMemcpyHostToDevice, c->stream));
+        LAUNCH_TS(c, k_build_nees, dim3(blocks(np + 1, 256), np), dim3(256), c->stream, n, np, c->ld, c->ldzn, (const TS*)c->sigma(), c->d_gamma, c->d_Zn);
+        hipLaunchKernelGGL(k_iota, dim3(blocks(np, 256)), dim3(256), 0, c->stream, np, c->d_perm);
+        const int pstride = c->ncap + 2;
+        for (int k = 0; k < np; ++k)
+            hipLaunchKernelGGL(k_ge_step, dim3(std::max(1, blocks(np - k - 1, GE_ROWS))), dim3(256), 0, c->stream, np, c->ldzn, k, c->d_Zn, c->d_perm + (k & 1) * pstride,
+                               c->d_perm + ((k + 1) & 1) * pstride);
+        hipLaunchKernelGGL(k_ge_back, dim3(1), dim3(1024), sizeof(double) * (np + 16), c->stream, n, np, c->ldzn, c->d_Zn, c->d_perm + (np & 1) * pstride, c->d_gamma, c->d_stats);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->h_buf, c->d_stats, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        { int _r = sync_ctx(c); if (_r) return _r; }
+    }
     *nees = c->h_buf[0] / (double)n;
+    return 0;
+}
+
+int eqf_nees_lu_fallbacks(eqf_ctx* c, long* count) {
+    if (!c || !count)
+        return EQF_E_BAD_ARG;
+    *count = c->nees_lu_fallbacks;
     return 0;
 }
 

@@ -2360,6 +2360,102 @@ __global__ void __launch_bounds__(256) k_sumsq_row(int np, int ldzn, const doubl
         out[0] = sp[0];
 }
 
+// computeNEES when Sigma is positive definite only up to rounding (the factorisation chain reports a non-positive pivot): the reference
+// inverts Sigma by partial-pivot LU and always returns a number (VIO_eqf.cpp:166-168), so the fallback is Gaussian elimination with
+// partial pivoting on the augmented matrix [Sigma | eps], one launch per pivot. Sigma is symmetric, so the column-major Z = [Sigma ; eps^T]
+// of k_build_nees is read as ROW-major M[i][j] = Z[j + i ldzn] (j = np is the right-hand side): rows are contiguous. Rows are never
+// moved: a permutation (ping-pong between launches) maps logical to physical rows. Every workgroup repeats the pivot search (np strided
+// reads); the pivot row is read-only in its launch and every other row belongs to exactly one workgroup.
+constexpr int GE_ROWS = 4;
+__global__ void __launch_bounds__(256) k_ge_step(int np, int ldzn, int k, double* __restrict__ Z, const int* __restrict__ perm_in, int* __restrict__ perm_out) {
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    double best = -1.0;
+    int bi = k;
+    for (int i = k + threadIdx.x; i < np; i += 256) {
+        const double v = fabs(Z[k + (size_t)perm_in[i] * ldzn]);
+        if (v > best) { // strict: the first maximum wins, as in LAPACK / Eigen
+            best = v;
+            bi = i;
+        }
+    }
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            const double o = sv[threadIdx.x + st];
+            const int oi = si[threadIdx.x + st];
+            if (o > sv[threadIdx.x] || (o == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+                sv[threadIdx.x] = o;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int p = si[0];
+    const int rk = perm_in[p]; // physical pivot row
+    const double piv = Z[k + (size_t)rk * ldzn];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < np; i += 256)
+            perm_out[i] = i == k ? rk : (i == p ? perm_in[k] : perm_in[i]);
+    for (int r = 0; r < GE_ROWS; ++r) {
+        const int i = k + 1 + blockIdx.x * GE_ROWS + r;
+        if (i >= np)
+            break;
+        const int phys = i == p ? perm_in[k] : perm_in[i];
+        double* row = Z + (size_t)phys * ldzn;
+        const double* prow = Z + (size_t)rk * ldzn;
+        const double l = row[k] / piv;
+        for (int j = k + 1 + threadIdx.x; j <= np; j += 256)
+            row[j] -= l * prow[j];
+    }
+}
+__global__ void __launch_bounds__(256) k_iota(int n, int* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        out[i] = i;
+}
+// back substitution U x = b and NEES * n = eps . x (one workgroup; x in LDS)
+__global__ void __launch_bounds__(1024) k_ge_back(int n, int np, int ldzn, const double* __restrict__ Z, const int* __restrict__ perm, const double* __restrict__ eps,
+                                                  double* __restrict__ out) {
+    extern __shared__ double xs[]; // np + 16
+    __shared__ double red[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = np - 1; k >= 0; --k) {
+        const double* row = Z + (size_t)perm[k] * ldzn;
+        double s = 0.0;
+        for (int j = k + 1 + threadIdx.x; j < np; j += 1024)
+            s += row[j] * xs[j];
+        for (int o = 32; o > 0; o >>= 1)
+            s += __shfl_down(s, o, 64);
+        if (lane == 0)
+            red[wv] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 16; ++w)
+                t += red[w];
+            xs[k] = (row[np] - t) / row[k];
+        }
+        __syncthreads();
+    }
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n; j += 1024)
+        s += eps[j] * xs[j];
+    for (int o = 32; o > 0; o >>= 1)
+        s += __shfl_down(s, o, 64);
+    if (lane == 0)
+        red[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w)
+            t += red[w];
+        out[0] = t;
+    }
+}
+
 // fp64 MFMA issue-rate micro-benchmark: 4 independent accumulators per wave, no memory traffic.
 __global__ void __launch_bounds__(256) k_mfma_peak(int iters, double* __restrict__ out) {
     d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;

@@ -155,8 +155,12 @@ int eqf_last_gamma(eqf_ctx* ctx, double* out, int cap);
 
 /* VIO_eqf::computeNEES (VIO_eqf.cpp:153-170): eps = stateChart(stateGroupAction(X^-1, trueState restricted to X.id), xi0),
  * NEES = eps^T Sigma^-1 eps / dim. The true state must contain every landmark id of the filter state. Sigma^-1 eps is
- * never formed: Sigma = L L^T is factorised with the same blocked chain as the vision update and NEES = |L^-1 eps|^2 / n. */
+ * never formed: Sigma = L L^T is factorised with the same blocked chain as the vision update and NEES = |L^-1 eps|^2 / n.
+ * When that factorisation meets a non-positive pivot (Sigma positive definite only up to rounding) the call does what the
+ * reference's LU-based Sigma.inverse() does (VIO_eqf.cpp:166-168) and still returns a number: Gaussian elimination with partial
+ * pivoting on [Sigma | eps], on the device. eqf_nees_lu_fallbacks counts those calls. */
 int eqf_compute_nees(eqf_ctx* ctx, const double* true_sensor, const int* true_ids, const double* true_p, int n_true, double* nees);
+int eqf_nees_lu_fallbacks(eqf_ctx* ctx, long* count);
 
 /* EqF matrices as the device assembled them, expanded to the reference's dense layout for parity tests:
  * A (n x n), B (n x 12) from stateMatrixA / inputMatrixB (coordinateSuite/euclid.cpp:99-233,

@@ -171,3 +171,96 @@ def test_feature_predictions_match():
     assert n_checked > 100
     off = VIOFilter(sim_settings(COORD_INVDEPTH), max_landmarks=64, sensor=sensor, ids=ids, p=p, time=0.0)
     assert len(off.get_feature_predictions(world.cam, 0.1)[0]) == 0  # disabled by default, like the reference
+
+
+def test_remove_invalid_landmarks_fires():
+    """VIO_eqf::removeInvalidLandmarks (VIO_eqf.cpp:213-223): landmarks whose SOT(3) scale left (1e-8, 1e8] are dropped after the update.
+    The scale never gets there in a healthy run, so the test plants it: two landmarks out of range (1e-9, 2e8), two far from one
+    but valid (1e-4, 1e4). A landmark's pixel depends on its direction only, so the update itself stays ordinary; ids, the compacted
+    Sigma and the state must follow the oracle's filter, which runs the reference's own loop. Scales of 1e8 stretch the dynamic range of
+    C and Sigma in the frame they take part in; a second oracle in the other dense arithmetic ("efficient" vs "as written") measures
+    the floor that leaves to any two fp64 evaluations, and the device is held to that floor."""
+    import ctypes as C
+
+    from eqvio_amd.capi import load_eqf_lib
+    from oracle_binding import ARITH_AS_WRITTEN, ARITH_EFFICIENT
+
+    world = SimWorld(seed=21, num_points=900, max_features=24, trajectory="hover", noise_px=0.3)
+    settings = sim_settings(COORD_INVDEPTH)
+    ids0, _ = world.vision(0.0)
+    sensor, ids, p = world.true_state(0.0, ids0)
+    orc = OracleFilter(settings, sensor, ids, p, 0.0)
+    orc2 = OracleFilter(settings, sensor, ids, p, 0.0)
+    orc.set_arithmetic(ARITH_AS_WRITTEN)
+    orc2.set_arithmetic(ARITH_EFFICIENT)
+    flt = VIOFilter(settings, max_landmarks=64, sensor=sensor, ids=ids, p=p, time=0.0)
+    lib = load_eqf_lib()
+    removed = None
+    for f, (imus, stamp, mid, y) in enumerate(world.frames(8)):
+        for s in range(len(imus)):
+            orc.process_imu(imus[s])
+            orc2.process_imu(imus[s])
+            flt.process_imu(imus[s])
+        if f == 3:
+            for o in (orc, orc2):
+                xi0, Xs, lid, q0, Q = o.get_eqf()
+                n_before = len(lid)
+                Q[2, 4], Q[5, 4], Q[7, 4], Q[11, 4] = 1e-9, 2e8, 1e-4, 1e4
+                removed = {int(lid[2]), int(lid[5])}
+                o.set_eqf(xi0, Xs, lid, q0, Q, o.get_sigma(), o.get_time())
+            gx, gX, gid, gq0, gQ = flt.get_eqf()
+            assert np.array_equal(gid, lid)
+            gQ[:, 4] = Q[:, 4]
+            f64p = C.POINTER(C.c_double)
+            a = [np.ascontiguousarray(v, dtype=np.float64) for v in (gx, gX, gq0, gQ)]
+            gid = np.ascontiguousarray(gid, dtype=np.int32)
+            assert lib.eqf_set_state(flt.core_handle(), a[0].ctypes.data_as(f64p), a[1].ctypes.data_as(f64p), gid.ctypes.data_as(C.POINTER(C.c_int)), a[2].ctypes.data_as(f64p),
+                                     a[3].ctypes.data_as(f64p), len(gid)) == 0
+        for o in (orc, orc2):
+            o.process_vision(stamp, world.cam, mid, y)
+        flt.process_vision(stamp, world.cam, mid, y)
+        if f == 3:
+            kept = set(flt.state_estimate()[1].tolist())
+            assert removed.isdisjoint(kept) and len(kept) == n_before - 2
+            assert set(orc.state_estimate()[1].tolist()) == kept
+            assert flt.sigma_dim() == 21 + 3 * (n_before - 2)
+        if f < 3:
+            compare(flt, orc)
+        else:
+            assert np.array_equal(flt.state_estimate()[1], orc.state_estimate()[1])
+            floor = rel_fro(orc2.get_sigma(), orc.get_sigma())
+            err = rel_fro(flt.get_sigma(), orc.get_sigma())
+            assert err <= max(TOL, 2.0 * floor), (f, err, floor)
+            s_g, _, p_g = flt.state_estimate()
+            s_o, _, p_o = orc.state_estimate()
+            s_2, _, p_2 = orc2.state_estimate()
+            fl = max(np.max(np.abs(s_2 - s_o)), np.max(np.abs(p_2 - p_o) / np.maximum(1.0, np.abs(p_o))))
+            assert max(np.max(np.abs(s_g - s_o)), np.max(np.abs(p_g - p_o) / np.maximum(1.0, np.abs(p_o)))) <= max(TOL, 2.0 * fl)
+    assert removed is not None
+
+
+def test_remove_invalid_landmarks_boundaries_exact():
+    """The interval is (1e-8, 1e8]: a <= 1e-8 and a > 1e8 are invalid (VIO_eqf.cpp:216). Core level, no update in between: decisions on the
+    boundary values themselves and their fp64 neighbours, Sigma compaction bit-exact."""
+    from eqvio_amd.capi import EqfCore
+    from util import random_spd, reasonable_state
+
+    rng = np.random.default_rng(4)
+    N = 9
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N, shuffle_ids=True)
+    Q[1, 4] = 1e-8                       # invalid (<=)
+    Q[2, 4] = np.nextafter(1e-8, 1.0)    # valid
+    Q[4, 4] = 1e8                        # valid (the interval is closed there)
+    Q[6, 4] = np.nextafter(1e8, np.inf)  # invalid
+    Q[7, 4] = 0.0                        # invalid
+    S = random_spd(rng, 21 + 3 * N)
+    core = EqfCore(N, COORD_EUCLIDEAN)
+    core.set_state(xi0, Xs, ids, q0, Q)
+    core.set_sigma(S)
+    assert core.remove_invalid_landmarks() == 3
+    _, _, ids2, q02, Q2 = core.get_state()
+    keep = np.array([0, 2, 3, 4, 5, 8])
+    assert np.array_equal(ids2, ids[keep]) and np.array_equal(q02, q0[keep]) and np.array_equal(Q2[:, 4], Q[keep, 4])
+    rows = np.concatenate([np.arange(21)] + [21 + 3 * k + np.arange(3) for k in keep])
+    assert np.array_equal(core.get_sigma(), S[np.ix_(rows, rows)])
+    assert core.remove_invalid_landmarks() == 0

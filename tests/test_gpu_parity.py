@@ -4,7 +4,7 @@ relative on pose, landmarks and Sigma (kernel-level blocks are held to much tigh
 import numpy as np
 import pytest
 
-from eqvio_amd.capi import OPT_RICCATI_DENSE, EqfCore, EqfError
+from eqvio_amd.capi import COORD_INVDEPTH, OPT_RICCATI_DENSE, EqfCore, EqfError
 from oracle_binding import OracleFilter, se3_log_dist
 from util import CHARTS, default_camera, euroc_camera, random_imu, random_spd, reasonable_state, rel_fro, settings_for, synth_measurement
 
@@ -472,3 +472,61 @@ def test_two_phase_factorisation_steps_are_bit_identical():
             assert np.array_equal(u, v)
     orc.vision_update(cam, mid, y)
     assert rel_fro(outs[1][0], orc.get_sigma()) <= 1e-9
+
+
+def test_nees_returns_a_number_when_sigma_is_not_numerically_spd():
+    """The reference inverts Sigma by partial-pivot LU and returns a number whatever Sigma is (VIO_eqf.cpp:166-168); the device's
+    Cholesky-type chain meets a non-positive pivot when Sigma is positive definite only up to rounding and must then fall back to
+    an elimination with partial pivoting (on the device) instead of reporting EQF_E_NOT_SPD."""
+    rng = np.random.default_rng(77)
+    N = 20
+    n = 21 + 3 * N
+    chart = COORD_INVDEPTH
+    settings = settings_for(chart)
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N)
+    V, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    lam = np.exp(rng.uniform(np.log(1e-3), np.log(10.0), n))
+    lam[3] = -1e-9  # slightly indefinite: what rounding leaves of a zero eigenvalue
+    S = (V * lam) @ V.T
+    S = 0.5 * (S + S.T)
+    core = EqfCore(N, chart)
+    core.set_state(xi0, Xs, ids, q0, Q)
+    core.set_sigma(S)
+    orc = OracleFilter(settings)
+    orc.set_eqf(xi0, Xs, ids, q0, Q, S)
+    es, eids, ep = orc.state_estimate()
+    ts = es.copy()
+    ts[0:6] += rng.normal(size=6) * 1e-3
+    ts[13:16] += rng.normal(size=3) * 1e-2
+    tp = ep + rng.normal(size=ep.shape) * 1e-2
+    assert core.nees_lu_fallbacks() == 0
+    nees = core.compute_nees(ts, eids, tp)
+    assert core.nees_lu_fallbacks() == 1
+    ref = orc.compute_nees(ts, eids, tp)
+    assert np.isfinite(nees) and abs(nees - ref) <= 1e-6 * abs(ref), (nees, ref)
+    # an SPD matrix takes the factorisation path and leaves the counter alone
+    lam[3] = 1e-3
+    S2 = (V * lam) @ V.T
+    core.set_sigma(0.5 * (S2 + S2.T))
+    orc.set_eqf(xi0, Xs, ids, q0, Q, 0.5 * (S2 + S2.T))
+    n2 = core.compute_nees(ts, eids, tp)
+    assert core.nees_lu_fallbacks() == 1 and abs(n2 - orc.compute_nees(ts, eids, tp)) <= 1e-9 * abs(n2)
+    # odd and even dimensions both work (the chain pads odd n)
+    for N2 in (7, 8):
+        n2_ = 21 + 3 * N2
+        xi0b, Xsb, idsb, q0b, Qb = reasonable_state(rng, N2)
+        Vb, _ = np.linalg.qr(rng.normal(size=(n2_, n2_)))
+        lb = np.exp(rng.uniform(np.log(1e-2), np.log(5.0), n2_))
+        lb[0] = -1e-8
+        Sb = (Vb * lb) @ Vb.T
+        Sb = 0.5 * (Sb + Sb.T)
+        cb = EqfCore(N2, chart)
+        cb.set_state(xi0b, Xsb, idsb, q0b, Qb)
+        cb.set_sigma(Sb)
+        ob = OracleFilter(settings)
+        ob.set_eqf(xi0b, Xsb, idsb, q0b, Qb, Sb)
+        esb, eidb, epb = ob.state_estimate()
+        tpb = epb + rng.normal(size=epb.shape) * 1e-2
+        v = cb.compute_nees(esb, eidb, tpb)
+        r = ob.compute_nees(esb, eidb, tpb)
+        assert cb.nees_lu_fallbacks() == 1 and abs(v - r) <= 1e-6 * abs(r), (N2, v, r)
