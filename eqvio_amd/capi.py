@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_TWO_PHASE, OPT_FUSED_ASSEMBLY, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_TWO_PHASE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -204,6 +204,8 @@ def load_eqf_lib():
         "eqf_compute_nees": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p]),
         "eqf_nees_lu_fallbacks": (C.c_int, [vp, C.POINTER(C.c_long)]),
         "eqf_debug_matrices_AB": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
+        "eqf_debug_get_W": (C.c_int, [vp, c_double_p, C.c_int, C.c_int]),
+        "eqf_debug_lookahead_stamps": (C.c_int, [vp, C.POINTER(C.c_ulonglong)]),
         "eqf_debug_matrix_C": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p]),
         "eqf_mfma_f64_peak": (C.c_int, [vp, c_double_p]),
         "eqf_last_kernel_times": (C.c_int, [vp, c_int_p, P(C.c_float), C.c_int]),
@@ -371,6 +373,11 @@ class EqfCore:
         out = C.c_long()
         self._chk0(self.lib.eqf_nees_lu_fallbacks(self.h, C.byref(out)))
         return out.value
+
+    def debug_get_W(self, rows, cols):
+        out = np.zeros((rows, cols), order="F")
+        self._chk0(self.lib.eqf_debug_get_W(self.h, out.ctypes.data_as(c_double_p), rows, cols))
+        return out
 
     def debug_matrices_AB(self, imu13):
         imu13 = _f64(imu13)

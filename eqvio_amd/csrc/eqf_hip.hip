@@ -1,6 +1,7 @@
 // eqf_hip.hip — context + C-ABI of the MI355X EqF core (see include/eqf_hip.h). gfx950 only.
 #include "eqf_hip.h"
 #include "eqf_kernels.hpp"
+#include "eqf_lookahead.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -154,6 +155,10 @@ struct eqf_ctx {
     double *d_Ebuf = nullptr, *d_Yl = nullptr, *d_Fl = nullptr, *d_PhiB = nullptr; // accurate Riccati (lazily allocated)
     int* d_expinfo = nullptr;
     double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
+    char* d_pub = nullptr;                   // look-ahead factorisation: published tiles (16-byte value + sequence words), la_pub_bytes(NJcap)
+    int la_njcap = 0, la_seq = 0;
+    unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
+    int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int* d_perm = nullptr;                   // 2 x (ncap + 2) row permutations of the NEES elimination fallback
     long nees_lu_fallbacks = 0;              // computeNEES calls answered by the partial-pivot elimination (Sigma not numerically SPD)
     int ldzn = 0;
@@ -554,6 +559,9 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipMalloc(&c->d_Linv, sizeof(double) * 2048));
     HIPCHK(hipMalloc(&c->d_gamma, sizeof(double) * (c->ncap + 8)));
     HIPCHK(hipMalloc(&c->d_gpart, sizeof(double) * (GAMMA_G + 1) * (size_t)c->ld));
+    c->la_njcap = std::min(32, blocks(c->mcap, 32));
+    HIPCHK(hipMalloc(&c->d_pub, la_pub_bytes(c->la_njcap)));
+    HIPCHK(hipMemsetAsync(c->d_pub, 0, la_pub_bytes(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
@@ -613,6 +621,9 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_Linv);
     hipFree(c->d_gamma);
     hipFree(c->d_gpart);
+    hipFree(c->d_pub);
+    if (c->d_ladbg)
+        hipFree(c->d_ladbg);
     if (c->d_trace)
         hipFree(c->d_trace);
     hipFree(c->d_est);
@@ -726,11 +737,18 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case EQF_OPT_TWO_PHASE:
         c->opt_two_phase = value;
         return 0;
+    case EQF_OPT_LOOKAHEAD:
+        c->opt_lookahead = value;
+        return 0;
     case EQF_OPT_TRACE: {
         { int _r = sync_ctx(c); if (_r) return _r; }
         if (value && !c->d_trace) {
             HIPCHK(hipMalloc(&c->d_trace, sizeof(trace_t) * TR_FRAMES * TR_SLOTS));
             HIPCHK(hipMemset(c->d_trace, 0, sizeof(trace_t) * TR_FRAMES * TR_SLOTS));
+            if (!c->d_ladbg) {
+                HIPCHK(hipMalloc(&c->d_ladbg, 96 * 8 * sizeof(unsigned long long)));
+                HIPCHK(hipMemset(c->d_ladbg, 0, 96 * 8 * sizeof(unsigned long long)));
+            }
             c->h_trace.assign((size_t)TR_FRAMES * TR_HOST, 0);
         } else if (!value && c->d_trace) {
             hipFree(c->d_trace);
@@ -1362,6 +1380,41 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
     return 0;
 }
 
+// The same factorisation as launch_chain(first_tile_done = true) in ONE persistent kernel with a look-ahead schedule (eqf_lookahead.hpp):
+// bit-identical W; Gamma arrives complete in d_gamma (no partial vectors). Eligible: 3 <= NJ <= 32 panels (64 < m <= 1024).
+static bool lookahead_eligible(const eqf_ctx* c, int m) {
+    const int NJ = blocks(m, 32);
+    return c->opt_lookahead && !c->opt_fused && c->d_pub && NJ >= 3 && NJ <= c->la_njcap;
+}
+static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq) {
+    LaArgs a{};
+    a.rows = rows;
+    a.m = m;
+    a.ldz = ldz;
+    a.NJ = blocks(m, 32);
+    a.NI = a.NJ + blocks(rows - m, 32);
+    if (++c->la_seq == 0)
+        ++c->la_seq;
+    a.seq = c->la_seq;
+    a.Z = c->d_Z;
+    a.W = c->d_W;
+    a.Linv0 = c->d_Linv; // k_build_Z leaves L_0^-1 where step 0 of the launch chain reads it
+    a.pub = c->d_pub;
+    a.gamma = c->d_gamma;
+    a.flags = c->d_flags;
+    a.spec = spec;
+    a.spec_seq = spec_seq;
+    a.tr_steps = trace_slot(c, TR_STEP0);
+    a.dbg = c->d_trace ? c->d_ladbg : nullptr;
+    KTimer t(c, KN_CHOL_PANEL, a.NJ); // reported per panel, like the launch chain it replaces
+    if (a.NJ <= 14)
+        hipLaunchKernelGGL(k_chol_lookahead<7>, dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(k_chol_lookahead<16>, dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // the statistics kernel's input: the measurement by landmark in the pinned packet
 static const double* pack_by_landmark(eqf_ctx* c, const int* measof, const double* y) {
     const size_t Ncap = (size_t)c->Ncap;
@@ -1521,17 +1574,19 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         if (rc)
             return rc;
     } else {
-        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
+        const bool la = lookahead_eligible(c, m); // one persistent kernel instead of one launch per panel; Gamma complete in d_gamma
+        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq)
+                : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
         if (rc)
             return rc;
         if (c->opt_early) { // Gamma, landmark lift, result packet and doorbell BEFORE the covariance update: the host round trip overlaps with it
-            rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, c->d_gpart);
+            rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, la ? nullptr : c->d_gpart);
             if (rc)
                 return rc;
         }
         const int nt = blocks(n, 32);
         KTimer t(c, KN_SYRK);
-        if (c->opt_early) {
+        if (c->opt_early || la) {
             if (c->sig32)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<float, false>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (float*)c->sigma(), nt,
                                    c->d_gamma, spec, spec_seq, 0, trace_slot(c, TR_SYRK));
@@ -1597,6 +1652,8 @@ static int finish_update(eqf_ctx* c, int discreteCorr) {
         if (r)
             return r;
     }
+    if (c->h_resflags[3])
+        return EQF_E_STALLED; // a bounded wait of the look-ahead factorisation ran out (its workgroups were not all resident)
     if (c->h_flags[0])
         return EQF_E_NOT_SPD;
     if (c->h_flags[1])
@@ -1884,6 +1941,22 @@ int eqf_compute_nees(eqf_ctx* c, const double* ts, const int* tids, const double
         { int _r = sync_ctx(c); if (_r) return _r; }
     }
     *nees = c->h_buf[0] / (double)n;
+    return 0;
+}
+
+int eqf_debug_get_W(eqf_ctx* c, double* out, int rows, int cols) {
+    if (!c || !out || rows <= 0 || cols <= 0 || rows > c->ldz || cols > c->mcap)
+        return EQF_E_BAD_ARG;
+    { int _r = sync_ctx(c); if (_r) return _r; }
+    HIPCHK(hipMemcpy2D(out, sizeof(double) * rows, c->d_W, sizeof(double) * c->ldz, sizeof(double) * rows, cols, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int eqf_debug_lookahead_stamps(eqf_ctx* c, unsigned long long* out768) {
+    if (!c || !out768 || !c->d_ladbg)
+        return EQF_E_BAD_ARG;
+    { int _r = sync_ctx(c); if (_r) return _r; }
+    HIPCHK(hipMemcpy(out768, c->d_ladbg, 96 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -967,8 +967,10 @@ __device__ __forceinline__ void ldl16_inverse_wave(double (&a)[4], double (&out)
 // column-major) to LinvOut. swork: LDL_SBUF doubles of LDS. Call after a workgroup barrier; only wave 0 does the work
 // (the whole chain is sequential; one wave avoids every barrier), the other waves return immediately.
 constexpr int LDL_SBUF = 7 * 256 + 32;
-__device__ __forceinline__ void ldl_inverse_tile(const double* __restrict__ sD, int ldd, int w, double* __restrict__ LinvOut, int* __restrict__ flags,
-                                                 double* __restrict__ swork) {
+// The result leaves through put(r, c, v) (every entry of the 32x32 factor exactly once, zeros above the diagonal blocks included):
+// ldl_inverse_tile stores it column-major to global memory, the look-ahead kernel keeps it in LDS and publishes it.
+template <typename Put>
+__device__ __forceinline__ void ldl_inverse_tile_put(const double* __restrict__ sD, int ldd, int w, Put put, int* __restrict__ flags, double* __restrict__ swork) {
     if (threadIdx.x >= 64)
         return;
     // this wave is the critical path of the whole frame: win the issue arbitration against co-resident workgroups
@@ -995,8 +997,8 @@ __device__ __forceinline__ void ldl_inverse_tile(const double* __restrict__ sD, 
         const int c = lk + 4 * k;
         sLi11[lr + c * 16] = o[k];
         sLi11T[c + lr * 16] = o[k];
-        LinvOut[lr + 32 * c] = o[k];
-        LinvOut[lr + 32 * (c + 16)] = 0.0;
+        put(lr, c, o[k]);
+        put(lr, c + 16, 0.0);
     }
     // B. L21 = D21 L11inv^T ; S22 = D22 - L21 L21^T ; Y = L21 L11inv   (fp64 MFMA 16x16x4)
     {
@@ -1022,15 +1024,20 @@ __device__ __forceinline__ void ldl_inverse_tile(const double* __restrict__ sD, 
     for (int k = 0; k < 4; ++k) {
         const int c = lk + 4 * k;
         sS22[lr + c * 16] = o[k];
-        LinvOut[16 + lr + 32 * (16 + c)] = o[k];
+        put(16 + lr, 16 + c, o[k]);
     }
     // D. X = -L22inv Y
     {
         const d4 x = mfma16_nt(sS22, 16, sYJ, 16); // X[i][c] = sum_p L22inv[i][p] Y[p][c]
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            LinvOut[16 + lr + 32 * (lk + 4 * q)] = -x[q];
+            put(16 + lr, lk + 4 * q, -x[q]);
     }
+}
+
+__device__ __forceinline__ void ldl_inverse_tile(const double* __restrict__ sD, int ldd, int w, double* __restrict__ LinvOut, int* __restrict__ flags,
+                                                 double* __restrict__ swork) {
+    ldl_inverse_tile_put(sD, ldd, w, [LinvOut](int r, int c, double v) { LinvOut[r + 32 * c] = v; }, flags, swork);
 }
 
 // L_00^-1 for the first panel (the only elimination that is not the tail of a step kernel). One workgroup.
@@ -1839,11 +1846,15 @@ __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int dis
     const double gs = gamma_row(gamma, gpart, ldg, i < 21 ? i : 0);
     const double g0 = gamma_row(gamma, gpart, ldg, 21 + 3 * ic), g1 = gamma_row(gamma, gpart, ldg, 21 + 3 * ic + 1), g2 = gamma_row(gamma, gpart, ldg, 21 + 3 * ic + 2);
     const LiftIn in = lift_load(ic, Ncap, chart, discrete, q0, Qq, Qa);
-    const int f0 = flags[0], f1 = flags[1];
+    const int f0 = flags[0], f1 = flags[1], f3 = flags[3];
     const int specv = spec ? __hip_atomic_load(spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const bool aborted = spec && specv == spec_seq; // speculative tail cancelled by the statistics kernel
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         flags_host[2] = aborted ? 1 : 0;
+        flags_host[3] = f3; // look-ahead factorisation: a bounded wait ran out (EQF_E_STALLED)
+        if (f3)
+            ((int*)flags)[3] = 0;
+    }
     if (!aborted) {
         if (i < 21) {
             gamma_host[i] = gs;

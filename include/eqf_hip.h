@@ -29,7 +29,9 @@ enum {
     EQF_E_BAD_ARG = -3,
     EQF_E_CAPACITY = -4,   /* more landmarks than max_landmarks */
     EQF_E_NO_DEVICE = -5,
-    EQF_E_UNSUPPORTED = -6 /* option combination not implemented on the device path */
+    EQF_E_UNSUPPORTED = -6, /* option combination not implemented on the device path */
+    EQF_E_STALLED = -7      /* a bounded device-side wait of the look-ahead factorisation ran out (20 ms): its workgroups were not all
+                               resident, e.g. the GPU is oversubscribed by other processes. Nothing was modified except scratch. */
 };
 
 /* options for eqf_set_option */
@@ -53,6 +55,10 @@ enum {
                                   block row once, then the tile updates); default 700 (N = 500: the first 19 of 32 steps, +9 %; never at N = 200); 0: never */
     EQF_OPT_FUSED_ASSEMBLY = 11, /* 1 (default): eqf_propagate_fast has no assembly launch: the propagation kernel's workgroups evaluate the rows of
                                   A and B they need themselves and its observer blocks write the second landmark buffer; 0: k_assemble_AB first */
+    EQF_OPT_LOOKAHEAD = 12,    /* 1 (default): the factorisation of [S ; T ; y^T] runs as ONE persistent kernel with a look-ahead schedule (one owner
+                                  workgroup walks the pivot chain, one workgroup per 32-row block row keeps its tiles in registers and follows one to
+                                  two panels behind; hand-offs as 16-byte value + sequence words, no flags, no fences) when the update has 3 .. 32
+                                  panels (32 < M <= 512 measurements); bit-identical W / Sigma to the chain. 0: one launch per panel (k_chol_step) */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati and the fused update return EQF_E_UNSUPPORTED.
@@ -166,6 +172,9 @@ int eqf_nees_lu_fallbacks(eqf_ctx* ctx, long* count);
  * A (n x n), B (n x 12) from stateMatrixA / inputMatrixB (coordinateSuite/euclid.cpp:99-233,
  * invdepth.cpp:36-181); C (2M x n) from outputMatrixC (EqFMatrices.cpp:43-82). Column-major. */
 int eqf_debug_matrices_AB(eqf_ctx* ctx, const double* imu13, double* A_out, double* B_out);
+/* the work matrix of the last vision update, column-major rows x cols: rows [2M, 2M + n) hold W = Sigma C^T L^-T, row 2M + n holds z^T = yTilde^T L^-T
+ * (Sigma+ = Sigma - W W^T, Gamma = W z); rows < 2M are scratch. For the bit-identity tests of the factorisation variants. */
+int eqf_debug_get_W(eqf_ctx* ctx, double* out, int rows, int cols);
 int eqf_debug_matrix_C(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, int useEquivariantOutput, double* C_out, double* ytilde_out);
 
 /* fp64 MFMA micro-benchmark (v_mfma_f64_16x16x4_f64 issue rate): returns achieved TFLOP/s over the whole
@@ -185,6 +194,11 @@ int eqf_trace_read(eqf_ctx* ctx, unsigned long long* device_ticks, long long* ho
 /* Host-side view of the frame since the last reset: calls[0] / seconds[0] = doorbell waits and the wall time the host spent spinning
  * in them; calls[1] / seconds[1] = kernel launch calls and the wall time spent inside them. (frame period - wait time per frame) is
  * the host's own share; a wait time near zero means the frame is host-bound. Both arrays have two entries. */
+/* EQF_OPT_TRACE = 1 and the look-ahead factorisation: device wall-clock stamps (100 MHz) of the LAST frame from inside the persistent
+ * kernel, 96 rows of 8: rows [0, 32) the owner's step k (0 pre-work starts, 1 U tiles arrived, 2 b arrived, 3 pre-work done, 4 elimination of
+ * D_k done, 5 past the first barrier, 6 D_(k+1) handed to the elimination); rows [32, 64) the first T block row and rows [64, 96) S block row
+ * NJ-2, panel p (0 L_p^-1 and the panel tile in LDS, 1 P_I done and published, 2 tile updates done). */
+int eqf_debug_lookahead_stamps(eqf_ctx* ctx, unsigned long long* out768);
 int eqf_host_wait_stats(eqf_ctx* ctx, long* calls, double* seconds, int reset);
 const char* eqf_kernel_name(int which);
 

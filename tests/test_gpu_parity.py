@@ -530,3 +530,72 @@ def test_nees_returns_a_number_when_sigma_is_not_numerically_spd():
         v = cb.compute_nees(esb, eidb, tpb)
         r = ob.compute_nees(esb, eidb, tpb)
         assert cb.nees_lu_fallbacks() == 1 and abs(v - r) <= 1e-6 * abs(r), (N2, v, r)
+
+
+@pytest.mark.parametrize("N,M", [(200, 200), (50, 50), (40, 40), (60, 33), (224, 224), (130, 97), (256, 250)])
+def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
+    """EQF_OPT_LOOKAHEAD: the factorisation of [S ; T ; y^T] as ONE persistent kernel (owner workgroup on the pivot chain, one workgroup
+    per block row following behind, hand-offs as 16-byte value + sequence words) against one launch per panel. Same tile arithmetic in
+    the same order: W and Sigma must not change by a bit; Gamma is summed in another (fixed) order, so it and the lifted state agree to
+    rounding. Sizes: 13 panels (the headline), 4, 3 (smallest eligible), a last panel of 2 columns, 14 panels (largest of the small
+    instantiation), M < N with a ragged last panel, and the larger instantiation (16 panels). A second update on the same context
+    meets the first one's words in the hand-off buffers (the sequence number tells them apart)."""
+    from eqvio_amd.capi import OPT_LOOKAHEAD
+
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=N + M, useDiscreteInnovationLift=0)
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=np.sort(rng.permutation(N)[:M]))
+    rows, m = 2 * M + 21 + 3 * N + 1, 2 * M
+    outs = []
+    cores = []
+    for la in (0, 1, 1):
+        c = EqfCore(N, CHARTS["invdepth"])
+        c.set_state(xi0, Xs, ids, q0, Q)
+        c.set_sigma(S)
+        c.set_option(OPT_LOOKAHEAD, la)
+        c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+        outs.append((c.get_sigma(), c.get_state(), c.last_gamma(), c.debug_get_W(rows, m)[m:]))
+        cores.append(c)
+    for S1, st1, g1, W1 in outs[1:]:
+        assert np.array_equal(W1, outs[0][3])
+        assert np.array_equal(S1, outs[0][0])
+        assert np.linalg.norm(g1 - outs[0][2]) <= 1e-12 * np.linalg.norm(outs[0][2])
+        for u, v in zip(st1, outs[0][1]):
+            assert np.allclose(u, v, rtol=1e-12, atol=1e-13)
+    assert np.array_equal(outs[1][2], outs[2][2])  # Gamma is deterministic
+    # second frame on every context (propagation in between keeps the problem well posed)
+    imu = random_imu(rng)
+    y2 = y + rng.normal(size=y.shape) * 0.5
+    S2 = []
+    for c in cores:
+        c.integrate_riccati_fast(imu, 0.05, settings.input_gain_diag12(), settings.state_gain_diag8())
+        c.vision_update(cam, mid, y2, settings.measurementNoise**2, True, False)
+        S2.append(c.get_sigma())
+    assert rel_fro(S2[1], S2[0]) <= 1e-11 and np.array_equal(S2[1], S2[2])
+    if N <= 60:
+        orc.vision_update(cam, mid, y)
+        assert rel_fro(outs[1][0], orc.get_sigma()) <= 1e-9
+
+
+def test_lookahead_factorisation_soak():
+    """The hand-offs of the persistent kernel under repetition: fresh contexts (zeroed buffers, sequence 1) and one context reused
+    (every word of the previous launch still in place), every result compared bit by bit with the launch chain's."""
+    from eqvio_amd.capi import OPT_LOOKAHEAD
+
+    for N, M in ((200, 200), (40, 40), (60, 33)):
+        rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=N + M, useDiscreteInnovationLift=0)
+        cam = default_camera()
+        mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=np.sort(rng.permutation(N)[:M]))
+        ref = None
+        kept = EqfCore(N, CHARTS["invdepth"])
+        for it in range(61):
+            c = EqfCore(N, CHARTS["invdepth"]) if it <= 20 else kept
+            c.set_state(xi0, Xs, ids, q0, Q)
+            c.set_sigma(S)
+            c.set_option(OPT_LOOKAHEAD, 0 if it == 0 else 1)
+            c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+            Sg = c.get_sigma()
+            if it == 0:
+                ref = Sg
+            else:
+                assert np.array_equal(Sg, ref), (N, it, np.abs(Sg - ref).max())
