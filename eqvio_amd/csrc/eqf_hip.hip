@@ -155,7 +155,9 @@ struct eqf_ctx {
     double *d_Ebuf = nullptr, *d_Yl = nullptr, *d_Fl = nullptr, *d_PhiB = nullptr; // accurate Riccati (lazily allocated)
     int* d_expinfo = nullptr;
     double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
-    char* d_pub = nullptr;                   // look-ahead factorisation: published tiles (16-byte value + sequence words), la_pub_bytes(NJcap)
+    double* d_pub = nullptr;                 // look-ahead factorisation: published tiles (la_pub_tiles(NJcap) x 8 KB), their flags, the yTilde rows
+    int* d_pubf = nullptr;
+    char* d_puby = nullptr;
     int la_njcap = 0, la_seq = 0;
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
@@ -559,9 +561,12 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipMalloc(&c->d_Linv, sizeof(double) * 2048));
     HIPCHK(hipMalloc(&c->d_gamma, sizeof(double) * (c->ncap + 8)));
     HIPCHK(hipMalloc(&c->d_gpart, sizeof(double) * (GAMMA_G + 1) * (size_t)c->ld));
-    c->la_njcap = std::min(32, blocks(c->mcap, 32));
-    HIPCHK(hipMalloc(&c->d_pub, la_pub_bytes(c->la_njcap)));
-    HIPCHK(hipMemsetAsync(c->d_pub, 0, la_pub_bytes(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
+    c->la_njcap = std::min(16, blocks(c->mcap, 32));
+    HIPCHK(hipMalloc(&c->d_pub, sizeof(double) * LA_TILE * la_pub_tiles(c->la_njcap)));
+    HIPCHK(hipMalloc(&c->d_pubf, sizeof(int) * la_pub_tiles(c->la_njcap)));
+    HIPCHK(hipMalloc(&c->d_puby, 512 * (size_t)c->la_njcap));
+    HIPCHK(hipMemsetAsync(c->d_pubf, 0, sizeof(int) * la_pub_tiles(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
+    HIPCHK(hipMemsetAsync(c->d_puby, 0, 512 * (size_t)c->la_njcap, c->stream));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
@@ -622,6 +627,8 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_gamma);
     hipFree(c->d_gpart);
     hipFree(c->d_pub);
+    hipFree(c->d_pubf);
+    hipFree(c->d_puby);
     if (c->d_ladbg)
         hipFree(c->d_ladbg);
     if (c->d_trace)
@@ -1381,7 +1388,7 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
 }
 
 // The same factorisation as launch_chain(first_tile_done = true) in ONE persistent kernel with a look-ahead schedule (eqf_lookahead.hpp):
-// bit-identical W; Gamma arrives complete in d_gamma (no partial vectors). Eligible: 3 <= NJ <= 32 panels (64 < m <= 1024).
+// bit-identical W; Gamma arrives complete in d_gamma (no partial vectors). Eligible: 3 <= NJ <= 16 panels (64 < m <= 512).
 static bool lookahead_eligible(const eqf_ctx* c, int m) {
     const int NJ = blocks(m, 32);
     return c->opt_lookahead && !c->opt_fused && c->d_pub && NJ >= 3 && NJ <= c->la_njcap;
@@ -1400,6 +1407,8 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.W = c->d_W;
     a.Linv0 = c->d_Linv; // k_build_Z leaves L_0^-1 where step 0 of the launch chain reads it
     a.pub = c->d_pub;
+    a.pubf = c->d_pubf;
+    a.puby = c->d_puby;
     a.gamma = c->d_gamma;
     a.flags = c->d_flags;
     a.spec = spec;
@@ -1407,10 +1416,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.tr_steps = trace_slot(c, TR_STEP0);
     a.dbg = c->d_trace ? c->d_ladbg : nullptr;
     KTimer t(c, KN_CHOL_PANEL, a.NJ); // reported per panel, like the launch chain it replaces
-    if (a.NJ <= 14)
-        hipLaunchKernelGGL(k_chol_lookahead<7>, dim3(a.NI), dim3(LA_T), 0, c->stream, a);
-    else
-        hipLaunchKernelGGL(k_chol_lookahead<16>, dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+    hipLaunchKernelGGL(k_chol_lookahead<2>, dim3(a.NI), dim3(LA_T), 0, c->stream, a); // every wave of a block row owns at most 2 of its <= 16 tiles
     HIPCHK(hipGetLastError());
     return 0;
 }

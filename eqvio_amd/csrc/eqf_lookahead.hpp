@@ -14,15 +14,19 @@
 //    whole factorisation (8 waves: two groups of four, even / odd tile columns). Per panel p: receive L_p^-1, compute P^(p)_I =
 //    Z(I,p) L_p^-T (final W rows for the T block rows; factor rows, published, for the S block rows), receive P^(p)_J of the S block
 //    rows J > p and apply Z(I,J) -= P_I P_J^T. S block rows hand U1 / U0 to the owner after panel I-3 and publish b after L_(I-2)^-1.
-//    They run one to two panels behind the owner; nothing they do is on the critical path as long as a hand-off takes < ~3 us.
-//  * HAND-OFF without flags and without fences: every published double travels as one 16-byte (value, sequence, ~sequence) word written
-//    by ONE global_store_dwordx4 sc1 (write-through to the agent coherence point) and read by ONE global_load_dwordx4 sc1; a consumer
-//    polls exactly the words it needs, all loads of a tile in flight together, until every one carries the launch's sequence number.
-//    A 16-byte aligned access never straddles a 32-byte sector, so value and sequence arrive together (scripts/ubench/pingpong2.hip:
-//    1.0 us per 8 KB tile hop against 2.1 us with a separate flag and 2.7 us with release / acquire fences; 20 000 x 2 x 1024 words checked).
-//    The sequence number changes with every launch: the buffers are never cleared.
-//  * Gamma = W z is accumulated by the T block rows on the way (z_p = yTilde_p L_p^-T from the published yTilde row, one fma chain per
-//    row over all columns), so the lift kernel finds Gamma complete.
+//    They run one to two panels behind the owner; nothing they do is on the critical path as long as they keep the owner's pace.
+//  * HAND-OFF: a published tile is 8 KB of doubles written with write-through stores (global_store sc1: the data is at the agent
+//    coherence point when the store completes), then s_waitcnt vmcnt(0), a workgroup barrier and ONE flag word = the launch's sequence
+//    number. A consumer polls the flag words it needs with one cache-bypassing load per wave (all flags of a panel are contiguous) and
+//    then reads the tiles with ordinary cached loads, every load of the step in flight at once. No release / acquire fence: nothing is
+//    dirty in an L2 (write-through), and no line of a tile is ever read before its flag is up, so no L2 or L1 can hold a stale copy of
+//    it (tiles are 8 KB aligned; caches are invalidated at the kernel boundary; the sequence number changes with every launch, the
+//    buffers are never cleared). The first version published every double as a 16-byte (value, sequence) word read with cache-bypassing
+//    loads: 1.0 us per hop in isolation (scripts/ubench/pingpong2.hip) but 30 workgroups fetching the same tiles past the L2 saturate the
+//    few memory channels a tile lives in (2.5 us per round trip under load): the cached version lets every XCD fetch a tile once.
+//    The yTilde row (32 doubles per panel) still travels as 16-byte words.
+//  * Gamma = W z is accumulated by the T block rows on the way (z_p = yTilde_p L_p^-T from the published yTilde row), so the lift
+//    kernel finds Gamma complete.
 //  * Every poll is bounded (20 ms of device wall clock); a timeout raises flags[3] (EQF_E_STALLED) and the workgroups drain.
 //    Dependencies point from higher to lower block rows and to the owner only, and NI <= 80 workgroups of 64 KB LDS always fit the chip.
 #pragma once
@@ -31,8 +35,8 @@
 namespace eqf {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int LA_T = 512;            // threads per workgroup (8 waves)
-constexpr int LA_TILE_B = 16 * 1024; // bytes of a published 32 x 32 tile of 16-byte words
+constexpr int LA_T = 512;                       // threads per workgroup (8 waves)
+constexpr int LA_TILE = 1024;                   // doubles of a published 32 x 32 tile, [r + 32 c]
 constexpr long long LA_TIMEOUT_TICKS = 2000000; // 20 ms at 100 MHz
 
 struct LaArgs {
@@ -40,38 +44,32 @@ struct LaArgs {
     const double* Z;     // [S ; T ; y^T] from k_build_Z (plain memory; complete when this kernel starts)
     double* W;           // out, plain: rows >= m receive W = T L^-T and the z row
     const double* Linv0; // L_0^-1, 32 x 32 column-major, from k_build_Z's first-tile elimination
-    char* pub;           // published tiles (see the offsets below)
+    double* pub;         // published tiles (offsets below)
+    int* pubf;           // their flags
+    char* puby;          // the yTilde row of every panel as 16-byte (value, sequence) words
     double* gamma;       // out: Gamma[n]
     int* flags;          // [0] non-positive pivot, [3] stalled
     const int* spec;
     int spec_seq;
-    trace_t* tr_steps;   // EQF_OPT_TRACE: slot of step 0 (the owner stamps one slot per step), or nullptr
+    trace_t* tr_steps;       // EQF_OPT_TRACE: slot of step 0 (the owner stamps one slot per step), or nullptr
     unsigned long long* dbg; // EQF_OPT_TRACE: per-step stamps inside the owner ([k][8]) and two block rows ([32 + p][8], [64 + p][8]), or nullptr
 };
-// published tiles: [0, NJ) L_p^-1 | [NJ, NJ + NJ^2) P^(p)_J at J NJ + p | then U1, U0 of every S block row | then the yTilde row per panel
-__device__ __forceinline__ char* la_linv(const LaArgs& a, int p) { return a.pub + (size_t)LA_TILE_B * p; }
-__device__ __forceinline__ char* la_p(const LaArgs& a, int J, int p) { return a.pub + (size_t)LA_TILE_B * (a.NJ + J * a.NJ + p); }
-__device__ __forceinline__ char* la_u(const LaArgs& a, int I, int which) { return a.pub + (size_t)LA_TILE_B * (a.NJ + a.NJ * a.NJ + 2 * I + which); }
-__device__ __forceinline__ char* la_y(const LaArgs& a, int p) { return a.pub + (size_t)LA_TILE_B * (a.NJ + a.NJ * a.NJ + 2 * a.NJ) + 512 * (size_t)p; }
-inline size_t la_pub_bytes(int NJ) { return (size_t)LA_TILE_B * (NJ + (size_t)NJ * NJ + 2 * NJ) + 512 * (size_t)NJ; }
+// tiles: [0, NJ) L_p^-1 | [NJ, NJ + NJ^2) P^(p)_J at p NJ + J (a panel's tiles are neighbours) | then U1, U0 of every S block row
+// flags: the same indices (one int per tile; U1 / U0 share the flag of U1)
+__device__ __forceinline__ int la_i_linv(const LaArgs& a, int p) { return p; }
+__device__ __forceinline__ int la_i_p(const LaArgs& a, int J, int p) { return a.NJ + p * a.NJ + J; }
+__device__ __forceinline__ int la_i_u(const LaArgs& a, int I, int which) { return a.NJ + a.NJ * a.NJ + 2 * I + which; }
+inline size_t la_pub_tiles(int NJ) { return (size_t)NJ + (size_t)NJ * NJ + 2 * (size_t)NJ; }
+__device__ __forceinline__ double* la_tile(const LaArgs& a, int idx) { return a.pub + (size_t)LA_TILE * idx; }
 
-__device__ __forceinline__ void la_put(char* p, double v, int seq) {
-    v4i x;
-    x.x = __double2loint(v);
-    x.y = __double2hiint(v);
-    x.z = seq;
-    x.w = ~seq;
-    // s_nop: a VALU write of the data registers must not follow a store of more than 64 bits within one wait state; the compiler cannot see
-    // that this asm is such a store
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
-}
+__device__ __forceinline__ void la_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } // global_store_dwordx2 sc1
+__device__ __forceinline__ void la_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void la_raise(const LaArgs& a, int idx) { __hip_atomic_store(a.pubf + idx, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct LaPoll {
     long long deadline;
     int seq;
     int* s_abort;
 };
-__device__ __forceinline__ bool la_ok(const v4i& r, int seq) { return r.z == seq && r.w == ~seq; }
-__device__ __forceinline__ double la_val(const v4i& r) { return __hiloint2double(r.y, r.x); }
 __device__ __forceinline__ bool la_retry(const LaPoll& pl) {
     if ((long long)wall_clock64() > pl.deadline) {
         *pl.s_abort = 1;
@@ -80,160 +78,45 @@ __device__ __forceinline__ bool la_retry(const LaPoll& pl) {
     __builtin_amdgcn_s_sleep(1);
     return true;
 }
-__device__ __forceinline__ double la_get1(const char* p0, const LaPoll& pl) {
+// wait until the `count` (<= 64) consecutive flags at f carry the launch's sequence number: lane j watches flag j
+__device__ __forceinline__ void la_wait(const int* f, int count, const LaPoll& pl) {
+    const int lane = threadIdx.x & 63;
+    if (lane < count) {
+        for (;;) {
+            const int v = __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // global_load_dword sc1: not served by a cache
+            if (v == pl.seq || !la_retry(pl))
+                break;
+        }
+    }
+    asm volatile("" ::: "memory"); // the tile loads below must not be hoisted over the wait
+}
+// the yTilde row: 16-byte (value, sequence, ~sequence) words, one store / one load each (32 doubles per panel: no traffic to speak of)
+__device__ __forceinline__ void la_put16(char* p, double v, int seq) {
+    v4i x;
+    x.x = __double2loint(v);
+    x.y = __double2hiint(v);
+    x.z = seq;
+    x.w = ~seq;
+    // s_nop: a VALU write of the data registers must not follow a store of more than 64 bits within one wait state, and the compiler
+    // cannot see that this asm is such a store (without it: wrong values with a valid sequence number in ~8 % of the launches)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ double la_get16(const char* p0, const LaPoll& pl) {
     v4i r;
     for (;;) {
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p0) : "memory");
-        if (la_ok(r, pl.seq) || !la_retry(pl))
+        if ((r.z == pl.seq && r.w == ~pl.seq) || !la_retry(pl))
             break;
     }
-    return la_val(r);
-}
-// While a tile is not there yet, poll ONE of its words (every lane the same address: one request per wave) instead of re-requesting
-// all of them: 30 workgroups spinning on whole tiles saturate the few memory channels a 16 KB tile lives in and slow down the very
-// stores they wait for. The sentinel is a word the producer writes late; it is a hint only - every word is still validated by its own
-// sequence number when the tile is fetched.
-__device__ __forceinline__ void la_wait_word(const char* word, const LaPoll& pl) {
-    v4i r;
-    for (;;) {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(word) : "memory");
-        if (la_ok(r, pl.seq) || !la_retry(pl))
-            break;
-    }
-}
-constexpr int LA_SENT_TILE = 16 * 1023; // byte offset of the sentinel word of a published P / U tile (entry (31, 31): stored last)
-constexpr int LA_SENT_LINV = 16 * 511;  // ... of L^-1 (entry (31, 15): the elimination's last stage)
-__device__ __forceinline__ void la_get2(const char* p0, const char* p1, const LaPoll& pl, double& v0, double& v1) {
-    v4i r0, r1;
-    for (;;) {
-        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
-                     "global_load_dwordx4 %1, %3, off sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1)
-                     : "v"(p0), "v"(p1)
-                     : "memory");
-        if ((la_ok(r0, pl.seq) && la_ok(r1, pl.seq)) || !la_retry(pl))
-            break;
-    }
-    v0 = la_val(r0);
-    v1 = la_val(r1);
-}
-// accumulator layout: the four entries [i][j + 4 q] a lane holds of a 16 x 16 sub-tile; e0 = 16-byte index of entry q = 0, entries 4 columns = 128 words apart
-__device__ __forceinline__ void la_get_acc(const char* tile, int e0, const LaPoll& pl, double (&v)[4]) {
-    const char* p0 = tile + 16 * (size_t)e0;
-    v4i r0, r1, r2, r3;
-    for (;;) {
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                     "global_load_dwordx4 %1, %4, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %2, %5, off sc1\n\t"
-                     "global_load_dwordx4 %3, %5, off offset:2048 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                     : "v"(p0), "v"(p0 + 4096)
-                     : "memory");
-        if ((la_ok(r0, pl.seq) && la_ok(r1, pl.seq) && la_ok(r2, pl.seq) && la_ok(r3, pl.seq)) || !la_retry(pl))
-            break;
-    }
-    v[0] = la_val(r0);
-    v[1] = la_val(r1);
-    v[2] = la_val(r2);
-    v[3] = la_val(r3);
+    return __hiloint2double(r.y, r.x);
 }
 // MFMA operand layout: lane (lr, lk) receives v[st] = X[16 h + lr][4 st + lk], st = 0..7, of a published tile X[row + 32 k]
-__device__ __forceinline__ void la_get_operand(const char* tile, int h, const LaPoll& pl, double (&v)[8]) {
+__device__ __forceinline__ void la_operand(const double* __restrict__ tile, int h, double (&v)[8]) {
     const int lane = threadIdx.x & 63;
-    const char* p0 = tile + 16 * (size_t)((16 * h + (lane & 15)) + 32 * (lane >> 4)); // + 2048 st
-    v4i r0, r1, r2, r3, r4, r5, r6, r7;
-    for (;;) {
-        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
-                     "global_load_dwordx4 %1, %8, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %2, %9, off sc1\n\t"
-                     "global_load_dwordx4 %3, %9, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %4, %10, off sc1\n\t"
-                     "global_load_dwordx4 %5, %10, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %6, %11, off sc1\n\t"
-                     "global_load_dwordx4 %7, %11, off offset:2048 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
-                     : "v"(p0), "v"(p0 + 4096), "v"(p0 + 8192), "v"(p0 + 12288)
-                     : "memory");
-        const bool ok = la_ok(r0, pl.seq) && la_ok(r1, pl.seq) && la_ok(r2, pl.seq) && la_ok(r3, pl.seq) && la_ok(r4, pl.seq) && la_ok(r5, pl.seq) && la_ok(r6, pl.seq) &&
-                        la_ok(r7, pl.seq);
-        if (ok || !la_retry(pl))
-            break;
-    }
-    v[0] = la_val(r0);
-    v[1] = la_val(r1);
-    v[2] = la_val(r2);
-    v[3] = la_val(r3);
-    v[4] = la_val(r4);
-    v[5] = la_val(r5);
-    v[6] = la_val(r6);
-    v[7] = la_val(r7);
-}
-
-// two tiles at once (16 loads in flight, ONE round trip): the block rows' update loop and the owner's pre-work are bound by the number of
-// dependent round trips, not by bytes
-__device__ __forceinline__ void la_get_operand2(const char* tileA, const char* tileB, int h, const LaPoll& pl, double (&va)[8], double (&vb)[8]) {
-    const int lane = threadIdx.x & 63;
-    const size_t off = 16 * (size_t)((16 * h + (lane & 15)) + 32 * (lane >> 4));
-    const char* pa = tileA + off;
-    const char* pb = tileB + off;
-    v4i r0, r1, r2, r3, r4, r5, r6, r7, s0, s1, s2, s3, s4, s5, s6, s7;
-    for (;;) {
-        asm volatile("global_load_dwordx4 %0, %16, off sc1\n\t"
-                     "global_load_dwordx4 %1, %16, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %2, %17, off sc1\n\t"
-                     "global_load_dwordx4 %3, %17, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %4, %18, off sc1\n\t"
-                     "global_load_dwordx4 %5, %18, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %6, %19, off sc1\n\t"
-                     "global_load_dwordx4 %7, %19, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %8, %20, off sc1\n\t"
-                     "global_load_dwordx4 %9, %20, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %10, %21, off sc1\n\t"
-                     "global_load_dwordx4 %11, %21, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %12, %22, off sc1\n\t"
-                     "global_load_dwordx4 %13, %22, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %14, %23, off sc1\n\t"
-                     "global_load_dwordx4 %15, %23, off offset:2048 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(s4), "=&v"(s5),
-                       "=&v"(s6), "=&v"(s7)
-                     : "v"(pa), "v"(pa + 4096), "v"(pa + 8192), "v"(pa + 12288), "v"(pb), "v"(pb + 4096), "v"(pb + 8192), "v"(pb + 12288)
-                     : "memory");
-        const int q = pl.seq;
-        const bool ok = la_ok(r0, q) && la_ok(r1, q) && la_ok(r2, q) && la_ok(r3, q) && la_ok(r4, q) && la_ok(r5, q) && la_ok(r6, q) && la_ok(r7, q) && la_ok(s0, q) && la_ok(s1, q) &&
-                        la_ok(s2, q) && la_ok(s3, q) && la_ok(s4, q) && la_ok(s5, q) && la_ok(s6, q) && la_ok(s7, q);
-        if (ok || !la_retry(pl))
-            break;
-    }
-    va[0] = la_val(r0), va[1] = la_val(r1), va[2] = la_val(r2), va[3] = la_val(r3), va[4] = la_val(r4), va[5] = la_val(r5), va[6] = la_val(r6), va[7] = la_val(r7);
-    vb[0] = la_val(s0), vb[1] = la_val(s1), vb[2] = la_val(s2), vb[3] = la_val(s3), vb[4] = la_val(s4), vb[5] = la_val(s5), vb[6] = la_val(s6), vb[7] = la_val(s7);
-}
-__device__ __forceinline__ void la_get_acc2(const char* tileA, const char* tileB, int e0, const LaPoll& pl, double (&va)[4], double (&vb)[4]) {
-    const char* pa = tileA + 16 * (size_t)e0;
-    const char* pb = tileB + 16 * (size_t)e0;
-    v4i r0, r1, r2, r3, s0, s1, s2, s3;
-    for (;;) {
-        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
-                     "global_load_dwordx4 %1, %8, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %2, %9, off sc1\n\t"
-                     "global_load_dwordx4 %3, %9, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %4, %10, off sc1\n\t"
-                     "global_load_dwordx4 %5, %10, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %6, %11, off sc1\n\t"
-                     "global_load_dwordx4 %7, %11, off offset:2048 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
-                     : "v"(pa), "v"(pa + 4096), "v"(pb), "v"(pb + 4096)
-                     : "memory");
-        const int q = pl.seq;
-        if ((la_ok(r0, q) && la_ok(r1, q) && la_ok(r2, q) && la_ok(r3, q) && la_ok(s0, q) && la_ok(s1, q) && la_ok(s2, q) && la_ok(s3, q)) || !la_retry(pl))
-            break;
-    }
-    va[0] = la_val(r0), va[1] = la_val(r1), va[2] = la_val(r2), va[3] = la_val(r3);
-    vb[0] = la_val(s0), vb[1] = la_val(s1), vb[2] = la_val(s2), vb[3] = la_val(s3);
+    const double* p0 = tile + (16 * h + (lane & 15)) + 32 * (lane >> 4);
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+        v[st] = p0[128 * st];
 }
 
 // ---- the owner --------------------------------------------------------------------------------------------------------------------
@@ -244,11 +127,18 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     double* sY = smem + 2 * 32 * CH_LDP; // R1 (written by the pre-work, read by the post-work)
     double* sD = smem + 3 * 32 * CH_LDP; // the diagonal tile handed to the elimination
     double* swork = smem + 4 * 32 * CH_LDP;
-    const int NJ = a.NJ, seq = a.seq;
-    for (int e = tid; e < 1024; e += LA_T) {
-        const double v = a.Linv0[e];
-        sLk[(e & 31) + (e >> 5) * CH_LDP] = v;
-        la_put(la_linv(a, 0) + 16 * (size_t)e, v, seq);
+    const int NJ = a.NJ;
+    {
+        double* l0 = la_tile(a, la_i_linv(a, 0));
+        for (int e = tid; e < 1024; e += LA_T) {
+            const double v = a.Linv0[e];
+            sLk[(e & 31) + (e >> 5) * CH_LDP] = v;
+            la_st(l0 + e, v);
+        }
+        la_stores_done();
+        __syncthreads();
+        if (tid == 0)
+            la_raise(a, la_i_linv(a, 0));
     }
     const bool prod = wave >= 4;
     const int pw = wave & 3, ihU = pw & 1, jhU = pw >> 1;
@@ -259,26 +149,28 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             a.tr_steps[k] = wall_clock64();
         if (prod) {
             // pre-work (runs while wave 0 eliminates D_k): tiles of block row I with the panels <= I-3 applied, panel I-2 applied here
-            double u1[4], u0[4];
-            const int e0 = (16 * ihU + lr) + 32 * (16 * jhU + lk);
             if (a.dbg && wave == 4 && lane == 0)
                 a.dbg[8 * k + 0] = wall_clock64();
-            la_wait_word(la_u(a, I, 1) + LA_SENT_TILE, pl);
-            la_get_acc2(la_u(a, I, 0), la_u(a, I, 1), e0, pl, u1, u0);
+            la_wait(a.pubf + la_i_u(a, I, 0), 1, pl);
+            if (k >= 1)
+                la_wait(a.pubf + la_i_p(a, I, k - 1), 1, pl);
             if (a.dbg && wave == 4 && lane == 0)
                 a.dbg[8 * k + 1] = wall_clock64();
+            double u1[4], u0[4];
+            {
+                const double* t1 = la_tile(a, la_i_u(a, I, 0)) + (16 * ihU + lr) + 32 * (16 * jhU + lk);
+                const double* t0 = la_tile(a, la_i_u(a, I, 1)) + (16 * ihU + lr) + 32 * (16 * jhU + lk);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u1[q] = t1[128 * q];
+                    u0[q] = t0[128 * q];
+                }
+            }
             if (k >= 1) {
                 double bi[8], bj[8];
-                la_wait_word(la_p(a, I, k - 1) + LA_SENT_TILE, pl);
-                if (jhU == ihU) {
-                    la_get_operand(la_p(a, I, k - 1), ihU, pl, bi);
-#pragma unroll
-                    for (int st = 0; st < 8; ++st)
-                        bj[st] = bi[st];
-                } else { // the two halves of the same tile: one round trip
-                    const char* bt = la_p(a, I, k - 1);
-                    la_get_operand2(bt + 16 * 16 * (size_t)ihU, bt + 16 * 16 * (size_t)jhU, 0, pl, bi, bj);
-                }
+                const double* bt = la_tile(a, la_i_p(a, I, k - 1));
+                la_operand(bt, ihU, bi);
+                la_operand(bt, jhU, bj);
                 if (a.dbg && wave == 4 && lane == 0)
                     a.dbg[8 * k + 2] = wall_clock64();
                 d4 r = {0, 0, 0, 0}, d = {0, 0, 0, 0};
@@ -307,6 +199,8 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             return;
         if (a.dbg && tid == 0)
             a.dbg[8 * k + 5] = wall_clock64();
+        if (tid == 0 && k >= 1)
+            la_raise(a, la_i_linv(a, k)); // wave 0 stored L_k^-1 and waited for its stores before the barrier
         if (prod) {
             // c = P^(k)_I = R1 L_k^-T : sub-tile (ih, ch) = (pw & 1, pw >> 1)
             const int ih = pw & 1, ch = pw >> 1;
@@ -314,11 +208,12 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 #pragma unroll
             for (int st = 0; st < 8; ++st)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLk[16 * ch + lr + (4 * st + lk) * CH_LDP], sY[16 * ih + lr + (4 * st + lk) * CH_LDP], acc, 0, 0, 0);
+            double* ct = la_tile(a, la_i_p(a, I, k));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r_ = 16 * ih + lr, c_ = 16 * ch + lk + 4 * q;
                 sX[r_ + c_ * CH_LDP] = acc[q];
-                la_put(la_p(a, I, k) + 16 * (size_t)(r_ + 32 * c_), acc[q], seq);
+                la_st(ct + r_ + 32 * c_, acc[q]);
             }
         }
         __syncthreads(); // B1.5: c in sX
@@ -335,27 +230,37 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 const int r_ = 16 * ihU + lr, c_ = 16 * jhU + lk + 4 * q;
                 sD[r_ + c_ * CH_LDP] = (r_ >= w2 || c_ >= w2) ? ((r_ == c_) ? 1.0 : 0.0) : dacc[q] - acc[q];
             }
+            la_stores_done(); // the write-through stores of c have had the product above to complete
         }
-        __syncthreads(); // B2: D in sD
+        __syncthreads(); // B2: D in sD; c written through
+        if (tid == 0)
+            la_raise(a, la_i_p(a, I, k));
         if (a.dbg && tid == 0)
             a.dbg[8 * k + 6] = wall_clock64();
         if (wave == 0) {
             const int w2 = min(32, a.m - 32 * I);
-            char* lp = la_linv(a, I);
+            double* lt = la_tile(a, la_i_linv(a, I));
             ldl_inverse_tile_put(
                 sD, CH_LDP, w2,
-                [sLk, lp, seq](int r, int c, double v) {
+                [sLk, lt](int r, int c, double v) {
                     sLk[r + c * CH_LDP] = v;
-                    la_put(lp + 16 * (size_t)(r + 32 * c), v, seq);
+                    la_st(lt + r + 32 * c, v);
                 },
                 a.flags, swork);
+            la_stores_done(); // the flag of L_(k+1)^-1 goes up right after the next barrier
         }
     }
+    __syncthreads();
+    if (tid == 0)
+        la_raise(a, la_i_linv(a, NJ - 1));
     if (a.tr_steps && tid == 0 && NJ - 1 < 32)
         a.tr_steps[NJ - 1] = wall_clock64();
 }
 
 // ---- a block row --------------------------------------------------------------------------------------------------------------------
+// Wave wv of the 8 owns the WHOLE tiles Z(I, J), J = wv + 8 t (four 16 x 16 accumulator sub-tiles each): a panel step touches at most
+// MAXT tiles per wave, and their operands (two 16-row halves of P_J, 16 doubles per lane and tile) are all requested before the first
+// product: one memory round trip per step instead of one per tile.
 template <int MAXT>
 __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* smem, int* s_abort, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -371,59 +276,72 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
     const int Jmax = srow ? I : NJ - 1;
     const bool ylast = (!srow) && (rows - 1 >= row0) && (rows - 1 < row0 + 32); // this block row holds the yTilde row
     const int yloc = rows - 1 - row0;
-    const int g = wave >> 2, wq = wave & 3, ihU = wq & 1, jhU = wq >> 1;
-    const int ri = row0 + 16 * ihU + lr;
-    const int ric = min(ri, ilim - 1);
-    double acc[MAXT][4];
+    double acc[MAXT][4][4]; // [tile][sub-tile s = ih + 2 jh][q]: entry [16 ih + lr][16 jh + lk + 4 q]
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        const int J = 2 * t + g;
+        const int J = wave + 8 * t;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = min(32 * J + 16 * jhU + lk + 4 * q, m - 1);
-            acc[t][q] = (J <= Jmax) ? a.Z[ric + (size_t)j * ldz] : 0.0;
+        for (int sb = 0; sb < 4; ++sb) {
+            const int i = min(row0 + 16 * (sb & 1) + lr, ilim - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = min(32 * J + 16 * (sb >> 1) + lk + 4 * q, m - 1);
+                acc[t][sb][q] = (J <= Jmax) ? a.Z[i + (size_t)j * ldz] : 0.0;
+            }
         }
     }
     if (ylast && tid < 32)
-        la_put(la_y(a, 0) + 16 * (size_t)tid, a.Z[(rows - 1) + (size_t)min(tid, m - 1) * ldz], seq);
+        la_put16(a.puby + 16 * (size_t)tid, a.Z[(rows - 1) + (size_t)min(tid, m - 1) * ldz], seq);
     double gsum = 0.0; // thread (r = tid & 31, h = tid >> 5 < 8): Gamma share of row row0 + r over the columns 4 h .. 4 h + 3 of every panel
     // S block rows: panels 0 .. I-3 with updates, then the hand-off of U1 / U0, then panel I-2 (b) without updates. T block rows: all panels.
     const int np = srow ? I - 1 : NJ;
-    for (int p = 0; p < np; ++p) {
-        const bool do_update = srow ? (p <= I - 3) : true;
-        if (srow && p == I - 2) {
-            // hand-off to the owner: U1 = Z(I, I-1), U0 = Z(I, I) with the panels <= I-3 applied
+    auto hand_off = [&]() {
+        // to the owner: U1 = Z(I, I-1), U0 = Z(I, I) with the panels <= I-3 applied (all waves of the workgroup call this)
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int J = 2 * t + g;
-                if (J == I - 1 || J == I) {
-                    char* u = la_u(a, I, J == I ? 1 : 0);
+        for (int t = 0; t < MAXT; ++t) {
+            const int J = wave + 8 * t;
+            if (J == I - 1 || J == I) {
+                double* u = la_tile(a, la_i_u(a, I, J == I ? 1 : 0));
+#pragma unroll
+                for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        la_put(u + 16 * (size_t)((16 * ihU + lr) + 32 * (16 * jhU + lk + 4 * q)), acc[t][q], seq);
-                }
+                        la_st(u + (16 * (sb & 1) + lr) + 32 * (16 * (sb >> 1) + lk + 4 * q), acc[t][sb][q]);
             }
         }
+        la_stores_done();
+        __syncthreads();
+        if (tid == 0)
+            la_raise(a, la_i_u(a, I, 0));
+    };
+    for (int p = 0; p < np; ++p) {
+        const bool do_update = srow ? (p <= I - 3) : true;
+        if (srow && p == I - 2)
+            hand_off();
         const int w = min(32, m - 32 * p);
         // (a) L_p^-1 -> LDS; the panel tile Z(I, p) -> LDS in operand layout (masked like the chain's operand loads); yTilde row of the panel
+        la_wait(a.pubf + la_i_linv(a, p), 1, pl);
         {
-            double v0, v1;
-            la_wait_word(la_linv(a, p) + (p == 0 ? 16 * 1023 : LA_SENT_LINV), pl);
-            la_get2(la_linv(a, p) + 16 * (size_t)tid, la_linv(a, p) + 16 * (size_t)(tid + LA_T), pl, v0, v1);
+            const double* lt = la_tile(a, la_i_linv(a, p));
+            const double v0 = lt[tid], v1 = lt[tid + LA_T];
             sLinv[(tid & 31) + (tid >> 5) * CH_LDP] = v0;
             sLinv[((tid + LA_T) & 31) + ((tid + LA_T) >> 5) * CH_LDP] = v1;
         }
+        if (wave == (p & 7)) {
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (2 * t + g == p) {
+            for (int t = 0; t < MAXT; ++t)
+                if (t == (p >> 3)) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 16 * jhU + lk + 4 * q;
-                    sT[16 * ihU + lr + c * CH_LDP] = (ri < ilim && c < w) ? acc[t][q] : 0.0;
+                    for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r = 16 * (sb & 1) + lr, c = 16 * (sb >> 1) + lk + 4 * q;
+                            sT[r + c * CH_LDP] = (row0 + r < ilim && c < w) ? acc[t][sb][q] : 0.0;
+                        }
                 }
-            }
-        if (!srow && wave == 7 && lane < 32) {
-            const double yv = la_get1(la_y(a, p) + 16 * (size_t)lane, pl);
+        }
+        if (!srow && wave == ((p + 1) & 7) && lane < 32) {
+            const double yv = la_get16(a.puby + 512 * (size_t)p + 16 * (size_t)lane, pl);
             sYv[lane] = lane < w ? yv : 0.0;
         }
         __syncthreads();
@@ -433,7 +351,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         unsigned long long* dbr = a.dbg + 8 * ((I == NJ ? 32 : 64) + p);
         if (dbg_row)
             dbr[0] = wall_clock64();
-        // (b) P_I = Z(I, p) L_p^-T on waves 0..3 (sub-tile (ih, ch)); z_p on wave 4
+        // (b) P_I = Z(I, p) L_p^-T on waves 0..3 (sub-tile (ih, ch)); z_p partials on waves 4..7
         if (wave < 4) {
             const int ih = wave & 1, ch = wave >> 1;
             d4 pacc = {0, 0, 0, 0};
@@ -443,6 +361,13 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 sPI[16 * ih + lr + (16 * ch + lk + 4 * q) * CH_LDP] = pacc[q];
+            if (srow) { // the factor rows leave for the other block rows straight from the accumulators
+                double* pt = la_tile(a, la_i_p(a, I, p));
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    la_st(pt + (16 * ih + lr) + 32 * (16 * ch + lk + 4 * q), pacc[q]);
+                la_stores_done();
+            }
         } else if (!srow) {
             // z_p[c] = sum_q yTilde_p[q] L_p^-1[c][q] as 8 partial sums (thread (c, h): q = 4 h .. 4 h + 3), summed in a fixed order by the readers
             const int c = tid & 31, h = (tid >> 5) & 7;
@@ -453,11 +378,10 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             sZp[32 * h + c] = z;
         }
         __syncthreads();
-        // (c) P_I leaves: published for the S block rows (the factor), stored as final W rows for the T block rows (+ Gamma)
+        // (c) P_I: flag for the S block rows; final W rows (+ Gamma) for the T block rows
         if (srow) {
-            char* pp = la_p(a, I, p);
-            la_put(pp + 16 * (size_t)tid, sPI[(tid & 31) + (tid >> 5) * CH_LDP], seq);
-            la_put(pp + 16 * (size_t)(tid + LA_T), sPI[((tid + LA_T) & 31) + ((tid + LA_T) >> 5) * CH_LDP], seq);
+            if (tid == 0)
+                la_raise(a, la_i_p(a, I, p));
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -479,86 +403,67 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             dbr[1] = wall_clock64();
         if (!do_update)
             continue;
-        double aI[8];
+        // every P^(p)_J this row needs: flags p NJ + (p+1 .. Jmax) are neighbours -> one polling load per wave; then all operands at once
+        {
+            const int jn = min(Jmax, NJ - 1);
+            const int cnt = (srow ? jn - 1 : jn) - p; // an S block row's own P_I (J = I) is in LDS
+            if (cnt > 0)
+                la_wait(a.pubf + la_i_p(a, p + 1, p), cnt, pl);
+        }
+        double bJ[MAXT][2][8];
 #pragma unroll
-        for (int st = 0; st < 8; ++st)
-            aI[st] = sPI[16 * ihU + lr + (4 * st + lk) * CH_LDP];
-        // two tiles per round trip: the operands P^(p)_J of both are requested together
-#pragma unroll
-        for (int tt = 0; tt < MAXT; tt += 2) {
-            const int JA = 2 * tt + g, JB = 2 * (tt + 1) + g;
-            const bool actA = JA > p && JA <= Jmax;
-            const bool actB = (tt + 1 < MAXT) && JB > p && JB <= Jmax;
-            if (!actA && !actB)
-                continue;
-            const bool pollA = actA && JA != I, pollB = actB && JB != I; // the diagonal tile of an S block row takes both operands from P_I
-            double bA[8], bB[8];
-            if (pollB)
-                la_wait_word(la_p(a, JB, p) + LA_SENT_TILE, pl);
-            else if (pollA)
-                la_wait_word(la_p(a, JA, p) + LA_SENT_TILE, pl);
-            if (pollA && pollB)
-                la_get_operand2(la_p(a, JA, p), la_p(a, JB, p), jhU, pl, bA, bB);
-            else if (pollA)
-                la_get_operand(la_p(a, JA, p), jhU, pl, bA);
-            else if (pollB)
-                la_get_operand(la_p(a, JB, p), jhU, pl, bB);
-            if (actA && !pollA) {
-#pragma unroll
-                for (int st = 0; st < 8; ++st)
-                    bA[st] = sPI[16 * jhU + lr + (4 * st + lk) * CH_LDP];
+        for (int t = 0; t < MAXT; ++t) {
+            const int J = wave + 8 * t;
+            if (J > p && J <= Jmax && J != I) {
+                const double* pt = la_tile(a, la_i_p(a, J, p));
+                la_operand(pt, 0, bJ[t][0]);
+                la_operand(pt, 1, bJ[t][1]);
             }
-            if (actB && !pollB) {
+        }
+        double aI[2][8];
 #pragma unroll
-                for (int st = 0; st < 8; ++st)
-                    bB[st] = sPI[16 * jhU + lr + (4 * st + lk) * CH_LDP];
-            }
-            if (actA) {
-                d4 d = {0, 0, 0, 0};
+        for (int st = 0; st < 8; ++st) {
+            aI[0][st] = sPI[lr + (4 * st + lk) * CH_LDP];
+            aI[1][st] = sPI[16 + lr + (4 * st + lk) * CH_LDP];
+        }
 #pragma unroll
-                for (int st = 0; st < 8; ++st)
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(bA[st], aI[st], d, 0, 0, 0);
+        for (int t = 0; t < MAXT; ++t) {
+            const int J = wave + 8 * t;
+            if (J > p && J <= Jmax) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[tt][q] -= d[q];
-                if (ylast && JA == p + 1 && 16 * ihU + lr == yloc) {
+                for (int sb = 0; sb < 4; ++sb) {
+                    const int ih = sb & 1, jh = sb >> 1;
+                    d4 d = {0, 0, 0, 0};
+                    if (J == I) { // diagonal tile of an S block row: both operands are P_I
+#pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[jh][st], aI[ih][st], d, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[t][jh][st], aI[ih][st], d, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[t][sb][q] -= d[q];
+                }
+                if (ylast && J == p + 1 && lr == (yloc & 15)) {
                     // the yTilde row of the next panel is final now: publish it for every T block row's z_(p+1)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        la_put(la_y(a, p + 1) + 16 * (size_t)(16 * jhU + lk + 4 * q), acc[tt][q], seq);
-                }
-            }
-            if (actB) {
-                d4 d = {0, 0, 0, 0};
+                    for (int sb = 0; sb < 4; ++sb)
+                        if ((sb & 1) == (yloc >> 4)) {
 #pragma unroll
-                for (int st = 0; st < 8; ++st)
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(bB[st], aI[st], d, 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[(tt + 1 < MAXT) ? tt + 1 : tt][q] -= d[q];
-                if (ylast && JB == p + 1 && 16 * ihU + lr == yloc) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        la_put(la_y(a, p + 1) + 16 * (size_t)(16 * jhU + lk + 4 * q), acc[(tt + 1 < MAXT) ? tt + 1 : tt][q], seq);
+                            for (int q = 0; q < 4; ++q)
+                                la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * (sb >> 1) + lk + 4 * q), acc[t][sb][q], seq);
+                        }
                 }
             }
         }
         if (dbg_row)
             dbr[2] = wall_clock64();
     }
-    if (srow && I == 1) {
-        // block row 1 has no panel of its own to wait for: its two tiles go to the owner as they are
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            const int J = 2 * t + g;
-            if (J == 0 || J == 1) {
-                char* u = la_u(a, 1, J == 1 ? 1 : 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    la_put(u + 16 * (size_t)((16 * ihU + lr) + 32 * (16 * jhU + lk + 4 * q)), acc[t][q], seq);
-            }
-        }
-    }
+    if (srow && I == 1)
+        hand_off(); // block row 1 has no panel of its own to wait for: its two tiles go to the owner as they are
     if (!srow) {
         __syncthreads(); // the last panel's readers of sZp are done
         if (tid < 256)
