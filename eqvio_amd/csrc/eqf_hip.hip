@@ -157,7 +157,7 @@ struct eqf_ctx {
     double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
     double* d_pub = nullptr;                 // look-ahead factorisation: published tiles (la_pub_tiles(NJcap) x 8 KB), their flags, the yTilde rows
     int* d_pubf = nullptr;
-    char* d_puby = nullptr;
+    char *d_puby = nullptr, *d_publ = nullptr;
     int la_njcap = 0, la_seq = 0;
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
@@ -567,6 +567,9 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipMalloc(&c->d_puby, 512 * (size_t)c->la_njcap));
     HIPCHK(hipMemsetAsync(c->d_pubf, 0, sizeof(int) * la_pub_tiles(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
     HIPCHK(hipMemsetAsync(c->d_puby, 0, 512 * (size_t)c->la_njcap, c->stream));
+    HIPCHK(hipMalloc(&c->d_publ, 16384 * (size_t)c->la_njcap));
+    HIPCHK(hipMemsetAsync(c->d_publ, 0, 16384 * (size_t)c->la_njcap, c->stream));
+    HIPCHK(hipFuncSetAttribute((const void*)k_chol_lookahead<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LA_LDS_BYTES));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
@@ -629,6 +632,7 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_pub);
     hipFree(c->d_pubf);
     hipFree(c->d_puby);
+    hipFree(c->d_publ);
     if (c->d_ladbg)
         hipFree(c->d_ladbg);
     if (c->d_trace)
@@ -1409,6 +1413,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.pub = c->d_pub;
     a.pubf = c->d_pubf;
     a.puby = c->d_puby;
+    a.publ = c->d_publ;
     a.gamma = c->d_gamma;
     a.flags = c->d_flags;
     a.spec = spec;
@@ -1416,7 +1421,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.tr_steps = trace_slot(c, TR_STEP0);
     a.dbg = c->d_trace ? c->d_ladbg : nullptr;
     KTimer t(c, KN_CHOL_PANEL, a.NJ); // reported per panel, like the launch chain it replaces
-    hipLaunchKernelGGL(k_chol_lookahead<2>, dim3(a.NI), dim3(LA_T), 0, c->stream, a); // every wave of a block row owns at most 2 of its <= 16 tiles
+    hipLaunchKernelGGL(k_chol_lookahead<2>, dim3(a.NI), dim3(LA_T), LA_LDS_BYTES, c->stream, a); // every wave of a block row owns at most 2 of its <= 16 tiles
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -11,11 +11,16 @@
 //    previous step). When L_k^-1 appears they finish: c = R1 L_k^-T, D = D' - c c^T, and wave 0 eliminates D. Per step on the critical
 //    path: elimination + two products + three workgroup barriers; no launch boundary, no memory round trip, no cross-workgroup hop.
 //  * one ROW workgroup per 32-row block row I >= 1 keeps ALL tiles Z(I, 0 .. min(I, NJ-1)) in its MFMA accumulator registers for the
-//    whole factorisation (8 waves: two groups of four, even / odd tile columns). Per panel p: receive L_p^-1, compute P^(p)_I =
-//    Z(I,p) L_p^-T (final W rows for the T block rows; factor rows, published, for the S block rows), receive P^(p)_J of the S block
-//    rows J > p and apply Z(I,J) -= P_I P_J^T. S block rows hand U1 / U0 to the owner after panel I-3 and publish b after L_(I-2)^-1.
-//    They run one to two panels behind the owner; nothing they do is on the critical path as long as they keep the owner's pace.
-//  * HAND-OFF: a published tile is 8 KB of doubles written with write-through stores (global_store sc1: the data is at the agent
+//    whole factorisation (8 waves, wave wv owns the whole tiles J = wv, wv + 8). Per panel p it needs ONE thing that is new: L_p^-1.
+//    Everything else it consumes was final a panel earlier: the raw panel tiles R^(p)_J = Z(J, p) (all panels < p applied) of the S block
+//    rows J > p, which their owners publish the moment they become final. With L_p^-1 it computes P^(p)_I = Z(I,p) L_p^-T (final W rows
+//    for the T block rows) and, per owned tile, P^(p)_J = R^(p)_J L_p^-T itself (as every workgroup of the launch chain does), then
+//    Z(I,J) -= P_I P_J^T. One dependent hand-off per panel instead of two (L_p^-1 -> P^(p)_J -> update): the block rows keep the owner's
+//    pace. S block rows hand U1 / U0 to the owner after panel I-3 and send it b = P^(I-2)_I after L_(I-2)^-1.
+//  * HAND-OFF of L_p^-1 (the latency-critical one, one tile per panel): 16-byte (value, sequence, ~sequence) words, ONE
+//    global_store_dwordx4 sc1 / ONE global_load_dwordx4 sc1 each, no flag and no waiting for store completion; a consumer polls exactly
+//    the words it needs (1.0 us per hop, scripts/ubench/pingpong2.hip; 1.6e9 words checked for torn accesses: none).
+//  * HAND-OFF of everything else (raw panel tiles, U1 / U0, b: a panel of slack): a published tile is 8 KB of doubles written with write-through stores (global_store sc1: the data is at the agent
 //    coherence point when the store completes), then s_waitcnt vmcnt(0), a workgroup barrier and ONE flag word = the launch's sequence
 //    number. A consumer polls the flag words it needs with one cache-bypassing load per wave (all flags of a panel are contiguous) and
 //    then reads the tiles with ordinary cached loads, every load of the step in flight at once. No release / acquire fence: nothing is
@@ -24,7 +29,7 @@
 //    buffers are never cleared). The first version published every double as a 16-byte (value, sequence) word read with cache-bypassing
 //    loads: 1.0 us per hop in isolation (scripts/ubench/pingpong2.hip) but 30 workgroups fetching the same tiles past the L2 saturate the
 //    few memory channels a tile lives in (2.5 us per round trip under load): the cached version lets every XCD fetch a tile once.
-//    The yTilde row (32 doubles per panel) still travels as 16-byte words.
+//    The yTilde row (32 doubles per panel) travels as 16-byte words too.
 //  * Gamma = W z is accumulated by the T block rows on the way (z_p = yTilde_p L_p^-T from the published yTilde row), so the lift
 //    kernel finds Gamma complete.
 //  * Every poll is bounded (20 ms of device wall clock); a timeout raises flags[3] (EQF_E_STALLED) and the workgroups drain.
@@ -47,6 +52,7 @@ struct LaArgs {
     double* pub;         // published tiles (offsets below)
     int* pubf;           // their flags
     char* puby;          // the yTilde row of every panel as 16-byte (value, sequence) words
+    char* publ;          // L_p^-1 of every panel as 16-byte words (16 KB each)
     double* gamma;       // out: Gamma[n]
     int* flags;          // [0] non-positive pivot, [3] stalled
     const int* spec;
@@ -54,12 +60,12 @@ struct LaArgs {
     trace_t* tr_steps;       // EQF_OPT_TRACE: slot of step 0 (the owner stamps one slot per step), or nullptr
     unsigned long long* dbg; // EQF_OPT_TRACE: per-step stamps inside the owner ([k][8]) and two block rows ([32 + p][8], [64 + p][8]), or nullptr
 };
-// tiles: [0, NJ) L_p^-1 | [NJ, NJ + NJ^2) P^(p)_J at p NJ + J (a panel's tiles are neighbours) | then U1, U0 of every S block row
+// tiles: [0, NJ) unused | [NJ, NJ + NJ^2) the raw panel tile R^(p)_J = Z(J, p) at p NJ + J | then U1, U0, b of every S block row
 // flags: the same indices (one int per tile; U1 / U0 share the flag of U1)
 __device__ __forceinline__ int la_i_linv(const LaArgs& a, int p) { return p; }
 __device__ __forceinline__ int la_i_p(const LaArgs& a, int J, int p) { return a.NJ + p * a.NJ + J; }
-__device__ __forceinline__ int la_i_u(const LaArgs& a, int I, int which) { return a.NJ + a.NJ * a.NJ + 2 * I + which; }
-inline size_t la_pub_tiles(int NJ) { return (size_t)NJ + (size_t)NJ * NJ + 2 * (size_t)NJ; }
+__device__ __forceinline__ int la_i_u(const LaArgs& a, int I, int which) { return a.NJ + a.NJ * a.NJ + 3 * I + which; }
+inline size_t la_pub_tiles(int NJ) { return (size_t)NJ + (size_t)NJ * NJ + 3 * (size_t)NJ; }
 __device__ __forceinline__ double* la_tile(const LaArgs& a, int idx) { return a.pub + (size_t)LA_TILE * idx; }
 
 __device__ __forceinline__ void la_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } // global_store_dwordx2 sc1
@@ -110,6 +116,21 @@ __device__ __forceinline__ double la_get16(const char* p0, const LaPoll& pl) {
     }
     return __hiloint2double(r.y, r.x);
 }
+__device__ __forceinline__ void la_get16x2(const char* p0, const char* p1, const LaPoll& pl, double& v0, double& v1) {
+    v4i r0, r1;
+    for (;;) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                     "global_load_dwordx4 %1, %3, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1)
+                     : "v"(p0), "v"(p1)
+                     : "memory");
+        if ((r0.z == pl.seq && r0.w == ~pl.seq && r1.z == pl.seq && r1.w == ~pl.seq) || !la_retry(pl))
+            break;
+    }
+    v0 = __hiloint2double(r0.y, r0.x);
+    v1 = __hiloint2double(r1.y, r1.x);
+}
 // MFMA operand layout: lane (lr, lk) receives v[st] = X[16 h + lr][4 st + lk], st = 0..7, of a published tile X[row + 32 k]
 __device__ __forceinline__ void la_operand(const double* __restrict__ tile, int h, double (&v)[8]) {
     const int lane = threadIdx.x & 63;
@@ -127,18 +148,11 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     double* sY = smem + 2 * 32 * CH_LDP; // R1 (written by the pre-work, read by the post-work)
     double* sD = smem + 3 * 32 * CH_LDP; // the diagonal tile handed to the elimination
     double* swork = smem + 4 * 32 * CH_LDP;
-    const int NJ = a.NJ;
-    {
-        double* l0 = la_tile(a, la_i_linv(a, 0));
-        for (int e = tid; e < 1024; e += LA_T) {
-            const double v = a.Linv0[e];
-            sLk[(e & 31) + (e >> 5) * CH_LDP] = v;
-            la_st(l0 + e, v);
-        }
-        la_stores_done();
-        __syncthreads();
-        if (tid == 0)
-            la_raise(a, la_i_linv(a, 0));
+    const int NJ = a.NJ, seq = a.seq;
+    for (int e = tid; e < 1024; e += LA_T) {
+        const double v = a.Linv0[e];
+        sLk[(e & 31) + (e >> 5) * CH_LDP] = v;
+        la_put16(a.publ + 16 * (size_t)e, v, seq);
     }
     const bool prod = wave >= 4;
     const int pw = wave & 3, ihU = pw & 1, jhU = pw >> 1;
@@ -153,7 +167,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 a.dbg[8 * k + 0] = wall_clock64();
             la_wait(a.pubf + la_i_u(a, I, 0), 1, pl);
             if (k >= 1)
-                la_wait(a.pubf + la_i_p(a, I, k - 1), 1, pl);
+                la_wait(a.pubf + la_i_u(a, I, 2), 1, pl);
             if (a.dbg && wave == 4 && lane == 0)
                 a.dbg[8 * k + 1] = wall_clock64();
             double u1[4], u0[4];
@@ -168,7 +182,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             }
             if (k >= 1) {
                 double bi[8], bj[8];
-                const double* bt = la_tile(a, la_i_p(a, I, k - 1));
+                const double* bt = la_tile(a, la_i_u(a, I, 2));
                 la_operand(bt, ihU, bi);
                 la_operand(bt, jhU, bj);
                 if (a.dbg && wave == 4 && lane == 0)
@@ -186,21 +200,26 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                     u0[q] -= d[q];
                 }
             }
+            // R1 = Z(I, k) with every panel < k applied is the raw panel tile R^(k)_I of the block rows below: it leaves now, a whole
+            // elimination before they can use it
+            double* rt = la_tile(a, la_i_p(a, I, k));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 dacc[q] = u0[q];
                 sY[16 * ihU + lr + (16 * jhU + lk + 4 * q) * CH_LDP] = u1[q];
+                la_st(rt + (16 * ihU + lr) + 32 * (16 * jhU + lk + 4 * q), u1[q]);
             }
+            la_stores_done();
         }
         if (a.dbg && lane == 0 && (wave == 4 || wave == 0))
             a.dbg[8 * k + (wave == 4 ? 3 : 4)] = wall_clock64();
-        __syncthreads(); // B1: L_k^-1 in sLk (wave 0), R1 in sY (waves 4..7)
+        __syncthreads(); // B1: L_k^-1 in sLk (wave 0), R1 in sY and written through (waves 4..7)
         if (*s_abort)
             return;
+        if (tid == 0)
+            la_raise(a, la_i_p(a, I, k));
         if (a.dbg && tid == 0)
             a.dbg[8 * k + 5] = wall_clock64();
-        if (tid == 0 && k >= 1)
-            la_raise(a, la_i_linv(a, k)); // wave 0 stored L_k^-1 and waited for its stores before the barrier
         if (prod) {
             // c = P^(k)_I = R1 L_k^-T : sub-tile (ih, ch) = (pw & 1, pw >> 1)
             const int ih = pw & 1, ch = pw >> 1;
@@ -208,13 +227,9 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 #pragma unroll
             for (int st = 0; st < 8; ++st)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLk[16 * ch + lr + (4 * st + lk) * CH_LDP], sY[16 * ih + lr + (4 * st + lk) * CH_LDP], acc, 0, 0, 0);
-            double* ct = la_tile(a, la_i_p(a, I, k));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r_ = 16 * ih + lr, c_ = 16 * ch + lk + 4 * q;
-                sX[r_ + c_ * CH_LDP] = acc[q];
-                la_st(ct + r_ + 32 * c_, acc[q]);
-            }
+            for (int q = 0; q < 4; ++q)
+                sX[16 * ih + lr + (16 * ch + lk + 4 * q) * CH_LDP] = acc[q];
         }
         __syncthreads(); // B1.5: c in sX
         if (prod) {
@@ -230,45 +245,40 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 const int r_ = 16 * ihU + lr, c_ = 16 * jhU + lk + 4 * q;
                 sD[r_ + c_ * CH_LDP] = (r_ >= w2 || c_ >= w2) ? ((r_ == c_) ? 1.0 : 0.0) : dacc[q] - acc[q];
             }
-            la_stores_done(); // the write-through stores of c have had the product above to complete
         }
-        __syncthreads(); // B2: D in sD; c written through
-        if (tid == 0)
-            la_raise(a, la_i_p(a, I, k));
+        __syncthreads(); // B2: D in sD
         if (a.dbg && tid == 0)
             a.dbg[8 * k + 6] = wall_clock64();
         if (wave == 0) {
             const int w2 = min(32, a.m - 32 * I);
-            double* lt = la_tile(a, la_i_linv(a, I));
+            char* lp = a.publ + (size_t)16384 * I;
             ldl_inverse_tile_put(
                 sD, CH_LDP, w2,
-                [sLk, lt](int r, int c, double v) {
+                [sLk, lp, seq](int r, int c, double v) {
                     sLk[r + c * CH_LDP] = v;
-                    la_st(lt + r + 32 * c, v);
+                    la_put16(lp + 16 * (size_t)(r + 32 * c), v, seq); // leaves at once: the block rows poll these words
                 },
                 a.flags, swork);
-            la_stores_done(); // the flag of L_(k+1)^-1 goes up right after the next barrier
         }
     }
-    __syncthreads();
-    if (tid == 0)
-        la_raise(a, la_i_linv(a, NJ - 1));
     if (a.tr_steps && tid == 0 && NJ - 1 < 32)
         a.tr_steps[NJ - 1] = wall_clock64();
 }
 
 // ---- a block row --------------------------------------------------------------------------------------------------------------------
 // Wave wv of the 8 owns the WHOLE tiles Z(I, J), J = wv + 8 t (four 16 x 16 accumulator sub-tiles each): a panel step touches at most
-// MAXT tiles per wave, and their operands (two 16-row halves of P_J, 16 doubles per lane and tile) are all requested before the first
-// product: one memory round trip per step instead of one per tile.
+// MAXT tiles per wave. LDS: L_p^-1, the panel tile and P_I in operand layout, and one private 32 x 32 scratch per wave in which the wave's
+// own P^(p)_J changes from accumulator to operand layout.
+constexpr int LA_ROW_LDS = 4 * 32 * CH_LDP + 32 + 256 + 8 * 32 * CH_LDP; // doubles
 template <int MAXT>
 __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* smem, int* s_abort, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-    double* sLinv = smem;
-    double* sT = smem + 32 * CH_LDP;
-    double* sPI = smem + 2 * 32 * CH_LDP;
-    double* sYv = smem + 3 * 32 * CH_LDP; // yTilde row of the panel (32)
-    double* sZp = sYv + 32;               // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
+    // L_p^-1 is double-buffered: a wave that is done with panel p may fetch L_(p+1)^-1 while others still form their P^(p)_J with L_p^-1
+    double* sT = smem + 2 * 32 * CH_LDP;
+    double* sPI = smem + 3 * 32 * CH_LDP;
+    double* sYv = smem + 4 * 32 * CH_LDP;                    // yTilde row of the panel (32)
+    double* sZp = sYv + 32;                                  // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
+    double* sW = sZp + 256 + (size_t)wave * 32 * CH_LDP;     // this wave's scratch
     const int NJ = a.NJ, m = a.m, rows = a.rows, ldz = a.ldz, seq = a.seq;
     const bool srow = I < NJ;
     const int row0 = srow ? 32 * I : m + 32 * (I - NJ);
@@ -319,11 +329,43 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         if (srow && p == I - 2)
             hand_off();
         const int w = min(32, m - 32 * p);
-        // (a) L_p^-1 -> LDS; the panel tile Z(I, p) -> LDS in operand layout (masked like the chain's operand loads); yTilde row of the panel
-        la_wait(a.pubf + la_i_linv(a, p), 1, pl);
+        double* sLinv = smem + (p & 1) * 32 * CH_LDP;
+        // (0) the raw panel tile R^(p)_J of this wave's FIRST tile of the step goes into the wave's scratch now, before the wait for
+        //     L_p^-1 (it has been final since the previous panel; panel 0: straight from Z, rows >= m masked like the chain's operand loads)
+        auto stage_R = [&](int J) {
+            if (p == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int e = lane + 64 * i, r = e & 31, c = e >> 5;
+                    const int rj = 32 * J + r;
+                    sW[r + c * CH_LDP] = a.Z[min(rj, m - 1) + (size_t)c * ldz] * (rj < m ? 1.0 : 0.0);
+                }
+            } else {
+                la_wait(a.pubf + la_i_p(a, J, p), 1, pl);
+                const double* pt = la_tile(a, la_i_p(a, J, p));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int e = lane + 64 * i;
+                    sW[(e & 31) + (e >> 5) * CH_LDP] = pt[e];
+                }
+            }
+        };
+        int staged = -1; // the tile whose R is in the scratch
+        if (do_update) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int J = wave + 8 * t;
+                if (staged < 0 && J > p && J <= Jmax && J != I) {
+                    stage_R(J);
+                    staged = J;
+                }
+            }
+        }
+        // (a) L_p^-1 -> LDS; the panel tile Z(I, p) -> LDS in operand layout; yTilde row of the panel
         {
-            const double* lt = la_tile(a, la_i_linv(a, p));
-            const double v0 = lt[tid], v1 = lt[tid + LA_T];
+            const char* lp = a.publ + (size_t)16384 * p;
+            double v0, v1;
+            la_get16x2(lp + 16 * (size_t)tid, lp + 16 * (size_t)(tid + LA_T), pl, v0, v1);
             sLinv[(tid & 31) + (tid >> 5) * CH_LDP] = v0;
             sLinv[((tid + LA_T) & 31) + ((tid + LA_T) >> 5) * CH_LDP] = v1;
         }
@@ -361,8 +403,8 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 sPI[16 * ih + lr + (16 * ch + lk + 4 * q) * CH_LDP] = pacc[q];
-            if (srow) { // the factor rows leave for the other block rows straight from the accumulators
-                double* pt = la_tile(a, la_i_p(a, I, p));
+            if (srow && p == I - 2) { // b = P^(I-2)_I for the owner, straight from the accumulators
+                double* pt = la_tile(a, la_i_u(a, I, 2));
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     la_st(pt + (16 * ih + lr) + 32 * (16 * ch + lk + 4 * q), pacc[q]);
@@ -378,10 +420,10 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             sZp[32 * h + c] = z;
         }
         __syncthreads();
-        // (c) P_I: flag for the S block rows; final W rows (+ Gamma) for the T block rows
+        // (c) b: flag for the owner; final W rows (+ Gamma) for the T block rows
         if (srow) {
-            if (tid == 0)
-                la_raise(a, la_i_p(a, I, p));
+            if (tid == 0 && p == I - 2)
+                la_raise(a, la_i_u(a, I, 2));
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -403,59 +445,79 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             dbr[1] = wall_clock64();
         if (!do_update)
             continue;
-        // every P^(p)_J this row needs: flags p NJ + (p+1 .. Jmax) are neighbours -> one polling load per wave; then all operands at once
-        {
-            const int jn = min(Jmax, NJ - 1);
-            const int cnt = (srow ? jn - 1 : jn) - p; // an S block row's own P_I (J = I) is in LDS
-            if (cnt > 0)
-                la_wait(a.pubf + la_i_p(a, p + 1, p), cnt, pl);
-        }
-        double bJ[MAXT][2][8];
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            const int J = wave + 8 * t;
-            if (J > p && J <= Jmax && J != I) {
-                const double* pt = la_tile(a, la_i_p(a, J, p));
-                la_operand(pt, 0, bJ[t][0]);
-                la_operand(pt, 1, bJ[t][1]);
-            }
-        }
-        double aI[2][8];
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            aI[0][st] = sPI[lr + (4 * st + lk) * CH_LDP];
-            aI[1][st] = sPI[16 + lr + (4 * st + lk) * CH_LDP];
-        }
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             const int J = wave + 8 * t;
             if (J > p && J <= Jmax) {
+                double bJ[2][8];
+                if (J == I) { // diagonal tile of an S block row: both operands are P_I
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) {
+                        bJ[0][st] = sPI[lr + (4 * st + lk) * CH_LDP];
+                        bJ[1][st] = sPI[16 + lr + (4 * st + lk) * CH_LDP];
+                    }
+                } else {
+                    if (staged != J)
+                        stage_R(J);
+                    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the wave reads what its own lanes wrote
+                    // P_J = R_J L_p^-T, sub-tile (ih, ch); then through the same scratch from accumulator into operand layout
+                    d4 pj[4];
+#pragma unroll
+                    for (int sb = 0; sb < 4; ++sb) {
+                        const int ih = sb & 1, ch = sb >> 1;
+                        pj[sb] = d4{0, 0, 0, 0};
+#pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            pj[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lr + (4 * st + lk) * CH_LDP], sW[16 * ih + lr + (4 * st + lk) * CH_LDP], pj[sb], 0, 0, 0);
+                        asm volatile("" ::: "memory"); // keeps the next sub-tile's 16 operand reads from being hoisted up here: registers, not latency, are scarce
+                    }
+#pragma unroll
+                    for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            sW[16 * (sb & 1) + lr + (16 * (sb >> 1) + lk + 4 * q) * CH_LDP] = pj[sb][q];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) {
+                        bJ[0][st] = sW[lr + (4 * st + lk) * CH_LDP];
+                        bJ[1][st] = sW[16 + lr + (4 * st + lk) * CH_LDP];
+                    }
+                }
 #pragma unroll
                 for (int sb = 0; sb < 4; ++sb) {
                     const int ih = sb & 1, jh = sb >> 1;
                     d4 d = {0, 0, 0, 0};
-                    if (J == I) { // diagonal tile of an S block row: both operands are P_I
 #pragma unroll
-                        for (int st = 0; st < 8; ++st)
-                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[jh][st], aI[ih][st], d, 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int st = 0; st < 8; ++st)
-                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[t][jh][st], aI[ih][st], d, 0, 0, 0);
-                    }
+                    for (int st = 0; st < 8; ++st)
+                        d = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[jh][st], sPI[16 * ih + lr + (4 * st + lk) * CH_LDP], d, 0, 0, 0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         acc[t][sb][q] -= d[q];
+                    asm volatile("" ::: "memory");
                 }
-                if (ylast && J == p + 1 && lr == (yloc & 15)) {
-                    // the yTilde row of the next panel is final now: publish it for every T block row's z_(p+1)
+                if (J == p + 1) {
+                    // Z(I, p+1) is final now: it is the raw panel tile R^(p+1)_I of the block rows below (S rows, as long as they do not
+                    // hand it to the owner instead) and its yTilde row feeds every T block row's z_(p+1)
+                    if (srow && p + 1 <= I - 2) {
+                        double* rt = la_tile(a, la_i_p(a, I, p + 1));
 #pragma unroll
-                    for (int sb = 0; sb < 4; ++sb)
-                        if ((sb & 1) == (yloc >> 4)) {
+                        for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * (sb >> 1) + lk + 4 * q), acc[t][sb][q], seq);
-                        }
+                                la_st(rt + (16 * (sb & 1) + lr) + 32 * (16 * (sb >> 1) + lk + 4 * q), (row0 + 16 * (sb & 1) + lr < ilim) ? acc[t][sb][q] : 0.0);
+                        la_stores_done();
+                        if (lane == 0)
+                            la_raise(a, la_i_p(a, I, p + 1)); // one wave owns the tile: no workgroup barrier
+                    }
+                    if (ylast && lr == (yloc & 15)) {
+#pragma unroll
+                        for (int sb = 0; sb < 4; ++sb)
+                            if ((sb & 1) == (yloc >> 4)) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * (sb >> 1) + lk + 4 * q), acc[t][sb][q], seq);
+                            }
+                    }
                 }
             }
         }
@@ -475,11 +537,12 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
     }
 }
 
+constexpr size_t LA_LDS_BYTES = sizeof(double) * (LA_ROW_LDS > 4 * 32 * CH_LDP + LDL_SBUF ? LA_ROW_LDS : 4 * 32 * CH_LDP + LDL_SBUF);
 template <int MAXT>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (a.spec && *a.spec == a.spec_seq)
         return; // cancelled speculative tail
-    __shared__ double smem[4 * 32 * CH_LDP + LDL_SBUF];
+    extern __shared__ double smem[]; // LA_LDS_BYTES: the block rows need 137 KB (one private scratch tile per wave), the owner 64 KB
     __shared__ int s_abort;
     if (threadIdx.x == 0)
         s_abort = 0;
