@@ -325,18 +325,25 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             la_raise(a, la_i_u(a, I, 0));
     };
     for (int p = 0; p < np; ++p) {
+        // The lane coordinates are laundered once per panel: otherwise every address / mask expression of the body is loop invariant, gets
+        // hoisted in front of the loop and the whole lot (50 registers) is spilled there and reloaded from scratch in every step.
+        int lrv = lr, lkv = lk, lanev = lane;
+        asm volatile("" : "+v"(lrv), "+v"(lkv), "+v"(lanev));
         const bool do_update = srow ? (p <= I - 3) : true;
         if (srow && p == I - 2)
             hand_off();
         const int w = min(32, m - 32 * p);
         double* sLinv = smem + (p & 1) * 32 * CH_LDP;
+        unsigned long long* dbq = (a.dbg && tid == 0 && (I == NJ || I == NJ - 2) && p < 32) ? a.dbg + 8 * ((I == NJ ? 32 : 64) + p) : nullptr;
+        if (dbq)
+            dbq[3] = wall_clock64();
         // (0) the raw panel tile R^(p)_J of this wave's FIRST tile of the step goes into the wave's scratch now, before the wait for
         //     L_p^-1 (it has been final since the previous panel; panel 0: straight from Z, rows >= m masked like the chain's operand loads)
         auto stage_R = [&](int J) {
             if (p == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int e = lane + 64 * i, r = e & 31, c = e >> 5;
+                    const int e = lanev + 64 * i, r = e & 31, c = e >> 5;
                     const int rj = 32 * J + r;
                     sW[r + c * CH_LDP] = a.Z[min(rj, m - 1) + (size_t)c * ldz] * (rj < m ? 1.0 : 0.0);
                 }
@@ -345,7 +352,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
                 const double* pt = la_tile(a, la_i_p(a, J, p));
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int e = lane + 64 * i;
+                    const int e = lanev + 64 * i;
                     sW[(e & 31) + (e >> 5) * CH_LDP] = pt[e];
                 }
             }
@@ -361,14 +368,21 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
                 }
             }
         }
+        if (dbq)
+            dbq[4] = wall_clock64();
         // (a) L_p^-1 -> LDS; the panel tile Z(I, p) -> LDS in operand layout; yTilde row of the panel
         {
             const char* lp = a.publ + (size_t)16384 * p;
             double v0, v1;
+            // while L_p^-1 is not there, poll ONE of its words (every lane the same address: one request per wave), the one the elimination
+            // stores last: 250 waves re-requesting whole tiles past the caches slow down the very stores they are waiting for
+            (void)la_get16(lp + 16 * 511, pl);
             la_get16x2(lp + 16 * (size_t)tid, lp + 16 * (size_t)(tid + LA_T), pl, v0, v1);
             sLinv[(tid & 31) + (tid >> 5) * CH_LDP] = v0;
             sLinv[((tid + LA_T) & 31) + ((tid + LA_T) >> 5) * CH_LDP] = v1;
         }
+        if (dbq)
+            dbq[5] = wall_clock64();
         if (wave == (p & 7)) {
 #pragma unroll
             for (int t = 0; t < MAXT; ++t)
@@ -377,14 +391,14 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
                     for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int r = 16 * (sb & 1) + lr, c = 16 * (sb >> 1) + lk + 4 * q;
+                            const int r = 16 * (sb & 1) + lrv, c = 16 * (sb >> 1) + lkv + 4 * q;
                             sT[r + c * CH_LDP] = (row0 + r < ilim && c < w) ? acc[t][sb][q] : 0.0;
                         }
                 }
         }
-        if (!srow && wave == ((p + 1) & 7) && lane < 32) {
-            const double yv = la_get16(a.puby + 512 * (size_t)p + 16 * (size_t)lane, pl);
-            sYv[lane] = lane < w ? yv : 0.0;
+        if (!srow && wave == ((p + 1) & 7) && lanev < 32) {
+            const double yv = la_get16(a.puby + 512 * (size_t)p + 16 * (size_t)lanev, pl);
+            sYv[lanev] = lanev < w ? yv : 0.0;
         }
         __syncthreads();
         if (*s_abort)
@@ -399,15 +413,15 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             d4 pacc = {0, 0, 0, 0};
 #pragma unroll
             for (int st = 0; st < 8; ++st)
-                pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lr + (4 * st + lk) * CH_LDP], sT[16 * ih + lr + (4 * st + lk) * CH_LDP], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lrv + (4 * st + lkv) * CH_LDP], sT[16 * ih + lrv + (4 * st + lkv) * CH_LDP], pacc, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                sPI[16 * ih + lr + (16 * ch + lk + 4 * q) * CH_LDP] = pacc[q];
+                sPI[16 * ih + lrv + (16 * ch + lkv + 4 * q) * CH_LDP] = pacc[q];
             if (srow && p == I - 2) { // b = P^(I-2)_I for the owner, straight from the accumulators
                 double* pt = la_tile(a, la_i_u(a, I, 2));
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    la_st(pt + (16 * ih + lr) + 32 * (16 * ch + lk + 4 * q), pacc[q]);
+                    la_st(pt + (16 * ih + lrv) + 32 * (16 * ch + lkv + 4 * q), pacc[q]);
                 la_stores_done();
             }
         } else if (!srow) {
@@ -453,8 +467,8 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
                 if (J == I) { // diagonal tile of an S block row: both operands are P_I
 #pragma unroll
                     for (int st = 0; st < 8; ++st) {
-                        bJ[0][st] = sPI[lr + (4 * st + lk) * CH_LDP];
-                        bJ[1][st] = sPI[16 + lr + (4 * st + lk) * CH_LDP];
+                        bJ[0][st] = sPI[lrv + (4 * st + lkv) * CH_LDP];
+                        bJ[1][st] = sPI[16 + lrv + (4 * st + lkv) * CH_LDP];
                     }
                 } else {
                     if (staged != J)
@@ -468,19 +482,19 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
                         pj[sb] = d4{0, 0, 0, 0};
 #pragma unroll
                         for (int st = 0; st < 8; ++st)
-                            pj[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lr + (4 * st + lk) * CH_LDP], sW[16 * ih + lr + (4 * st + lk) * CH_LDP], pj[sb], 0, 0, 0);
+                            pj[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lrv + (4 * st + lkv) * CH_LDP], sW[16 * ih + lrv + (4 * st + lkv) * CH_LDP], pj[sb], 0, 0, 0);
                         asm volatile("" ::: "memory"); // keeps the next sub-tile's 16 operand reads from being hoisted up here: registers, not latency, are scarce
                     }
 #pragma unroll
                     for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            sW[16 * (sb & 1) + lr + (16 * (sb >> 1) + lk + 4 * q) * CH_LDP] = pj[sb][q];
+                            sW[16 * (sb & 1) + lrv + (16 * (sb >> 1) + lkv + 4 * q) * CH_LDP] = pj[sb][q];
                     __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
                     for (int st = 0; st < 8; ++st) {
-                        bJ[0][st] = sW[lr + (4 * st + lk) * CH_LDP];
-                        bJ[1][st] = sW[16 + lr + (4 * st + lk) * CH_LDP];
+                        bJ[0][st] = sW[lrv + (4 * st + lkv) * CH_LDP];
+                        bJ[1][st] = sW[16 + lrv + (4 * st + lkv) * CH_LDP];
                     }
                 }
 #pragma unroll
@@ -489,7 +503,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
                     d4 d = {0, 0, 0, 0};
 #pragma unroll
                     for (int st = 0; st < 8; ++st)
-                        d = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[jh][st], sPI[16 * ih + lr + (4 * st + lk) * CH_LDP], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[jh][st], sPI[16 * ih + lrv + (4 * st + lkv) * CH_LDP], d, 0, 0, 0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         acc[t][sb][q] -= d[q];
@@ -504,18 +518,18 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
                         for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                la_st(rt + (16 * (sb & 1) + lr) + 32 * (16 * (sb >> 1) + lk + 4 * q), (row0 + 16 * (sb & 1) + lr < ilim) ? acc[t][sb][q] : 0.0);
+                                la_st(rt + (16 * (sb & 1) + lrv) + 32 * (16 * (sb >> 1) + lkv + 4 * q), (row0 + 16 * (sb & 1) + lrv < ilim) ? acc[t][sb][q] : 0.0);
                         la_stores_done();
-                        if (lane == 0)
+                        if (lanev == 0)
                             la_raise(a, la_i_p(a, I, p + 1)); // one wave owns the tile: no workgroup barrier
                     }
-                    if (ylast && lr == (yloc & 15)) {
+                    if (ylast && lrv == (yloc & 15)) {
 #pragma unroll
                         for (int sb = 0; sb < 4; ++sb)
                             if ((sb & 1) == (yloc >> 4)) {
 #pragma unroll
                                 for (int q = 0; q < 4; ++q)
-                                    la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * (sb >> 1) + lk + 4 * q), acc[t][sb][q], seq);
+                                    la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * (sb >> 1) + lkv + 4 * q), acc[t][sb][q], seq);
                             }
                     }
                 }
