@@ -76,21 +76,23 @@ struct LaPoll {
     int seq;
     int* s_abort;
 };
-__device__ __forceinline__ bool la_retry(const LaPoll& pl) {
-    if ((long long)wall_clock64() > pl.deadline) {
+// A failed poll: look at the clock only every 64th time. s_memrealtime is a scalar MEMORY read of a far-away counter (microseconds of
+// latency): reading it after every failed poll quantised every hand-off to ~2.5 us.
+__device__ __forceinline__ bool la_retry(const LaPoll& pl, int& it) {
+    if (((++it) & 63) == 0 && (long long)wall_clock64() > pl.deadline) {
         *pl.s_abort = 1;
         return false;
     }
-    __builtin_amdgcn_s_sleep(1);
     return true;
 }
 // wait until the `count` (<= 64) consecutive flags at f carry the launch's sequence number: lane j watches flag j
 __device__ __forceinline__ void la_wait(const int* f, int count, const LaPoll& pl) {
     const int lane = threadIdx.x & 63;
     if (lane < count) {
+        int it = 0;
         for (;;) {
             const int v = __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // global_load_dword sc1: not served by a cache
-            if (v == pl.seq || !la_retry(pl))
+            if (v == pl.seq || !la_retry(pl, it))
                 break;
         }
     }
@@ -109,15 +111,17 @@ __device__ __forceinline__ void la_put16(char* p, double v, int seq) {
 }
 __device__ __forceinline__ double la_get16(const char* p0, const LaPoll& pl) {
     v4i r;
+    int it = 0;
     for (;;) {
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p0) : "memory");
-        if ((r.z == pl.seq && r.w == ~pl.seq) || !la_retry(pl))
+        if ((r.z == pl.seq && r.w == ~pl.seq) || !la_retry(pl, it))
             break;
     }
     return __hiloint2double(r.y, r.x);
 }
 __device__ __forceinline__ void la_get16x2(const char* p0, const char* p1, const LaPoll& pl, double& v0, double& v1) {
     v4i r0, r1;
+    int it = 0;
     for (;;) {
         asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
                      "global_load_dwordx4 %1, %3, off sc1\n\t"
@@ -125,7 +129,7 @@ __device__ __forceinline__ void la_get16x2(const char* p0, const char* p1, const
                      : "=&v"(r0), "=&v"(r1)
                      : "v"(p0), "v"(p1)
                      : "memory");
-        if ((r0.z == pl.seq && r0.w == ~pl.seq && r1.z == pl.seq && r1.w == ~pl.seq) || !la_retry(pl))
+        if ((r0.z == pl.seq && r0.w == ~pl.seq && r1.z == pl.seq && r1.w == ~pl.seq) || !la_retry(pl, it))
             break;
     }
     v0 = __hiloint2double(r0.y, r0.x);
@@ -149,10 +153,17 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     double* sD = smem + 3 * 32 * CH_LDP; // the diagonal tile handed to the elimination
     double* swork = smem + 4 * 32 * CH_LDP;
     const int NJ = a.NJ, seq = a.seq;
-    for (int e = tid; e < 1024; e += LA_T) {
-        const double v = a.Linv0[e];
-        sLk[(e & 31) + (e >> 5) * CH_LDP] = v;
-        la_put16(a.publ + 16 * (size_t)e, v, seq);
+    {
+        double* l0 = la_tile(a, la_i_linv(a, 0));
+        for (int e = tid; e < 1024; e += LA_T) {
+            const double v = a.Linv0[e];
+            sLk[(e & 31) + (e >> 5) * CH_LDP] = v;
+            la_st(l0 + e, v);
+        }
+        la_stores_done();
+        __syncthreads();
+        if (tid == 0)
+            la_raise(a, la_i_linv(a, 0));
     }
     const bool prod = wave >= 4;
     const int pw = wave & 3, ihU = pw & 1, jhU = pw >> 1;
@@ -216,8 +227,11 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         __syncthreads(); // B1: L_k^-1 in sLk (wave 0), R1 in sY and written through (waves 4..7)
         if (*s_abort)
             return;
-        if (tid == 0)
+        if (tid == 0) {
             la_raise(a, la_i_p(a, I, k));
+            if (k >= 1)
+                la_raise(a, la_i_linv(a, k)); // wave 0 stored L_k^-1 and waited for its stores before the barrier
+        }
         if (a.dbg && tid == 0)
             a.dbg[8 * k + 5] = wall_clock64();
         if (prod) {
@@ -251,16 +265,20 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             a.dbg[8 * k + 6] = wall_clock64();
         if (wave == 0) {
             const int w2 = min(32, a.m - 32 * I);
-            char* lp = a.publ + (size_t)16384 * I;
+            double* lt = la_tile(a, la_i_linv(a, I));
             ldl_inverse_tile_put(
                 sD, CH_LDP, w2,
-                [sLk, lp, seq](int r, int c, double v) {
+                [sLk, lt](int r, int c, double v) {
                     sLk[r + c * CH_LDP] = v;
-                    la_put16(lp + 16 * (size_t)(r + 32 * c), v, seq); // leaves at once: the block rows poll these words
+                    la_st(lt + r + 32 * c, v);
                 },
                 a.flags, swork);
+            la_stores_done(); // the flag of L_(k+1)^-1 goes up right after the next barrier
         }
     }
+    __syncthreads();
+    if (tid == 0)
+        la_raise(a, la_i_linv(a, NJ - 1));
     if (a.tr_steps && tid == 0 && NJ - 1 < 32)
         a.tr_steps[NJ - 1] = wall_clock64();
 }
@@ -324,65 +342,71 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         if (tid == 0)
             la_raise(a, la_i_u(a, I, 0));
     };
+    // Everything a panel step consumes is requested ONE STEP AHEAD (the block rows run about a panel behind the owner, so it is there):
+    // L_(p+1)^-1 goes into the other L buffer and the raw panel tile of the wave's first tile of step p+1 into its scratch at the end of
+    // step p. A memory round trip costs ~2 us while 33 workgroups hammer the same few tiles; a step has room for none of them.
+    auto fetch_L = [&](int p) {
+        double* sL = smem + (p & 1) * 32 * CH_LDP;
+        la_wait(a.pubf + la_i_linv(a, p), 1, pl);
+        const double* lt = la_tile(a, la_i_linv(a, p));
+        const double v0 = lt[tid], v1 = lt[tid + LA_T];
+        sL[(tid & 31) + (tid >> 5) * CH_LDP] = v0;
+        sL[((tid + LA_T) & 31) + ((tid + LA_T) >> 5) * CH_LDP] = v1;
+    };
+    auto stage_R = [&](int J, int p) { // raw panel tile R^(p)_J -> this wave's scratch (panel 0: straight from Z, rows >= m masked)
+        int lanev = lane;
+        asm volatile("" : "+v"(lanev));
+        if (p == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = lanev + 64 * i, r = e & 31, c = e >> 5;
+                const int rj = 32 * J + r;
+                sW[r + c * CH_LDP] = a.Z[min(rj, m - 1) + (size_t)c * ldz] * (rj < m ? 1.0 : 0.0);
+            }
+        } else {
+            la_wait(a.pubf + la_i_p(a, J, p), 1, pl);
+            const double* pt = la_tile(a, la_i_p(a, J, p));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = lanev + 64 * i;
+                sW[(e & 31) + (e >> 5) * CH_LDP] = pt[e];
+            }
+        }
+    };
+    auto first_tile = [&](int p) { // the first tile this wave updates in step p (not the diagonal one), or -1
+        const bool upd = srow ? (p <= I - 3) : (p < NJ);
+        int first = -1;
+        if (upd) {
+#pragma unroll
+            for (int t = MAXT - 1; t >= 0; --t) {
+                const int J = wave + 8 * t;
+                if (J > p && J <= Jmax && J != I)
+                    first = J;
+            }
+        }
+        return first;
+    };
+    int staged = -1;
+    if (np > 0) {
+        if (srow && I == 2)
+            hand_off(); // its two tiles go to the owner before panel 0 (= I - 2)
+        fetch_L(0);
+        staged = first_tile(0);
+        if (staged >= 0)
+            stage_R(staged, 0);
+    }
     for (int p = 0; p < np; ++p) {
         // The lane coordinates are laundered once per panel: otherwise every address / mask expression of the body is loop invariant, gets
         // hoisted in front of the loop and the whole lot (50 registers) is spilled there and reloaded from scratch in every step.
         int lrv = lr, lkv = lk, lanev = lane;
         asm volatile("" : "+v"(lrv), "+v"(lkv), "+v"(lanev));
         const bool do_update = srow ? (p <= I - 3) : true;
-        if (srow && p == I - 2)
-            hand_off();
         const int w = min(32, m - 32 * p);
         double* sLinv = smem + (p & 1) * 32 * CH_LDP;
         unsigned long long* dbq = (a.dbg && tid == 0 && (I == NJ || I == NJ - 2) && p < 32) ? a.dbg + 8 * ((I == NJ ? 32 : 64) + p) : nullptr;
         if (dbq)
             dbq[3] = wall_clock64();
-        // (0) the raw panel tile R^(p)_J of this wave's FIRST tile of the step goes into the wave's scratch now, before the wait for
-        //     L_p^-1 (it has been final since the previous panel; panel 0: straight from Z, rows >= m masked like the chain's operand loads)
-        auto stage_R = [&](int J) {
-            if (p == 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int e = lanev + 64 * i, r = e & 31, c = e >> 5;
-                    const int rj = 32 * J + r;
-                    sW[r + c * CH_LDP] = a.Z[min(rj, m - 1) + (size_t)c * ldz] * (rj < m ? 1.0 : 0.0);
-                }
-            } else {
-                la_wait(a.pubf + la_i_p(a, J, p), 1, pl);
-                const double* pt = la_tile(a, la_i_p(a, J, p));
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int e = lanev + 64 * i;
-                    sW[(e & 31) + (e >> 5) * CH_LDP] = pt[e];
-                }
-            }
-        };
-        int staged = -1; // the tile whose R is in the scratch
-        if (do_update) {
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int J = wave + 8 * t;
-                if (staged < 0 && J > p && J <= Jmax && J != I) {
-                    stage_R(J);
-                    staged = J;
-                }
-            }
-        }
-        if (dbq)
-            dbq[4] = wall_clock64();
-        // (a) L_p^-1 -> LDS; the panel tile Z(I, p) -> LDS in operand layout; yTilde row of the panel
-        {
-            const char* lp = a.publ + (size_t)16384 * p;
-            double v0, v1;
-            // while L_p^-1 is not there, poll ONE of its words (every lane the same address: one request per wave), the one the elimination
-            // stores last: 250 waves re-requesting whole tiles past the caches slow down the very stores they are waiting for
-            (void)la_get16(lp + 16 * 511, pl);
-            la_get16x2(lp + 16 * (size_t)tid, lp + 16 * (size_t)(tid + LA_T), pl, v0, v1);
-            sLinv[(tid & 31) + (tid >> 5) * CH_LDP] = v0;
-            sLinv[((tid + LA_T) & 31) + ((tid + LA_T) >> 5) * CH_LDP] = v1;
-        }
-        if (dbq)
-            dbq[5] = wall_clock64();
+        // (a) the panel tile Z(I, p) -> LDS in operand layout; yTilde row of the panel (L_p^-1 is in LDS already)
         if (wave == (p & 7)) {
 #pragma unroll
             for (int t = 0; t < MAXT; ++t)
@@ -457,86 +481,97 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         }
         if (dbg_row)
             dbr[1] = wall_clock64();
-        if (!do_update)
-            continue;
+        if (do_update) {
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            const int J = wave + 8 * t;
-            if (J > p && J <= Jmax) {
-                double bJ[2][8];
-                if (J == I) { // diagonal tile of an S block row: both operands are P_I
+            for (int t = 0; t < MAXT; ++t) {
+                const int J = wave + 8 * t;
+                if (J > p && J <= Jmax) {
+                    double bJ[2][8];
+                    if (J == I) { // diagonal tile of an S block row: both operands are P_I
 #pragma unroll
-                    for (int st = 0; st < 8; ++st) {
-                        bJ[0][st] = sPI[lrv + (4 * st + lkv) * CH_LDP];
-                        bJ[1][st] = sPI[16 + lrv + (4 * st + lkv) * CH_LDP];
-                    }
-                } else {
-                    if (staged != J)
-                        stage_R(J);
-                    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the wave reads what its own lanes wrote
-                    // P_J = R_J L_p^-T, sub-tile (ih, ch); then through the same scratch from accumulator into operand layout
-                    d4 pj[4];
+                        for (int st = 0; st < 8; ++st) {
+                            bJ[0][st] = sPI[lrv + (4 * st + lkv) * CH_LDP];
+                            bJ[1][st] = sPI[16 + lrv + (4 * st + lkv) * CH_LDP];
+                        }
+                    } else {
+                        if (staged != J)
+                            stage_R(J, p);
+                        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the wave reads what its own lanes wrote
+                        // P_J = R_J L_p^-T, sub-tile (ih, ch); then through the same scratch from accumulator into operand layout
+                        d4 pj[4];
 #pragma unroll
-                    for (int sb = 0; sb < 4; ++sb) {
-                        const int ih = sb & 1, ch = sb >> 1;
-                        pj[sb] = d4{0, 0, 0, 0};
+                        for (int sb = 0; sb < 4; ++sb) {
+                            const int ih = sb & 1, ch = sb >> 1;
+                            pj[sb] = d4{0, 0, 0, 0};
 #pragma unroll
-                        for (int st = 0; st < 8; ++st)
-                            pj[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lrv + (4 * st + lkv) * CH_LDP], sW[16 * ih + lrv + (4 * st + lkv) * CH_LDP], pj[sb], 0, 0, 0);
-                        asm volatile("" ::: "memory"); // keeps the next sub-tile's 16 operand reads from being hoisted up here: registers, not latency, are scarce
-                    }
-#pragma unroll
-                    for (int sb = 0; sb < 4; ++sb)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            sW[16 * (sb & 1) + lrv + (16 * (sb >> 1) + lkv + 4 * q) * CH_LDP] = pj[sb][q];
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-                    for (int st = 0; st < 8; ++st) {
-                        bJ[0][st] = sW[lrv + (4 * st + lkv) * CH_LDP];
-                        bJ[1][st] = sW[16 + lrv + (4 * st + lkv) * CH_LDP];
-                    }
-                }
-#pragma unroll
-                for (int sb = 0; sb < 4; ++sb) {
-                    const int ih = sb & 1, jh = sb >> 1;
-                    d4 d = {0, 0, 0, 0};
-#pragma unroll
-                    for (int st = 0; st < 8; ++st)
-                        d = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[jh][st], sPI[16 * ih + lrv + (4 * st + lkv) * CH_LDP], d, 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[t][sb][q] -= d[q];
-                    asm volatile("" ::: "memory");
-                }
-                if (J == p + 1) {
-                    // Z(I, p+1) is final now: it is the raw panel tile R^(p+1)_I of the block rows below (S rows, as long as they do not
-                    // hand it to the owner instead) and its yTilde row feeds every T block row's z_(p+1)
-                    if (srow && p + 1 <= I - 2) {
-                        double* rt = la_tile(a, la_i_p(a, I, p + 1));
+                            for (int st = 0; st < 8; ++st)
+                                pj[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lrv + (4 * st + lkv) * CH_LDP], sW[16 * ih + lrv + (4 * st + lkv) * CH_LDP], pj[sb], 0, 0, 0);
+                            asm volatile("" ::: "memory"); // keeps the next sub-tile's 16 operand reads from being hoisted up here: registers, not latency, are scarce
+                        }
 #pragma unroll
                         for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                la_st(rt + (16 * (sb & 1) + lrv) + 32 * (16 * (sb >> 1) + lkv + 4 * q), (row0 + 16 * (sb & 1) + lrv < ilim) ? acc[t][sb][q] : 0.0);
-                        la_stores_done();
-                        if (lanev == 0)
-                            la_raise(a, la_i_p(a, I, p + 1)); // one wave owns the tile: no workgroup barrier
-                    }
-                    if (ylast && lrv == (yloc & 15)) {
+                                sW[16 * (sb & 1) + lrv + (16 * (sb >> 1) + lkv + 4 * q) * CH_LDP] = pj[sb][q];
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
-                        for (int sb = 0; sb < 4; ++sb)
-                            if ((sb & 1) == (yloc >> 4)) {
+                        for (int st = 0; st < 8; ++st) {
+                            bJ[0][st] = sW[lrv + (4 * st + lkv) * CH_LDP];
+                            bJ[1][st] = sW[16 + lrv + (4 * st + lkv) * CH_LDP];
+                        }
+                    }
+#pragma unroll
+                    for (int sb = 0; sb < 4; ++sb) {
+                        const int ih = sb & 1, jh = sb >> 1;
+                        d4 d = {0, 0, 0, 0};
+#pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[jh][st], sPI[16 * ih + lrv + (4 * st + lkv) * CH_LDP], d, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[t][sb][q] -= d[q];
+                        asm volatile("" ::: "memory");
+                    }
+                    if (J == p + 1) {
+                        // Z(I, p+1) is final now: it is the raw panel tile R^(p+1)_I of the block rows below (S rows, as long as they do not
+                        // hand it to the owner instead) and its yTilde row feeds every T block row's z_(p+1)
+                        if (srow && p + 1 <= I - 2) {
+                            double* rt = la_tile(a, la_i_p(a, I, p + 1));
+#pragma unroll
+                            for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q)
-                                    la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * (sb >> 1) + lkv + 4 * q), acc[t][sb][q], seq);
-                            }
+                                    la_st(rt + (16 * (sb & 1) + lrv) + 32 * (16 * (sb >> 1) + lkv + 4 * q), (row0 + 16 * (sb & 1) + lrv < ilim) ? acc[t][sb][q] : 0.0);
+                            la_stores_done();
+                            if (lanev == 0)
+                                la_raise(a, la_i_p(a, I, p + 1)); // one wave owns the tile: no workgroup barrier
+                        }
+                        if (ylast && lrv == (yloc & 15)) {
+#pragma unroll
+                            for (int sb = 0; sb < 4; ++sb)
+                                if ((sb & 1) == (yloc >> 4)) {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * (sb >> 1) + lkv + 4 * q), acc[t][sb][q], seq);
+                                }
+                        }
                     }
                 }
             }
         }
         if (dbg_row)
             dbr[2] = wall_clock64();
+        // the hand-off must not wait behind the fetch of an L^-1 the owner produces only after it
+        if (srow && p + 1 == I - 2)
+            hand_off();
+        if (p + 1 < np) {
+            fetch_L(p + 1);
+            staged = first_tile(p + 1);
+            if (staged >= 0)
+                stage_R(staged, p + 1);
+        }
+        if (dbq)
+            dbq[4] = wall_clock64();
     }
     if (srow && I == 1)
         hand_off(); // block row 1 has no panel of its own to wait for: its two tiles go to the owner as they are

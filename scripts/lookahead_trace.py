@@ -29,8 +29,8 @@ for k in range(NJ - 1):
     per = (a[k + 1, 6] - a[k, 6]) if k + 2 < NJ else float("nan")
     print(f"  k={k:2d}  " + "  ".join(f"{v:8.2f}" if a[k, i] > 0 else "       -" for i, v in enumerate(r[:7])) + f" | {per:6.2f}")
 for name, base in (("first T block row", 32), (f"S block row {NJ - 2}", 64)):
-    print(name + ", panel p: step-start  R-staged  L-in-LDS | L+tile in LDS   P done   updates done")
+    print(name + ", panel p: L+tile in LDS   P done   updates done")
     for p in range(NJ):
         if a[base + p, 0] > 0:
             r = a[base + p] - t0
-            print(f"  p={p:2d}  " + "  ".join(f"{r[i]:8.2f}" if a[base + p, i] > 0 else "       -" for i in (3, 4, 5)) + " | " + "  ".join(f"{v:8.2f}" if a[base + p, i] > 0 else "       -" for i, v in enumerate(r[:3])))
+            print(f"  p={p:2d}  " + "  ".join(f"{v:8.2f}" if a[base + p, i] > 0 else "       -" for i, v in enumerate(r[:3])))
