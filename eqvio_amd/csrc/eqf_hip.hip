@@ -569,7 +569,6 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     HIPCHK(hipMemsetAsync(c->d_puby, 0, 512 * (size_t)c->la_njcap, c->stream));
     HIPCHK(hipMalloc(&c->d_publ, 16384 * (size_t)c->la_njcap));
     HIPCHK(hipMemsetAsync(c->d_publ, 0, 16384 * (size_t)c->la_njcap, c->stream));
-    HIPCHK(hipFuncSetAttribute((const void*)k_chol_lookahead<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LA_LDS_BYTES));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
@@ -1421,7 +1420,10 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.tr_steps = trace_slot(c, TR_STEP0);
     a.dbg = c->d_trace ? c->d_ladbg : nullptr;
     KTimer t(c, KN_CHOL_PANEL, a.NJ); // reported per panel, like the launch chain it replaces
-    hipLaunchKernelGGL(k_chol_lookahead<2>, dim3(a.NI), dim3(LA_T), LA_LDS_BYTES, c->stream, a); // every wave of a block row owns at most 2 of its <= 16 tiles
+    if (a.NJ <= 14)
+        hipLaunchKernelGGL(k_chol_lookahead<7>, dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(k_chol_lookahead<8>, dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }

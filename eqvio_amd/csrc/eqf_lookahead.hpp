@@ -11,16 +11,11 @@
 //    previous step). When L_k^-1 appears they finish: c = R1 L_k^-T, D = D' - c c^T, and wave 0 eliminates D. Per step on the critical
 //    path: elimination + two products + three workgroup barriers; no launch boundary, no memory round trip, no cross-workgroup hop.
 //  * one ROW workgroup per 32-row block row I >= 1 keeps ALL tiles Z(I, 0 .. min(I, NJ-1)) in its MFMA accumulator registers for the
-//    whole factorisation (8 waves, wave wv owns the whole tiles J = wv, wv + 8). Per panel p it needs ONE thing that is new: L_p^-1.
-//    Everything else it consumes was final a panel earlier: the raw panel tiles R^(p)_J = Z(J, p) (all panels < p applied) of the S block
-//    rows J > p, which their owners publish the moment they become final. With L_p^-1 it computes P^(p)_I = Z(I,p) L_p^-T (final W rows
-//    for the T block rows) and, per owned tile, P^(p)_J = R^(p)_J L_p^-T itself (as every workgroup of the launch chain does), then
-//    Z(I,J) -= P_I P_J^T. One dependent hand-off per panel instead of two (L_p^-1 -> P^(p)_J -> update): the block rows keep the owner's
-//    pace. S block rows hand U1 / U0 to the owner after panel I-3 and send it b = P^(I-2)_I after L_(I-2)^-1.
-//  * HAND-OFF of L_p^-1 (the latency-critical one, one tile per panel): 16-byte (value, sequence, ~sequence) words, ONE
-//    global_store_dwordx4 sc1 / ONE global_load_dwordx4 sc1 each, no flag and no waiting for store completion; a consumer polls exactly
-//    the words it needs (1.0 us per hop, scripts/ubench/pingpong2.hip; 1.6e9 words checked for torn accesses: none).
-//  * HAND-OFF of everything else (raw panel tiles, U1 / U0, b: a panel of slack): a published tile is 8 KB of doubles written with write-through stores (global_store sc1: the data is at the agent
+//    whole factorisation (8 waves: two groups of four, even / odd tile columns). Per panel p: receive L_p^-1, compute P^(p)_I =
+//    Z(I,p) L_p^-T (final W rows for the T block rows; factor rows, published, for the S block rows), receive P^(p)_J of the S block
+//    rows J > p and apply Z(I,J) -= P_I P_J^T. S block rows hand U1 / U0 to the owner after panel I-3 and publish b after L_(I-2)^-1.
+//    They run one to two panels behind the owner; nothing they do is on the critical path as long as they keep the owner's pace.
+//  * HAND-OFF: a published tile is 8 KB of doubles written with write-through stores (global_store sc1: the data is at the agent
 //    coherence point when the store completes), then s_waitcnt vmcnt(0), a workgroup barrier and ONE flag word = the launch's sequence
 //    number. A consumer polls the flag words it needs with one cache-bypassing load per wave (all flags of a panel are contiguous) and
 //    then reads the tiles with ordinary cached loads, every load of the step in flight at once. No release / acquire fence: nothing is
@@ -29,7 +24,7 @@
 //    buffers are never cleared). The first version published every double as a 16-byte (value, sequence) word read with cache-bypassing
 //    loads: 1.0 us per hop in isolation (scripts/ubench/pingpong2.hip) but 30 workgroups fetching the same tiles past the L2 saturate the
 //    few memory channels a tile lives in (2.5 us per round trip under load): the cached version lets every XCD fetch a tile once.
-//    The yTilde row (32 doubles per panel) travels as 16-byte words too.
+//    The yTilde row (32 doubles per panel) still travels as 16-byte words.
 //  * Gamma = W z is accumulated by the T block rows on the way (z_p = yTilde_p L_p^-T from the published yTilde row), so the lift
 //    kernel finds Gamma complete.
 //  * Every poll is bounded (20 ms of device wall clock); a timeout raises flags[3] (EQF_E_STALLED) and the workgroups drain.
@@ -52,7 +47,7 @@ struct LaArgs {
     double* pub;         // published tiles (offsets below)
     int* pubf;           // their flags
     char* puby;          // the yTilde row of every panel as 16-byte (value, sequence) words
-    char* publ;          // L_p^-1 of every panel as 16-byte words (16 KB each)
+    char* publ;          // unused (an experimental variant published L^-1 as 16-byte words here)
     double* gamma;       // out: Gamma[n]
     int* flags;          // [0] non-positive pivot, [3] stalled
     const int* spec;
@@ -60,12 +55,12 @@ struct LaArgs {
     trace_t* tr_steps;       // EQF_OPT_TRACE: slot of step 0 (the owner stamps one slot per step), or nullptr
     unsigned long long* dbg; // EQF_OPT_TRACE: per-step stamps inside the owner ([k][8]) and two block rows ([32 + p][8], [64 + p][8]), or nullptr
 };
-// tiles: [0, NJ) unused | [NJ, NJ + NJ^2) the raw panel tile R^(p)_J = Z(J, p) at p NJ + J | then U1, U0, b of every S block row
+// tiles: [0, NJ) L_p^-1 | [NJ, NJ + NJ^2) P^(p)_J at p NJ + J (a panel's tiles are neighbours) | then U1, U0 of every S block row
 // flags: the same indices (one int per tile; U1 / U0 share the flag of U1)
 __device__ __forceinline__ int la_i_linv(const LaArgs& a, int p) { return p; }
 __device__ __forceinline__ int la_i_p(const LaArgs& a, int J, int p) { return a.NJ + p * a.NJ + J; }
-__device__ __forceinline__ int la_i_u(const LaArgs& a, int I, int which) { return a.NJ + a.NJ * a.NJ + 3 * I + which; }
-inline size_t la_pub_tiles(int NJ) { return (size_t)NJ + (size_t)NJ * NJ + 3 * (size_t)NJ; }
+__device__ __forceinline__ int la_i_u(const LaArgs& a, int I, int which) { return a.NJ + a.NJ * a.NJ + 2 * I + which; }
+inline size_t la_pub_tiles(int NJ) { return (size_t)NJ + (size_t)NJ * NJ + 2 * (size_t)NJ; }
 __device__ __forceinline__ double* la_tile(const LaArgs& a, int idx) { return a.pub + (size_t)LA_TILE * idx; }
 
 __device__ __forceinline__ void la_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } // global_store_dwordx2 sc1
@@ -76,23 +71,21 @@ struct LaPoll {
     int seq;
     int* s_abort;
 };
-// A failed poll: look at the clock only every 64th time. s_memrealtime is a scalar MEMORY read of a far-away counter (microseconds of
-// latency): reading it after every failed poll quantised every hand-off to ~2.5 us.
-__device__ __forceinline__ bool la_retry(const LaPoll& pl, int& it) {
-    if (((++it) & 63) == 0 && (long long)wall_clock64() > pl.deadline) {
+__device__ __forceinline__ bool la_retry(const LaPoll& pl) {
+    if ((long long)wall_clock64() > pl.deadline) {
         *pl.s_abort = 1;
         return false;
     }
+    __builtin_amdgcn_s_sleep(1);
     return true;
 }
 // wait until the `count` (<= 64) consecutive flags at f carry the launch's sequence number: lane j watches flag j
 __device__ __forceinline__ void la_wait(const int* f, int count, const LaPoll& pl) {
     const int lane = threadIdx.x & 63;
     if (lane < count) {
-        int it = 0;
         for (;;) {
             const int v = __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // global_load_dword sc1: not served by a cache
-            if (v == pl.seq || !la_retry(pl, it))
+            if (v == pl.seq || !la_retry(pl))
                 break;
         }
     }
@@ -111,29 +104,12 @@ __device__ __forceinline__ void la_put16(char* p, double v, int seq) {
 }
 __device__ __forceinline__ double la_get16(const char* p0, const LaPoll& pl) {
     v4i r;
-    int it = 0;
     for (;;) {
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p0) : "memory");
-        if ((r.z == pl.seq && r.w == ~pl.seq) || !la_retry(pl, it))
+        if ((r.z == pl.seq && r.w == ~pl.seq) || !la_retry(pl))
             break;
     }
     return __hiloint2double(r.y, r.x);
-}
-__device__ __forceinline__ void la_get16x2(const char* p0, const char* p1, const LaPoll& pl, double& v0, double& v1) {
-    v4i r0, r1;
-    int it = 0;
-    for (;;) {
-        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
-                     "global_load_dwordx4 %1, %3, off sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1)
-                     : "v"(p0), "v"(p1)
-                     : "memory");
-        if ((r0.z == pl.seq && r0.w == ~pl.seq && r1.z == pl.seq && r1.w == ~pl.seq) || !la_retry(pl, it))
-            break;
-    }
-    v0 = __hiloint2double(r0.y, r0.x);
-    v1 = __hiloint2double(r1.y, r1.x);
 }
 // MFMA operand layout: lane (lr, lk) receives v[st] = X[16 h + lr][4 st + lk], st = 0..7, of a published tile X[row + 32 k]
 __device__ __forceinline__ void la_operand(const double* __restrict__ tile, int h, double (&v)[8]) {
@@ -152,7 +128,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     double* sY = smem + 2 * 32 * CH_LDP; // R1 (written by the pre-work, read by the post-work)
     double* sD = smem + 3 * 32 * CH_LDP; // the diagonal tile handed to the elimination
     double* swork = smem + 4 * 32 * CH_LDP;
-    const int NJ = a.NJ, seq = a.seq;
+    const int NJ = a.NJ;
     {
         double* l0 = la_tile(a, la_i_linv(a, 0));
         for (int e = tid; e < 1024; e += LA_T) {
@@ -178,7 +154,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 a.dbg[8 * k + 0] = wall_clock64();
             la_wait(a.pubf + la_i_u(a, I, 0), 1, pl);
             if (k >= 1)
-                la_wait(a.pubf + la_i_u(a, I, 2), 1, pl);
+                la_wait(a.pubf + la_i_p(a, I, k - 1), 1, pl);
             if (a.dbg && wave == 4 && lane == 0)
                 a.dbg[8 * k + 1] = wall_clock64();
             double u1[4], u0[4];
@@ -193,7 +169,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             }
             if (k >= 1) {
                 double bi[8], bj[8];
-                const double* bt = la_tile(a, la_i_u(a, I, 2));
+                const double* bt = la_tile(a, la_i_p(a, I, k - 1));
                 la_operand(bt, ihU, bi);
                 la_operand(bt, jhU, bj);
                 if (a.dbg && wave == 4 && lane == 0)
@@ -211,29 +187,21 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                     u0[q] -= d[q];
                 }
             }
-            // R1 = Z(I, k) with every panel < k applied is the raw panel tile R^(k)_I of the block rows below: it leaves now, a whole
-            // elimination before they can use it
-            double* rt = la_tile(a, la_i_p(a, I, k));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 dacc[q] = u0[q];
                 sY[16 * ihU + lr + (16 * jhU + lk + 4 * q) * CH_LDP] = u1[q];
-                la_st(rt + (16 * ihU + lr) + 32 * (16 * jhU + lk + 4 * q), u1[q]);
             }
-            la_stores_done();
         }
         if (a.dbg && lane == 0 && (wave == 4 || wave == 0))
             a.dbg[8 * k + (wave == 4 ? 3 : 4)] = wall_clock64();
-        __syncthreads(); // B1: L_k^-1 in sLk (wave 0), R1 in sY and written through (waves 4..7)
+        __syncthreads(); // B1: L_k^-1 in sLk (wave 0), R1 in sY (waves 4..7)
         if (*s_abort)
             return;
-        if (tid == 0) {
-            la_raise(a, la_i_p(a, I, k));
-            if (k >= 1)
-                la_raise(a, la_i_linv(a, k)); // wave 0 stored L_k^-1 and waited for its stores before the barrier
-        }
         if (a.dbg && tid == 0)
             a.dbg[8 * k + 5] = wall_clock64();
+        if (tid == 0 && k >= 1)
+            la_raise(a, la_i_linv(a, k)); // wave 0 stored L_k^-1 and waited for its stores before the barrier
         if (prod) {
             // c = P^(k)_I = R1 L_k^-T : sub-tile (ih, ch) = (pw & 1, pw >> 1)
             const int ih = pw & 1, ch = pw >> 1;
@@ -241,9 +209,13 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 #pragma unroll
             for (int st = 0; st < 8; ++st)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLk[16 * ch + lr + (4 * st + lk) * CH_LDP], sY[16 * ih + lr + (4 * st + lk) * CH_LDP], acc, 0, 0, 0);
+            double* ct = la_tile(a, la_i_p(a, I, k));
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                sX[16 * ih + lr + (16 * ch + lk + 4 * q) * CH_LDP] = acc[q];
+            for (int q = 0; q < 4; ++q) {
+                const int r_ = 16 * ih + lr, c_ = 16 * ch + lk + 4 * q;
+                sX[r_ + c_ * CH_LDP] = acc[q];
+                la_st(ct + r_ + 32 * c_, acc[q]);
+            }
         }
         __syncthreads(); // B1.5: c in sX
         if (prod) {
@@ -259,8 +231,11 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 const int r_ = 16 * ihU + lr, c_ = 16 * jhU + lk + 4 * q;
                 sD[r_ + c_ * CH_LDP] = (r_ >= w2 || c_ >= w2) ? ((r_ == c_) ? 1.0 : 0.0) : dacc[q] - acc[q];
             }
+            la_stores_done(); // the write-through stores of c have had the product above to complete
         }
-        __syncthreads(); // B2: D in sD
+        __syncthreads(); // B2: D in sD; c written through
+        if (tid == 0)
+            la_raise(a, la_i_p(a, I, k));
         if (a.dbg && tid == 0)
             a.dbg[8 * k + 6] = wall_clock64();
         if (wave == 0) {
@@ -284,19 +259,14 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 }
 
 // ---- a block row --------------------------------------------------------------------------------------------------------------------
-// Wave wv of the 8 owns the WHOLE tiles Z(I, J), J = wv + 8 t (four 16 x 16 accumulator sub-tiles each): a panel step touches at most
-// MAXT tiles per wave. LDS: L_p^-1, the panel tile and P_I in operand layout, and one private 32 x 32 scratch per wave in which the wave's
-// own P^(p)_J changes from accumulator to operand layout.
-constexpr int LA_ROW_LDS = 4 * 32 * CH_LDP + 32 + 256 + 8 * 32 * CH_LDP; // doubles
 template <int MAXT>
 __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* smem, int* s_abort, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-    // L_p^-1 is double-buffered: a wave that is done with panel p may fetch L_(p+1)^-1 while others still form their P^(p)_J with L_p^-1
-    double* sT = smem + 2 * 32 * CH_LDP;
-    double* sPI = smem + 3 * 32 * CH_LDP;
-    double* sYv = smem + 4 * 32 * CH_LDP;                    // yTilde row of the panel (32)
-    double* sZp = sYv + 32;                                  // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
-    double* sW = sZp + 256 + (size_t)wave * 32 * CH_LDP;     // this wave's scratch
+    double* sLinv = smem;
+    double* sT = smem + 32 * CH_LDP;
+    double* sPI = smem + 2 * 32 * CH_LDP;
+    double* sYv = smem + 3 * 32 * CH_LDP; // yTilde row of the panel (32)
+    double* sZp = sYv + 32;               // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
     const int NJ = a.NJ, m = a.m, rows = a.rows, ldz = a.ldz, seq = a.seq;
     const bool srow = I < NJ;
     const int row0 = srow ? 32 * I : m + 32 * (I - NJ);
@@ -304,18 +274,17 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
     const int Jmax = srow ? I : NJ - 1;
     const bool ylast = (!srow) && (rows - 1 >= row0) && (rows - 1 < row0 + 32); // this block row holds the yTilde row
     const int yloc = rows - 1 - row0;
-    double acc[MAXT][4][4]; // [tile][sub-tile s = ih + 2 jh][q]: entry [16 ih + lr][16 jh + lk + 4 q]
+    const int g = wave >> 2, wq = wave & 3, ihU = wq & 1, jhU = wq >> 1;
+    const int ri = row0 + 16 * ihU + lr;
+    const int ric = min(ri, ilim - 1);
+    double acc[MAXT][4];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        const int J = wave + 8 * t;
+        const int J = 2 * t + g;
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
-            const int i = min(row0 + 16 * (sb & 1) + lr, ilim - 1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = min(32 * J + 16 * (sb >> 1) + lk + 4 * q, m - 1);
-                acc[t][sb][q] = (J <= Jmax) ? a.Z[i + (size_t)j * ldz] : 0.0;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int j = min(32 * J + 16 * jhU + lk + 4 * q, m - 1);
+            acc[t][q] = (J <= Jmax) ? a.Z[ric + (size_t)j * ldz] : 0.0;
         }
     }
     if (ylast && tid < 32)
@@ -327,14 +296,12 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         // to the owner: U1 = Z(I, I-1), U0 = Z(I, I) with the panels <= I-3 applied (all waves of the workgroup call this)
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            const int J = wave + 8 * t;
+            const int J = 2 * t + g;
             if (J == I - 1 || J == I) {
                 double* u = la_tile(a, la_i_u(a, I, J == I ? 1 : 0));
 #pragma unroll
-                for (int sb = 0; sb < 4; ++sb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        la_st(u + (16 * (sb & 1) + lr) + 32 * (16 * (sb >> 1) + lk + 4 * q), acc[t][sb][q]);
+                for (int q = 0; q < 4; ++q)
+                    la_st(u + (16 * ihU + lr) + 32 * (16 * jhU + lk + 4 * q), acc[t][q]);
             }
         }
         la_stores_done();
@@ -342,87 +309,31 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         if (tid == 0)
             la_raise(a, la_i_u(a, I, 0));
     };
-    // Everything a panel step consumes is requested ONE STEP AHEAD (the block rows run about a panel behind the owner, so it is there):
-    // L_(p+1)^-1 goes into the other L buffer and the raw panel tile of the wave's first tile of step p+1 into its scratch at the end of
-    // step p. A memory round trip costs ~2 us while 33 workgroups hammer the same few tiles; a step has room for none of them.
-    auto fetch_L = [&](int p) {
-        double* sL = smem + (p & 1) * 32 * CH_LDP;
-        la_wait(a.pubf + la_i_linv(a, p), 1, pl);
-        const double* lt = la_tile(a, la_i_linv(a, p));
-        const double v0 = lt[tid], v1 = lt[tid + LA_T];
-        sL[(tid & 31) + (tid >> 5) * CH_LDP] = v0;
-        sL[((tid + LA_T) & 31) + ((tid + LA_T) >> 5) * CH_LDP] = v1;
-    };
-    auto stage_R = [&](int J, int p) { // raw panel tile R^(p)_J -> this wave's scratch (panel 0: straight from Z, rows >= m masked)
-        int lanev = lane;
-        asm volatile("" : "+v"(lanev));
-        if (p == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int e = lanev + 64 * i, r = e & 31, c = e >> 5;
-                const int rj = 32 * J + r;
-                sW[r + c * CH_LDP] = a.Z[min(rj, m - 1) + (size_t)c * ldz] * (rj < m ? 1.0 : 0.0);
-            }
-        } else {
-            la_wait(a.pubf + la_i_p(a, J, p), 1, pl);
-            const double* pt = la_tile(a, la_i_p(a, J, p));
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int e = lanev + 64 * i;
-                sW[(e & 31) + (e >> 5) * CH_LDP] = pt[e];
-            }
-        }
-    };
-    auto first_tile = [&](int p) { // the first tile this wave updates in step p (not the diagonal one), or -1
-        const bool upd = srow ? (p <= I - 3) : (p < NJ);
-        int first = -1;
-        if (upd) {
-#pragma unroll
-            for (int t = MAXT - 1; t >= 0; --t) {
-                const int J = wave + 8 * t;
-                if (J > p && J <= Jmax && J != I)
-                    first = J;
-            }
-        }
-        return first;
-    };
-    int staged = -1;
-    if (np > 0) {
-        if (srow && I == 2)
-            hand_off(); // its two tiles go to the owner before panel 0 (= I - 2)
-        fetch_L(0);
-        staged = first_tile(0);
-        if (staged >= 0)
-            stage_R(staged, 0);
-    }
     for (int p = 0; p < np; ++p) {
-        // The lane coordinates are laundered once per panel: otherwise every address / mask expression of the body is loop invariant, gets
-        // hoisted in front of the loop and the whole lot (50 registers) is spilled there and reloaded from scratch in every step.
-        int lrv = lr, lkv = lk, lanev = lane;
-        asm volatile("" : "+v"(lrv), "+v"(lkv), "+v"(lanev));
         const bool do_update = srow ? (p <= I - 3) : true;
+        if (srow && p == I - 2)
+            hand_off();
         const int w = min(32, m - 32 * p);
-        double* sLinv = smem + (p & 1) * 32 * CH_LDP;
-        unsigned long long* dbq = (a.dbg && tid == 0 && (I == NJ || I == NJ - 2) && p < 32) ? a.dbg + 8 * ((I == NJ ? 32 : 64) + p) : nullptr;
-        if (dbq)
-            dbq[3] = wall_clock64();
-        // (a) the panel tile Z(I, p) -> LDS in operand layout; yTilde row of the panel (L_p^-1 is in LDS already)
-        if (wave == (p & 7)) {
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t)
-                if (t == (p >> 3)) {
-#pragma unroll
-                    for (int sb = 0; sb < 4; ++sb)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int r = 16 * (sb & 1) + lrv, c = 16 * (sb >> 1) + lkv + 4 * q;
-                            sT[r + c * CH_LDP] = (row0 + r < ilim && c < w) ? acc[t][sb][q] : 0.0;
-                        }
-                }
+        // (a) L_p^-1 -> LDS; the panel tile Z(I, p) -> LDS in operand layout (masked like the chain's operand loads); yTilde row of the panel
+        la_wait(a.pubf + la_i_linv(a, p), 1, pl);
+        {
+            const double* lt = la_tile(a, la_i_linv(a, p));
+            const double v0 = lt[tid], v1 = lt[tid + LA_T];
+            sLinv[(tid & 31) + (tid >> 5) * CH_LDP] = v0;
+            sLinv[((tid + LA_T) & 31) + ((tid + LA_T) >> 5) * CH_LDP] = v1;
         }
-        if (!srow && wave == ((p + 1) & 7) && lanev < 32) {
-            const double yv = la_get16(a.puby + 512 * (size_t)p + 16 * (size_t)lanev, pl);
-            sYv[lanev] = lanev < w ? yv : 0.0;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (2 * t + g == p) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 16 * jhU + lk + 4 * q;
+                    sT[16 * ihU + lr + c * CH_LDP] = (ri < ilim && c < w) ? acc[t][q] : 0.0;
+                }
+            }
+        if (!srow && wave == 7 && lane < 32) {
+            const double yv = la_get16(a.puby + 512 * (size_t)p + 16 * (size_t)lane, pl);
+            sYv[lane] = lane < w ? yv : 0.0;
         }
         __syncthreads();
         if (*s_abort)
@@ -437,15 +348,15 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             d4 pacc = {0, 0, 0, 0};
 #pragma unroll
             for (int st = 0; st < 8; ++st)
-                pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lrv + (4 * st + lkv) * CH_LDP], sT[16 * ih + lrv + (4 * st + lkv) * CH_LDP], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lr + (4 * st + lk) * CH_LDP], sT[16 * ih + lr + (4 * st + lk) * CH_LDP], pacc, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                sPI[16 * ih + lrv + (16 * ch + lkv + 4 * q) * CH_LDP] = pacc[q];
-            if (srow && p == I - 2) { // b = P^(I-2)_I for the owner, straight from the accumulators
-                double* pt = la_tile(a, la_i_u(a, I, 2));
+                sPI[16 * ih + lr + (16 * ch + lk + 4 * q) * CH_LDP] = pacc[q];
+            if (srow) { // the factor rows leave for the other block rows straight from the accumulators
+                double* pt = la_tile(a, la_i_p(a, I, p));
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    la_st(pt + (16 * ih + lrv) + 32 * (16 * ch + lkv + 4 * q), pacc[q]);
+                    la_st(pt + (16 * ih + lr) + 32 * (16 * ch + lk + 4 * q), pacc[q]);
                 la_stores_done();
             }
         } else if (!srow) {
@@ -458,10 +369,10 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             sZp[32 * h + c] = z;
         }
         __syncthreads();
-        // (c) b: flag for the owner; final W rows (+ Gamma) for the T block rows
+        // (c) P_I: flag for the S block rows; final W rows (+ Gamma) for the T block rows
         if (srow) {
-            if (tid == 0 && p == I - 2)
-                la_raise(a, la_i_u(a, I, 2));
+            if (tid == 0)
+                la_raise(a, la_i_p(a, I, p));
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -481,97 +392,47 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         }
         if (dbg_row)
             dbr[1] = wall_clock64();
-        if (do_update) {
+        if (!do_update)
+            continue;
+        double aI[8];
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int J = wave + 8 * t;
-                if (J > p && J <= Jmax) {
-                    double bJ[2][8];
-                    if (J == I) { // diagonal tile of an S block row: both operands are P_I
+        for (int st = 0; st < 8; ++st)
+            aI[st] = sPI[16 * ihU + lr + (4 * st + lk) * CH_LDP];
+        // every P^(p)_J this row needs: flags p NJ + (p+1 .. Jmax) are neighbours -> one polling load per wave
+        {
+            const int jn = min(Jmax, NJ - 1);
+            const int cnt = (srow ? jn - 1 : jn) - p; // an S block row's own P_I (J = I) is in LDS
+            if (cnt > 0)
+                la_wait(a.pubf + la_i_p(a, p + 1, p), cnt, pl);
+        }
 #pragma unroll
-                        for (int st = 0; st < 8; ++st) {
-                            bJ[0][st] = sPI[lrv + (4 * st + lkv) * CH_LDP];
-                            bJ[1][st] = sPI[16 + lrv + (4 * st + lkv) * CH_LDP];
-                        }
-                    } else {
-                        if (staged != J)
-                            stage_R(J, p);
-                        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the wave reads what its own lanes wrote
-                        // P_J = R_J L_p^-T, sub-tile (ih, ch); then through the same scratch from accumulator into operand layout
-                        d4 pj[4];
+        for (int t = 0; t < MAXT; ++t) {
+            const int J = 2 * t + g;
+            if (J > p && J <= Jmax) {
+                double bj[8];
+                if (J == I) { // diagonal tile of an S block row: both operands are P_I
 #pragma unroll
-                        for (int sb = 0; sb < 4; ++sb) {
-                            const int ih = sb & 1, ch = sb >> 1;
-                            pj[sb] = d4{0, 0, 0, 0};
+                    for (int st = 0; st < 8; ++st)
+                        bj[st] = sPI[16 * jhU + lr + (4 * st + lk) * CH_LDP];
+                } else
+                    la_operand(la_tile(a, la_i_p(a, J, p)), jhU, bj);
+                d4 d = {0, 0, 0, 0};
 #pragma unroll
-                            for (int st = 0; st < 8; ++st)
-                                pj[sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lrv + (4 * st + lkv) * CH_LDP], sW[16 * ih + lrv + (4 * st + lkv) * CH_LDP], pj[sb], 0, 0, 0);
-                            asm volatile("" ::: "memory"); // keeps the next sub-tile's 16 operand reads from being hoisted up here: registers, not latency, are scarce
-                        }
+                for (int st = 0; st < 8; ++st)
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], aI[st], d, 0, 0, 0);
 #pragma unroll
-                        for (int sb = 0; sb < 4; ++sb)
+                for (int q = 0; q < 4; ++q)
+                    acc[t][q] -= d[q];
+                if (ylast && J == p + 1 && 16 * ihU + lr == yloc) {
+                    // the yTilde row of the next panel is final now: publish it for every T block row's z_(p+1)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                sW[16 * (sb & 1) + lrv + (16 * (sb >> 1) + lkv + 4 * q) * CH_LDP] = pj[sb][q];
-                        __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-                        for (int st = 0; st < 8; ++st) {
-                            bJ[0][st] = sW[lrv + (4 * st + lkv) * CH_LDP];
-                            bJ[1][st] = sW[16 + lrv + (4 * st + lkv) * CH_LDP];
-                        }
-                    }
-#pragma unroll
-                    for (int sb = 0; sb < 4; ++sb) {
-                        const int ih = sb & 1, jh = sb >> 1;
-                        d4 d = {0, 0, 0, 0};
-#pragma unroll
-                        for (int st = 0; st < 8; ++st)
-                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(bJ[jh][st], sPI[16 * ih + lrv + (4 * st + lkv) * CH_LDP], d, 0, 0, 0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[t][sb][q] -= d[q];
-                        asm volatile("" ::: "memory");
-                    }
-                    if (J == p + 1) {
-                        // Z(I, p+1) is final now: it is the raw panel tile R^(p+1)_I of the block rows below (S rows, as long as they do not
-                        // hand it to the owner instead) and its yTilde row feeds every T block row's z_(p+1)
-                        if (srow && p + 1 <= I - 2) {
-                            double* rt = la_tile(a, la_i_p(a, I, p + 1));
-#pragma unroll
-                            for (int sb = 0; sb < 4; ++sb)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    la_st(rt + (16 * (sb & 1) + lrv) + 32 * (16 * (sb >> 1) + lkv + 4 * q), (row0 + 16 * (sb & 1) + lrv < ilim) ? acc[t][sb][q] : 0.0);
-                            la_stores_done();
-                            if (lanev == 0)
-                                la_raise(a, la_i_p(a, I, p + 1)); // one wave owns the tile: no workgroup barrier
-                        }
-                        if (ylast && lrv == (yloc & 15)) {
-#pragma unroll
-                            for (int sb = 0; sb < 4; ++sb)
-                                if ((sb & 1) == (yloc >> 4)) {
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q)
-                                        la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * (sb >> 1) + lkv + 4 * q), acc[t][sb][q], seq);
-                                }
-                        }
-                    }
+                    for (int q = 0; q < 4; ++q)
+                        la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jhU + lk + 4 * q), acc[t][q], seq);
                 }
             }
         }
         if (dbg_row)
             dbr[2] = wall_clock64();
-        // the hand-off must not wait behind the fetch of an L^-1 the owner produces only after it
-        if (srow && p + 1 == I - 2)
-            hand_off();
-        if (p + 1 < np) {
-            fetch_L(p + 1);
-            staged = first_tile(p + 1);
-            if (staged >= 0)
-                stage_R(staged, p + 1);
-        }
-        if (dbq)
-            dbq[4] = wall_clock64();
     }
     if (srow && I == 1)
         hand_off(); // block row 1 has no panel of its own to wait for: its two tiles go to the owner as they are
@@ -586,12 +447,12 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
     }
 }
 
-constexpr size_t LA_LDS_BYTES = sizeof(double) * (LA_ROW_LDS > 4 * 32 * CH_LDP + LDL_SBUF ? LA_ROW_LDS : 4 * 32 * CH_LDP + LDL_SBUF);
+constexpr size_t LA_LDS_BYTES = 0; // static LDS only
 template <int MAXT>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (a.spec && *a.spec == a.spec_seq)
         return; // cancelled speculative tail
-    extern __shared__ double smem[]; // LA_LDS_BYTES: the block rows need 137 KB (one private scratch tile per wave), the owner 64 KB
+    __shared__ double smem[4 * 32 * CH_LDP + LDL_SBUF];
     __shared__ int s_abort;
     if (threadIdx.x == 0)
         s_abort = 0;
