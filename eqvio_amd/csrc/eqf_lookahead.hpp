@@ -310,6 +310,9 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             la_raise(a, la_i_u(a, I, 0));
     };
     for (int p = 0; p < np; ++p) {
+        // laundered once per panel: otherwise the body's address / mask expressions are loop invariant, get hoisted and spilled
+        int lrv = lr, lkv = lk;
+        asm volatile("" : "+v"(lrv), "+v"(lkv));
         const bool do_update = srow ? (p <= I - 3) : true;
         if (srow && p == I - 2)
             hand_off();
@@ -405,29 +408,41 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             if (cnt > 0)
                 la_wait(a.pubf + la_i_p(a, p + 1, p), cnt, pl);
         }
+        // two tiles per round trip: both operand sets are requested before the first product needs one (the loads sit behind branches on
+        // the runtime panel index, which the compiler does not hoist them over by itself)
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            const int J = 2 * t + g;
-            if (J > p && J <= Jmax) {
-                double bj[8];
-                if (J == I) { // diagonal tile of an S block row: both operands are P_I
+        for (int t0 = 0; t0 < MAXT; t0 += 2) {
+            double bjs[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int J = 2 * (t0 + u) + g;
+                if (t0 + u < MAXT && J > p && J <= Jmax) {
+                    if (J == I) { // diagonal tile of an S block row: both operands are P_I
+#pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            bjs[u][st] = sPI[16 * jhU + lrv + (4 * st + lkv) * CH_LDP];
+                    } else
+                        la_operand(la_tile(a, la_i_p(a, J, p)), jhU, bjs[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = (t0 + u < MAXT) ? t0 + u : MAXT - 1;
+                const int J = 2 * (t0 + u) + g;
+                if (t0 + u < MAXT && J > p && J <= Jmax) {
+                    d4 d = {0, 0, 0, 0};
 #pragma unroll
                     for (int st = 0; st < 8; ++st)
-                        bj[st] = sPI[16 * jhU + lr + (4 * st + lk) * CH_LDP];
-                } else
-                    la_operand(la_tile(a, la_i_p(a, J, p)), jhU, bj);
-                d4 d = {0, 0, 0, 0};
-#pragma unroll
-                for (int st = 0; st < 8; ++st)
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], aI[st], d, 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[t][q] -= d[q];
-                if (ylast && J == p + 1 && 16 * ihU + lr == yloc) {
-                    // the yTilde row of the next panel is final now: publish it for every T block row's z_(p+1)
+                        d = __builtin_amdgcn_mfma_f64_16x16x4f64(bjs[u][st], aI[st], d, 0, 0, 0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jhU + lk + 4 * q), acc[t][q], seq);
+                        acc[t][q] -= d[q];
+                    if (ylast && J == p + 1 && 16 * ihU + lrv == yloc) {
+                        // the yTilde row of the next panel is final now: publish it for every T block row's z_(p+1)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jhU + lkv + 4 * q), acc[t][q], seq);
+                    }
                 }
             }
         }
