@@ -39,7 +39,13 @@ def eurocish_settings():
     from eqvio_amd.capi import COORD_INVDEPTH, Settings
 
     s = Settings.defaults()
-    # eqf block of configs/EQVIO_config_EuRoC_stationary.yaml:17-56 (rounded)
+    # The structure of the eqf block of configs/EQVIO_config_EuRoC_stationary.yaml:17-56 (InvDepth chart, fast Riccati, discrete velocity
+    # lift, continuous innovation lift, equivariant output, fixed scene depth 5.0, pixel noise 1.93, process / IMU noise values rounded),
+    # with these values REPLACED for the synthetic steady-state workload: initialPointVariance 1.0 (shipped 129.9),
+    # initialBiasOmegaVariance 0.01 (shipped 97162.8), outlierThresholdAbs / Prob 1e8 / 1e8 (shipped 4.852 / 0.0323): with the thresholds
+    # off no landmark ever becomes an outlier candidate and, in the 'hover' world, none enters or leaves, so EVERY frame takes the
+    # one-round-trip path (speculative tail never cancelled). That is the best case; `frame_mix` in the output line reports the same
+    # filter with landmark turnover and with the shipped thresholds.
     s.coordinateChoice = COORD_INVDEPTH
     s.fastRiccati = 1
     s.useDiscreteInnovationLift = 0
@@ -123,6 +129,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-multi-filter", action="store_true")
+    ap.add_argument("--no-frame-mix", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -189,6 +196,9 @@ def main():
     multi = None
     if rank == 0 and world_size == 1 and not args.no_multi_filter:
         multi = several_filters_on_one_gpu(settings, N, local_rank, Filter, lib)
+    mix = None
+    if rank == 0 and world_size == 1 and not args.no_frame_mix:
+        mix = frame_mix(N, local_rank, lib)
 
     if rank == 0:
         out = {
@@ -221,9 +231,59 @@ def main():
             out["cpu_baseline"] = cpu
         if multi is not None:
             out["several_filters_one_gpu"] = multi
+        if mix is not None:
+            out["frame_mix"] = mix
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def frame_mix(N, device, lib, n_frames=1200, n_warm=200):
+    """The headline workload is the best case (see eurocish_settings). Here the same filter runs on the 'wave' world (SimWorld, the
+    reference's wave trajectory, SimulationDataServer.cpp:46-65): ~9 of 200 tracked features change per frame (removeOldLandmarks +
+    addNewLandmarks: Sigma compaction and growth, a second host round trip), first with the outlier thresholds off, then with the shipped
+    EuRoC thresholds / retention / point variance (EQVIO_config_EuRoC_stationary.yaml:26-32: 4.852 px, 0.0323, 0.186, 129.9), where the
+    statistics kernel cancels the speculative tail whenever a landmark is an outlier candidate (VIOFilter.cpp:304-364)."""
+    import ctypes as C
+    import time
+
+    from eqvio_amd.capi import PreparedFrames, VIOFilter
+    from simworld import SimWorld
+
+    out = []
+    for name, thr_abs, thr_prob, pvar in (("wave world, landmark turnover, outlier thresholds off", 1e8, 1e8, 1.0),
+                                          ("wave world, landmark turnover, shipped EuRoC outlier thresholds 4.852 px / 0.0323, retention 0.186, point variance 129.9", 4.852186665580312,
+                                           0.03229809583062128, 129.90415638150924)):
+        s = eurocish_settings()
+        s.outlierThresholdAbs, s.outlierThresholdProb, s.featureRetention, s.initialPointVariance = thr_abs, thr_prob, 0.18594708334486176, pvar
+        world = SimWorld(seed=321, num_points=2500, max_features=N, trajectory="wave", noise_px=0.5)
+        frames = list(world.frames(n_warm + n_frames))
+        ids0 = frames[0][2]
+        sensor, ids, p = world.true_state(0.0, ids0)
+        p = p * (1.0 + 0.05 * np.random.default_rng(7).normal(size=(len(ids), 1)))
+        flt = VIOFilter(s, max_landmarks=N + 120, device=device, sensor=sensor, ids=ids, p=p, time=0.0)
+        core = flt.core_handle()
+        prepared = PreparedFrames(world.cam, *flatten_frames(frames))
+        turn = float(np.mean([len(set(a[2].tolist()) ^ set(b[2].tolist())) for a, b in zip(frames[n_warm:-1], frames[n_warm + 1:])]))
+        flt.run_prepared(prepared, 0, n_warm)
+        lib.eqf_synchronize(core)
+        c0, q0, x0 = C.c_long(), C.c_long(), C.c_long()
+        lib.eqf_speculation_stats(core, C.byref(c0), C.byref(q0), C.byref(x0), 1)
+        dims = []
+        t0 = time.perf_counter()
+        for k in range(0, n_frames, 100):
+            flt.run_prepared(prepared, n_warm + k, min(100, n_frames - k))
+            dims.append(flt.sigma_dim())
+        lib.eqf_synchronize(core)
+        el = time.perf_counter() - t0
+        lib.eqf_speculation_stats(core, C.byref(c0), C.byref(q0), C.byref(x0), 0)
+        S = flt.get_sigma()
+        ok = bool(np.all(np.isfinite(S)))
+        flt.close()
+        out.append({"workload": name, "value": n_frames / el, "unit": "updates/s", "frames": n_frames, "features_changed_per_frame": round(turn, 2),
+                    "mean_landmarks": (float(np.mean(dims)) - 21.0) / 3.0, "frames_with_tail_queued_speculatively": q0.value / max(c0.value, 1),
+                    "frames_with_tail_cancelled_on_device": x0.value / max(c0.value, 1), "sigma_finite": ok})
+    return out
 
 
 def several_filters_on_one_gpu(settings, N, device, Filter, lib, n_filters=4, n_frames=400, n_warm=100):
@@ -300,7 +360,8 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
     lib.eqf_mfma_f64_peak(core, C.byref(tpeak))
     # kernel families and their algorithmic (dense-formulation) flops per frame
     fam = {
-        "cholesky+trsm chain (k_chol_step x13; first tile inside k_build_Z)": (["k_chol_first", "k_chol_step"], m**3 / 3.0 + 2.0 * n * m * m),
+        "cholesky+trsm factorisation of [S; T; y^T] (k_chol_lookahead: one persistent kernel per frame; or k_chol_step, one launch per panel; first tile inside k_build_Z)": (
+            ["k_chol_first", "k_chol_step", "k_chol_lookahead"], m**3 / 3.0 + 2.0 * n * m * m),
         "Sigma -= K T^T (k_syrk_sub)": (["k_syrk_sub"], 2.0 * n * n * m),
         "T = Sigma C^T, S = C T + R (k_build_Z)": (["k_build_Z"], 2.0 * n * n * m + 2.0 * n * m * m),
         "propagate F Sigma F^T (k_propagate_main | k_gemm_nt)": (["k_propagate_main", "k_gemm_nt"], flops_propagate(n)),
@@ -313,13 +374,14 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
     # HBM-side traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with the
     # same bench command; bench.py cannot run the profiler on itself)
     traffic, traffic_note = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v11_pmc_traffic.json")))["kernels"]
+    try:  # per size: profiles/r02_pmc_traffic.json is written by scripts/pmc_traffic_json.py from the PMC passes of scripts/collect_profiles.sh
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pmc = pmc_all.get("N%d" % ((n - 21) // 3), {}).get("kernels", {})
         kn = [k_ for k_ in fam[dom][0] if k_ in pmc and launches.get(k_, 0) > 0]
         if kn:
             tot_l = sum(launches[k_] for k_ in kn)
             traffic = 1024.0 * sum((pmc[k_]["fetch_kib_per_launch"] + pmc[k_]["write_kib_per_launch"]) * launches[k_] for k_ in kn) / tot_l
-            traffic_note = "bytes per launch, FETCH_SIZE + WRITE_SIZE from profiles/r01_v11_pmc_*.csv (N=200)"
+            traffic_note = "bytes per launch, FETCH_SIZE + WRITE_SIZE (as reported, uncalibrated for 8 B/lane accesses) from " + pmc_all["N%d" % ((n - 21) // 3)]["source"]
     except Exception:
         pass
     return {
@@ -336,7 +398,7 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
         "algorithmic_flops_per_launch": fam[dom][1] / max(dom_launches, 1.0),
         "measured_mfma_f64_issue_ceiling_tflops": tpeak.value,
         "per_kernel_us_per_frame": {k_: round(v, 2) for k_, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
-        "note": "hipEvent spans on the filter's own stream over %d frames of the same workload right after the timed region; the factorisation chain is ONE span over its back-to-back launches divided by their number (launch boundaries included, no events between the steps), the other kernels one span each" % k,
+        "note": "hipEvent spans on the filter's own stream over %d frames of the same workload right after the timed region, one span per launch (the launch chain k_chol_step, when selected, is ONE span over its back-to-back launches divided by their number)" % k,
     }
 
 

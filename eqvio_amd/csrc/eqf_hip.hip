@@ -29,10 +29,11 @@ enum KName {
     KN_LIFT,
     KN_DENSE_GEMM,
     KN_MISC,
+    KN_CHOL_LOOKAHEAD,
     KN_COUNT
 };
 const char* kNames[KN_COUNT] = {"k_assemble_AB", "k_observer",    "k_propagate_G", "k_propagate_main", "k_measure", "k_outlier_stats", "k_build_Z",
-                                "k_chol_step",   "k_chol_first", "k_gamma",       "k_syrk_sub",       "k_lift",    "k_gemm_nt",       "misc"};
+                                "k_chol_step",   "k_chol_first", "k_gamma",       "k_syrk_sub",       "k_lift",    "k_gemm_nt",       "misc", "k_chol_lookahead"};
 
 int roundup(int x, int m) { return (x + m - 1) / m * m; }
 int pick_ld(int x) {
@@ -162,6 +163,7 @@ struct eqf_ctx {
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int* d_perm = nullptr;                   // 2 x (ncap + 2) row permutations of the NEES elimination fallback
+    long spec_calls = 0, spec_queued = 0, spec_cancelled = 0; // eqf_stats_then_update: calls, tails queued speculatively, tails cancelled on the device
     long nees_lu_fallbacks = 0;              // computeNEES calls answered by the partial-pivot elimination (Sigma not numerically SPD)
     int ldzn = 0;
     double *d_Z = nullptr, *d_W = nullptr, *d_Linv = nullptr, *d_gamma = nullptr, *d_gpart = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
@@ -1419,7 +1421,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.spec_seq = spec_seq;
     a.tr_steps = trace_slot(c, TR_STEP0);
     a.dbg = c->d_trace ? c->d_ladbg : nullptr;
-    KTimer t(c, KN_CHOL_PANEL, a.NJ); // reported per panel, like the launch chain it replaces
+    KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
     if (a.NJ <= 14)
         hipLaunchKernelGGL(k_chol_lookahead<7>, dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     else
@@ -1760,6 +1762,7 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
                           int discreteCorr, double* absErr, double* probErr, double* depth2, int* updated) {
     if (!c || !cam || !updated || M <= 0 || !ids || !y || !camera_ok(cam))
         return EQF_E_BAD_ARG;
+    ++c->spec_calls;
     *updated = 0;
     const int N = c->N;
     if (N == 0 || M > N) {
@@ -1848,7 +1851,9 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     if (rc)
         return rc;
     copy_stats();
+    ++c->spec_queued;
     if (c->h_resflags[2]) { // cancelled on the device: nothing was modified, C / residuals of the statistics kernel are still valid
+        ++c->spec_cancelled;
         c->meas_valid = true;
         return 0;
     }
@@ -1970,6 +1975,17 @@ int eqf_debug_lookahead_stamps(eqf_ctx* c, unsigned long long* out768) {
         return EQF_E_BAD_ARG;
     { int _r = sync_ctx(c); if (_r) return _r; }
     HIPCHK(hipMemcpy(out768, c->d_ladbg, 96 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int eqf_speculation_stats(eqf_ctx* c, long* calls, long* queued, long* cancelled, int reset) {
+    if (!c || !calls || !queued || !cancelled)
+        return EQF_E_BAD_ARG;
+    *calls = c->spec_calls;
+    *queued = c->spec_queued;
+    *cancelled = c->spec_cancelled;
+    if (reset)
+        c->spec_calls = c->spec_queued = c->spec_cancelled = 0;
     return 0;
 }
 

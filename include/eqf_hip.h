@@ -156,6 +156,11 @@ int eqf_stage_measurement(eqf_ctx* ctx, const int* ids, const double* y_px, int 
 int eqf_stats_then_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y_px, int M, double thrAbs, double thrProb, double meas_var,
                           int useEquivariantOutput, int discreteCorrection, double* absErr, double* probErr, double* depth2, int* updated);
 
+/* How the frames went through eqf_stats_then_update since the last reset: calls; calls that queued the update tail speculatively behind the
+ * statistics kernel (every measured id already a landmark); of those, tails the device cancelled because a landmark exceeded an outlier
+ * threshold (the caller then takes the two-round-trip path: removeOutliers / addNewLandmarks / eqf_vision_update). */
+int eqf_speculation_stats(eqf_ctx* ctx, long* calls, long* queued, long* cancelled, int reset);
+
 /* Gamma of the last update (n doubles) — for parity checks. */
 int eqf_last_gamma(eqf_ctx* ctx, double* out, int cap);
 

@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/$V
 mkdir -p $OUT
 ST=50; WU=10
 if [ "$NL" -ge 400 ]; then ST=30; WU=5; fi
-BCMD="python $R/bench.py --landmarks $NL --steps $ST --warmup $WU --no-cpu-baseline --no-roofline --no-multi-filter"
+BCMD="python $R/bench.py --landmarks $NL --steps $ST --warmup $WU --no-cpu-baseline --no-roofline --no-multi-filter --no-frame-mix"
 rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w /tmp/p_m
 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- $BCMD > /tmp/kt.log 2>&1
 DB=$(find /tmp/p_kt -name "*.db" | head -1)
