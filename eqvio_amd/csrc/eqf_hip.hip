@@ -163,6 +163,13 @@ struct eqf_ctx {
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int* d_perm = nullptr;                   // 2 x (ncap + 2) row permutations of the NEES elimination fallback
+    // landmark bookkeeping staging: a ring of pinned packets, one per eqf_remove_landmarks / eqf_add_landmarks call, so that those calls need not
+    // drain the stream before reusing a buffer (every frame has a host wait behind them; 8 slots cover the <= 4 calls of a frame twice)
+    static constexpr int kRing = 8;
+    int* h_keep_ring = nullptr;    // kRing x Ncap
+    double* h_newp_ring = nullptr; // kRing x 3 Ncap
+    int ring_pos = 0;
+    int spec_backoff = 0, spec_backoff_len = 0; // frames left without speculation after cancelled tails (doubling, <= 16), see eqf_stats_then_update
     long spec_calls = 0, spec_queued = 0, spec_cancelled = 0; // eqf_stats_then_update: calls, tails queued speculatively, tails cancelled on the device
     long nees_lu_fallbacks = 0;              // computeNEES calls answered by the partial-pivot elimination (Sigma not numerically SPD)
     int ldzn = 0;
@@ -581,6 +588,8 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     c->hbuf_doubles = (size_t)c->ld * c->ncap; // large enough for a full Sigma transfer
     HIPCHK(hipHostMalloc(&c->h_buf, sizeof(double) * c->hbuf_doubles));
     HIPCHK(hipHostMalloc(&c->h_ibuf, sizeof(int) * 4 * (size_t)c->Ncap));
+    HIPCHK(hipHostMalloc(&c->h_keep_ring, sizeof(int) * eqf_ctx::kRing * (size_t)c->Ncap));
+    HIPCHK(hipHostMalloc(&c->h_newp_ring, sizeof(double) * eqf_ctx::kRing * 3 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 4));
     HIPCHK(hipHostMalloc(&c->h_lmidx, sizeof(int) * 2 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_y, sizeof(double) * 2 * (size_t)c->Ncap));
@@ -663,6 +672,8 @@ void eqf_destroy(eqf_ctx* c) {
     hipHostFree(c->h_steps);
     hipHostFree(c->h_buf);
     hipHostFree(c->h_ibuf);
+    hipHostFree(c->h_keep_ring);
+    hipHostFree(c->h_newp_ring);
     hipHostFree(c->h_flags);
     hipHostFree(c->h_lmidx);
     hipHostFree(c->h_y);
@@ -969,9 +980,10 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
     if (c->N + k > c->Ncap)
         return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
-    { int _r = sync_ctx(c); if (_r) return _r; } // staging reuse
-    std::memcpy(c->h_buf, p, sizeof(double) * 3 * k);
-    HIPCHK(hipMemcpyAsync(c->d_scratch, c->h_buf, sizeof(double) * 3 * k, hipMemcpyHostToDevice, c->stream));
+    { int _r = join_observer(c); if (_r) return _r; } // landmark kernels of a stand-alone observer call run on the second stream
+    double* stage = c->h_newp_ring + (size_t)(c->ring_pos++ % eqf_ctx::kRing) * 3 * c->Ncap; // no stream drain: see h_newp_ring
+    std::memcpy(stage, p, sizeof(double) * 3 * k);
+    HIPCHK(hipMemcpyAsync(c->d_scratch, stage, sizeof(double) * 3 * k, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_scatter_landmarks, dim3(blocks(k, 64)), dim3(64), 0, c->stream, k, c->N, c->Ncap, c->d_scratch, (const double*)nullptr, c->q0(), c->Qq(),
                        c->Qa());
     HIPCHK(hipGetLastError());
@@ -999,16 +1011,17 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
         drop[indices[t]] = 1;
     }
     HIPCHK(hipSetDevice(c->device));
-    { int _r = sync_ctx(c); if (_r) return _r; } // staging reuse
+    { int _r = join_observer(c); if (_r) return _r; }
+    int* keep = c->h_keep_ring + (size_t)(c->ring_pos++ % eqf_ctx::kRing) * c->Ncap; // no stream drain: see h_keep_ring
     std::vector<int> newids;
     int Nnew = 0;
     for (int i = 0; i < c->N; ++i)
         if (!drop[i]) {
-            c->h_ibuf[Nnew++] = i;
+            keep[Nnew++] = i;
             newids.push_back(c->ids[i]);
         }
     if (Nnew > 0)
-        HIPCHK(hipMemcpyAsync(c->d_keep, c->h_ibuf, sizeof(int) * Nnew, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_keep, keep, sizeof(int) * Nnew, hipMemcpyHostToDevice, c->stream));
     const int nnew = 21 + 3 * Nnew;
     {
         KTimer t(c, KN_MISC);
@@ -1772,7 +1785,14 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     HIPCHK(hipSetDevice(c->device));
     host_stamp(c, TH_TAIL_ENTRY);
     // speculation needs the doorbell-free conditions of both waits and the equivariant-output cache of the statistics kernel
-    const bool speculate = c->opt_spec && !c->opt_check && !c->obs_pending;
+    // A cancelled tail costs the frame a wasted launch sequence on top of the two-round-trip path it falls back to. Where outlier candidates
+    // show up frame after frame (tight thresholds) speculation backs off: after a cancellation the next 1, 2, 4 .. 16 frames only compute
+    // the statistics; a frame without a candidate resets it. A scheduling choice only: both paths give bit-identical results.
+    bool speculate = c->opt_spec && !c->opt_check && !c->obs_pending;
+    if (speculate && c->opt_spec == 1 && c->spec_backoff > 0) {
+        --c->spec_backoff;
+        speculate = false;
+    }
     const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
     // staged by eqf_stage_measurement and copied to HBM by the propagation kernel: same measurement, same landmark set?
     const bool staged = speculate && c->staged_valid && c->staged_gen == c->lm_gen && c->staged_M == M && std::equal(ids, ids + M, c->staged_ids.begin()) &&
@@ -1825,6 +1845,11 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
         if (rc)
             return rc;
         copy_stats();
+        bool candidate = false; // a frame without an outlier candidate ends the back-off
+        for (int i = 0; i < N && !candidate; ++i)
+            candidate = c->h_res[i] > thrAbs || c->h_res[N + i] > thrProb;
+        if (!candidate)
+            c->spec_backoff = c->spec_backoff_len = 0;
         return 0;
     }
     // Speculative tail: measurement, statistics and Z in ONE kernel (k_build_Z with measurement fusion), then the factorisation,
@@ -1854,9 +1879,12 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     ++c->spec_queued;
     if (c->h_resflags[2]) { // cancelled on the device: nothing was modified, C / residuals of the statistics kernel are still valid
         ++c->spec_cancelled;
+        c->spec_backoff_len = std::min(16, std::max(1, 2 * c->spec_backoff_len));
+        c->spec_backoff = c->spec_backoff_len;
         c->meas_valid = true;
         return 0;
     }
+    c->spec_backoff = c->spec_backoff_len = 0;
     *updated = 1;
     return finish_update(c, discreteCorr);
 }

@@ -566,6 +566,14 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     loopTimer.startTiming("preprocessing");
     if (settings->removeLostLandmarks)
         removeOldLandmarks(measurement.getIds());
+    // With a fixed initial depth (both shipped dataset configurations) a new landmark depends on its pixel only, and the outlier test
+    // never looks at it (it is not in the state yet in the reference's order; here its residual is zero by construction): appending the
+    // new landmarks BEFORE the test instead of after it gives the same state - removing outliers afterwards only compacts the older rows,
+    // the new rows keep their relative order at the end - and lets a frame with landmark turnover take the one-round-trip path too
+    // (statistics + update queued back to back) instead of statistics -> host -> append -> update.
+    const bool earlyAdd = !settings->useMedianDepth;
+    if (earlyAdd)
+        addNewLandmarks(measurement, nullptr);
     std::vector<double> depth2;
     // Every measured id already in the state (no landmark to add) and something to update: queue the outlier statistics and
     // the update back to back (eqf_stats_then_update). If a measured landmark exceeds a threshold the device cancels the
@@ -588,7 +596,8 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     }
     VisionMeasurement matchedMeasurement = measurement;
     removeOutliers(matchedMeasurement, depth2, haveStats ? &absErr : nullptr, haveStats ? &probErr : nullptr);
-    addNewLandmarks(matchedMeasurement, &depth2);
+    if (!earlyAdd)
+        addNewLandmarks(matchedMeasurement, &depth2);
     loopTimer.endTiming("preprocessing");
 
     if (matchedMeasurement.camCoordinates.empty())

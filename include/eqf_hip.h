@@ -42,8 +42,9 @@ enum {
     EQF_OPT_FUSED_UPDATE = 4,  /* 1: Sigma -= W W^T and Gamma = W z ride along in the factorisation step kernels;
                                   0 (default): one split-K SYRK kernel after the chain. Measured: the fused form re-dirties all
                                   of Sigma in every step and the per-kernel write-back costs more than the saved launch. */
-    EQF_OPT_SPECULATIVE = 7,   /* 1 (default): eqf_stats_then_update queues the update behind the statistics kernel; 0: it only computes
-                                  the statistics */
+    EQF_OPT_SPECULATIVE = 7,   /* 1 (default): eqf_stats_then_update queues the update behind the statistics kernel, and backs off where that does not
+                                  pay: after a tail the device had to cancel, the next 1, 2, 4 .. 16 calls only compute the statistics (*updated = 0),
+                                  until a frame shows no outlier candidate; 2: always queue the tail; 0: never (statistics only) */
     EQF_OPT_DOORBELL = 6,      /* 1 (default): the two per-frame host waits poll a sequence number that the last workgroup of the
                                   kernel writes into the pinned result packet (~6 us earlier than the stream's completion signal);
                                   0: wait on the stream */

@@ -310,8 +310,11 @@ def test_speculative_tail_equals_stats_plus_update(chart):
     """eqf_stats_then_update: with no outlier candidate the state equals eqf_outlier_stats + eqf_vision_update bit for bit;
     with a threshold that one landmark exceeds the device cancels the queued update: nothing is modified, the statistics are
     returned, and the classic calls still work afterwards (oracle parity)."""
+    from eqvio_amd.capi import OPT_SPECULATIVE
+
     N = 19
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=77, useDiscreteInnovationLift=0)
+    core.set_option(OPT_SPECULATIVE, 2)  # always queue the tail (the default backs off for a frame after a cancellation, see below)
     twin = EqfCore(N, CHARTS[chart])
     twin.set_state(xi0, Xs, ids, q0, Q)
     twin.set_sigma(S)
@@ -350,6 +353,18 @@ def test_speculative_tail_equals_stats_plus_update(chart):
     upd, _, _, _ = core.stats_then_update(cam, np.array([10**6], np.int32), np.array([1.0, 2.0]), 1e8, 1e8, var, True, False)
     assert upd == -1 and np.array_equal(core.get_sigma(), S_now)
     twin.vision_update(cam, mid2, y2, var, True, False)
+    assert np.array_equal(core.get_sigma(), twin.get_sigma())
+    # default mode (1): a cancelled tail is followed by a statistics-only call (back-off), a frame without a candidate ends it
+    core.set_option(OPT_SPECULATIVE, 1)
+    mid3, y3 = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=rng.permutation(N)[:12])
+    a_ref, p_ref, _ = twin.outlier_stats(cam, mid3, y3)
+    upd, _, _, _ = core.stats_then_update(cam, mid3, y3, 1e8, 0.999 * np.max(p_ref), var, True, False)
+    assert upd == 0  # cancelled on the device
+    upd, a4, p4, _ = core.stats_then_update(cam, mid3, y3, 1e8, 1e8, var, True, False)
+    assert upd == 0 and np.array_equal(p4, p_ref)  # backed off: statistics only, no candidate -> back-off over
+    upd, _, _, _ = core.stats_then_update(cam, mid3, y3, 1e8, 1e8, var, True, False)
+    assert upd == 1
+    twin.vision_update(cam, mid3, y3, var, True, False)
     assert np.array_equal(core.get_sigma(), twin.get_sigma())
 
 
