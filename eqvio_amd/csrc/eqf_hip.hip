@@ -520,8 +520,8 @@ const char* eqf_error_string(int code) {
 const char* eqf_kernel_name(int which) { return (which >= 0 && which < KN_COUNT) ? kNames[which] : "?"; }
 
 int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choice) {
-    if (!out || max_landmarks < 1 || (coordinate_choice != EQVIO_COORD_EUCLIDEAN && coordinate_choice != EQVIO_COORD_INVDEPTH))
-        return coordinate_choice == EQVIO_COORD_NORMAL ? EQF_E_UNSUPPORTED : EQF_E_BAD_ARG;
+    if (!out || max_landmarks < 1 || (coordinate_choice != EQVIO_COORD_EUCLIDEAN && coordinate_choice != EQVIO_COORD_INVDEPTH && coordinate_choice != EQVIO_COORD_NORMAL))
+        return EQF_E_BAD_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device >= ndev)
         return EQF_E_NO_DEVICE;
@@ -1080,9 +1080,37 @@ int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const
 }
 // Sigma' = F Sigma F^T + dt (B Q B^T + P) once A_l / B_l are assembled (arrow form, or the dense GEMM pair)
 // obs != nullptr (arrow form only): obs_k observer steps for the landmarks ride along as extra blocks of k_propagate_main
+// Normal chart (coordinateSuite/normal.cpp:37-45): Sigma <- T Sigma T^T with T = M (dir > 0, plus dt P on the diagonal) or M^-1 (dir < 0),
+// out of place into the other Sigma buffer. See k_congruence_normal.
+static int normal_congruence(eqf_ctx* c, int dir, double dt, const double* Pdiag8) {
+    NormalM nm{};
+    nm.dir = dir;
+    nm.v0[0] = c->xi0.vel.x, nm.v0[1] = c->xi0.vel.y, nm.v0[2] = c->xi0.vel.z;
+    const M6 Ad = se3_Adjoint(pose_inv(c->xi0.cam));
+    for (int r = 0; r < 6; ++r)
+        for (int q = 0; q < 6; ++q)
+            nm.Ad[6 * r + q] = Ad.a[6 * r + q];
+    nm.addP = (dir > 0 && Pdiag8) ? 1 : 0;
+    for (int k = 0; k < 8; ++k)
+        nm.dtP[k] = Pdiag8 ? dt * Pdiag8[k] : 0.0;
+    const int n = c->n();
+    LAUNCH_TS(c, k_congruence_normal, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->Ncap, c->ld, nm, c->q0(), (const TS*)c->d_sigma[c->cur], (TS*)c->d_sigma[1 - c->cur]);
+    HIPCHK(hipGetLastError());
+    c->cur = 1 - c->cur;
+    return 0;
+}
 static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs, int obs_k, bool fused) {
     int rc = 0;
     static const ObsSteps kNoSteps{};
+    const bool normal = c->chart == EQVIO_COORD_NORMAL;
+    static const double kZero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double* Pfull = Pdiag8;
+    if (normal) { // Euclidean propagation of M^-1 Sigma M^-T without process noise; M ( . ) M^T + dt P follows below
+        rc = normal_congruence(c, -1, dt, nullptr);
+        if (rc)
+            return rc;
+        Pdiag8 = kZero8;
+    }
     RiccatiArgs ra;
     ra.dt = dt;
     std::memcpy(ra.Qd, Qdiag12, sizeof(ra.Qd));
@@ -1151,6 +1179,11 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
         HIPCHK(hipGetLastError());
     }
     c->cur = 1 - c->cur;
+    if (normal) {
+        rc = normal_congruence(c, +1, dt, Pfull);
+        if (rc)
+            return rc;
+    }
     { int _r = round_sigma(c); if (_r) return _r; }
     if (c->opt_check) {
         LAUNCH_TS(c, k_check_finite, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->ld, (const TS*)c->sigma(), c->d_flags);
@@ -1188,10 +1221,17 @@ int eqf_integrate_riccati_accurate(eqf_ctx* c, const double* imu13, double dt, c
     rc = launch_assemble(c);
     if (rc)
         return rc;
+    const bool normal = c->chart == EQVIO_COORD_NORMAL;
+    static const double kZero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (normal) { // expm(dt [[A_n, B_n],[0,0]]) = blkdiag(M, I) expm(dt [[A_e, B_e],[0,0]]) blkdiag(M^-1, I): the same two congruences
+        rc = normal_congruence(c, -1, dt, nullptr);
+        if (rc)
+            return rc;
+    }
     RiccatiArgs ra;
     ra.dt = dt;
     std::memcpy(ra.Qd, Qdiag12, sizeof(ra.Qd));
-    std::memcpy(ra.Pd, Pdiag8, sizeof(ra.Pd));
+    std::memcpy(ra.Pd, normal ? kZero8 : Pdiag8, sizeof(ra.Pd));
     const int N = c->N, n = c->n();
     double* Sin = c->d_sigma[c->cur];
     double* Sout = c->d_sigma[1 - c->cur];
@@ -1211,6 +1251,11 @@ int eqf_integrate_riccati_accurate(eqf_ctx* c, const double* imu13, double dt, c
     hipLaunchKernelGGL(k_add_noise_dense, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->ld, ra, c->d_PhiB, Sout);
     HIPCHK(hipGetLastError());
     c->cur = 1 - c->cur;
+    if (normal) {
+        rc = normal_congruence(c, +1, dt, Pdiag8);
+        if (rc)
+            return rc;
+    }
     return round_sigma(c);
 }
 
@@ -1658,9 +1703,25 @@ static int finish_update(eqf_ctx* c, int discreteCorr) {
     GroupSensor D;
     D.bgyr = v3(g[0], g[1], g[2]);
     D.bacc = v3(g[3], g[4], g[5]);
-    const V3 gw = v3(g[6], g[7], g[8]), gv = v3(g[9], g[10], g[11]), gvel = v3(g[12], g[13], g[14]);
-    const V3 cw = v3(g[15], g[16], g[17]), cv = v3(g[18], g[19], g[20]);
-    if (discreteCorr) {
+    V3 gw = v3(g[6], g[7], g[8]), gv = v3(g[9], g[10], g[11]), gvel = v3(g[12], g[13], g[14]);
+    V3 cw = v3(g[15], g[16], g[17]), cv = v3(g[18], g[19], g[20]);
+    const bool normal = c->chart == EQVIO_COORD_NORMAL;
+    if (normal && !discreteCorr) {
+        // liftInnovation_normal = liftInnovation_euclid(M^-1 Gamma) (normal.cpp:47-50); sensor block of M^-1: [12:15,6:9] = skew(v0), [15:21,6:12] = -Ad(T0^-1)
+        gvel = gvel + cross(c->xi0.vel, gw);
+        const V6 UA = Ad_apply(pose_inv(c->xi0.cam), V6{gw, gv});
+        cw = cw - UA.w;
+        cv = cv - UA.v;
+    }
+    if (normal && discreteCorr) {
+        // liftInnovationDiscrete_normal (normal.cpp:52-55) = the Euclidean discrete lift of chart_euclid(chart_normal^-1(Gamma)). With
+        // (R, x0, x1) = SE_2(3).exp(Gamma[6:15]) (sensorChart_normal.inv, VIOState.cpp:138-151) that composition collapses to
+        // A = (R, x0), w = -x1, B = SE3.exp(Gamma[15:21]).
+        const M3 V = so3_V(gw);
+        D.A = Pose{so3_exp(gw), V * gv};
+        D.w = -(V * gvel);
+        D.B = se3_exp(cw, cv);
+    } else if (discreteCorr) {
         // liftInnovationDiscrete sensor part (euclid.cpp:74-79 == invdepth.cpp:228-233)
         D.A = se3_exp(gw, gv);
         D.w = c->xi0.vel - q_rot(D.A.R, c->xi0.vel + gvel);
@@ -1922,11 +1983,19 @@ int eqf_compute_nees(eqf_ctx* c, const double* ts, const int* tids, const double
     Xi.w = -q_rot(q_inv(c->X.A.R), c->X.w);
     const SensorState se = sensor_action(Xi, tsn);
     std::vector<double> eps(np, 0.0);
-    // sensorChart_std (VIOState.cpp:104-113)
-    const V3 db = se.bgyr - c->xi0.bgyr, da = se.bacc - c->xi0.bacc, dv = se.vel - c->xi0.vel;
+    // sensorChart_std (VIOState.cpp:104-113); Normal chart: sensorChart_normal (:123-137)
+    const V3 db = se.bgyr - c->xi0.bgyr, da = se.bacc - c->xi0.bacc;
+    V3 dv = se.vel - c->xi0.vel;
     V3 om, tr, omc, trc;
-    se3_log(pose_mul(pose_inv(c->xi0.pose), se.pose), om, tr);
-    se3_log(pose_mul(pose_inv(c->xi0.cam), se.cam), omc, trc);
+    const Pose Arel = pose_mul(pose_inv(c->xi0.pose), se.pose);
+    se3_log(Arel, om, tr);
+    if (c->chart == EQVIO_COORD_NORMAL) {
+        // SE_2(3).log(A.R, A.x, v_A), v_A = R0^T (R v - R0 v0); B = T0^-1 A T
+        const V3 vA = q_rot(q_inv(c->xi0.pose.R), q_rot(se.pose.R, se.vel) - q_rot(c->xi0.pose.R, c->xi0.vel));
+        dv = so3_Vinv(om) * vA;
+        se3_log(pose_mul(pose_mul(pose_inv(c->xi0.cam), Arel), se.cam), omc, trc);
+    } else
+        se3_log(pose_mul(pose_inv(c->xi0.cam), se.cam), omc, trc);
     const V3 parts[7] = {db, da, om, tr, dv, omc, trc};
     for (int b = 0; b < 7; ++b)
         pack_v3(parts[b], eps.data() + 3 * b);
@@ -1942,7 +2011,8 @@ int eqf_compute_nees(eqf_ctx* c, const double* ts, const int* tids, const double
         const V3 ptrue = v3(tp[3 * jt], tp[3 * jt + 1], tp[3 * jt + 2]);
         const Qt qi{Q[5 * i], Q[5 * i + 1], Q[5 * i + 2], Q[5 * i + 3]};
         const V3 pe = Q[5 * i + 4] * q_rot(qi, ptrue); // (Q_i^-1)^-1 * p = a R p
-        const V3 e = point_chart(c->chart == EQVIO_COORD_INVDEPTH, pe, v3(q0[3 * i], q0[3 * i + 1], q0[3 * i + 2]));
+        const V3 q0i = v3(q0[3 * i], q0[3 * i + 1], q0[3 * i + 2]);
+        const V3 e = c->chart == EQVIO_COORD_NORMAL ? normal_chart(pe, q0i) : point_chart(c->chart == EQVIO_COORD_INVDEPTH, pe, q0i);
         pack_v3(e, eps.data() + 21 + 3 * i);
     }
     // device: Z = [Sigma ; eps^T], factorise, NEES = |z|^2 / n
@@ -2065,6 +2135,70 @@ int eqf_debug_matrices_AB(eqf_ctx* c, const double* imu13, double* A_out, double
             for (int r = 0; r < 3; ++r)
                 for (int cc = 0; cc < 3; ++cc)
                     B_out[21 + 3 * i + r + (size_t)cc * n] = Bl[(r * 3 + cc) * (size_t)Ncap + i];
+    }
+    if (c->chart == EQVIO_COORD_NORMAL) {
+        // what was expanded above is the Euclidean pair (the device propagates M^-1 Sigma M^-T with it); the Normal suite's matrices are
+        // A_n = M A_e M^-1, B_n = M B_e (normal.cpp:37-45) with the closed-form block-diagonal M
+        std::vector<double> q0(3 * (size_t)N + 3), Q(5 * (size_t)N + 5);
+        std::vector<int> ids(N + 1);
+        double s0[23], g0[23];
+        rc = eqf_get_state(c, s0, g0, ids.data(), q0.data(), Q.data(), N);
+        if (rc < 0)
+            return rc;
+        std::vector<double> Md((size_t)n * n, 0.0), Mi((size_t)n * n, 0.0); // column-major
+        for (int i = 0; i < n; ++i)
+            Md[i + (size_t)i * n] = Mi[i + (size_t)i * n] = 1.0;
+        const M3 K = skew(c->xi0.vel);
+        const M6 Ad = se3_Adjoint(pose_inv(c->xi0.cam));
+        const double Kd[9] = {K.a00, K.a01, K.a02, K.a10, K.a11, K.a12, K.a20, K.a21, K.a22};
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) {
+                Md[12 + r + (size_t)(6 + q) * n] = -Kd[3 * r + q];
+                Mi[12 + r + (size_t)(6 + q) * n] = Kd[3 * r + q];
+            }
+        for (int r = 0; r < 6; ++r)
+            for (int q = 0; q < 6; ++q) {
+                Md[15 + r + (size_t)(6 + q) * n] = Ad.a[6 * r + q];
+                Mi[15 + r + (size_t)(6 + q) * n] = -Ad.a[6 * r + q];
+            }
+        for (int i = 0; i < N; ++i) {
+            const V3 p0 = v3(q0[3 * i], q0[3 * i + 1], q0[3 * i + 2]);
+            const M3 Mb = normal_M(p0), Mv = normal_Minv(p0);
+            const double mb[9] = {Mb.a00, Mb.a01, Mb.a02, Mb.a10, Mb.a11, Mb.a12, Mb.a20, Mb.a21, Mb.a22};
+            const double mv[9] = {Mv.a00, Mv.a01, Mv.a02, Mv.a10, Mv.a11, Mv.a12, Mv.a20, Mv.a21, Mv.a22};
+            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 3; ++q) {
+                    Md[21 + 3 * i + r + (size_t)(21 + 3 * i + q) * n] = mb[3 * r + q];
+                    Mi[21 + 3 * i + r + (size_t)(21 + 3 * i + q) * n] = mv[3 * r + q];
+                }
+        }
+        auto mul = [n](const std::vector<double>& X, const double* Y, int cols, std::vector<double>& Z) { // Z = X Y, X n x n with few non-zeros
+            Z.assign((size_t)n * cols, 0.0);
+            for (int k = 0; k < n; ++k)
+                for (int i = 0; i < n; ++i) {
+                    const double x = X[i + (size_t)k * n];
+                    if (x != 0.0)
+                        for (int j = 0; j < cols; ++j)
+                            Z[i + (size_t)j * n] += x * Y[k + (size_t)j * n];
+                }
+        };
+        std::vector<double> T1, T2;
+        if (A_out) {
+            mul(Md, A_out, n, T1);                        // M A_e
+            T2.assign((size_t)n * n, 0.0);                // (M A_e) M^-1
+            for (int k = 0; k < n; ++k)
+                for (int j = 0; j < n; ++j) {
+                    const double x = Mi[k + (size_t)j * n];
+                    if (x != 0.0)
+                        for (int i = 0; i < n; ++i)
+                            T2[i + (size_t)j * n] += T1[i + (size_t)k * n] * x;
+                }
+            std::copy(T2.begin(), T2.end(), A_out);
+        }
+        if (B_out) {
+            mul(Md, B_out, 12, T1);
+            std::copy(T1.begin(), T1.end(), B_out);
+        }
     }
     return 0;
 }

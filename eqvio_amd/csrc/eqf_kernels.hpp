@@ -685,6 +685,20 @@ __device__ __forceinline__ MeasOut measure_one(int chart, const Cam& cam, V3 p0,
     o.yt[0] = yu - hu;
     o.yt[1] = yv - hv;
     const V3 yHat = normalized(qh);
+    if (chart == EQVIO_COORD_NORMAL) {
+        // EqFoutputMatrixCiStar_normal (coordinateSuite/normal.cpp:57-65): [J(yHat) R_Q^T chartInvDiff0_normal(q0) | 0], yHat = R_Q^T y0; the pixel is not used
+        V3 j0, j1, d0, d1;
+        cam_jac(cam, transpose(RQ) * normalized(p0), j0, j1);
+        normal_invdiff0(p0, d0, d1);
+        const V3 e0 = transpose(RQ) * d0, e1 = transpose(RQ) * d1;
+        o.c[0] = dot(j0, e0);
+        o.c[1] = dot(j0, e1);
+        o.c[2] = 0.0;
+        o.c[3] = dot(j1, e0);
+        o.c[4] = dot(j1, e1);
+        o.c[5] = 0.0;
+        return o;
+    }
     const V3 yTru = star ? cam_undistort(cam, yu, yv) : cam_undistort(cam, hu, hv);
     V3 a0, a1, b0, b1;
     cam_jac_skew(cam, yTru, a0, a1);
@@ -1801,11 +1815,13 @@ __device__ __forceinline__ void lift_landmark(int i, const V3 g, const LiftIn& i
     Qt Dq;
     double Da;
     if (discrete) {
-        const V3 q1 = (chart == EQVIO_COORD_INVDEPTH) ? invdepth_chart_inv(g, p0) : p0 + g;
+        // liftInnovationDiscrete: q1 = chart^-1(gamma_i) about q0 (euclid.cpp:86-91, invdepth.cpp:242-247; normal.cpp:52-55 goes through the Normal chart's inverse)
+        const V3 q1 = (chart == EQVIO_COORD_INVDEPTH) ? invdepth_chart_inv(g, p0) : ((chart == EQVIO_COORD_NORMAL) ? normal_chart_inv(g, p0) : p0 + g);
         Dq = so3_from_vectors(normalized(q1), normalized(p0));
         Da = norm(p0) / norm(q1);
     } else {
-        const V3 ge = (chart == EQVIO_COORD_INVDEPTH) ? in.r0m * g : g;
+        // liftInnovation_normal = liftInnovation_euclid(M^-1 gamma) (normal.cpp:47-50)
+        const V3 ge = (chart == EQVIO_COORD_INVDEPTH) ? in.r0m * g : ((chart == EQVIO_COORD_NORMAL) ? normal_Minv(p0) * g : g);
         const double iq2 = 1.0 / norm2(p0);
         const V3 Wr = (-iq2) * cross(p0, ge);
         const double Ws = -iq2 * dot(p0, ge);
@@ -1934,6 +1950,65 @@ __global__ void k_gather_landmarks_aos(int N, int Ncap, const double* __restrict
 }
 // removal of landmarks: new index -> old index map `keep` (length Nnew). Sigma_new = Sigma_old[map, map]
 // (removeRows/removeCols, VIO_eqf.cpp:27-45) written to the other buffer.
+// Normal chart: A_n = M A_e M^-1, B_n = M B_e with the block-diagonal change of coordinates M (eqf_math.hpp, normal_M), so a Riccati step is
+//   Sigma' = M [ F_e (M^-1 Sigma M^-T) F_e^T + dt B_e Q B_e^T (or the accurate form) ] M^T + dt P
+// i.e. the Euclidean propagation between two congruences. This kernel is one of them: out = T Sigma T^T, T = M (dir > 0) or M^-1
+// (dir < 0), plus dt P on the diagonal if addP. One thread per output entry; a row of T has at most 7 non-zeros.
+struct NormalM {
+    double v0[3];  // xi0 velocity
+    double Ad[36]; // Adjoint(T0^-1), row-major 6 x 6, T0 = xi0 camera offset
+    double dtP[8]; // dt * process variances by class (bias omega / accel, attitude, position, velocity, camera attitude / position, point)
+    int dir, addP;
+};
+__device__ __forceinline__ int normal_row(const NormalM& nm, int i, int Ncap, const double* __restrict__ q0, int (&idx)[7], double (&co)[7]) {
+    if (i < 21) {
+        idx[0] = i;
+        co[0] = 1.0;
+        int k = 1;
+        const double sg = nm.dir > 0 ? 1.0 : -1.0;
+        if (i >= 12 && i < 15) { // [12:15, 6:9] = -skew(v0) (inverse: +skew(v0))
+            const M3 K = skew(V3{nm.v0[0], nm.v0[1], nm.v0[2]});
+            const V3 r = row(K, i - 12);
+            idx[1] = 6, idx[2] = 7, idx[3] = 8;
+            co[1] = -sg * r.x, co[2] = -sg * r.y, co[3] = -sg * r.z;
+            k = 4;
+        } else if (i >= 15) { // [15:21, 6:12] = Ad(T0^-1) (inverse: -Ad(T0^-1))
+            for (int c = 0; c < 6; ++c) {
+                idx[1 + c] = 6 + c;
+                co[1 + c] = sg * nm.Ad[6 * (i - 15) + c];
+            }
+            k = 7;
+        }
+        return k;
+    }
+    const int l = (i - 21) / 3, r = (i - 21) % 3;
+    const V3 p0 = ld3(q0, Ncap, l);
+    const M3 T = nm.dir > 0 ? normal_M(p0) : normal_Minv(p0);
+    const V3 tr = row(T, r);
+    idx[0] = 21 + 3 * l, idx[1] = idx[0] + 1, idx[2] = idx[0] + 2;
+    co[0] = tr.x, co[1] = tr.y, co[2] = tr.z;
+    return 3;
+}
+template <typename TS>
+__global__ void __launch_bounds__(256) k_congruence_normal(int n, int Ncap, int ld, NormalM nm, const double* __restrict__ q0, const TS* __restrict__ Sin, TS* __restrict__ Sout) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= n || j >= n || i < j)
+        return; // lower triangle, mirrored below: Sigma stays exactly symmetric
+    int ii[7], jj[7];
+    double ci[7], cj[7];
+    const int ni = normal_row(nm, i, Ncap, q0, ii, ci), nj = normal_row(nm, j, Ncap, q0, jj, cj);
+    double acc = 0.0;
+    for (int b = 0; b < nj; ++b) {
+        double t = 0.0;
+        for (int a = 0; a < ni; ++a)
+            t = fma(ci[a], (double)Sin[ii[a] + (size_t)jj[b] * ld], t);
+        acc = fma(cj[b], t, acc);
+    }
+    if (nm.addP && i == j)
+        acc += nm.dtP[i < 21 ? i / 3 : 7];
+    Sout[i + (size_t)j * ld] = (TS)acc;
+    Sout[j + (size_t)i * ld] = (TS)acc;
+}
 template <typename TS>
 __global__ void __launch_bounds__(256) k_compact_sigma(int nnew, int ld, const int* __restrict__ keep, const TS* __restrict__ Sin, TS* __restrict__ Sout) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;

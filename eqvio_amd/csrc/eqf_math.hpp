@@ -434,5 +434,42 @@ HD V3 invdepth_chart_inv(V3 eps, V3 q0) {
         rho = 1e-6;
     return (1.0 / rho) * y;
 }
+// ---- Normal chart (sphereChart_normal / pointChart_normal, VIOState.cpp:188-209, 309-353; coordinateSuite/normal.cpp) ----------------
+// The reference obtains the change of coordinates M = D(normal o euclid^-1)(0) by central differences (VIOState.cpp:391-401); it is
+// block diagonal and has a closed form. With Rn = rot(y0 -> e3), r0 = |q0|, y0 = q0 / r0:
+//   landmark block  M_i = [Rn.row1 / r0 ; -Rn.row0 / r0 ; -y0^T / r0],   M_i^-1 = [r0 Rn.row1^T | -r0 Rn.row0^T | -q0]
+//   sensor block    identity except  [12:15, 6:9] = -skew(v0)  and  [15:21, 6:12] = Ad(T0^-1)   (inverse: +skew(v0), -Ad(T0^-1))
+HD M3 normal_rot(V3 q0) { return q_mat(so3_from_vectors(normalized(q0), V3{0, 0, 1})); }
+HD M3 normal_M(V3 q0) {
+    const double ir = 1.0 / norm(q0);
+    const M3 Rn = normal_rot(q0);
+    return m3_rows(ir * row(Rn, 1), (-ir) * row(Rn, 0), (-ir * ir) * q0);
+}
+HD M3 normal_Minv(V3 q0) {
+    const double r0 = norm(q0);
+    const M3 Rn = normal_rot(q0);
+    return m3_cols(r0 * row(Rn, 1), (-r0) * row(Rn, 0), -q0);
+}
+// sphereChart_normal.chartInvDiff0(pole) (VIOState.cpp:345-352): R^T [[0,-1],[1,0],[0,0]], as two columns
+HD void normal_invdiff0(V3 q0, V3& c0, V3& c1) {
+    const M3 Rn = normal_rot(q0);
+    c0 = row(Rn, 1);
+    c1 = -row(Rn, 0);
+}
+// pointChart_normal forward / inverse (VIOState.cpp:188-209)
+HD V3 normal_chart(V3 q, V3 q0) {
+    const double rho = 1.0 / norm(q), rho0 = 1.0 / norm(q0);
+    const V3 y = normal_rot(q0) * (rho * q);
+    const V3 ye3{y.y, -y.x, 0.0}; // skew(y) e3
+    const double sin_th = sqrt(ye3.x * ye3.x + ye3.y * ye3.y), cos_th = y.z;
+    const double th = atan2(sin_th, cos_th);
+    const double k = (fabs(th) < 1e-8) ? 1.0 : th / sin_th;
+    return V3{k * ye3.x, k * ye3.y, log(rho / rho0)};
+}
+HD V3 normal_chart_inv(V3 eps, V3 q0) {
+    const double r0 = norm(q0);
+    const V3 y = q_rot(so3_exp(V3{-eps.x, -eps.y, 0.0}), V3{0, 0, 1});
+    return (r0 * exp(-eps.z)) * (transpose(normal_rot(q0)) * y);
+}
 
 } // namespace eqf
