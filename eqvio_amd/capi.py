@@ -191,6 +191,7 @@ def load_eqf_lib():
         "eqf_remove_invalid_landmarks": (C.c_int, [vp]),
         "eqf_integrate_riccati_fast": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p]),
         "eqf_integrate_riccati_accurate": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p]),
+        "eqf_integrate_riccati_discrete": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p]),
         "eqf_integrate_observer": (C.c_int, [vp, c_double_p, c_double_p, C.c_int, C.c_int]),
         "eqf_outlier_stats": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]),
         "eqf_propagate_fast": (C.c_int, [vp, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int]),
@@ -321,6 +322,10 @@ class EqfCore:
     def integrate_riccati_accurate(self, imu13, dt, Qdiag12, Pdiag8):
         imu13, Qd, Pd = _f64(imu13), _f64(Qdiag12), _f64(Pdiag8)
         self._chk0(self.lib.eqf_integrate_riccati_accurate(self.h, _dp(imu13), dt, _dp(Qd), _dp(Pd)))
+
+    def integrate_riccati_discrete(self, imu13, dt, Qdiag12, Pdiag8):
+        imu13, Qdiag12, Pdiag8 = _f64(imu13), _f64(Qdiag12), _f64(Pdiag8)
+        self._chk0(self.lib.eqf_integrate_riccati_discrete(self.h, _dp(imu13), dt, _dp(Qdiag12), _dp(Pdiag8)))
 
     def integrate_observer(self, imu13_k, dt_k, discrete=True):
         imu13_k, dt_k = _f64(imu13_k).reshape(-1, 13), _f64(dt_k).reshape(-1)

@@ -1259,6 +1259,110 @@ int eqf_integrate_riccati_accurate(eqf_ctx* c, const double* imu13, double dt, c
     return round_sigma(c);
 }
 
+// ---- integrateRiccatiStateDiscrete (VIO_eqf.cpp:93-103, EqFMatrices.cpp:24-41) -----------------------------------------------------------
+static GroupSensor lift_discrete_sensor(const SensorState& xs, const double* imu, double dt) { // liftVelocityDiscrete, sensor part (VIOGroup.cpp:229-250)
+    const V3 gyr = v3(imu[1], imu[2], imu[3]) - xs.bgyr;
+    const V3 acc = v3(imu[4], imu[5], imu[6]) - xs.bacc;
+    const V3 gdir = q_rot(q_inv(xs.pose.R), v3(0, 0, 1));
+    GroupSensor L;
+    L.bgyr = dt * v3(imu[7], imu[8], imu[9]);
+    L.bacc = dt * v3(imu[10], imu[11], imu[12]);
+    L.A.R = so3_exp(dt * gyr);
+    const V3 x = dt * q_rot(xs.pose.R, xs.vel) + (0.5 * dt * dt) * (q_rot(xs.pose.R, acc) + v3(0, 0, -kGravity));
+    L.A.x = q_rot(q_inv(xs.pose.R), x);
+    L.B = pose_mul(pose_mul(pose_inv(xs.cam), L.A), xs.cam);
+    L.w = xs.vel - (xs.vel + dt * (acc - kGravity * gdir));
+    return L;
+}
+static GroupSensor group_inv(const GroupSensor& X) { // VIOGroup::inverse, sensor part (VIOGroup.cpp:108-120)
+    GroupSensor r;
+    r.bgyr = -X.bgyr;
+    r.bacc = -X.bacc;
+    r.A = pose_inv(X.A);
+    r.B = pose_inv(X.B);
+    r.w = -q_rot(q_inv(X.A.R), X.w);
+    return r;
+}
+int eqf_integrate_riccati_discrete(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
+    if (!c || !imu13 || !Qdiag12 || !Pdiag8 || !(dt > 0.0))
+        return EQF_E_BAD_ARG;
+    if (c->sig32 || c->chart == EQVIO_COORD_NORMAL)
+        return EQF_E_UNSUPPORTED; // float store: structured fast path only; Normal chart: its input matrix would need M B_e as a third dense term
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
+    if (!c->d_F)
+        HIPCHK(hipMalloc(&c->d_F, bytes));
+    if (!c->d_tmp)
+        HIPCHK(hipMalloc(&c->d_tmp, bytes));
+    int rc = upload_common(c, imu13); // B_t at the current X (inputMatrixB), for dt (B Q B^T + P)
+    if (rc)
+        return rc;
+    rc = launch_assemble(c, false); // "the last reader of Q" is k_discrete_A below, not k_assemble_AB: the event is recorded there
+    if (rc)
+        return rc;
+    // sensor-level part of a0Discrete: nominal + 21 x (+h, -h)
+    const double h = std::cbrt(2.220446049250313e-16);
+    const SensorState xhat = sensor_action(c->X, c->xi0);
+    const GroupSensor Lh = lift_discrete_sensor(xhat, imu13, dt), Lh_inv = group_inv(Lh), Xinv = group_inv(c->X);
+    DiscreteAArgs da;
+    da.h = h;
+    da.cpc[0] = pose_mul(pose_mul(pose_inv(xhat.cam), pose_inv(Lh.A)), xhat.cam);
+    double Ass[21 * 21]; // column-major
+    double col[2][21];
+    for (int j = 0; j < 21; ++j) {
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            double e[21] = {0};
+            e[j] = sgn == 0 ? h : -h;
+            // xi_e = sensorChart_std.inv(e, xi0) (VIOState.cpp:114-121)
+            SensorState se;
+            se.bgyr = c->xi0.bgyr + v3(e[0], e[1], e[2]);
+            se.bacc = c->xi0.bacc + v3(e[3], e[4], e[5]);
+            se.pose = pose_mul(c->xi0.pose, se3_exp(v3(e[6], e[7], e[8]), v3(e[9], e[10], e[11])));
+            se.vel = c->xi0.vel + v3(e[12], e[13], e[14]);
+            se.cam = pose_mul(c->xi0.cam, se3_exp(v3(e[15], e[16], e[17]), v3(e[18], e[19], e[20])));
+            const SensorState xs = sensor_action(c->X, se);
+            const GroupSensor L = lift_discrete_sensor(xs, imu13, dt);
+            da.cpc[1 + 2 * j + sgn] = pose_mul(pose_mul(pose_inv(xs.cam), pose_inv(L.A)), xs.cam);
+            const GroupSensor G = group_mul(group_mul(c->X, group_mul(L, Lh_inv)), Xinv);
+            const SensorState s1 = sensor_action(G, se);
+            V3 om, tr, omc, trc;
+            se3_log(pose_mul(pose_inv(c->xi0.pose), s1.pose), om, tr);
+            se3_log(pose_mul(pose_inv(c->xi0.cam), s1.cam), omc, trc);
+            const V3 parts[7] = {s1.bgyr - c->xi0.bgyr, s1.bacc - c->xi0.bacc, om, tr, s1.vel - c->xi0.vel, omc, trc};
+            for (int b = 0; b < 7; ++b)
+                pack_v3(parts[b], col[sgn] + 3 * b);
+        }
+        for (int r = 0; r < 21; ++r)
+            Ass[r + 21 * j] = (col[0][r] - col[1][r]) / (2.0 * h);
+    }
+    const int N = c->N, n = c->n();
+    { int _r = sync_ctx(c); if (_r) return _r; } // h_buf staging
+    std::memcpy(c->h_buf, Ass, sizeof(Ass));
+    HIPCHK(hipMemsetAsync(c->d_F, 0, bytes, c->stream));
+    HIPCHK(hipMemcpy2DAsync(c->d_F, sizeof(double) * c->ld, c->h_buf, sizeof(double) * 21, sizeof(double) * 21, 21, hipMemcpyHostToDevice, c->stream));
+    if (N > 0) {
+        hipLaunchKernelGGL(k_discrete_A, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, c->chart, da, c->q0(), c->Qq(), c->Qa(), c->d_F);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev_early, c->stream)); // an observer call that follows may overwrite Q from here on (observer_launch)
+    c->ev_assembled_early = true;
+    RiccatiArgs ra;
+    ra.dt = dt;
+    std::memcpy(ra.Qd, Qdiag12, sizeof(ra.Qd));
+    std::memcpy(ra.Pd, Pdiag8, sizeof(ra.Pd));
+    double* Sin = c->d_sigma[c->cur];
+    double* Sout = c->d_sigma[1 - c->cur];
+    KTimer t(c, KN_DENSE_GEMM);
+    hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(256), 0, c->stream, n, n, n, c->d_F, c->ld, Sin, c->ld, c->d_tmp, c->ld);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_gemm_nt, dim3(blocks(n, 32), blocks(n, 32)), dim3(256), 0, c->stream, n, n, n, c->d_tmp, c->ld, c->d_F, c->ld, Sout, c->ld);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_add_noise, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, N, c->Ncap, n, c->ld, ra, c->d_common, c->d_Bl, Sout);
+    HIPCHK(hipGetLastError());
+    c->cur = 1 - c->cur;
+    return round_sigma(c);
+}
+
 // Host half of integrateObserverState for `chunk` consecutive IMU samples: the sensor-level group element Lambda of every
 // step (VIOGroup.cpp:190-271), applied to the host-authoritative X right away, and the per-step terms the landmark kernel needs.
 static void observer_host_steps(eqf_ctx* c, const double* imu13_k, const double* dt_k, int chunk, int discreteLift, ObsSteps& steps_arg) {

@@ -1950,6 +1950,67 @@ __global__ void k_gather_landmarks_aos(int N, int Ncap, const double* __restrict
 }
 // removal of landmarks: new index -> old index map `keep` (length Nnew). Sigma_new = Sigma_old[map, map]
 // (removeRows/removeCols, VIO_eqf.cpp:27-45) written to the other buffer.
+// integrateRiccatiStateDiscrete (VIO_eqf.cpp:93-103): A_d = numericalDifferential of a0Discrete (EqFMatrices.cpp:24-41) at 0, central
+// differences with h = cbrt(eps) (Geometry.cpp:25-36). a0Discrete has the arrow structure of A: a landmark's coordinates move only its own
+// three rows; the 21 sensor coordinates move everything. The sensor-level part of the 43 evaluations (nominal + 21 x +-h) is O(1) and done
+// on the host; what a landmark needs of each is the camera-frame pose change cpc = T^-1 A^-1 T of the discrete lift (VIOGroup.cpp:252).
+// One lane per landmark: its 3 x 21 sensor columns and its own 3 x 3 block of the dense A_d.
+struct DiscreteAArgs {
+    double h;
+    Pose cpc[43]; // [0] nominal, [1 + 2 j + s] sensor coordinate j perturbed by +h (s = 0) / -h (s = 1)
+};
+struct Sot3 {
+    Qt R;
+    double a;
+};
+__device__ __forceinline__ Sot3 sot3_mul(const Sot3& x, const Sot3& y) { return Sot3{q_mul(x.R, y.R), x.a * y.a}; }
+__device__ __forceinline__ Sot3 sot3_inv(const Sot3& x) { return Sot3{q_inv(x.R), 1.0 / x.a}; }
+__device__ __forceinline__ Sot3 lift_q(const Pose& cpc, V3 p0) { // liftVelocityDiscrete landmark part (VIOGroup.cpp:255-268)
+    const V3 p1 = pose_act(cpc, p0);
+    return Sot3{so3_from_vectors(normalized(p1), normalized(p0)), norm(p0) / norm(p1)};
+}
+__device__ __forceinline__ V3 chart_fwd(int chart, V3 q, V3 q0) { return chart == EQVIO_COORD_NORMAL ? normal_chart(q, q0) : point_chart(chart == EQVIO_COORD_INVDEPTH, q, q0); }
+__device__ __forceinline__ V3 chart_bwd(int chart, V3 e, V3 q0) {
+    return chart == EQVIO_COORD_INVDEPTH ? invdepth_chart_inv(e, q0) : (chart == EQVIO_COORD_NORMAL ? normal_chart_inv(e, q0) : q0 + e);
+}
+// epsilon_1 of landmark i for the perturbed origin point qe (= q0 for a sensor perturbation) and the lift's pose change cpc
+__device__ __forceinline__ V3 a0_discrete_landmark(int chart, const Sot3& Qi, const Sot3& QLh_inv, const Pose& cpc, V3 qe, V3 q0) {
+    const V3 q = (1.0 / Qi.a) * q_rot(q_inv(Qi.R), qe);              // phi(X, xi_e): Q_i^-1 q_e
+    const Sot3 Lt = sot3_mul(lift_q(cpc, q), QLh_inv);               // LambdaTilde_i
+    const Sot3 G = sot3_mul(sot3_mul(Qi, Lt), sot3_inv(Qi));         // (X LambdaTilde X^-1)_i
+    const V3 q1 = (1.0 / G.a) * q_rot(q_inv(G.R), qe);               // phi(., xi_e)
+    return chart_fwd(chart, q1, q0);
+}
+__global__ void __launch_bounds__(64) k_discrete_A(int N, int Ncap, int ldf, int chart, DiscreteAArgs da, const double* __restrict__ q0p, const double* __restrict__ Qq,
+                                                  const double* __restrict__ Qa, double* __restrict__ F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const V3 q0 = ld3(q0p, Ncap, i);
+    const Sot3 Qi{ldq(Qq, Ncap, i), Qa[i]};
+    const V3 qh = (1.0 / Qi.a) * q_rot(q_inv(Qi.R), q0);
+    const Sot3 QLh_inv = sot3_inv(lift_q(da.cpc[0], qh)); // liftVelocityDiscrete(xi_hat)^-1, landmark i
+    const double ih2 = 1.0 / (2.0 * da.h);
+    const int r0 = 21 + 3 * i;
+    for (int j = 0; j < 21; ++j) {
+        const V3 ep = a0_discrete_landmark(chart, Qi, QLh_inv, da.cpc[1 + 2 * j], q0, q0);
+        const V3 em = a0_discrete_landmark(chart, Qi, QLh_inv, da.cpc[2 + 2 * j], q0, q0);
+        const V3 d = ih2 * (ep - em);
+        F[r0 + (size_t)j * ldf] = d.x;
+        F[r0 + 1 + (size_t)j * ldf] = d.y;
+        F[r0 + 2 + (size_t)j * ldf] = d.z;
+    }
+    for (int k = 0; k < 3; ++k) {
+        const V3 e = V3{k == 0 ? da.h : 0.0, k == 1 ? da.h : 0.0, k == 2 ? da.h : 0.0};
+        const V3 ep = a0_discrete_landmark(chart, Qi, QLh_inv, da.cpc[0], chart_bwd(chart, e, q0), q0);
+        const V3 em = a0_discrete_landmark(chart, Qi, QLh_inv, da.cpc[0], chart_bwd(chart, -e, q0), q0);
+        const V3 d = ih2 * (ep - em);
+        F[r0 + (size_t)(r0 + k) * ldf] = d.x;
+        F[r0 + 1 + (size_t)(r0 + k) * ldf] = d.y;
+        F[r0 + 2 + (size_t)(r0 + k) * ldf] = d.z;
+    }
+}
+
 // Normal chart: A_n = M A_e M^-1, B_n = M B_e with the block-diagonal change of coordinates M (eqf_math.hpp, normal_M), so a Riccati step is
 //   Sigma' = M [ F_e (M^-1 Sigma M^-T) F_e^T + dt B_e Q B_e^T (or the accurate form) ] M^T + dt P
 // i.e. the Euclidean propagation between two congruences. This kernel is one of them: out = T Sigma T^T, T = M (dir > 0) or M^-1

@@ -272,6 +272,11 @@ void VIO_eqf::integrateRiccatiStateAccurate(const IMUVelocity& v, const double& 
     v.pack(imu);
     check(eqf_integrate_riccati_accurate(ctx, imu, dt, Qd.data(), Pd8.data()), "integrateRiccatiStateAccurate");
 }
+void VIO_eqf::integrateRiccatiStateDiscrete(const IMUVelocity& v, const double& dt, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8) { // VIO_eqf.cpp:93-103
+    double imu[13];
+    v.pack(imu);
+    check(eqf_integrate_riccati_discrete(ctx, imu, dt, Qd.data(), Pd8.data()), "integrateRiccatiStateDiscrete");
+}
 void VIO_eqf::propagateFast(const IMUVelocity& mean, const double& dtTotal, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8,
                             const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift) {
     double m13[13];
@@ -535,12 +540,14 @@ bool VIOFilter::integrateUpToTime(const double& newTime) { // :134-192
         filterState.propagateFast(accumulatedVelocity, accumulatedTime, settings->constructInputGainDiag(), settings->constructStateGainDiag8(), velocityBuffer, dts,
                                   settings->useDiscreteVelocityLift);
     } else {
-        if (settings->useDiscreteStateMatrix) // integrateRiccatiStateDiscrete (VIO_eqf.cpp:93-103): SURVEY.md §8 row a7, oracle only
-            throw std::runtime_error("VIOFilter: settings.useDiscreteStateMatrix = true is not supported by the MI355X path (EQF_E_UNSUPPORTED)");
-        // VIOFilter.cpp:128-139: per IMU sample, the accurate Riccati step at the current X, then the observer step
+        // VIOFilter.cpp:160-178: per IMU sample, the discrete-A or the accurate Riccati step at the current X, then the observer step
         for (size_t i = 0; i < velocityBuffer.size(); ++i) {
-            if (dts[i] > 0)
-                filterState.integrateRiccatiStateAccurate(velocityBuffer.at(i), dts[i], settings->constructInputGainDiag(), settings->constructStateGainDiag8());
+            if (dts[i] > 0) {
+                if (settings->useDiscreteStateMatrix)
+                    filterState.integrateRiccatiStateDiscrete(velocityBuffer.at(i), dts[i], settings->constructInputGainDiag(), settings->constructStateGainDiag8());
+                else
+                    filterState.integrateRiccatiStateAccurate(velocityBuffer.at(i), dts[i], settings->constructInputGainDiag(), settings->constructStateGainDiag8());
+            }
             filterState.integrateObserverState(velocityBuffer.at(i), dts[i], settings->useDiscreteVelocityLift);
         }
     }

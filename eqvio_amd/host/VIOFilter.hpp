@@ -165,6 +165,7 @@ struct VIO_eqf {
     void propagateFast(const IMUVelocity& meanVelocity, const double& dtTotal, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8,
                        const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift);
     void integrateRiccatiStateAccurate(const IMUVelocity& imuVelocity, const double& dt, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8);
+    void integrateRiccatiStateDiscrete(const IMUVelocity& imuVelocity, const double& dt, const std::array<double, 12>& inputGainDiag, const std::array<double, 8>& stateGainDiag8);
     void performVisionUpdate(const VisionMeasurement& measurement, double outputGainVar, const bool& useEquivariantOutput = true, const bool& discreteCorrection = false);
     VIOState stateEstimate() const;
     VIOState predictState(const double& stamp, const std::vector<IMUVelocity>& imuVelocities) const; // VIO_eqf.cpp:139-151 (host: O(kN))

@@ -133,16 +133,24 @@ def test_template_config_accurate_riccati(chart):
         compare(flt, orc)
 
 
-def test_discrete_state_matrix_is_refused_loudly():
-    """Row a7 (integrateRiccatiStateDiscrete) is oracle-only: the product refuses it instead of falling back."""
-    world = SimWorld(seed=1, num_points=100, max_features=5, trajectory="hover")
-    settings = sim_settings(COORD_EUCLIDEAN, fastRiccati=0, useDiscreteStateMatrix=1)
-    ids0, y0 = world.vision(0.0)
+@pytest.mark.parametrize("chart", [COORD_EUCLIDEAN, COORD_INVDEPTH])
+def test_discrete_state_matrix_filter_run(chart):
+    """Row a7: useDiscreteStateMatrix (integrateRiccatiStateDiscrete, VIO_eqf.cpp:93-103; the mode the reference's own statistical test runs,
+    test_FilterStatistics.cpp:110,132), free running against the oracle's filter. A_d comes from central differences with h = cbrt(eps) on
+    both sides: two evaluations of that agree to the differencing's rounding noise, a few 1e-9 (tests/test_indep_restatement.py)."""
+    world = SimWorld(seed=13, num_points=500, max_features=14, trajectory="wave", noise_px=0.3)
+    settings = sim_settings(chart, fastRiccati=0, useDiscreteStateMatrix=1)
+    ids0, _ = world.vision(0.0)
     sensor, ids, p = world.true_state(0.0, ids0)
-    flt = VIOFilter(settings, max_landmarks=16, sensor=sensor, ids=ids, p=p, time=0.0)
-    flt.process_imu(world.imu(0.0))
-    with pytest.raises(RuntimeError):
-        flt.process_vision(0.05, world.cam, ids0, y0)
+    orc = OracleFilter(settings, sensor, ids, p, 0.0)
+    flt = VIOFilter(settings, max_landmarks=48, sensor=sensor, ids=ids, p=p, time=0.0)
+    for imus, stamp, mid, y in world.frames(6):
+        for s in range(len(imus)):
+            orc.process_imu(imus[s])
+            flt.process_imu(imus[s])
+        orc.process_vision(stamp, world.cam, mid, y)
+        flt.process_vision(stamp, world.cam, mid, y)
+        compare(flt, orc, 2e-8)
 
 
 def test_feature_predictions_match():

@@ -614,3 +614,20 @@ def test_lookahead_factorisation_soak():
                 ref = Sg
             else:
                 assert np.array_equal(Sg, ref), (N, it, np.abs(Sg - ref).max())
+
+
+@pytest.mark.parametrize("chart", list(CHARTS))
+@pytest.mark.parametrize("N", [0, 1, 9, 40])
+def test_riccati_discrete(chart, N):
+    """eqf_integrate_riccati_discrete (row a7) against the oracle's integrateRiccatiStateDiscrete: same central differences (h = cbrt(eps)) of
+    a0Discrete, 43 sensor-level evaluations on the host + one lane per landmark on the device. Tolerance = the differencing's rounding noise."""
+    rng, settings, orc, core, _ = make_pair(CHARTS[chart], max(N, 0), seed=300 + N, cap=max(N, 1)) if N > 0 else make_pair(CHARTS[chart], 0, seed=300, cap=1)
+    for rep in range(2):
+        imu = random_imu(rng, bias_vel=True)
+        dt = float(rng.uniform(0.004, 0.02))
+        core.integrate_riccati_discrete(imu, dt, settings.input_gain_diag12(), settings.state_gain_diag8())
+        orc.integrate_riccati_discrete(imu, dt)
+        Sg, So = core.get_sigma(), orc.get_sigma()
+        assert rel_fro(Sg, So) <= 5e-9, rel_fro(Sg, So)
+        core.integrate_observer(imu[None, :], np.array([dt]), True)
+        orc.integrate_observer(imu, dt, True)
