@@ -93,23 +93,91 @@ def make_filter(world, settings, N, device, frames, Filter):
     return Filter(settings, sensor, ids, p, 0.0)
 
 
-def cpu_baseline(world, frames, settings, N):
-    """Oracle (CPU restatement of the reference arithmetic) timed on this host: one core, bounded sample."""
-    from oracle_binding import ARITH_AS_WRITTEN, ARITH_EFFICIENT, OracleFilter
+def _oracle_warm(world, frames, settings):
+    from oracle_binding import OracleFilter
 
     ids0 = frames[0][2]
     sensor, ids, p = world.true_state(0.0, ids0)
     orc = OracleFilter(settings, sensor, ids, p, 0.0)
     imus, stamp, mid, y = frames[0]
-    dts = np.full(len(imus), 1.0 / world.imu_freq)
     # warm the state with one real frame so Sigma is dense
     for s in range(len(imus)):
         orc.process_imu(imus[s])
     orc.process_vision(stamp, world.cam, mid, y)
+    return orc
+
+
+def _cpu_batch_worker(idx, core, N, reps):
+    """One CPU oracle filter pinned to one core (the reference filter is single-threaded: one sequence per core is how a CPU host
+    would run the 8-sequence batch of BASELINE.json configs[3]). Child process of cpu_batch_baseline: prints READY, waits for a line on
+    stdin, times `reps` frames, prints the seconds."""
+    from oracle_binding import ARITH_EFFICIENT
+
+    try:
+        os.sched_setaffinity(0, {core})
+    except OSError:
+        pass
+    world, frames = build_workload(seed=900 + idx, n_frames=3, N=N)
+    orc = _oracle_warm(world, frames, eurocish_settings())
     imus, stamp, mid, y = frames[1]
+    dts = np.full(len(imus), 1.0 / world.imu_freq)
+    print("READY", flush=True)
+    sys.stdin.readline()
+    t0 = time.perf_counter()
+    orc.bench_frame(imus, dts, stamp, world.cam, mid, y, ARITH_EFFICIENT, reps)
+    print("T %.9f" % (time.perf_counter() - t0), flush=True)
+
+
+def cpu_batch_baseline(N, reps=3, max_procs=None, timeout=300.0):
+    """One-filter-per-core CPU batch: C independent oracle filters, one process pinned to each core this process may
+    run on, released together; aggregate = C * reps frames / slowest process."""
+    import subprocess
+
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = list(range(os.cpu_count() or 1))
+    if max_procs:
+        cores = cores[:max_procs]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-batch-worker", str(i), str(c), str(N), str(reps)], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, text=True) for i, c in enumerate(cores)]
+    try:
+        deadline = time.time() + timeout
+        for pr in procs:
+            line = pr.stdout.readline()
+            if line.strip() != "READY" or time.time() > deadline:
+                raise RuntimeError("CPU batch worker did not get ready: %r" % line)
+        for pr in procs:
+            pr.stdin.write("GO\n")
+            pr.stdin.flush()
+        times = []
+        for pr in procs:
+            line = pr.stdout.readline().split()
+            if len(line) != 2 or line[0] != "T":
+                raise RuntimeError("CPU batch worker died")
+            times.append(float(line[1]))
+    finally:
+        for pr in procs:
+            try:
+                pr.stdin.close()
+                pr.wait(timeout=30)
+            except Exception:
+                pr.kill()
+    return {"value": len(cores) * reps / max(times), "unit": "updates/s aggregate", "cores": len(cores), "frames_each": reps,
+            "slowest_s": max(times), "fastest_s": min(times),
+            "note": "one single-threaded oracle filter ('efficient dense' arithmetic) per host core, released together; the CPU column for the one-filter-per-GPU line"}
+
+
+def cpu_baseline(world, frames, settings, N, batch=True):
+    """Oracle (CPU restatement of the reference arithmetic) timed on this host: one core, bounded sample; then one filter per core."""
+    from oracle_binding import ARITH_AS_WRITTEN, ARITH_EFFICIENT
+
+    orc = _oracle_warm(world, frames, settings)
+    imus, stamp, mid, y = frames[1]
+    dts = np.full(len(imus), 1.0 / world.imu_freq)
     t_eff = orc.bench_frame(imus, dts, stamp, world.cam, mid, y, ARITH_EFFICIENT, 3)
     t_asw = orc.bench_frame(imus, dts, stamp, world.cam, mid, y, ARITH_AS_WRITTEN, 1)
-    return {
+    out = {
         "value": 1.0 / t_eff,
         "unit": "updates/s",
         "cores": 1,
@@ -118,6 +186,72 @@ def cpu_baseline(world, frames, settings, N):
         f"({t_eff * 1e3:.1f} ms/frame), 1 frame 'as written' (LU inverse, K evaluated twice, (K C) Sigma: {t_asw * 1e3:.1f} ms/frame = {1.0 / t_asw:.2f} updates/s); "
         f"host has {os.cpu_count()} cores, the reference filter is single-threaded",
     }
+    if batch:
+        try:
+            out["one_filter_per_core"] = cpu_batch_baseline(N)
+        except Exception as e:  # informational leg: never lose the bench line over it
+            out["one_filter_per_core"] = {"error": repr(e)}
+    return out
+
+
+class HipBackend:
+    """What a rank needs from the product: a filter on this rank's GPU, the prepared input containers, a device sync. The world_size-2 gloo
+    test (tests/test_replicas_gloo.py) passes a CPU stand-in with the same three members and runs everything else in rank_pass() as is."""
+
+    def __init__(self, local_rank):
+        import torch
+
+        from eqvio_amd.capi import load_eqf_lib
+
+        assert torch.cuda.is_available(), "bench.py needs an MI355X: the EqF path has no CPU fallback"
+        torch.cuda.set_device(local_rank)
+        self.torch, self.local_rank, self.lib = torch, local_rank, load_eqf_lib()
+
+    def make_filter(self, settings, N, sensor, ids, p, t):
+        from eqvio_amd.capi import VIOFilter
+
+        return VIOFilter(settings, max_landmarks=N, device=self.local_rank, sensor=sensor, ids=ids, p=p, time=t)
+
+    def prepare(self, cam, *flat):
+        from eqvio_amd.capi import PreparedFrames
+
+        return PreparedFrames(cam, *flat)
+
+    def sync(self, flt):
+        self.lib.eqf_synchronize(flt.core_handle())
+        self.torch.cuda.synchronize()
+
+
+def init_control_group(world_size):
+    """Replicas only: the ranks share NOTHING on the data path. The process group exists for the start/stop barrier and the MAX over the
+    ranks' wall times, both on CPU tensors over gloo, so no RCCL communicator is ever created (nothing to mis-price against xGMI)."""
+    if world_size <= 1:
+        return None
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    return dist
+
+
+def rank_pass(args, rank, world_size, dist, backend, settings=None):
+    """One rank's whole job: its own synthetic world (seeded by the rank), its own filter, W warm-up frames, K timed frames between
+    barriers. Returns (aggregate updates/s over all ranks, max-over-ranks seconds, filter, world, frames)."""
+    from eqvio_amd.replicas import timed_replica_run
+
+    N = args.landmarks
+    settings = settings if settings is not None else eurocish_settings()
+    world, frames = build_workload(seed=100 + rank, n_frames=args.warmup + args.steps + 2, N=N)
+    assert all(len(f[2]) == N for f in frames), "the hover world keeps every tracked feature in view"
+    flt = make_filter(world, settings, N, None, frames, lambda s, sensor, ids, p, t: backend.make_filter(s, N, sensor, ids, p, t))
+    # The input containers (IMU samples, one VisionMeasurement = std::map of pixel coordinates per frame: what the reference's
+    # tracker / data server hands to the filter) are built once, before the timed region; a step is processIMUData x k +
+    # processVisionData on them. The measurement itself still crosses the C-ABI from host memory every frame.
+    prepared = backend.prepare(world.cam, *flatten_frames(frames[: args.warmup + args.steps]))
+    if args.warmup:
+        flt.run_prepared(prepared, 0, args.warmup)
+    value, elapsed, _ = timed_replica_run(lambda: flt.run_prepared(prepared, args.warmup, args.steps), lambda: backend.sync(flt), args.steps, dist=dist)
+    return value, elapsed, flt, world, frames, settings
 
 
 def main():
@@ -132,50 +266,20 @@ def main():
     ap.add_argument("--no-frame-mix", action="store_true")
     args = ap.parse_args()
 
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X: the EqF path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world_size > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from eqvio_amd.capi import OPT_TIMING, EqfCore, VIOFilter, load_eqf_lib
-
+    backend = HipBackend(local_rank)
+    dist = init_control_group(world_size)
+    lib = backend.lib
     N = args.landmarks
-    settings = eurocish_settings()
-    world, frames = build_workload(seed=100 + rank, n_frames=args.warmup + args.steps + 2, N=N)
-    assert all(len(f[2]) == N for f in frames), "the hover world keeps every tracked feature in view"
 
     def Filter(settings, sensor, ids, p, t):
-        return VIOFilter(settings, max_landmarks=N, device=local_rank, sensor=sensor, ids=ids, p=p, time=t)
+        return backend.make_filter(settings, N, sensor, ids, p, t)
 
-    flt = make_filter(world, settings, N, local_rank, frames, Filter)
+    value, elapsed, flt, world, frames, settings = rank_pass(args, rank, world_size, dist, backend)
     cam = world.cam
-    # The input containers (IMU samples, one VisionMeasurement = std::map of pixel coordinates per frame: what the reference's
-    # tracker / data server hands to the filter) are built once, before the timed region; a step is processIMUData x k +
-    # processVisionData on them. The measurement itself still crosses the C-ABI from host memory every frame.
-    from eqvio_amd.capi import PreparedFrames
-
-    prepared = PreparedFrames(world.cam, *flatten_frames(frames[: args.warmup + args.steps]))
-    lib = load_eqf_lib()
     core = flt.core_handle()
-
-    from eqvio_amd.replicas import timed_replica_run
-
-    def sync():
-        lib.eqf_synchronize(core)
-        torch.cuda.synchronize()
-
-    if args.warmup:
-        flt.run_prepared(prepared, 0, args.warmup)
-    value, elapsed, _ = timed_replica_run(lambda: flt.run_prepared(prepared, args.warmup, args.steps), sync, args.steps, dist=dist,
-                                          device=torch.device("cuda", local_rank))
 
     # post-run sanity: the state is finite and Sigma is symmetric positive definite
     S = flt.get_sigma()
@@ -403,4 +507,7 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 6 and sys.argv[1] == "--cpu-batch-worker":
+        _cpu_batch_worker(*(int(v) for v in sys.argv[2:]))
+    else:
+        main()
