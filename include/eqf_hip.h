@@ -58,7 +58,7 @@ enum {
                                   A and B they need themselves and its observer blocks write the second landmark buffer; 0: k_assemble_AB first */
     EQF_OPT_LOOKAHEAD = 12,    /* 1 (default): the factorisation of [S ; T ; y^T] runs as ONE persistent kernel with a look-ahead schedule (one owner
                                   workgroup walks the pivot chain, one workgroup per 32-row block row keeps its tiles in registers and follows one to
-                                  two panels behind; hand-offs as 16-byte value + sequence words, no flags, no fences) when the update has 3 .. 16
+                                  two panels behind; hand-offs as write-through tile stores + one sequence-numbered flag per tile, never cleared) when the update has 3 .. 16
                                   panels (32 < M <= 256 measurements); bit-identical W / Sigma to the chain. 0: one launch per panel (k_chol_step) */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati

@@ -1,0 +1,110 @@
+// TEST SCAFFOLDING. The value types of the reference's EqF interface re-declared with the reference's type, member and function
+// NAMES and argument lists (include/eqvio/mathematical/{VIOState,VIOGroup,IMUVelocity,VisionMeasurement,VIO_eqf}.h), only as far as the
+// binding in tests/integration/VIO_eqf_mi355x.cpp touches them, over the stand-in Eigen / LiePP / GIFT headers next to this file.
+// The two marked places are the ONLY edits the binding needs in the reference's real VIO_eqf.h.
+#pragma once
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "Eigen/Dense"
+#include "GIFT/Camera.h"
+#include "liepp/SE3.h"
+
+struct Landmark {
+    Eigen::Vector3d p;
+    int id = -1;
+    constexpr static int CompDim = 3;
+};
+struct VIOSensorState {
+    Eigen::Matrix<double, 6, 1> inputBias;
+    liepp::SE3d pose;
+    Eigen::Vector3d velocity;
+    liepp::SE3d cameraOffset;
+    constexpr static int CompDim = 6 + 6 + 3 + 6;
+};
+struct VIOState {
+    VIOSensorState sensor;
+    std::vector<Landmark> cameraLandmarks;
+    std::vector<int> getIds() const {
+        std::vector<int> ids;
+        for (const Landmark& lm : cameraLandmarks) ids.push_back(lm.id);
+        return ids;
+    }
+};
+struct VIOGroup {
+    Eigen::Matrix<double, 6, 1> beta;
+    liepp::SE3d A;
+    Eigen::Vector3d w;
+    liepp::SE3d B;
+    std::vector<liepp::SOT3d> Q;
+    std::vector<int> id;
+    static VIOGroup Identity(const std::vector<int>& ids = {}) {
+        VIOGroup X;
+        X.id = ids;
+        X.Q.resize(ids.size());
+        return X;
+    }
+};
+struct IMUVelocity {
+    double stamp = 0;
+    Eigen::Vector3d gyr, acc;
+    Eigen::Vector3d gyrBiasVel = Eigen::Vector3d::Zero(), accBiasVel = Eigen::Vector3d::Zero();
+    constexpr static int CompDim = 12;
+};
+struct VisionMeasurement {
+    double stamp = 0;
+    std::map<int, Eigen::Vector2d> camCoordinates;
+    GIFT::GICameraPtr cameraPtr;
+};
+struct EqFCoordinateSuite {}; // the reference's struct of function objects; the binding only compares addresses
+extern const EqFCoordinateSuite EqFCoordinateSuite_euclid, EqFCoordinateSuite_invdepth, EqFCoordinateSuite_normal;
+
+// ---- ADDED for the MI355X binding (1 of 2): the device-side twin of one VIO_eqf. Copying a filter clones the twin.
+struct eqf_ctx; // include/eqf_hip.h
+namespace eqvio_mi355x {
+struct DeviceTwin {
+    eqf_ctx* ctx = nullptr;
+    int chart = -1, capacity = 0;
+    bool deviceNewer = false; // Sigma / X / xi0 numbers on the device are ahead of the host members
+    bool hostEdited = true;   // the host members were assigned (construction, VIOFilter::setState, ...): upload before the next call
+    DeviceTwin() = default;
+    DeviceTwin(const DeviceTwin& o);
+    DeviceTwin& operator=(const DeviceTwin& o);
+    DeviceTwin(DeviceTwin&& o) noexcept;
+    DeviceTwin& operator=(DeviceTwin&& o) noexcept;
+    ~DeviceTwin();
+};
+} // namespace eqvio_mi355x
+
+struct VIO_eqf {
+    EqFCoordinateSuite const* coordinateSuite = &EqFCoordinateSuite_euclid;
+    VIOState xi0;
+    VIOGroup X = VIOGroup::Identity();
+    Eigen::MatrixXd Sigma = Eigen::MatrixXd::Identity(VIOSensorState::CompDim, VIOSensorState::CompDim);
+    double currentTime = -1;
+
+    void addNewLandmarks(std::vector<Landmark>& newLandmarks, const Eigen::MatrixXd& newLandmarkCov);
+    void removeLandmarkByIndex(const int& idx);
+    void removeLandmarkById(const int& id);
+    void removeInvalidLandmarks();
+    Eigen::Matrix3d getLandmarkCovById(const int& id) const;
+    Eigen::Matrix2d getOutputCovById(const int& id, const Eigen::Vector2d& y, const GIFT::GICameraPtr& camPtr) const;
+    void integrateObserverState(const IMUVelocity& imuVelocity, const double& dt, const bool& discreteLift = true);
+    void integrateRiccatiStateFast(const IMUVelocity& imuVelocity, const double& dt, const Eigen::Matrix<double, IMUVelocity::CompDim, IMUVelocity::CompDim>& inputGainMatrix,
+                                   const Eigen::MatrixXd& stateGainMatrix);
+    void integrateRiccatiStateAccurate(const IMUVelocity& imuVelocity, const double& dt, const Eigen::Matrix<double, IMUVelocity::CompDim, IMUVelocity::CompDim>& inputGainMatrix,
+                                       const Eigen::MatrixXd& stateGainMatrix);
+    void integrateRiccatiStateDiscrete(const IMUVelocity& imuVelocity, const double& dt, const Eigen::Matrix<double, IMUVelocity::CompDim, IMUVelocity::CompDim>& inputGainMatrix,
+                                       const Eigen::MatrixXd& stateGainMatrix);
+    void performVisionUpdate(const VisionMeasurement& measurement, const Eigen::MatrixXd& outputGainMatrix, const bool& useEquivariantOutput = true,
+                             const bool& discreteCorrection = false);
+    VIOState stateEstimate() const;
+    double computeNEES(const VIOState& trueState) const;
+
+    // ---- ADDED for the MI355X binding (2 of 2). A trailing member with a default initialiser keeps VIO_eqf an aggregate:
+    // `VIO_eqf{suite, xi0, X, Sigma}` (test/test_FilterStatistics.cpp:40) and copies still work.
+    void pull() const;      // device -> host members, if the device is ahead (VIOFilter::viewEqFState() calls it before returning)
+    void markHostEdited() { twin.hostEdited = true; } // after code that assigns xi0 / X / Sigma directly (VIOFilter.cpp:33-108)
+    mutable eqvio_mi355x::DeviceTwin twin;
+};

@@ -256,3 +256,104 @@ def test_eqvio_sim_executable(tmp_path):
     assert pose_c.shape == (100, 13) and np.all(pose_c[:, 7:] > 0)  # variances
     # errors within 5 sigma of the filter's own uncertainty almost always (consistency of the whole chain)
     assert np.mean(np.abs(pose_c[10:, 1:7]) <= 5 * np.sqrt(pose_c[10:, 7:])) > 0.95
+
+
+def _csv(path):
+    return [[float(v) for v in l.split(", ")] for l in path.read_text().strip().splitlines()[1:]]
+
+
+def _qinv(q):
+    return np.array([q[0], -q[1], -q[2], -q[3]])
+
+
+def _angle(q):
+    return 2.0 * math.atan2(np.linalg.norm(q[1:4]), abs(q[0]))
+
+
+@pytest.mark.gpu
+def test_eqvio_sim_csv_values(tmp_path):
+    """Row f-2, values (not only headers and row counts) of what VIOWriter writes (src/VIOWriter.cpp:33-228):
+    (1) the files against each other: points.csv holds WORLD-frame points, so mapped back through IMUState.csv x camera.csv they must
+        reproduce landmarkError.csv against trueState.csv; the error columns of bias / pose / cameraConsistency.csv against trueState.csv and the
+        state files; nees.csv's PoseNEES / AttitudeNEES against the errors and variances of poseConsistency.csv;
+    (2) against a second run of the same scenario through the Python binding (same simulator settings and seed, device filter): state files,
+        points, variances and NEES of every frame, to the 6 significant digits the writer prints."""
+    from eqvio_amd.capi import VIOFilter
+
+    exe = os.path.join(ROOT, "eqvio_amd", "lib", "eqvio_sim")
+    run = tmp_path / "run"
+    out = subprocess.run([exe, "--duration", "3", "--maxFeatures", "25", "--numWalls", "4", "--seed", "3", "--coordinateChoice", "InvDepth", "--fastRiccati", "1",
+                          "--outputNoise", "--inputNoise", "--measurementNoise", "0.5", "--initialPointVariance", "0.01", "--quiet", "--output", str(run)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    imu_state, camera, bias, true_state = _csv(run / "IMUState.csv"), _csv(run / "camera.csv"), _csv(run / "bias.csv"), _csv(run / "trueState.csv")
+    points, lm_err, nees = _csv(run / "points.csv"), _csv(run / "landmarkError.csv"), _csv(run / "nees.csv")
+    pose_c, cam_c, bias_c = _csv(run / "poseConsistency.csv"), _csv(run / "cameraConsistency.csv"), _csv(run / "biasConsistency.csv")
+    F = len(imu_state)
+    assert F == 60
+    PRINT = 2e-5  # the writer prints 6 significant digits
+
+    for f in range(F):
+        t = imu_state[f][0]
+        assert all(abs(rows[f][0] - t) < 1e-12 for rows in (camera, bias, true_state, points, lm_err, nees, pose_c, cam_c, bias_c))
+        # (1a) points.csv -> camera frame -> distance to the true landmark = landmarkError.csv
+        x, q = np.array(imu_state[f][1:4]), np.array(imu_state[f][4:8])
+        cx, cq = np.array(camera[f][1:4]), np.array(camera[f][4:8])
+        PC_q, PC_x = qmul(q, cq), x + qrot(q, cx)
+        ts = true_state[f]
+        n_true = int(ts[24])
+        true_lm = {int(ts[25 + 4 * i]): np.array(ts[26 + 4 * i:29 + 4 * i]) for i in range(n_true)}
+        pts = points[f][1:]
+        est = {int(pts[4 * i]): qrot(_qinv(PC_q), np.array(pts[4 * i + 1:4 * i + 4]) - PC_x) for i in range(len(pts) // 4)}
+        assert len(est) > 0 and len(lm_err[f]) - 1 == n_true
+        for col, lid in enumerate(true_lm):
+            e = lm_err[f][1 + col]
+            if lid in est:
+                assert abs(np.linalg.norm(est[lid] - true_lm[lid]) - e) <= PRINT * max(1.0, np.linalg.norm(true_lm[lid])), (f, lid)
+            else:
+                assert math.isnan(e)
+        # (1b) bias error = true bias - estimated bias; the rotation parts of the pose / camera errors are conjugates of the attitude differences
+        tb = np.array(ts[18:24])
+        np.testing.assert_allclose(bias_c[f][1:7], tb - np.array(bias[f][1:7]), rtol=0, atol=PRINT)
+        tq, tcq = np.array(ts[4:8]), np.array(ts[14:18])
+        assert abs(np.linalg.norm(pose_c[f][1:4]) - _angle(qmul(tq, _qinv(q)))) <= PRINT
+        assert abs(np.linalg.norm(cam_c[f][1:4]) - _angle(qmul(tcq, _qinv(cq)))) <= PRINT
+        # (1c) NEES of a sub-vector is bounded below by every e_i^2 / Sigma_ii and the pose NEES by the attitude NEES
+        e6, v6 = np.array(pose_c[f][1:7]), np.array(pose_c[f][7:13])
+        assert np.all(v6 > 0) and np.all(np.array(cam_c[f][7:13]) > 0) and np.all(np.array(bias_c[f][7:13]) > 0)
+        pose_nees, att_nees = nees[f][3], nees[f][4]
+        assert pose_nees >= np.max(e6**2 / v6) * (1 - 1e-4) and att_nees >= np.max(e6[:3]**2 / v6[:3]) * (1 - 1e-4) and pose_nees >= att_nees * (1 - 1e-4)
+
+    # (2) the same scenario through the Python binding
+    fs = Settings.defaults()
+    fs.coordinateChoice, fs.fastRiccati, fs.measurementNoise, fs.initialPointVariance = COORD_INVDEPTH, 1, 0.5, 0.01
+    srv, fs = make_server(fs, duration=3.0, maxFeatures=25, numWalls=4, randomSeed=3, outputNoise=1, inputNoise=1)
+    s0, ids0, p0 = srv.true_state(0.0, True)
+    flt = VIOFilter(fs, max_landmarks=len(ids0) + 25, sensor=s0, ids=ids0, p=p0, time=0.0)
+    frame = [0]
+
+    def on_frame(stamp):
+        f = frame[0]
+        frame[0] += 1
+        s, ids, p = flt.state_estimate()
+        assert abs(imu_state[f][0] - flt.get_time()) < 1e-12
+        np.testing.assert_allclose(imu_state[f][1:], np.concatenate([s[10:13], s[6:10], s[13:16]]), rtol=PRINT, atol=PRINT)
+        np.testing.assert_allclose(camera[f][1:], np.concatenate([s[20:23], s[16:20]]), rtol=PRINT, atol=PRINT)
+        np.testing.assert_allclose(bias[f][1:], s[0:6], rtol=PRINT, atol=PRINT)
+        PC_q, PC_x = qmul(s[6:10], s[16:20]), s[10:13] + qrot(s[6:10], s[20:23])
+        pts = points[f][1:]
+        assert [int(pts[4 * i]) for i in range(len(pts) // 4)] == ids.tolist()
+        world = np.array([qrot(PC_q, q) + PC_x for q in p])
+        np.testing.assert_allclose(np.array(pts).reshape(-1, 4)[:, 1:], world, rtol=PRINT, atol=PRINT)
+        S = flt.get_sigma()
+        d = np.diag(S)
+        np.testing.assert_allclose(pose_c[f][7:13], d[6:12], rtol=PRINT)
+        np.testing.assert_allclose(cam_c[f][7:13], d[15:21], rtol=PRINT)
+        np.testing.assert_allclose(bias_c[f][7:13], d[0:6], rtol=PRINT)
+        e6 = np.array(pose_c[f][1:7])
+        assert abs(nees[f][3] - e6 @ np.linalg.solve(S[6:12, 6:12], e6)) <= 1e-3 * max(nees[f][3], 1e-12)  # e6 itself is rounded to 6 digits
+        ts, tids, tp = srv.true_state(flt.get_time())
+        assert abs(nees[f][1] - flt.compute_nees(ts, tids, tp)) <= PRINT * nees[f][1] and nees[f][2] == S.shape[0]
+
+    drive(srv, [flt], F, on_frame)
+    assert frame[0] == F
