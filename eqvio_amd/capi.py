@@ -228,7 +228,7 @@ class EqfCore:
         self.lib = load_eqf_lib()
         self.h = C.c_void_p()
         self._chk0(self.lib.eqf_create(C.byref(self.h), device, max_landmarks, coordinate_choice))
-        self.cap = max_landmarks + 16
+        self._cap0 = max_landmarks + 16
 
     def _chk0(self, rc):
         if rc != 0:
@@ -252,6 +252,10 @@ class EqfCore:
     @property
     def n(self):
         return 21 + 3 * self.N
+
+    @property
+    def cap(self):  # size of the output arrays: the context grows on demand (eqf_add_landmarks / eqf_set_state), so ask it
+        return max(self._cap0, self.N + 16)
 
     def set_option(self, opt, val):
         self._chk0(self.lib.eqf_set_option(self.h, opt, val))
@@ -464,7 +468,7 @@ class VIOFilter:
     def __init__(self, settings, max_landmarks=256, device=0, sensor=None, ids=None, p=None, time=0.0):
         self.lib = load_filter_lib()
         self.h = C.c_void_p()
-        self.cap = max_landmarks + 64
+        self._cap0 = max_landmarks + 64
         if sensor is None:
             rc = self.lib.eqvio_filter_create(C.byref(self.h), C.byref(settings), device, max_landmarks)
         else:
@@ -550,6 +554,10 @@ class VIOFilter:
 
     def core_handle(self):
         return self.lib.eqvio_filter_core(self.h)
+
+    @property
+    def cap(self):  # output array sizes follow the filter: its landmark capacity grows on demand
+        return max(self._cap0, (self.sigma_dim() - 21) // 3 + 64)
 
     def sigma_dim(self):
         return self.lib.eqvio_filter_sigma_dim(self.h)

@@ -519,6 +519,8 @@ const char* eqf_error_string(int code) {
 }
 const char* eqf_kernel_name(int which) { return (which >= 0 && which < KN_COUNT) ? kNames[which] : "?"; }
 
+static int create_buffers(eqf_ctx* c, int max_landmarks);
+static int grow_capacity(eqf_ctx* c, int new_cap);
 int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choice) {
     if (!out || max_landmarks < 1 || (coordinate_choice != EQVIO_COORD_EUCLIDEAN && coordinate_choice != EQVIO_COORD_INVDEPTH && coordinate_choice != EQVIO_COORD_NORMAL))
         return EQF_E_BAD_ARG;
@@ -536,6 +538,16 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     eqf_ctx* c = new eqf_ctx();
     c->device = device;
     c->chart = coordinate_choice;
+    const int rc = create_buffers(c, max_landmarks);
+    if (rc) { // a failed allocation half way (e.g. the pinned Sigma staging at a large capacity): release what exists
+        eqf_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return EQF_OK;
+}
+// every allocation of a context; on failure the caller destroys the partially built context (eqf_destroy accepts null members)
+static int create_buffers(eqf_ctx* c, int max_landmarks) {
     c->Ncap = roundup(max_landmarks, 16);
     c->ncap = 21 + 3 * c->Ncap;
     c->ld = pick_ld(c->ncap);
@@ -608,17 +620,17 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     const double s0[23] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     c->xi0 = unpack_sensor(s0);
     c->X = unpack_group(s0);
-    { int _r = sync_ctx(c); if (_r) return _r; }
-    *out = c;
-    return EQF_OK;
+    return sync_ctx(c);
 }
 
 void eqf_destroy(eqf_ctx* c) {
     if (!c)
         return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    hipStreamSynchronize(c->stream2);
+    if (c->stream)
+        hipStreamSynchronize(c->stream);
+    if (c->stream2)
+        hipStreamSynchronize(c->stream2);
     for (int b = 0; b < 2; ++b) {
         hipFree(c->d_sigma[b]);
         hipFree(c->d_lm[b]);
@@ -685,13 +697,18 @@ void eqf_destroy(eqf_ctx* c) {
     hipHostFree(c->h_door);
     hipFree(c->d_door);
     hipFree(c->d_spec);
-    hipEventDestroy(c->ev_assembled);
-    hipEventDestroy(c->ev_observer);
-    hipEventDestroy(c->ev_early);
-    hipStreamDestroy(c->stream2);
+    if (c->ev_assembled)
+        hipEventDestroy(c->ev_assembled);
+    if (c->ev_observer)
+        hipEventDestroy(c->ev_observer);
+    if (c->ev_early)
+        hipEventDestroy(c->ev_early);
+    if (c->stream2)
+        hipStreamDestroy(c->stream2);
     for (auto e : c->evpool)
         hipEventDestroy(e);
-    hipStreamDestroy(c->stream);
+    if (c->stream)
+        hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -820,9 +837,12 @@ void* eqf_stream(eqf_ctx* c) { return (void*)c->stream; }
 int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, const int* ids, const double* q0, const double* Q, int N) {
     if (!c || N < 0 || (N > 0 && (!ids || !q0 || !Q)))
         return EQF_E_BAD_ARG;
-    if (N > c->Ncap)
-        return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
+    if (N > c->Ncap) {
+        const int rc = grow_capacity(c, std::max(N, 2 * c->Ncap));
+        if (rc)
+            return rc;
+    }
     { int _r = sync_ctx(c); if (_r) return _r; }
     c->est_valid = false;
     c->meas_valid = false;
@@ -972,14 +992,61 @@ int eqf_state_estimate(eqf_ctx* c, double* sensor, int* ids, double* p, int cap)
     return N;
 }
 
+// More landmarks than the context was created for: build a context of the new capacity, move state, Sigma and options across through
+// the host (rare: capacities double), and exchange the two. Handles held by the caller stay valid (the eqf_ctx object is the same).
+static int grow_capacity(eqf_ctx* c, int new_cap) {
+    int rc = keep_last_gamma(c);
+    if (rc)
+        return rc;
+    const int N = c->N, n = c->n();
+    double xi0s[23], Xs[23];
+    std::vector<int> ids(std::max(N, 1));
+    std::vector<double> q0(3 * (size_t)std::max(N, 1)), Q(5 * (size_t)std::max(N, 1)), S((size_t)n * n);
+    rc = eqf_get_state(c, xi0s, Xs, ids.data(), q0.data(), Q.data(), std::max(N, 1));
+    if (rc < 0)
+        return rc;
+    rc = eqf_get_sigma(c, S.data(), n);
+    if (rc)
+        return rc;
+    eqf_ctx* t = nullptr;
+    rc = eqf_create(&t, c->device, new_cap, c->chart);
+    if (rc)
+        return rc == EQF_E_NO_DEVICE ? rc : EQF_E_CAPACITY; // allocation failure at the new size
+    const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_FUSED_UPDATE, c->opt_fused},
+                           {EQF_OPT_SPECULATIVE, c->opt_spec}, {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm},
+                           {EQF_OPT_TWO_PHASE, c->opt_two_phase}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+    for (const auto& o : opts)
+        if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
+            break;
+    if (!rc)
+        rc = eqf_set_state(t, xi0s, Xs, ids.data(), q0.data(), Q.data(), N);
+    if (!rc)
+        rc = eqf_set_sigma(t, S.data(), n);
+    if (rc) {
+        eqf_destroy(t);
+        return rc;
+    }
+    // what is not state of the filter but of the handle: counters, the last Gamma, the generation of the landmark set
+    t->last_gamma = c->last_gamma, t->n_at_update = c->n_at_update;
+    t->spec_calls = c->spec_calls, t->spec_queued = c->spec_queued, t->spec_cancelled = c->spec_cancelled, t->spec_backoff = c->spec_backoff, t->spec_backoff_len = c->spec_backoff_len;
+    t->nees_lu_fallbacks = c->nees_lu_fallbacks, t->wait_calls = c->wait_calls, t->launch_calls = c->launch_calls, t->wait_seconds = c->wait_seconds, t->launch_seconds = c->launch_seconds;
+    t->lm_gen = c->lm_gen + 1;
+    std::swap(*c, *t);
+    eqf_destroy(t);
+    return 0;
+}
+
 int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double var) {
     if (!c || k < 0 || (k > 0 && (!ids || !p)))
         return EQF_E_BAD_ARG;
     if (k == 0)
         return 0;
-    if (c->N + k > c->Ncap)
-        return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
+    if (c->N + k > c->Ncap) { // the reference has no cap (VIO_eqf.cpp:225-245 resizes Sigma): grow, at least doubling
+        const int rc = grow_capacity(c, std::max(c->N + k, 2 * c->Ncap));
+        if (rc)
+            return rc;
+    }
     { int _r = join_observer(c); if (_r) return _r; } // landmark kernels of a stand-alone observer call run on the second stream
     double* stage = c->h_newp_ring + (size_t)(c->ring_pos++ % eqf_ctx::kRing) * 3 * c->Ncap; // no stream drain: see h_newp_ring
     std::memcpy(stage, p, sizeof(double) * 3 * k);
@@ -1604,6 +1671,10 @@ static const double* pack_by_landmark(eqf_ctx* c, const int* measof, const doubl
     return c->h_ylm;
 }
 // map ascending measurement ids to state indices; returns 0 or EQF_E_BAD_ARG
+// The per-measurement packets (h_lmidx, h_y, d_meas ...) are sized by the landmark capacity. A frame may carry more features than that
+// (the ones without a landmark are about to be added, VIOFilter.cpp:217): grow first.
+static int fit_measurement(eqf_ctx* c, int M) { return M > c->Ncap ? grow_capacity(c, std::max(M, 2 * c->Ncap)) : 0; }
+
 static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, int* lmidx, int* measof) {
     // Consecutive frames usually measure the same ids: the previous mapping (still in the pinned packet, which only this function
     // writes) is reused when ids and landmark set are unchanged.
@@ -1641,9 +1712,8 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     const int N = c->N;
     if (N == 0)
         return 0;
-    if (M > c->Ncap)
-        return EQF_E_CAPACITY;
     HIPCHK(hipSetDevice(c->device));
+    { int _r = fit_measurement(c, M); if (_r) return _r; }
     c->staged_valid = c->stage_pending = c->stage_requested = false; // the pinned measurement packet is about to be rewritten
     if (c->busy_meas) {
         int r = sync_ctx(c);
@@ -1766,17 +1836,17 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         if (c->opt_early || la) {
             if (c->sig32)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<float, false>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (float*)c->sigma(), nt,
-                                   c->d_gamma, spec, spec_seq, 0, trace_slot(c, TR_SYRK));
+                                   c->d_gamma, spec, spec_seq, 0, c->d_flags, trace_slot(c, TR_SYRK));
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<double, false>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(), nt,
-                                   c->d_gamma, spec, spec_seq, 0, trace_slot(c, TR_SYRK));
+                                   c->d_gamma, spec, spec_seq, 0, c->d_flags, trace_slot(c, TR_SYRK));
         } else {
             if (c->sig32)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<float, true>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (float*)c->sigma(), nt,
-                                   c->d_gamma, spec, spec_seq, 1, trace_slot(c, TR_SYRK));
+                                   c->d_gamma, spec, spec_seq, 1, c->d_flags, trace_slot(c, TR_SYRK));
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<double, true>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(), nt,
-                                   c->d_gamma, spec, spec_seq, 1, trace_slot(c, TR_SYRK));
+                                   c->d_gamma, spec, spec_seq, 1, c->d_flags, trace_slot(c, TR_SYRK));
         }
         HIPCHK(hipGetLastError());
     }
@@ -1798,6 +1868,14 @@ static int finish_update(eqf_ctx* c, int discreteCorr) {
     const int N = c->N, n = c->n();
     c->h_flags[0] = c->h_resflags[0];
     c->h_flags[1] = c->h_resflags[1];
+    // A failed factorisation is reported BEFORE anything of the filter changes: the device kept Sigma and the landmarks (k_lift,
+    // k_syrk_sub), the sensor lift below is not applied. (EQF_OPT_FUSED_UPDATE folds the Sigma update into the factorisation steps and
+    // cannot offer this; it is off by default.)
+    if (c->h_resflags[3] || c->h_flags[0]) {
+        c->est_valid = false;
+        c->meas_valid = false;
+        return c->h_resflags[3] ? EQF_E_STALLED : EQF_E_NOT_SPD; // stalled: a bounded wait of the look-ahead kernel ran out (its workgroups were not all resident)
+    }
     c->gamma_stale = true;
     c->n_at_update = n;
     c->est_cache.assign(c->h_res + 3 * (size_t)c->Ncap, c->h_res + 3 * (size_t)c->Ncap + 4 * N);
@@ -1845,10 +1923,6 @@ static int finish_update(eqf_ctx* c, int discreteCorr) {
         if (r)
             return r;
     }
-    if (c->h_resflags[3])
-        return EQF_E_STALLED; // a bounded wait of the look-ahead factorisation ran out (its workgroups were not all resident)
-    if (c->h_flags[0])
-        return EQF_E_NOT_SPD;
     if (c->h_flags[1])
         return EQF_E_NONFINITE;
     for (int i = 0; i < 21; ++i)
@@ -1949,6 +2023,7 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     }
     HIPCHK(hipSetDevice(c->device));
     host_stamp(c, TH_TAIL_ENTRY);
+    { int _r = join_observer(c); if (_r) return _r; } // before the flags below are evaluated, as in eqf_outlier_stats: a stand-alone observer call does not cost the frame its doorbell
     // speculation needs the doorbell-free conditions of both waits and the equivariant-output cache of the statistics kernel
     // A cancelled tail costs the frame a wasted launch sequence on top of the two-round-trip path it falls back to. Where outlier candidates
     // show up frame after frame (tight thresholds) speculation backs off: after a cancellation the next 1, 2, 4 .. 16 frames only compute
@@ -1982,9 +2057,6 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
             }
         std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
     }
-    rc = join_observer(c);
-    if (rc)
-        return rc;
     const int seq = (int)(++c->door_seq);
     auto copy_stats = [&]() {
         if (absErr)
@@ -2308,7 +2380,7 @@ int eqf_debug_matrices_AB(eqf_ctx* c, const double* imu13, double* A_out, double
 }
 
 int eqf_debug_matrix_C(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, int useEqv, double* C_out, double* ytilde_out) {
-    if (!c || !cam || M <= 0 || !ids || !y)
+    if (!c || !cam || M <= 0 || !ids || !y || M > c->N)
         return EQF_E_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
     int rc = stage_measurement(c, ids, y, M);

@@ -729,6 +729,7 @@ __global__ void __launch_bounds__(64) k_measure(int M, int Mcap, int Ncap, int c
     if (j == 0) {
         flags[0] = 0;
         flags[1] = 0;
+        flags[3] = 0;
     }
     if (j >= M)
         return;
@@ -756,6 +757,7 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
     if (emit && i == 0) {
         flags[0] = 0;
         flags[1] = 0;
+        flags[3] = 0;
     }
     if (i >= N)
         return;
@@ -1149,6 +1151,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
             if (threadIdx.x == 0) { // this launch's only writer of the status flags
                 flags[0] = 0;
                 flags[1] = 0;
+                flags[3] = 0;
             }
             if (jj == 0 && i < M) {
                 int lidx;
@@ -1750,10 +1753,14 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
 template <typename TS, bool WITH_GAMMA>
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
-                                                  double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma, trace_t* tr) {
+                                                  double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma, const int* __restrict__ flags,
+                                                  trace_t* tr) {
     trace_start(tr);
+    const int failed = flags[0] | flags[3]; // requested together with the cancellation word: one round trip
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
+    if (failed)
+        return; // the factorisation failed (see k_lift): Sigma stays as it was
     __shared__ double sred[1024 * SYRK_NW];
     int b = blockIdx.x;
     int bj = 0;
@@ -1865,21 +1872,23 @@ __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int dis
     const int f0 = flags[0], f1 = flags[1], f3 = flags[3];
     const int specv = spec ? __hip_atomic_load(spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const bool aborted = spec && specv == spec_seq; // speculative tail cancelled by the statistics kernel
+    // A factorisation that met a non-positive pivot (flags[0], EQF_E_NOT_SPD) or whose bounded wait ran out (flags[3], EQF_E_STALLED) leaves
+    // the filter as it was: no landmark is lifted here, k_syrk_sub does not touch Sigma, the host does not apply the sensor lift. The
+    // status words are cleared by the first kernel of the next update.
+    const bool failed = f0 != 0 || f3 != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         flags_host[2] = aborted ? 1 : 0;
-        flags_host[3] = f3; // look-ahead factorisation: a bounded wait ran out (EQF_E_STALLED)
-        if (f3)
-            ((int*)flags)[3] = 0;
+        flags_host[3] = f3; // look-ahead factorisation: a bounded wait ran out
     }
-    if (!aborted) {
+    if (!aborted && i == 0) {
+        flags_host[0] = f0;
+        flags_host[1] = f1;
+    }
+    if (!aborted && !failed) {
         if (i < 21) {
             gamma_host[i] = gs;
             if (gpart)
                 gamma[i] = gs;
-        }
-        if (i == 0) {
-            flags_host[0] = f0;
-            flags_host[1] = f1;
         }
         if (lm) {
             if (gpart) {

@@ -27,7 +27,7 @@ enum {
     EQF_E_NONFINITE = -1,  /* NaN/Inf detected in Sigma or X (the reference's assert(!hasNaN())) */
     EQF_E_NOT_SPD = -2,    /* Cholesky pivot <= 0 in S = C Sigma C^T + R */
     EQF_E_BAD_ARG = -3,
-    EQF_E_CAPACITY = -4,   /* more landmarks than max_landmarks */
+    EQF_E_CAPACITY = -4,   /* an output array of the caller is too small; or the device buffers could not be grown (allocation failed) */
     EQF_E_NO_DEVICE = -5,
     EQF_E_UNSUPPORTED = -6, /* option combination not implemented on the device path */
     EQF_E_STALLED = -7      /* a bounded device-side wait of the look-ahead factorisation ran out (20 ms): its workgroups were not all
@@ -72,6 +72,8 @@ const char* eqf_error_string(int code);
 
 /* lifecycle. coordinate_choice: EQVIO_COORD_EUCLIDEAN | EQVIO_COORD_INVDEPTH
  * (EqFCoordinateSuite selection, include/eqvio/mathematical/EqFMatrices.h:81-90). */
+/* max_landmarks is the INITIAL capacity, not a limit (the reference has none): eqf_add_landmarks and eqf_set_state grow the device
+ * buffers (at least doubling, state and Sigma carried over) when more landmarks arrive. The handle stays valid. */
 int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choice);
 void eqf_destroy(eqf_ctx* ctx);
 int eqf_set_option(eqf_ctx* ctx, int option, int value);

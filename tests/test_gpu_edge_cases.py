@@ -49,35 +49,80 @@ def test_single_landmark_single_measurement():
     check_state(core, orc)
 
 
-def test_capacity_is_enforced():
-    N, cap = 14, 16  # the context rounds its capacity up to a multiple of 16 landmarks
+def test_capacity_grows_on_demand():
+    """max_landmarks of eqf_create is an initial capacity, not a limit (the reference has none: VIO_eqf.cpp:225-245 resizes Sigma). A context
+    created for 16 landmarks takes 14 + 2 (exactly full) + 30 more, keeps state, Sigma, options and counters across the growth, and the
+    propagation + update that follow agree with the oracle."""
+    from eqvio_amd.capi import OPT_LOOKAHEAD, OPT_TIMING
+    from oracle_binding import OracleFilter
+
+    N, cap = 14, 16
+    chart = CHARTS["invdepth"]
     rng = np.random.default_rng(4)
+    settings = settings_for(chart, useDiscreteInnovationLift=0)
     xi0, Xs, ids, q0, Q = reasonable_state(rng, N)
-    core = EqfCore(cap, CHARTS["euclid"])
+    S = np.diag(settings.initial_cov_diag(N)) + 1e-3 * random_spd(rng, 21 + 3 * N)
+    orc = OracleFilter(settings)
+    orc.set_eqf(xi0, Xs, ids, q0, Q, S)
+    core = EqfCore(cap, chart)
+    core.set_option(OPT_LOOKAHEAD, 0)
+    core.set_option(OPT_TIMING, 1)
     core.set_state(xi0, Xs, ids, q0, Q)
-    core.set_sigma(random_spd(rng, 21 + 3 * N))
-    core.add_landmarks(np.array([100, 101], np.int32), rng.normal(size=(2, 3)) + [0, 0, 5], 1.0)  # exactly full
-    assert core.N == cap
-    with pytest.raises(EqfError) as e:
-        core.add_landmarks(np.array([102], np.int32), np.array([[0.0, 0.0, 5.0]]), 1.0)
-    assert e.value.code == -4  # EQF_E_CAPACITY
-    assert core.N == cap and core.get_sigma().shape == (21 + 3 * cap, 21 + 3 * cap)  # state untouched
+    core.set_sigma(S)
+    for new_ids, var in ((np.array([100, 101], np.int32), 1.0), (np.arange(200, 230, dtype=np.int32), 0.4)):
+        p = rng.uniform(-1, 1, (len(new_ids), 3)) + [0, 0, 5]
+        orc.add_landmarks(new_ids, p, var)
+        core.add_landmarks(new_ids, p, var)
+    assert core.N == 46
+    assert np.array_equal(core.get_sigma(), orc.get_sigma())  # the move to the larger buffers copies bits
+    check_state(core, orc, 1e-15)
+    imu = random_imu(rng)
+    orc.integrate_riccati_fast(imu, 0.01)
+    core.integrate_riccati_fast(imu, 0.01, settings.input_gain_diag12(), settings.state_gain_diag8())
+    orc.integrate_observer(imu, 0.01, True)
+    core.integrate_observer(imu[None, :], np.array([0.01]), True)
+    _, _, ids_all, q0_all, Q_all = orc.get_eqf()
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids_all, q0_all, Q_all, noise_px=1.0)
+    orc.vision_update(cam, mid, y)
+    core.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+    check_sigma(core, orc)
+    check_state(core, orc)
+    # an option set before the growth is still in force: with the look-ahead kernel off the update ran as the launch chain
+    names = {name for name, _ in core.kernel_times()}
+    assert "k_chol_step" in names and "k_chol_lookahead" not in names
+    # set_state with more landmarks than the current capacity grows as well
     xi0b, Xsb, idsb, q0b, Qb = reasonable_state(rng, 20)
-    with pytest.raises(EqfError):
-        EqfCore(16, CHARTS["euclid"]).set_state(xi0b, Xsb, idsb, q0b, Qb)  # more landmarks than the context can hold
+    small = EqfCore(16, CHARTS["euclid"])
+    small.set_state(xi0b, Xsb, idsb, q0b, Qb)
+    assert small.N == 20 and np.array_equal(small.get_state()[2], idsb)
 
 
 def test_indefinite_innovation_covariance_is_reported():
     """The reference's LU inverse never fails; the factorisation here reports a non-positive pivot (EQF_E_NOT_SPD)
-    instead of producing garbage."""
-    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["euclid"], 5, seed=5)
-    core.set_sigma(-S)  # S_innov = C (-Sigma) C^T + R is indefinite for this Sigma
-    cam = default_camera()
-    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0)
-    with pytest.raises(EqfError) as e:
-        core.vision_update(cam, mid, y, 1e-6, True, False)
-        core.synchronize()
-    assert e.value.code == -2  # EQF_E_NOT_SPD
+    instead of producing garbage - and reports it with the filter untouched: Sigma, X (sensor part and landmarks) are what they were
+    before the call, for the one-panel chain (N = 5), the look-ahead kernel (N = 60) and the launch chain (N = 60, look-ahead off)."""
+    from eqvio_amd.capi import OPT_LOOKAHEAD
+
+    for N, la in ((5, 1), (60, 1), (60, 0)):
+        rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["euclid"], N, seed=5)
+        core.set_option(OPT_LOOKAHEAD, la)
+        core.set_sigma(-S)  # S_innov = C (-Sigma) C^T + R is indefinite for this Sigma
+        before = core.get_state()
+        cam = default_camera()
+        mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0)
+        with pytest.raises(EqfError) as e:
+            core.vision_update(cam, mid, y, 1e-6, True, False)
+            core.synchronize()
+        assert e.value.code == -2  # EQF_E_NOT_SPD
+        assert np.array_equal(core.get_sigma(), -S)
+        for a, b in zip(core.get_state(), before):
+            assert np.array_equal(a, b)
+        # and the context is usable afterwards: the same update on a proper Sigma matches the oracle
+        core.set_sigma(S)
+        orc.vision_update(cam, mid, y)
+        core.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+        check_sigma(core, orc)
 
 
 def test_non_finite_input_is_caught_when_checking_is_on():

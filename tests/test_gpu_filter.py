@@ -133,6 +133,26 @@ def test_template_config_accurate_riccati(chart):
         compare(flt, orc)
 
 
+def test_filter_grows_past_its_initial_capacity():
+    """Settings::maxLandmarks is an initial size, not a limit (the reference's filter has none). With removeLostLandmarks = 0 (a supported
+    reference setting, VIOFilter.cpp:207-211) the landmark count only grows: a filter created for 16 landmarks ends the run with several
+    times that, frame by frame in step with the oracle (no frame abandoned half done on a capacity error)."""
+    world = SimWorld(seed=5, num_points=1500, max_features=24, trajectory="wave", noise_px=0.3)
+    settings = sim_settings(COORD_INVDEPTH, removeLostLandmarks=0)
+    ids0, _ = world.vision(0.0)
+    sensor, ids, p = world.true_state(0.0, ids0[:10])
+    orc = OracleFilter(settings, sensor, ids, p, 0.0)
+    flt = VIOFilter(settings, max_landmarks=16, sensor=sensor, ids=ids, p=p, time=0.0)
+    for imus, stamp, mid, y in world.frames(40):
+        for s in range(len(imus)):
+            orc.process_imu(imus[s])
+            flt.process_imu(imus[s])
+        orc.process_vision(stamp, world.cam, mid, y)
+        flt.process_vision(stamp, world.cam, mid, y)
+        compare(flt, orc)
+    assert len(flt.state_estimate()[1]) > 40
+
+
 @pytest.mark.parametrize("chart", [COORD_EUCLIDEAN, COORD_INVDEPTH])
 def test_discrete_state_matrix_filter_run(chart):
     """Row a7: useDiscreteStateMatrix (integrateRiccatiStateDiscrete, VIO_eqf.cpp:93-103; the mode the reference's own statistical test runs,

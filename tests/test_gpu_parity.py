@@ -221,8 +221,12 @@ def test_landmark_bookkeeping(chart):
     orc.add_landmarks(new_ids, new_p, 1.0)
     core.add_landmarks(new_ids, new_p, 1.0)
     assert np.array_equal(core.get_sigma(), orc.get_sigma())
-    with pytest.raises(EqfError):
-        core.add_landmarks(np.arange(100, 200, dtype=np.int32), np.ones((100, 3)), 1.0)  # capacity
+    # far more landmarks than the context was created for (cap = 40): the reference has no cap (VIO_eqf.cpp:225-245); the context grows
+    many_ids, many_p = np.arange(100, 200, dtype=np.int32), rng.uniform(-1, 1, (100, 3)) + np.array([0, 0, 5.0])
+    orc.add_landmarks(many_ids, many_p, 0.7)
+    core.add_landmarks(many_ids, many_p, 0.7)
+    assert core.N == 103 and np.array_equal(core.get_sigma(), orc.get_sigma())
+    check_state(core, orc, 1e-15)
 
 
 @pytest.mark.parametrize("chart", list(CHARTS))
