@@ -162,6 +162,7 @@ struct eqf_ctx {
     int la_njcap = 0, la_seq = 0;
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
+    int opt_syrk_f32 = 0;                    // EQF_OPT_SYRK_F32
     int* d_perm = nullptr;                   // 2 x (ncap + 2) row permutations of the NEES elimination fallback
     // landmark bookkeeping staging: a ring of pinned packets, one per eqf_remove_landmarks / eqf_add_landmarks call, so that those calls need not
     // drain the stream before reusing a buffer (every frame has a host wait behind them; 8 slots cover the <= 4 calls of a frame twice)
@@ -777,6 +778,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case EQF_OPT_TWO_PHASE:
         c->opt_two_phase = value;
         return 0;
+    case EQF_OPT_SYRK_F32:
+        c->opt_syrk_f32 = value ? 1 : 0;
+        return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
         return 0;
@@ -1014,7 +1018,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
         return rc == EQF_E_NO_DEVICE ? rc : EQF_E_CAPACITY; // allocation failure at the new size
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_FUSED_UPDATE, c->opt_fused},
                            {EQF_OPT_SPECULATIVE, c->opt_spec}, {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm},
-                           {EQF_OPT_TWO_PHASE, c->opt_two_phase}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_TWO_PHASE, c->opt_two_phase}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead}, {EQF_OPT_SYRK_F32, c->opt_syrk_f32}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1833,21 +1837,19 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         }
         const int nt = blocks(n, 32);
         KTimer t(c, KN_SYRK);
-        if (c->opt_early || la) {
-            if (c->sig32)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<float, false>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (float*)c->sigma(), nt,
-                                   c->d_gamma, spec, spec_seq, 0, c->d_flags, trace_slot(c, TR_SYRK));
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<double, false>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(), nt,
-                                   c->d_gamma, spec, spec_seq, 0, c->d_flags, trace_slot(c, TR_SYRK));
+        const dim3 sg(nt * (nt + 1) / 2), sb(64 * SYRK_NW);
+#define SYRK_LAUNCH(TS_, G_, F_) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<TS_, G_, F_>), sg, sb, 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (TS_*)c->sigma(), nt, c->d_gamma, spec, spec_seq, G_ ? 1 : 0, c->d_flags, \
+                       trace_slot(c, TR_SYRK))
+        const bool wg = !(c->opt_early || la);
+        if (c->opt_syrk_f32) { // EQF_OPT_SYRK_F32: the fp32-arithmetic A/B (operands rounded to float, f32 MFMA)
+            if (c->sig32) { if (wg) SYRK_LAUNCH(float, true, true); else SYRK_LAUNCH(float, false, true); }
+            else { if (wg) SYRK_LAUNCH(double, true, true); else SYRK_LAUNCH(double, false, true); }
         } else {
-            if (c->sig32)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<float, true>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (float*)c->sigma(), nt,
-                                   c->d_gamma, spec, spec_seq, 1, c->d_flags, trace_slot(c, TR_SYRK));
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<double, true>), dim3(nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(), nt,
-                                   c->d_gamma, spec, spec_seq, 1, c->d_flags, trace_slot(c, TR_SYRK));
+            if (c->sig32) { if (wg) SYRK_LAUNCH(float, true, false); else SYRK_LAUNCH(float, false, false); }
+            else { if (wg) SYRK_LAUNCH(double, true, false); else SYRK_LAUNCH(double, false, false); }
         }
+#undef SYRK_LAUNCH
         HIPCHK(hipGetLastError());
     }
     { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }

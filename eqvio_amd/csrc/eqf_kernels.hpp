@@ -1647,7 +1647,10 @@ struct TileRed {
 };
 // If zvec != nullptr the workgroup also returns, in gv_out (valid in lanes 0..31 of the workgroup), the GEMV by-product
 // g[i0 + t] = sum_k P[i0 + t][k] * zvec[k * ldzv] from the operand values it loads anyway.
-template <bool WITH_GEMV, int NW = 4>
+// F32 (EQF_OPT_SYRK_F32, the fp32-arithmetic A/B of DESIGN.md §6): the operands are rounded to float and multiplied on
+// v_mfma_f32_16x16x4_f32 (twice the issue rate of the f64 form on gfx950; same A/B lane layout, C/D rows 4 (lane >> 4) + r instead of
+// (lane >> 4) + 4 r); a wave accumulates its K slice in f32, the slices are summed in fp64 as before.
+template <bool WITH_GEMV, int NW = 4, bool F32 = false>
 __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__ P, int ldp, int i0, int rowsP, const double* __restrict__ Qm, int ldq, int j0,
                                                       int rowsQ, int K, double* __restrict__ sred /* 4*1024 doubles */, const double* __restrict__ zvec = nullptr,
                                                       int ldzv = 0, double* gv_out = nullptr) {
@@ -1659,6 +1662,8 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
     const double zia = (i0 + lr < rowsP) ? 1.0 : 0.0, zib = (i0 + 16 + lr < rowsP) ? 1.0 : 0.0;
     const double zja = (j0 + lr < rowsQ) ? 1.0 : 0.0, zjb = (j0 + 16 + lr < rowsQ) ? 1.0 : 0.0;
     d4 acc00 = {0, 0, 0, 0}, acc10 = acc00, acc01 = acc00, acc11 = acc00;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 fcc00 = {0, 0, 0, 0}, fcc10 = fcc00, fcc01 = fcc00, fcc11 = fcc00;
     double ga = 0.0, gb = 0.0;
     const int nsteps = (K + 3) >> 2;
 #pragma unroll 4
@@ -1675,19 +1680,27 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
             ga = fma(pa, zv, ga);
             gb = fma(pb, zv, gb);
         }
-        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pa, acc00, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pb, acc10, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pa, acc01, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pb, acc11, 0, 0, 0);
+        if constexpr (F32) {
+            const float paf = (float)pa, pbf = (float)pb, qaf = (float)qa, qbf = (float)qb;
+            fcc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(qaf, paf, fcc00, 0, 0, 0);
+            fcc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(qaf, pbf, fcc10, 0, 0, 0);
+            fcc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(qbf, paf, fcc01, 0, 0, 0);
+            fcc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(qbf, pbf, fcc11, 0, 0, 0);
+        } else {
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pa, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pb, acc10, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pa, acc01, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pb, acc11, 0, 0, 0);
+        }
     }
     double* mine = sred + wave * 1024;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int j = lk + 4 * r;
-        mine[lr + 32 * j] = acc00[r];
-        mine[16 + lr + 32 * j] = acc10[r];
-        mine[lr + 32 * (16 + j)] = acc01[r];
-        mine[16 + lr + 32 * (16 + j)] = acc11[r];
+        const int j = F32 ? 4 * lk + r : lk + 4 * r;
+        mine[lr + 32 * j] = F32 ? (double)fcc00[r] : acc00[r];
+        mine[16 + lr + 32 * j] = F32 ? (double)fcc10[r] : acc10[r];
+        mine[lr + 32 * (16 + j)] = F32 ? (double)fcc01[r] : acc01[r];
+        mine[16 + lr + 32 * (16 + j)] = F32 ? (double)fcc11[r] : acc11[r];
     }
     __syncthreads();
     TileRed out;
@@ -1751,7 +1764,7 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 // That order gives the host the frame's results one kernel early: its round trip (results, filter logic, the next frame's
 // launches) overlaps with Sigma -= W W^T instead of leaving the GPU idle after it.
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
-template <typename TS, bool WITH_GAMMA>
+template <typename TS, bool WITH_GAMMA, bool F32 = false>
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
                                                   double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma, const int* __restrict__ flags,
                                                   trace_t* tr) {
@@ -1775,9 +1788,9 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
     double gv = 0.0;
     TileRed t;
     if (WITH_GAMMA && bi == bj)
-        t = mfma_tile32_splitk<true, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
+        t = mfma_tile32_splitk<true, SYRK_NW, F32>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
     else
-        t = mfma_tile32_splitk<false, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
+        t = mfma_tile32_splitk<false, SYRK_NW, F32>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
     if (WITH_GAMMA && bi == bj && threadIdx.x < 32 && i0 + threadIdx.x < n)
         gamma[i0 + threadIdx.x] = gv;
     if (threadIdx.x >= 256)
