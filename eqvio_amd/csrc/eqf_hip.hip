@@ -583,7 +583,7 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipMalloc(&c->d_Linv, sizeof(double) * 2048));
     HIPCHK(hipMalloc(&c->d_gamma, sizeof(double) * (c->ncap + 8)));
     HIPCHK(hipMalloc(&c->d_gpart, sizeof(double) * (GAMMA_G + 1) * (size_t)c->ld));
-    c->la_njcap = std::min(16, blocks(c->mcap, 32));
+    c->la_njcap = std::min(32, blocks(c->mcap, 32));
     HIPCHK(hipMalloc(&c->d_pub, sizeof(double) * LA_TILE * la_pub_tiles(c->la_njcap)));
     HIPCHK(hipMalloc(&c->d_pubf, sizeof(int) * la_pub_tiles(c->la_njcap)));
     HIPCHK(hipMalloc(&c->d_puby, 512 * (size_t)c->la_njcap));
@@ -1626,7 +1626,7 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
 }
 
 // The same factorisation as launch_chain(first_tile_done = true) in ONE persistent kernel with a look-ahead schedule (eqf_lookahead.hpp):
-// bit-identical W; Gamma arrives complete in d_gamma (no partial vectors). Eligible: 3 <= NJ <= 16 panels (64 < m <= 512).
+// bit-identical W; Gamma arrives complete in d_gamma (no partial vectors). Eligible: 3 <= NJ <= 32 panels (64 < m <= 1024, i.e. up to 512 measured landmarks).
 static bool lookahead_eligible(const eqf_ctx* c, int m) {
     const int NJ = blocks(m, 32);
     return c->opt_lookahead && !c->opt_fused && c->d_pub && NJ >= 3 && NJ <= c->la_njcap;
@@ -1655,10 +1655,22 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.tr_steps = trace_slot(c, TR_STEP0);
     a.dbg = c->d_trace ? c->d_ladbg : nullptr;
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
+    // MAXT = tiles a wave keeps in registers = ceil(NJ / 2)
+    // (the two large instantiations feed their operand tiles through an LDS ring and need more than the default 64 KB of dynamic LDS)
+    static bool ring_attr = false;
+    if (!ring_attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_chol_lookahead<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LA_LDS_RING));
+        HIPCHK(hipFuncSetAttribute((const void*)k_chol_lookahead<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LA_LDS_RING));
+        ring_attr = true;
+    }
     if (a.NJ <= 14)
-        hipLaunchKernelGGL(k_chol_lookahead<7>, dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<7, false>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+    else if (a.NJ <= 16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8, false>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+    else if (a.NJ <= 24)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<12, true>), dim3(a.NI), dim3(LA_T), LA_LDS_RING, c->stream, a);
     else
-        hipLaunchKernelGGL(k_chol_lookahead<8>, dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<16, true>), dim3(a.NI), dim3(LA_T), LA_LDS_RING, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -259,14 +259,29 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 }
 
 // ---- a block row --------------------------------------------------------------------------------------------------------------------
-template <int MAXT>
+// RING (the instantiations for 17 .. 32 panels): the P^(p)_J operand tiles of a panel do not travel through registers two at a time (one
+// memory round trip, ~2 us under load, per pair: with up to 16 tiles per wave that round trip, not the MFMA pipe, sets the pace) but through
+// a double-buffered ring in LDS, LA_RC = 8 tiles per half (tile columns 8 c .. 8 c + 7), filled by direct-to-LDS loads (global_load_lds_dwordx4: wave w copies tile w of the
+// chunk, no staging registers) while the previous chunk is multiplied. The destination of such a load is wave-uniform base + lane x 16 bytes,
+// i.e. linear; the k / k+1 bank separation the operand reads need comes from the SOURCE address instead: LDS slot (r', c) of a tile holds
+// element (r' ^ 16 (c & 1), c). Same products in the same order on the same accumulators: bit-identical to the register path.
+constexpr int LA_RC = 8;                                               // tiles per ring half (wave w loads tile w of the chunk)
+constexpr int LA_ROW_DOUBLES = 2 * 32 * CH_LDP + 32 + 256;             // with a ring: sLinv, sPI, sYv, sZp; sT lives in the ring's last tiles
+                                                                       // (dead once P_I exists; the ring's second half is first written after that)
+constexpr size_t LA_LDS_PLAIN = sizeof(double) * (4 * 32 * CH_LDP + LDL_SBUF); // the owner's need (and the rows' without a ring)
+constexpr size_t LA_LDS_RING = sizeof(double) * (LA_ROW_DOUBLES + 2 * LA_RC * LA_TILE);
+static_assert(LA_LDS_RING >= LA_LDS_PLAIN && LA_LDS_RING + 16 <= 160 * 1024, "LDS budget of a row workgroup with the operand ring");
+typedef __attribute__((address_space(3))) void la_lds_ptr;
+
+template <int MAXT, bool RING>
 __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* smem, int* s_abort, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     double* sLinv = smem;
-    double* sT = smem + 32 * CH_LDP;
-    double* sPI = smem + 2 * 32 * CH_LDP;
-    double* sYv = smem + 3 * 32 * CH_LDP; // yTilde row of the panel (32)
+    double* sPI = smem + 32 * CH_LDP;
+    double* sYv = smem + 2 * 32 * CH_LDP; // yTilde row of the panel (32)
     double* sZp = sYv + 32;               // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
+    double* ring = smem + LA_ROW_DOUBLES; // RING: 2 x LA_RC tiles
+    double* sT = RING ? ring + 2 * LA_RC * LA_TILE - 32 * CH_LDP : sZp + 256; // the panel tile in operand layout
     const int NJ = a.NJ, m = a.m, rows = a.rows, ldz = a.ldz, seq = a.seq;
     const bool srow = I < NJ;
     const int row0 = srow ? 32 * I : m + 32 * (I - NJ);
@@ -377,12 +392,14 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             if (tid == 0)
                 la_raise(a, la_i_p(a, I, p));
         } else {
+            if constexpr (!RING) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int e = tid + h * LA_T;
-                const int r = e & 31, c = e >> 5;
-                if (row0 + r < rows && c < w)
-                    a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = sPI[r + c * CH_LDP];
+                for (int h = 0; h < 2; ++h) {
+                    const int e = tid + h * LA_T;
+                    const int r = e & 31, c = e >> 5;
+                    if (row0 + r < rows && c < w)
+                        a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = sPI[r + c * CH_LDP];
+                }
             }
             if (tid < 256) {
                 const int r = tid & 31, h = tid >> 5;
@@ -408,40 +425,121 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             if (cnt > 0)
                 la_wait(a.pubf + la_i_p(a, p + 1, p), cnt, pl);
         }
-        // two tiles per round trip: both operand sets are requested before the first product needs one (the loads sit behind branches on
-        // the runtime panel index, which the compiler does not hoist them over by itself)
+        if constexpr (RING) {
+            // chunk cc = the tiles J = 8 cc .. 8 cc + 7 (static: wave w loads tile 8 cc + w, group g multiplies t = 4 cc + u, J = 2 t + g), in ring half
+            // cc & 1; the chunks that hold a tile in (p, Jmax] are walked in order. An S block row's own diagonal tile comes from sPI.
+            // (Measured at N = 500: this two-stage ring 311 us per factorisation; four stages of four tiles with three chunks in flight 328 us:
+            // the round trip is already hidden, the extra barriers are not free.)
+            const int cfirst = (p + 1) >> 3, clast = Jmax >> 3;
+            auto issue = [&](int cc) -> bool {
+                const int J = 8 * cc + wave;
+                if (J <= p || J > Jmax || (srow && J == I))
+                    return false;
+                const double* src = la_tile(a, la_i_p(a, J, p));
+                double* dst = ring + (size_t)((cc & 1) * LA_RC + wave) * LA_TILE;
 #pragma unroll
-        for (int t0 = 0; t0 < MAXT; t0 += 2) {
-            double bjs[2][8];
+                for (int i = 0; i < 8; ++i) { // 1 KB per instruction: columns 4 i .. 4 i + 3, lane -> (r' = 2 lane & 31, c = 4 i + (lane >> 4))
+                    const int cl = 4 * i + (lane >> 4), rp = (2 * lane) & 31;
+                    __builtin_amdgcn_global_load_lds((const void*)(src + (rp ^ (16 * (cl & 1))) + 32 * cl), (la_lds_ptr*)(dst + 128 * i), 16, 0, 0);
+                }
+                return true;
+            };
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing of this wave may be in flight besides the ring loads counted below
+            issue(cfirst);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int J = 2 * (t0 + u) + g;
-                if (t0 + u < MAXT && J > p && J <= Jmax) {
-                    if (J == I) { // diagonal tile of an S block row: both operands are P_I
+            for (int cc = 0; cc < MAXT / 4; ++cc) {
+                if (cc < cfirst || cc > clast)
+                    continue;
+                const bool nxt = (cc + 1 <= clast) && issue(cc + 1);
+                if (nxt)
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // loads return in order: chunk cc has landed, chunk cc + 1 may still fly
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const double* half = ring + (size_t)((cc & 1) * LA_RC) * LA_TILE;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = 4 * cc + u, J = 2 * t + g;
+                    if (J > p && J <= Jmax) {
+                        double bj[8];
+                        if (srow && J == I) {
+#pragma unroll
+                            for (int st = 0; st < 8; ++st)
+                                bj[st] = sPI[16 * jhU + lrv + (4 * st + lkv) * CH_LDP];
+                        } else {
+                            const double* tl = half + (size_t)(2 * u + g) * LA_TILE + ((16 * jhU + lrv) ^ (16 * (lkv & 1))) + 32 * lkv;
+#pragma unroll
+                            for (int st = 0; st < 8; ++st)
+                                bj[st] = tl[128 * st];
+                        }
+                        d4 d = {0, 0, 0, 0};
 #pragma unroll
                         for (int st = 0; st < 8; ++st)
-                            bjs[u][st] = sPI[16 * jhU + lrv + (4 * st + lkv) * CH_LDP];
-                    } else
-                        la_operand(la_tile(a, la_i_p(a, J, p)), jhU, bjs[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = (t0 + u < MAXT) ? t0 + u : MAXT - 1;
-                const int J = 2 * (t0 + u) + g;
-                if (t0 + u < MAXT && J > p && J <= Jmax) {
-                    d4 d = {0, 0, 0, 0};
-#pragma unroll
-                    for (int st = 0; st < 8; ++st)
-                        d = __builtin_amdgcn_mfma_f64_16x16x4f64(bjs[u][st], aI[st], d, 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[t][q] -= d[q];
-                    if (ylast && J == p + 1 && 16 * ihU + lrv == yloc) {
-                        // the yTilde row of the next panel is final now: publish it for every T block row's z_(p+1)
+                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], aI[st], d, 0, 0, 0);
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jhU + lkv + 4 * q), acc[t][q], seq);
+                            acc[t][q] -= d[q];
+                        if (ylast && J == p + 1 && 16 * ihU + lrv == yloc) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jhU + lkv + 4 * q), acc[t][q], seq);
+                        }
+                    }
+                }
+                if (cc + 2 <= clast) { // ring half cc & 1 is refilled by the next iteration's issue: every wave must be done reading it
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // sT of the next panel shares the ring's last tiles: every wave is done reading the ring
+            // the W rows of this panel (final since step (b), still in sPI): stored here so that no store is in flight while the ring loads are counted
+            if (!srow) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = tid + h * LA_T;
+                    const int r = e & 31, cw = e >> 5;
+                    if (row0 + r < rows && cw < w)
+                        a.W[(row0 + r) + (size_t)(32 * p + cw) * ldz] = sPI[r + cw * CH_LDP];
+                }
+            }
+        } else {
+        // two tiles per round trip: both operand sets are requested before the first product needs one (the loads sit behind branches on
+            // the runtime panel index, which the compiler does not hoist them over by itself)
+    #pragma unroll
+            for (int t0 = 0; t0 < MAXT; t0 += 2) {
+                double bjs[2][8];
+    #pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int J = 2 * (t0 + u) + g;
+                    if (t0 + u < MAXT && J > p && J <= Jmax) {
+                        if (J == I) { // diagonal tile of an S block row: both operands are P_I
+    #pragma unroll
+                            for (int st = 0; st < 8; ++st)
+                                bjs[u][st] = sPI[16 * jhU + lrv + (4 * st + lkv) * CH_LDP];
+                        } else
+                            la_operand(la_tile(a, la_i_p(a, J, p)), jhU, bjs[u]);
+                    }
+                }
+    #pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = (t0 + u < MAXT) ? t0 + u : MAXT - 1;
+                    const int J = 2 * (t0 + u) + g;
+                    if (t0 + u < MAXT && J > p && J <= Jmax) {
+                        d4 d = {0, 0, 0, 0};
+    #pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(bjs[u][st], aI[st], d, 0, 0, 0);
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[t][q] -= d[q];
+                        if (ylast && J == p + 1 && 16 * ihU + lrv == yloc) {
+                            // the yTilde row of the next panel is final now: publish it for every T block row's z_(p+1)
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jhU + lkv + 4 * q), acc[t][q], seq);
+                        }
                     }
                 }
             }
@@ -462,12 +560,15 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
     }
 }
 
-constexpr size_t LA_LDS_BYTES = 0; // static LDS only
-template <int MAXT>
+template <int MAXT, bool RING = false>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (a.spec && *a.spec == a.spec_seq)
         return; // cancelled speculative tail
-    __shared__ double smem[4 * 32 * CH_LDP + LDL_SBUF];
+    // static LDS without a ring (constant addresses: 2.6 us per factorisation at N = 200 against the same kernel on dynamic LDS), dynamic
+    // (LA_LDS_RING bytes, above the 64 KB a static array may have) with one
+    extern __shared__ double la_dyn_smem[];
+    __shared__ double la_st_smem[RING ? 1 : 4 * 32 * CH_LDP + LDL_SBUF];
+    double* smem = RING ? la_dyn_smem : la_st_smem;
     __shared__ int s_abort;
     if (threadIdx.x == 0)
         s_abort = 0;
@@ -476,7 +577,7 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (blockIdx.x == 0)
         la_owner(a, smem, &s_abort, pl);
     else
-        la_row<MAXT>(a, (int)blockIdx.x, smem, &s_abort, pl);
+        la_row<MAXT, RING>(a, (int)blockIdx.x, smem, &s_abort, pl);
     if (threadIdx.x == 0 && s_abort)
         a.flags[3] = 1;
 }
