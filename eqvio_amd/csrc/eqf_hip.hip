@@ -2,6 +2,7 @@
 #include "eqf_hip.h"
 #include "eqf_kernels.hpp"
 #include "eqf_lookahead.hpp"
+#include "host_prof.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -170,6 +171,17 @@ struct eqf_ctx {
     int* h_keep_ring = nullptr;    // kRing x Ncap
     double* h_newp_ring = nullptr; // kRing x 3 Ncap
     int ring_pos = 0;
+    // Deferred landmark bookkeeping: eqf_remove_landmarks / eqf_add_landmarks only record what they do (ids, N and the estimate cache follow at
+    // once); flush_reshape applies everything recorded since the last flush with ONE copy + ONE kernel (k_reshape) when the device state is
+    // next needed. A frame's removeOldLandmarks + removeOutliers + addNewLandmarks were 3 copies + 6 launches of host time and three passes over Sigma.
+    bool reshape_pending = false;
+    int dev_N = 0;                 // landmarks in the device arrays (before the pending reshape)
+    std::vector<int> pend_map;     // landmark -> device landmark (>= 0) or -(t + 1): t-th pending new landmark
+    std::vector<double> pend_p;    // 3 per pending new landmark
+    std::vector<double> pend_var;  // 1 per pending new landmark
+    char* h_rs_ring = nullptr;     // kRing pinned packets: map[Ncap] ints | newp[3 Ncap] | var[Ncap] doubles
+    char* d_rs = nullptr;
+    size_t rs_bytes = 0;
     int spec_backoff = 0, spec_backoff_len = 0; // frames left without speculation after cancelled tails (doubling, <= 16), see eqf_stats_then_update
     long spec_calls = 0, spec_queued = 0, spec_cancelled = 0; // eqf_stats_then_update: calls, tails queued speculatively, tails cancelled on the device
     long nees_lu_fallbacks = 0;              // computeNEES calls answered by the partial-pivot elimination (Sigma not numerically SPD)
@@ -209,6 +221,8 @@ struct eqf_ctx {
     double wait_seconds = 0.0, launch_seconds = 0.0;
     double* h_res = nullptr; // pinned result packet: stats[3 Ncap] | est[4 Ncap] | gamma[32]
     int* h_resflags = nullptr;
+    int* h_sel = nullptr; // pinned: k_select_outliers' verdict, [0, N) discarded flags, [Ncap] candidates, [Ncap + 1] discarded
+    long sel_frames = 0, sel_discarded = 0; // frames that took the device-side outlier decision, landmarks it discarded
     static constexpr int kMaxSteps = kObsChunk;
     CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
@@ -335,6 +349,7 @@ int sync_ctx(eqf_ctx* c) {
 // result store has been fenced at system scope). The stream is polled now and then so that a kernel fault is reported
 // instead of spinning forever; if the stream completes without the bell (cannot happen) the call fails loudly.
 int door_wait(eqf_ctx* c, int which, int seq) {
+    HP_SCOPE("abi.door_wait");
     volatile int* bell = reinterpret_cast<volatile int*>(c->h_door) + which;
     long spins_after_done = 0;
     const auto t0 = std::chrono::steady_clock::now();
@@ -522,6 +537,13 @@ const char* eqf_kernel_name(int which) { return (which >= 0 && which < KN_COUNT)
 
 static int create_buffers(eqf_ctx* c, int max_landmarks);
 static int grow_capacity(eqf_ctx* c, int new_cap);
+static int flush_reshape(eqf_ctx* c);
+static int round_sigma(eqf_ctx* c, const int* spec = nullptr, int spec_seq = 0);
+// first statement of every entry point that uses the device state: select the device, apply the recorded landmark bookkeeping
+static int enter(eqf_ctx* c) {
+    HIPCHK(hipSetDevice(c->device));
+    return flush_reshape(c);
+}
 int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choice) {
     if (!out || max_landmarks < 1 || (coordinate_choice != EQVIO_COORD_EUCLIDEAN && coordinate_choice != EQVIO_COORD_INVDEPTH && coordinate_choice != EQVIO_COORD_NORMAL))
         return EQF_E_BAD_ARG;
@@ -603,6 +625,9 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipHostMalloc(&c->h_ibuf, sizeof(int) * 4 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_keep_ring, sizeof(int) * eqf_ctx::kRing * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_newp_ring, sizeof(double) * eqf_ctx::kRing * 3 * (size_t)c->Ncap));
+    c->rs_bytes = (sizeof(int) + 4 * sizeof(double)) * (size_t)c->Ncap + 64;
+    HIPCHK(hipHostMalloc(&c->h_rs_ring, eqf_ctx::kRing * c->rs_bytes));
+    HIPCHK(hipMalloc(&c->d_rs, c->rs_bytes));
     HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 4));
     HIPCHK(hipHostMalloc(&c->h_lmidx, sizeof(int) * 2 * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_y, sizeof(double) * 2 * (size_t)c->Ncap));
@@ -611,6 +636,7 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipMalloc(&c->d_meas_idx, sizeof(int) * (size_t)c->Ncap));
     HIPCHK(hipHostMalloc(&c->h_res, sizeof(double) * (7 * (size_t)c->Ncap + 32)));
     HIPCHK(hipHostMalloc(&c->h_resflags, sizeof(int) * 4));
+    HIPCHK(hipHostMalloc(&c->h_sel, sizeof(int) * ((size_t)c->Ncap + 2)));
     HIPCHK(hipHostMalloc(&c->h_door, sizeof(int) * 4));
     std::memset(c->h_door, 0, sizeof(int) * 4);
     HIPCHK(hipMalloc(&c->d_door, sizeof(int) * 4));
@@ -687,6 +713,8 @@ void eqf_destroy(eqf_ctx* c) {
     hipHostFree(c->h_ibuf);
     hipHostFree(c->h_keep_ring);
     hipHostFree(c->h_newp_ring);
+    hipHostFree(c->h_rs_ring);
+    hipFree(c->d_rs);
     hipHostFree(c->h_flags);
     hipHostFree(c->h_lmidx);
     hipHostFree(c->h_y);
@@ -695,6 +723,7 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_meas_idx);
     hipHostFree(c->h_res);
     hipHostFree(c->h_resflags);
+    hipHostFree(c->h_sel);
     hipHostFree(c->h_door);
     hipFree(c->d_door);
     hipFree(c->d_spec);
@@ -742,7 +771,7 @@ static int set_sigma_storage(eqf_ctx* c, bool f32) {
     return 0;
 }
 
-static int round_sigma(eqf_ctx* c, const int* spec = nullptr, int spec_seq = 0) {
+static int round_sigma(eqf_ctx* c, const int* spec, int spec_seq) {
     if (c->opt_f32 != 1 || c->n() == 0) // 2 = real float storage: every store already rounds
         return 0;
     const int n = c->n();
@@ -811,6 +840,7 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         if (value == 2 && (c->opt_dense || c->opt_fused))
             return EQF_E_UNSUPPORTED; // the float store exists for the structured fast path only
         c->opt_f32 = value;
+        { int _e = enter(c); if (_e) return _e; } // the live Sigma is converted: pending landmark bookkeeping first
         const int rc = set_sigma_storage(c, value == 2);
         return rc ? rc : round_sigma(c);
     }
@@ -841,7 +871,7 @@ void* eqf_stream(eqf_ctx* c) { return (void*)c->stream; }
 int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, const int* ids, const double* q0, const double* Q, int N) {
     if (!c || N < 0 || (N > 0 && (!ids || !q0 || !Q)))
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     if (N > c->Ncap) {
         const int rc = grow_capacity(c, std::max(N, 2 * c->Ncap));
         if (rc)
@@ -854,6 +884,7 @@ int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, 
     c->X = unpack_group(X_sensor);
     c->ids.assign(ids, ids + N);
     c->N = N;
+    c->dev_N = N;
     ++c->lm_gen;
     if (N > 0) {
         std::memcpy(c->h_buf, q0, sizeof(double) * 3 * N);
@@ -878,7 +909,7 @@ int eqf_get_state(eqf_ctx* c, double* xi0_sensor, double* X_sensor, int* ids, do
     if (N > cap)
         return EQF_E_CAPACITY;
     if (N > 0) {
-        HIPCHK(hipSetDevice(c->device));
+        { int _e = enter(c); if (_e) return _e; }
         { int _r = join_observer(c); if (_r) return _r; }
         hipLaunchKernelGGL(k_gather_landmarks_aos, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->d_scratch);
         HIPCHK(hipGetLastError());
@@ -899,7 +930,7 @@ int eqf_get_state(eqf_ctx* c, double* xi0_sensor, double* X_sensor, int* ids, do
 int eqf_set_sigma(eqf_ctx* c, const double* sig, int n) {
     if (!c || !sig || n != c->n())
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     { int _r = sync_ctx(c); if (_r) return _r; }
     std::memcpy(c->h_buf, sig, sizeof(double) * (size_t)n * n);
     if (c->sig32) { // doubles land in the other buffer, the conversion kernel writes the float store
@@ -917,7 +948,7 @@ int eqf_set_sigma(eqf_ctx* c, const double* sig, int n) {
 int eqf_set_sigma_diag(eqf_ctx* c, const double* diag, int n) {
     if (!c || !diag || n != c->n())
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     { int _r = sync_ctx(c); if (_r) return _r; }
     { int _r = keep_last_gamma(c); if (_r) return _r; }
     std::memcpy(c->h_buf, diag, sizeof(double) * n);
@@ -933,7 +964,7 @@ int eqf_get_sigma_block(eqf_ctx* c, int r0, int c0, int rows, int cols, double* 
         return EQF_E_BAD_ARG;
     if (rows == 0 || cols == 0)
         return 0;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     const double* src = c->sigma();
     if (c->sig32) { // widen into the other buffer first
         const int n = c->n();
@@ -958,10 +989,11 @@ static int fetch_estimates(eqf_ctx* c) { // d_est -> h_buf (4 planes of stride N
     const int N = c->N;
     if (N == 0)
         return 0;
-    if (c->est_valid && (int)c->est_cache.size() == 4 * N) {
+    if (c->est_valid && (int)c->est_cache.size() == 4 * N) { // (kept current through landmark bookkeeping: no device work, no flush of a pending reshape)
         std::memcpy(c->h_buf, c->est_cache.data(), sizeof(double) * 4 * N);
         return 0;
     }
+    { int _e = enter(c); if (_e) return _e; }
     { int _r = join_observer(c); if (_r) return _r; }
     hipLaunchKernelGGL(k_estimate, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->d_est);
     HIPCHK(hipGetLastError());
@@ -1040,7 +1072,55 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     return 0;
 }
 
+// (all three below: see reshape_pending in eqf_ctx)
+static void pend_begin(eqf_ctx* c) {
+    if (!c->reshape_pending) {
+        c->pend_map.resize(c->dev_N);
+        for (int i = 0; i < c->dev_N; ++i)
+            c->pend_map[i] = i;
+        c->pend_p.clear();
+        c->pend_var.clear();
+        c->reshape_pending = true;
+    }
+}
+static int flush_reshape(eqf_ctx* c) {
+    if (!c->reshape_pending)
+        return 0;
+    HP_SCOPE("abi.flush_reshape");
+    c->reshape_pending = false;
+    const int Nnew = (int)c->pend_map.size(), knew = (int)c->pend_var.size();
+    bool identity = knew == 0 && Nnew == c->dev_N;
+    for (int i = 0; identity && i < Nnew; ++i)
+        identity = c->pend_map[i] == i;
+    if (identity)
+        return 0;
+    { int _r = join_observer(c); if (_r) return _r; } // landmark kernels of a stand-alone observer call run on the second stream
+    char* slot = c->h_rs_ring + (size_t)(c->ring_pos++ % eqf_ctx::kRing) * c->rs_bytes; // no stream drain: a ring of pinned packets
+    const size_t off_p = (sizeof(int) * (size_t)c->Ncap + 15) & ~(size_t)15, off_v = off_p + sizeof(double) * 3 * (size_t)c->Ncap;
+    std::memcpy(slot, c->pend_map.data(), sizeof(int) * Nnew);
+    if (knew) {
+        std::memcpy(slot + off_p, c->pend_p.data(), sizeof(double) * 3 * knew);
+        std::memcpy(slot + off_v, c->pend_var.data(), sizeof(double) * knew);
+    }
+    // compact compactly: only what is used travels (two contiguous ranges when there are new landmarks)
+    HIPCHK(hipMemcpyAsync(c->d_rs, slot, knew ? off_v + sizeof(double) * knew : sizeof(int) * std::max(Nnew, 1), hipMemcpyHostToDevice, c->stream));
+    const int nnew = 21 + 3 * Nnew;
+    {
+        KTimer t(c, KN_MISC);
+        LAUNCH_TS(c, k_reshape, dim3(blocks(nnew, 256), nnew + blocks(Nnew, 256)), dim3(256), c->stream, Nnew, c->Ncap, c->ld, (const int*)c->d_rs, (const double*)(c->d_rs + off_p),
+                  (const double*)(c->d_rs + off_v), (const TS*)c->d_sigma[c->cur], (TS*)c->d_sigma[1 - c->cur], (const double*)c->d_st[c->stcur], (const double*)c->d_lm[c->lmcur],
+                  c->d_st[1 - c->stcur], c->d_lm[1 - c->lmcur]);
+        HIPCHK(hipGetLastError());
+    }
+    c->cur = 1 - c->cur;
+    c->lmcur = 1 - c->lmcur;
+    c->stcur = 1 - c->stcur;
+    c->dev_N = Nnew;
+    return knew ? round_sigma(c) : 0; // (EQF_OPT_SIGMA_FP32 = 1 rounds after every store of Sigma: the appended variances)
+}
+
 int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double var) {
+    HP_SCOPE("abi.add_landmarks");
     if (!c || k < 0 || (k > 0 && (!ids || !p)))
         return EQF_E_BAD_ARG;
     if (k == 0)
@@ -1051,26 +1131,31 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
         if (rc)
             return rc;
     }
-    { int _r = join_observer(c); if (_r) return _r; } // landmark kernels of a stand-alone observer call run on the second stream
-    double* stage = c->h_newp_ring + (size_t)(c->ring_pos++ % eqf_ctx::kRing) * 3 * c->Ncap; // no stream drain: see h_newp_ring
-    std::memcpy(stage, p, sizeof(double) * 3 * k);
-    HIPCHK(hipMemcpyAsync(c->d_scratch, stage, sizeof(double) * 3 * k, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_scatter_landmarks, dim3(blocks(k, 64)), dim3(64), 0, c->stream, k, c->N, c->Ncap, c->d_scratch, (const double*)nullptr, c->q0(), c->Qq(),
-                       c->Qa());
-    HIPCHK(hipGetLastError());
-    const int nold = c->n();
-    const int nnew = nold + 3 * k;
-    LAUNCH_TS(c, k_append_sigma, dim3(blocks(nnew, 256), nnew), dim3(256), c->stream, nold, nnew, c->ld, var, (TS*)c->sigma());
-    HIPCHK(hipGetLastError());
+    pend_begin(c);
+    for (int t = 0; t < k; ++t) {
+        c->pend_map.push_back(-((int)c->pend_var.size() + 1));
+        c->pend_p.insert(c->pend_p.end(), p + 3 * t, p + 3 * t + 3);
+        c->pend_var.push_back(var);
+    }
+    if (c->est_valid) { // the estimate of a fresh landmark is its origin point (Q = identity): the cache follows without asking the device
+        const int N = c->N;
+        std::vector<double> e(4 * (size_t)(N + k));
+        for (int pl = 0; pl < 4; ++pl) {
+            std::copy(c->est_cache.begin() + (size_t)pl * N, c->est_cache.begin() + (size_t)(pl + 1) * N, e.begin() + (size_t)pl * (N + k));
+            for (int t = 0; t < k; ++t)
+                e[(size_t)pl * (N + k) + N + t] = pl < 3 ? p[3 * t + pl] : 0.0;
+        }
+        c->est_cache.swap(e);
+    }
     c->ids.insert(c->ids.end(), ids, ids + k);
     c->N += k;
     ++c->lm_gen;
-    c->est_valid = false;
     c->meas_valid = false;
-    return round_sigma(c);
+    return 0;
 }
 
 int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
+    HP_SCOPE("abi.remove_landmarks");
     if (!c || k < 0 || (k > 0 && !indices))
         return EQF_E_BAD_ARG;
     if (k == 0)
@@ -1081,43 +1166,50 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
             return EQF_E_BAD_ARG;
         drop[indices[t]] = 1;
     }
-    HIPCHK(hipSetDevice(c->device));
-    { int _r = join_observer(c); if (_r) return _r; }
-    int* keep = c->h_keep_ring + (size_t)(c->ring_pos++ % eqf_ctx::kRing) * c->Ncap; // no stream drain: see h_keep_ring
-    std::vector<int> newids;
-    int Nnew = 0;
-    for (int i = 0; i < c->N; ++i)
+    pend_begin(c);
+    const int N = c->N;
+    std::vector<int> newids, newmap;
+    for (int i = 0; i < N; ++i)
         if (!drop[i]) {
-            keep[Nnew++] = i;
             newids.push_back(c->ids[i]);
+            newmap.push_back(c->pend_map[i]);
         }
-    if (Nnew > 0)
-        HIPCHK(hipMemcpyAsync(c->d_keep, keep, sizeof(int) * Nnew, hipMemcpyHostToDevice, c->stream));
-    const int nnew = 21 + 3 * Nnew;
+    // pending new landmarks that were removed again: renumber the remaining ones
     {
-        KTimer t(c, KN_MISC);
-        LAUNCH_TS(c, k_compact_sigma, dim3(blocks(nnew, 256), nnew), dim3(256), c->stream, nnew, c->ld, c->d_keep, (const TS*)c->d_sigma[c->cur], (TS*)c->d_sigma[1 - c->cur]);
-        HIPCHK(hipGetLastError());
-        if (Nnew > 0) {
-            double* src = c->d_lm[c->lmcur];
-            double* dst = c->d_lm[1 - c->lmcur];
-            hipLaunchKernelGGL(k_compact_landmarks, dim3(blocks(Nnew, 64)), dim3(64), 0, c->stream, Nnew, c->Ncap, c->d_keep, c->d_st[c->stcur], src, src + 4 * (size_t)c->Ncap,
-                               c->d_st[1 - c->stcur], dst, dst + 4 * (size_t)c->Ncap);
-            HIPCHK(hipGetLastError());
-        }
+        std::vector<int> renum(c->pend_var.size(), -1);
+        std::vector<double> np, nv;
+        for (int& mo : newmap)
+            if (mo < 0) {
+                const int t = -mo - 1;
+                renum[t] = (int)nv.size();
+                np.insert(np.end(), c->pend_p.begin() + 3 * t, c->pend_p.begin() + 3 * t + 3);
+                nv.push_back(c->pend_var[t]);
+                mo = -(renum[t] + 1);
+            }
+        c->pend_p.swap(np);
+        c->pend_var.swap(nv);
     }
-    c->cur = 1 - c->cur;
-    c->lmcur = 1 - c->lmcur;
-    c->stcur = 1 - c->stcur;
-    c->ids = newids;
+    c->pend_map.swap(newmap);
+    const int Nnew = (int)newids.size();
+    if (c->est_valid) {
+        std::vector<double> e(4 * (size_t)Nnew);
+        for (int pl = 0; pl < 4; ++pl) {
+            int w = 0;
+            for (int i = 0; i < N; ++i)
+                if (!drop[i])
+                    e[(size_t)pl * Nnew + w++] = c->est_cache[(size_t)pl * N + i];
+        }
+        c->est_cache.swap(e);
+    }
+    c->ids.swap(newids);
     c->N = Nnew;
     ++c->lm_gen;
-    c->est_valid = false;
     c->meas_valid = false;
     return 0;
 }
 
 int eqf_remove_invalid_landmarks(eqf_ctx* c) {
+    HP_SCOPE("abi.remove_invalid");
     if (!c)
         return EQF_E_BAD_ARG;
     if (c->N == 0)
@@ -1140,7 +1232,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
 int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
     if (!c || !imu13 || !Qdiag12 || !Pdiag8)
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     int rc = upload_common(c, imu13);
     if (rc)
         return rc;
@@ -1273,7 +1365,7 @@ int eqf_integrate_riccati_accurate(eqf_ctx* c, const double* imu13, double dt, c
         return EQF_E_BAD_ARG;
     if (c->sig32)
         return EQF_E_UNSUPPORTED; // the float store exists for the structured fast path only
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
     if (!c->d_Ebuf) {
         HIPCHK(hipMalloc(&c->d_Ebuf, sizeof(double) * (EXPM_SMAX + 2) * 21 * 33));
@@ -1359,7 +1451,7 @@ int eqf_integrate_riccati_discrete(eqf_ctx* c, const double* imu13, double dt, c
         return EQF_E_BAD_ARG;
     if (c->sig32 || c->chart == EQVIO_COORD_NORMAL)
         return EQF_E_UNSUPPORTED; // float store: structured fast path only; Normal chart: its input matrix would need M B_e as a third dense term
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
     if (!c->d_F)
         HIPCHK(hipMalloc(&c->d_F, bytes));
@@ -1503,7 +1595,7 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
         return EQF_E_BAD_ARG;
     if (k == 0)
         return 0;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     c->est_valid = false;
     c->meas_valid = false;
     int done = 0;
@@ -1523,9 +1615,10 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
 static int stage_prepare(eqf_ctx* c);
 int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, const double* Qdiag12, const double* Pdiag8, const double* imu13_k, const double* dt_k,
                        int k, int discreteLift) {
+    HP_SCOPE("abi.propagate_fast");
     if (!c || !imu13_mean || !Qdiag12 || !Pdiag8 || k < 0 || (k > 0 && (!imu13_k || !dt_k)))
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     ++c->trace_frame; // EQF_OPT_TRACE: a frame starts here
     host_stamp(c, TH_PROP_ENTRY);
     // 1. A / B terms at the CURRENT X (before the observer steps move it): integrateRiccatiStateFast uses X as it is
@@ -1692,6 +1785,7 @@ static const double* pack_by_landmark(eqf_ctx* c, const int* measof, const doubl
 static int fit_measurement(eqf_ctx* c, int M) { return M > c->Ncap ? grow_capacity(c, std::max(M, 2 * c->Ncap)) : 0; }
 
 static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, int* lmidx, int* measof) {
+    HP_SCOPE("abi.map_measurement");
     // Consecutive frames usually measure the same ids: the previous mapping (still in the pinned packet, which only this function
     // writes) is reused when ids and landmark set are unchanged.
     if (c->map_gen == c->lm_gen && c->map_N == c->N && (int)c->map_ids.size() == M && lmidx == c->h_lmidx && (M == 0 || std::memcmp(ids, c->map_ids.data(), sizeof(int) * M) == 0) &&
@@ -1728,7 +1822,7 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     const int N = c->N;
     if (N == 0)
         return 0;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     { int _r = fit_measurement(c, M); if (_r) return _r; }
     c->staged_valid = c->stage_pending = c->stage_requested = false; // the pinned measurement packet is about to be rewritten
     if (c->busy_meas) {
@@ -1752,7 +1846,7 @@ int eqf_outlier_stats(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         c->busy_meas = true;
         LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
                   (const TS*)c->sigma(), c->h_res, 1, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, use_door ? c->d_door : nullptr, c->h_door, door_seq, 0.0, 0.0,
-                  (int*)nullptr, 0);
+                  (int*)nullptr, 0, (double*)nullptr);
         HIPCHK(hipGetLastError());
     }
     {
@@ -1804,6 +1898,7 @@ static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_s
 }
 static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq,
                               const MeasFuse* fuse = nullptr) {
+    HP_SCOPE("abi.launch_update_tail");
     const int n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
     int rc = 0;
@@ -1879,6 +1974,7 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
 // Host part after the wait: the lift kernel wrote Gamma's sensor part, the new estimates / invalid flags (4N) and the status
 // flags straight into the pinned result packet; the sensor part of Delta is lifted here.
 static int finish_update(eqf_ctx* c, int discreteCorr) {
+    HP_SCOPE("abi.finish_update");
     const int N = c->N, n = c->n();
     c->h_flags[0] = c->h_resflags[0];
     c->h_flags[1] = c->h_resflags[1];
@@ -1952,7 +2048,7 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
         return 0; // VIO_eqf.cpp:108-109
     if (M > c->N)
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     const bool reuse = c->meas_valid && c->meas_star == (useEqv ? 1 : 0) && (int)c->meas_ids.size() == M && std::equal(ids, ids + M, c->meas_ids.begin()) &&
                        std::memcmp(c->h_y, y, sizeof(double) * 2 * M) == 0;
     int rc = 0;
@@ -1981,6 +2077,7 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
 
 // See include/eqf_hip.h. Optional hint ahead of the propagation call of the same frame.
 int eqf_stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M) {
+    HP_SCOPE("abi.stage_measurement");
     if (!c || M < 0 || (M > 0 && (!ids || !y)))
         return EQF_E_BAD_ARG;
     c->stage_requested = c->stage_pending = c->staged_valid = false;
@@ -2024,8 +2121,10 @@ static int stage_prepare(eqf_ctx* c) {
 
 // See include/eqf_hip.h. Statistics and update queued back to back; the statistics kernel cancels the tail on the device if
 // the host has an outlier decision to make.
-int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double thrAbs, double thrProb, double meas_var, int useEqv,
-                          int discreteCorr, double* absErr, double* probErr, double* depth2, int* updated) {
+// max_outliers < 0: the caller decides about outliers itself (eqf_stats_then_update); >= 0: eqf_stats_select_update
+static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double thrAbs, double thrProb, double meas_var, int useEqv,
+                             int discreteCorr, double* absErr, double* probErr, double* depth2, int* updated, int max_outliers, int* removed_idx, int* n_removed) {
+    HP_SCOPE("abi.stats_then_update");
     if (!c || !cam || !updated || M <= 0 || !ids || !y || !camera_ok(cam))
         return EQF_E_BAD_ARG;
     ++c->spec_calls;
@@ -2035,7 +2134,7 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
         *updated = -1; // not applicable (a landmark has to be added first)
         return 0;
     }
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     host_stamp(c, TH_TAIL_ENTRY);
     { int _r = join_observer(c); if (_r) return _r; } // before the flags below are evaluated, as in eqf_outlier_stats: a stand-alone observer call does not cost the frame its doorbell
     // speculation needs the doorbell-free conditions of both waits and the equivariant-output cache of the statistics kernel
@@ -2083,12 +2182,52 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     c->meas_star = useEqv ? 1 : 0;
     c->meas_ids.assign(ids, ids + M);
     c->busy_meas = true;
+    if (!speculate && max_outliers >= 0 && N <= SEL_MAXN && !c->opt_fused) {
+        // Outlier candidates frame after frame (speculation has backed off): statistics, the outlier decision (k_select_outliers: the discarded
+        // landmarks' measurements are masked out of C) and the whole update queued at once, ONE host wait. The discarded landmarks leave the
+        // state after the update (an unmeasured landmark can be marginalised before or after it).
+        {
+            KTimer t(c, KN_STATS);
+            LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(),
+                      c->Qa(), (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, (int*)nullptr, c->h_door, seq, thrAbs, thrProb,
+                      (int*)nullptr, seq, c->d_stats);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_select_outliers, dim3(1), dim3(256), 0, c->stream, N, c->Ncap, M, c->d_stats, thrAbs, thrProb, max_outliers, c->d_lmidx, c->d_C, c->d_ytil, c->h_sel);
+            HIPCHK(hipGetLastError());
+        }
+        c->meas_valid = false;
+        rc = launch_update_tail(c, M, meas_var, discreteCorr, nullptr, 0, use_door, seq, nullptr);
+        if (rc)
+            return rc;
+        host_stamp(c, TH_TAIL_OUT);
+        rc = use_door ? door_wait(c, 1, seq) : sync_ctx(c);
+        if (rc)
+            return rc;
+        copy_stats();
+        ++c->sel_frames;
+        if (c->h_sel[c->Ncap] == 0) // a frame without an outlier candidate ends the back-off
+            c->spec_backoff = c->spec_backoff_len = 0;
+        *updated = 1;
+        rc = finish_update(c, discreteCorr);
+        if (rc)
+            return rc;
+        std::vector<int> idx;
+        for (int i = 0; i < N; ++i)
+            if (c->h_sel[i])
+                idx.push_back(i);
+        if (n_removed)
+            *n_removed = (int)idx.size();
+        if (removed_idx)
+            std::copy(idx.begin(), idx.end(), removed_idx);
+        c->sel_discarded += (long)idx.size();
+        return idx.empty() ? 0 : eqf_remove_landmarks(c, idx.data(), (int)idx.size());
+    }
     if (!speculate) { // plain statistics call: the caller decides and calls eqf_vision_update
         {
             KTimer t(c, KN_STATS);
             LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(),
                       c->Qa(), (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, use_door ? c->d_door : nullptr, c->h_door, seq, thrAbs,
-                      thrProb, (int*)nullptr, seq);
+                      thrProb, (int*)nullptr, seq, (double*)nullptr);
             HIPCHK(hipGetLastError());
         }
         c->meas_valid = true;
@@ -2140,6 +2279,29 @@ int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, c
     return finish_update(c, discreteCorr);
 }
 
+int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double thrAbs, double thrProb, double meas_var, int useEqv,
+                          int discreteCorr, double* absErr, double* probErr, double* depth2, int* updated) {
+    return stats_then_update(c, cam, ids, y, M, thrAbs, thrProb, meas_var, useEqv, discreteCorr, absErr, probErr, depth2, updated, -1, nullptr, nullptr);
+}
+int eqf_stats_select_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double thrAbs, double thrProb, int max_outliers, double meas_var,
+                            int useEqv, int discreteCorr, double* absErr, double* probErr, double* depth2, int* updated, int* removed_idx, int* n_removed) {
+    if (max_outliers < 0 || !n_removed)
+        return EQF_E_BAD_ARG;
+    *n_removed = 0;
+    return stats_then_update(c, cam, ids, y, M, thrAbs, thrProb, meas_var, useEqv, discreteCorr, absErr, probErr, depth2, updated, max_outliers, removed_idx, n_removed);
+}
+int eqf_selection_stats(eqf_ctx* c, long* frames, long* discarded, int reset) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    if (frames)
+        *frames = c->sel_frames;
+    if (discarded)
+        *discarded = c->sel_discarded;
+    if (reset)
+        c->sel_frames = c->sel_discarded = 0;
+    return 0;
+}
+
 int eqf_last_gamma(eqf_ctx* c, double* out, int cap) {
     if (!c || !out)
         return EQF_E_BAD_ARG;
@@ -2153,7 +2315,7 @@ int eqf_last_gamma(eqf_ctx* c, double* out, int cap) {
 int eqf_compute_nees(eqf_ctx* c, const double* ts, const int* tids, const double* tp, int ntrue, double* nees) {
     if (!c || !ts || !nees || ntrue < 0 || (ntrue > 0 && (!tids || !tp)))
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     const int N = c->N, n = c->n();
     const int np = n + (n & 1); // even dimension for the 2x2-pivot elimination: pad with a unit diagonal entry
     // landmark group elements from the device
@@ -2287,7 +2449,7 @@ int eqf_nees_lu_fallbacks(eqf_ctx* c, long* count) {
 int eqf_debug_matrices_AB(eqf_ctx* c, const double* imu13, double* A_out, double* B_out) {
     if (!c || !imu13)
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     { int _r = sync_ctx(c); if (_r) return _r; }
     int rc = upload_common(c, imu13);
     if (rc)
@@ -2396,7 +2558,7 @@ int eqf_debug_matrices_AB(eqf_ctx* c, const double* imu13, double* A_out, double
 int eqf_debug_matrix_C(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, int useEqv, double* C_out, double* ytilde_out) {
     if (!c || !cam || M <= 0 || !ids || !y || M > c->N)
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     int rc = stage_measurement(c, ids, y, M);
     if (rc)
         return rc;
@@ -2423,7 +2585,7 @@ int eqf_debug_matrix_C(eqf_ctx* c, const eqvio_camera* cam, const int* ids, cons
 int eqf_mfma_f64_peak(eqf_ctx* c, double* tflops) {
     if (!c || !tflops)
         return EQF_E_BAD_ARG;
-    HIPCHK(hipSetDevice(c->device));
+    { int _e = enter(c); if (_e) return _e; }
     const int nblk = 256 * 8, iters = 4096;
     double* d_out = nullptr;
     HIPCHK(hipMalloc(&d_out, sizeof(double) * nblk * 256));

@@ -820,15 +820,83 @@ __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, i
                                                       const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
                                                       double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags,
                                                       int* __restrict__ door_count, int* __restrict__ door_host, int door_seq, double thrAbs, double thrProb,
-                                                      int* __restrict__ spec, int spec_seq) {
+                                                      int* __restrict__ spec, int spec_seq, double* __restrict__ stats_dev) {
     double abs_err = -1.0, prob_err = -1.0; // stay negative for lanes without a measured landmark
     outlier_stats_body<TS>(N, Ncap, ld, chart, cam, ylm, q0, Qq, Qa, Sig, out, star, C, ytil, lmidx_dev, flags, abs_err, prob_err);
+    if (stats_dev) { // k_select_outliers, the next kernel of the stream, decides on the device: keep a copy of the two errors in HBM
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < N) {
+            stats_dev[i] = abs_err;
+            stats_dev[N + i] = prob_err;
+        }
+    }
     // Speculative frame tail (eqf_stats_then_update): the update kernels are already queued behind this one. If any measured
     // landmark is an outlier candidate (VIOFilter.cpp:316-330: absErr > thrAbs or probErr > thrProb) the host has a decision
     // to make, so the queued kernels must not run: they compare this word with their sequence number and return at once.
     if (spec && abs_err >= 0.0 && (abs_err > thrAbs || prob_err > thrProb)) // the comparisons of VIOFilter.cpp:316-330 (NaN: false)
         *spec = spec_seq;
     ring_doorbell(door_count, door_host, door_seq);
+}
+
+// VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) on the device, so that a frame with outlier candidates needs no host round trip
+// between the statistics and the update: candidates are the measured landmarks with absErr > thrAbs, else probErr > thrProb; they are ranked
+// absolute outliers first (largest absErr first), then probabilistic ones (largest probErr first), and the first max_outliers of them are
+// discarded. A discarded landmark's measurement is taken out of the update by zeroing its C block and its residual (its two columns of Z
+// become (0, R_jj, 0): decoupled, W = 0 there), which leaves every other state exactly where the reference's "erase, then update" puts
+// it: an unmeasured landmark can be marginalised before or after the update. The host removes the landmark rows after the update, from
+// the list in `removed_host` (pinned: [0, N) flags, [Ncap] count of candidates, [Ncap + 1] count of discarded).
+// One workgroup; sel (LDS) holds the rank keys of up to SEL_MAXN landmarks.
+constexpr int SEL_MAXN = 2048;
+__global__ void __launch_bounds__(256) k_select_outliers(int N, int Ncap, int M, const double* __restrict__ stats_dev, double thrAbs, double thrProb, int max_outliers,
+                                                         const int* __restrict__ lmidx_dev, double* __restrict__ C, double* __restrict__ ytil,
+                                                         int* __restrict__ removed_host) {
+    __shared__ double s_val[SEL_MAXN];
+    __shared__ signed char s_kind[SEL_MAXN]; // 0: no candidate, 1: probabilistic, 2: absolute
+    __shared__ unsigned char s_rm[SEL_MAXN];
+    __shared__ int s_cnt[2];
+    const int tid = threadIdx.x;
+    if (tid < 2)
+        s_cnt[tid] = 0;
+    for (int i = tid; i < N; i += 256) {
+        const double a = stats_dev[i], p = stats_dev[N + i];
+        const bool measured = a >= 0.0;
+        const bool isabs = measured && a > thrAbs; // the comparisons of VIOFilter.cpp:316, 330 (NaN: false)
+        const bool isprob = measured && !isabs && p > thrProb;
+        s_kind[i] = isabs ? 2 : (isprob ? 1 : 0);
+        s_val[i] = isabs ? a : p;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        int rank = 0;
+        const int ki = s_kind[i];
+        const double vi = s_val[i];
+        if (ki) {
+            for (int j = 0; j < N; ++j) {
+                const int kj = s_kind[j];
+                rank += (kj > ki) || (kj == ki && (s_val[j] > vi || (s_val[j] == vi && j < i)));
+            }
+            atomicAdd(&s_cnt[0], 1);
+        }
+        const bool rm = ki && rank < max_outliers;
+        s_rm[i] = rm;
+        removed_host[i] = rm ? 1 : 0;
+        if (rm)
+            atomicAdd(&s_cnt[1], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        removed_host[Ncap] = s_cnt[0];
+        removed_host[Ncap + 1] = s_cnt[1];
+    }
+    for (int j = tid; j < M; j += 256) {
+        if (s_rm[lmidx_dev[j]]) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                C[e * Ncap + j] = 0.0;
+            ytil[2 * j] = 0.0;
+            ytil[2 * j + 1] = 0.0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2115,6 +2183,65 @@ __global__ void k_compact_landmarks(int Nnew, int Ncap, const int* __restrict__ 
     Qao[i] = Qai[o];
     for (int c = CC_OFF; c < CC_OFF + CC_PLANES; ++c) // chart constants travel with their landmark
         q0o[(size_t)c * Ncap + i] = q0i[(size_t)c * Ncap + o];
+}
+// Landmark bookkeeping of a frame in ONE pass: removeLandmarkByIndex (VIO_eqf.cpp:172-178) and addNewLandmarks (:225-245) are recorded by the
+// host as a map new landmark -> old landmark (>= 0) or -(t + 1) for the t-th appended landmark, and applied here when the state is next needed:
+// Sigma_new = Sigma_old[map, map] with zero strips and var_t on the diagonal of appended landmarks, the landmark planes gathered / initialised
+// (Q = identity, chart constants of the new origin point), everything written to the other buffers. Pure data movement: the same bits as
+// one k_compact_sigma / k_compact_landmarks / k_scatter_landmarks / k_append_sigma sequence per call.
+// grid: (ceil(nnew / 256), nnew + ceil(Nnew / 256)); rows blockIdx.y >= nnew handle the landmark planes.
+template <typename TS>
+__global__ void __launch_bounds__(256) k_reshape(int Nnew, int Ncap, int ld, const int* __restrict__ map, const double* __restrict__ newp, const double* __restrict__ newvar,
+                                                 const TS* __restrict__ Sin, TS* __restrict__ Sout, const double* __restrict__ st_in, const double* __restrict__ lm_in,
+                                                 double* __restrict__ st_out, double* __restrict__ lm_out) {
+    const int nnew = 21 + 3 * Nnew;
+    if ((int)blockIdx.y < nnew) {
+        const int r = blockIdx.x * blockDim.x + threadIdx.x;
+        const int c = blockIdx.y;
+        if (r >= nnew)
+            return;
+        const int mr = r < 21 ? 0 : map[(r - 21) / 3], mc = c < 21 ? 0 : map[(c - 21) / 3];
+        TS v;
+        if (mr >= 0 && mc >= 0) {
+            const int ro = r < 21 ? r : 21 + 3 * mr + (r - 21) % 3;
+            const int co = c < 21 ? c : 21 + 3 * mc + (c - 21) % 3;
+            v = Sin[ro + (size_t)co * ld];
+        } else
+            v = (TS)((r == c) ? newvar[-mr - 1] : 0.0);
+        Sout[r + (size_t)c * ld] = v;
+        return;
+    }
+    if (blockIdx.x != 0)
+        return;
+    const int i = ((int)blockIdx.y - nnew) * 256 + threadIdx.x;
+    if (i >= Nnew)
+        return;
+    const int o = map[i];
+    double* Qqo = lm_out;
+    double* Qao = lm_out + 4 * (size_t)Ncap;
+    if (o >= 0) {
+        for (int c = 0; c < CC_OFF + CC_PLANES; ++c) // origin point and its chart constants travel with the landmark
+            if (c < 3 || c >= CC_OFF)
+                st_out[(size_t)c * Ncap + i] = st_in[(size_t)c * Ncap + o];
+        for (int c = 0; c < 4; ++c)
+            Qqo[c * Ncap + i] = lm_in[c * Ncap + o];
+        Qao[i] = lm_in[4 * (size_t)Ncap + o];
+    } else {
+        const int t = -o - 1;
+        const V3 p{newp[3 * t], newp[3 * t + 1], newp[3 * t + 2]};
+        st_out[i] = p.x;
+        st_out[Ncap + i] = p.y;
+        st_out[2 * Ncap + i] = p.z;
+        double* cc = st_out + (size_t)CC_OFF * Ncap;
+        st_plane9(cc, Ncap, i, CC_E2I, conv_euc2ind(p));
+        st_plane9(cc, Ncap, i, CC_I2E, conv_ind2euc(p));
+        st_plane9(cc, Ncap, i, CC_R0, ind2euc_r0(p));
+        Qqo[i] = 1.0;
+        Qqo[Ncap + i] = 0.0;
+        Qqo[2 * Ncap + i] = 0.0;
+        Qqo[3 * Ncap + i] = 0.0;
+        Qao[i] = 1.0;
+    }
 }
 // append: zero the new strips, put var on the new diagonal (addNewLandmarks, VIO_eqf.cpp:239-244)
 template <typename TS>

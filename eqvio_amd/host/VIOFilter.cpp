@@ -1,6 +1,7 @@
 // Host-side control logic of the filter (mirror of src/VIOFilter.cpp and the VIO_eqf bookkeeping of
 // src/mathematical/VIO_eqf.cpp); every matrix operation goes through the C-ABI of include/eqf_hip.h.
 #include "VIOFilter.hpp"
+#include "../csrc/host_prof.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -36,12 +37,21 @@ std::vector<int> VIOState::getIds() const {
     std::transform(cameraLandmarks.begin(), cameraLandmarks.end(), ids.begin(), [](const Landmark& lm) { return lm.id; });
     return ids;
 }
-std::vector<int> VisionMeasurement::getIds() const {
-    std::vector<int> ids;
-    ids.reserve(camCoordinates.size());
-    for (const auto& kv : camCoordinates)
-        ids.push_back(kv.first);
-    return ids;
+std::vector<int> VisionMeasurement::getIds() const { return flatIds(); }
+void VisionMeasurement::refreshFlat() const {
+    const size_t n = camCoordinates.size();
+    if (flatN_ == n && (n == 0 || (flatIds_.front() == camCoordinates.begin()->first && flatIds_.back() == camCoordinates.rbegin()->first)))
+        return;
+    flatIds_.clear();
+    flatY_.clear();
+    flatIds_.reserve(n);
+    flatY_.reserve(2 * n);
+    for (const auto& kv : camCoordinates) {
+        flatIds_.push_back(kv.first);
+        flatY_.push_back(kv.second[0]);
+        flatY_.push_back(kv.second[1]);
+    }
+    flatN_ = n;
 }
 IMUVelocity IMUVelocity::operator+(const IMUVelocity& o) const { // src/mathematical/IMUVelocity.cpp:42-50
     IMUVelocity r;
@@ -99,15 +109,8 @@ VIOSensorState unpackSensor(const double* d) {
     return s;
 }
 void flatten(const VisionMeasurement& m, std::vector<int>& ids, std::vector<double>& y) {
-    ids.clear();
-    y.clear();
-    ids.reserve(m.camCoordinates.size());
-    y.reserve(2 * m.camCoordinates.size());
-    for (const auto& kv : m.camCoordinates) {
-        ids.push_back(kv.first);
-        y.push_back(kv.second[0]);
-        y.push_back(kv.second[1]);
-    }
+    ids = m.flatIds();
+    y = m.flatY();
 }
 } // namespace
 
@@ -351,7 +354,7 @@ void VIO_eqf::stageMeasurement(const VisionMeasurement& m) {
     check(eqf_stage_measurement(ctx, ids.data(), y.data(), (int)ids.size()), "eqf_stage_measurement");
 }
 int VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double thrProb, double var, bool useEqv, bool discreteCorrection, std::vector<double>& absErr,
-                              std::vector<double>& probErr, std::vector<double>& depth2) {
+                              std::vector<double>& probErr, std::vector<double>& depth2, long maxOutliers) {
     const int N = numLandmarks();
     absErr.assign(N, -1.0);
     probErr.assign(N, -1.0);
@@ -360,9 +363,28 @@ int VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double t
     std::vector<double> y;
     flatten(m, ids, y);
     int updated = 0;
-    check(eqf_stats_then_update(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), thrAbs, thrProb, var, useEqv ? 1 : 0, discreteCorrection ? 1 : 0, absErr.data(),
-                                probErr.data(), depth2.data(), &updated),
-          "eqf_stats_then_update");
+    if (maxOutliers < 0) {
+        check(eqf_stats_then_update(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), thrAbs, thrProb, var, useEqv ? 1 : 0, discreteCorrection ? 1 : 0,
+                                    absErr.data(), probErr.data(), depth2.data(), &updated),
+              "eqf_stats_then_update");
+        return updated;
+    }
+    // removeOutliers' decision may be taken on the device (eqf_hip.h): the landmarks it discarded are gone from the state when the call returns
+    std::vector<int> removed(N + 1);
+    int nRemoved = 0;
+    check(eqf_stats_select_update(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), thrAbs, thrProb, (int)std::min<long>(maxOutliers, 1 << 30), var, useEqv ? 1 : 0,
+                                  discreteCorrection ? 1 : 0, absErr.data(), probErr.data(), depth2.data(), &updated, removed.data(), &nRemoved),
+          "eqf_stats_select_update");
+    if (nRemoved > 0) {
+        std::vector<char> drop(ids_.size(), 0);
+        for (int t = 0; t < nRemoved; ++t)
+            drop[removed[t]] = 1;
+        std::vector<int> kept;
+        for (size_t i = 0; i < ids_.size(); ++i)
+            if (!drop[i])
+                kept.push_back(ids_[i]);
+        ids_ = kept;
+    }
     return updated;
 }
 
@@ -560,27 +582,38 @@ bool VIOFilter::integrateUpToTime(const double& newTime) { // :134-192
     return true;
 }
 void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :194-241
+    HP_SCOPE("processVisionData");
     loopTimer.startTiming("propagation");
     // The measurement is in hand before the propagation (VIOFilter.cpp:194-196): hand it to the device now, so that it travels to
     // HBM inside the propagation kernel instead of across PCIe in the update's first kernel (a hint: ignored if an id is unknown).
-    if (initialisedFlag && settings->fastRiccati)
+    if (initialisedFlag && settings->fastRiccati) {
+        HP_SCOPE("pv.stageMeasurement");
         filterState.stageMeasurement(measurement);
-    const bool integrationFlag = integrateUpToTime(measurement.stamp);
+    }
+    bool integrationFlag;
+    {
+        HP_SCOPE("pv.integrateUpToTime");
+        integrationFlag = integrateUpToTime(measurement.stamp);
+    }
     if (!integrationFlag || !initialisedFlag)
         return;
     loopTimer.endTiming("propagation");
 
     loopTimer.startTiming("preprocessing");
-    if (settings->removeLostLandmarks)
+    if (settings->removeLostLandmarks) {
+        HP_SCOPE("pv.removeOldLandmarks");
         removeOldLandmarks(measurement.getIds());
+    }
     // With a fixed initial depth (both shipped dataset configurations) a new landmark depends on its pixel only, and the outlier test
     // never looks at it (it is not in the state yet in the reference's order; here its residual is zero by construction): appending the
     // new landmarks BEFORE the test instead of after it gives the same state - removing outliers afterwards only compacts the older rows,
     // the new rows keep their relative order at the end - and lets a frame with landmark turnover take the one-round-trip path too
     // (statistics + update queued back to back) instead of statistics -> host -> append -> update.
     const bool earlyAdd = !settings->useMedianDepth;
-    if (earlyAdd)
+    if (earlyAdd) {
+        HP_SCOPE("pv.addNewLandmarks");
         addNewLandmarks(measurement, nullptr);
+    }
     std::vector<double> depth2;
     // Every measured id already in the state (no landmark to add) and something to update: queue the outlier statistics and
     // the update back to back (eqf_stats_then_update). If a measured landmark exceeds a threshold the device cancels the
@@ -590,8 +623,12 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     bool haveStats = false;
     std::vector<double> absErr, probErr;
     if (!measurement.camCoordinates.empty() && filterState.numLandmarks() > 0) {
+        // With the new landmarks already in the state (earlyAdd) nothing of the frame needs the host between the statistics and the update, so
+        // the outlier decision itself may run on the device (maxOutliers as in removeOutliers, VIOFilter.cpp:305); otherwise the decision stays here.
+        HP_SCOPE("pv.statsThenUpdate");
+        const long maxOutliers = earlyAdd ? (long)(size_t)((1.0 - settings->featureRetention) * measurement.camCoordinates.size()) : -1;
         const int r = filterState.statsThenUpdate(measurement, settings->outlierThresholdAbs, settings->outlierThresholdProb, settings->constructOutputGainVar(),
-                                                  settings->useEquivariantOutput, settings->useDiscreteInnovationLift, absErr, probErr, depth2);
+                                                  settings->useEquivariantOutput, settings->useDiscreteInnovationLift, absErr, probErr, depth2, maxOutliers);
         if (r == 1) {
             loopTimer.endTiming("preprocessing");
             loopTimer.startTiming("correction");
@@ -671,10 +708,12 @@ void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std:
     std::vector<Landmark> newLandmarks;
     std::vector<int> have = filterState.ids(); // sorted copy: O(M log N) membership instead of the reference's O(M N) scan
     std::sort(have.begin(), have.end());
-    for (const auto& cc : measurement.camCoordinates) {
-        const int& ccId = cc.first;
+    const std::vector<int>& mids = measurement.flatIds();
+    const std::vector<double>& my = measurement.flatY();
+    for (size_t j = 0; j < mids.size(); ++j) {
+        const int ccId = mids[j];
         if (!std::binary_search(have.begin(), have.end(), ccId)) {
-            const V3 bearing = measurement.cameraPtr->undistortPoint(cc.second[0], cc.second[1]);
+            const V3 bearing = measurement.cameraPtr->undistortPoint(my[2 * j], my[2 * j + 1]);
             newLandmarks.emplace_back(Landmark{bearing, ccId});
         }
     }

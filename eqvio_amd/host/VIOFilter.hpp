@@ -114,6 +114,18 @@ struct VisionMeasurement {
     std::map<int, std::array<double, 2>> camCoordinates; // ascending id == the reference's row order
     GICameraPtr cameraPtr;
     std::vector<int> getIds() const;
+    // The same measurement as two flat arrays (ids ascending, pixels u0 v0 u1 v1 ...), the form the C-ABI takes. Built from the map on first use
+    // and rebuilt whenever the map's size or end points differ from what was flattened; code that edits pixel values IN PLACE calls
+    // invalidateFlat(). The replay path builds it once per frame, before the timed region, next to the map itself (eqvio_frames_create).
+    const std::vector<int>& flatIds() const { return refreshFlat(), flatIds_; }
+    const std::vector<double>& flatY() const { return refreshFlat(), flatY_; }
+    void invalidateFlat() const { flatIds_.clear(), flatY_.clear(), flatN_ = (size_t)-1; }
+
+  private:
+    void refreshFlat() const;
+    mutable std::vector<int> flatIds_;
+    mutable std::vector<double> flatY_;
+    mutable size_t flatN_ = (size_t)-1;
 };
 
 enum class CoordinateChoice { Euclidean = 0, InvDepth = 1, Normal = 2 };
@@ -177,7 +189,7 @@ struct VIO_eqf {
     // (a measurement id is not in the state; nothing computed).
     void stageMeasurement(const VisionMeasurement& measurement); // eqf_stage_measurement: hint ahead of the propagation of the same frame
     int statsThenUpdate(const VisionMeasurement& measurement, double thrAbs, double thrProb, double outputGainVar, bool useEquivariantOutput, bool discreteCorrection,
-                         std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2);
+                         std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2, long maxOutliers = -1);
 
   private:
     std::vector<int> ids_;

@@ -44,6 +44,7 @@ VisionMeasurement makeMeasurement(double stamp, const GICameraPtr& cam, const in
     m.cameraPtr = cam;
     for (int i = 0; i < M; ++i)
         m.camCoordinates[ids[i]] = {y[2 * i], y[2 * i + 1]};
+    m.flatIds(); // flat form next to the map, built here with it
     return m;
 }
 GICameraPtr makeCamera(const eqvio_camera* c) {

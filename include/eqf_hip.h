@@ -172,6 +172,17 @@ int eqf_stats_then_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids,
  * statistics kernel (every measured id already a landmark); of those, tails the device cancelled because a landmark exceeded an outlier
  * threshold (the caller then takes the two-round-trip path: removeOutliers / addNewLandmarks / eqf_vision_update). */
 int eqf_speculation_stats(eqf_ctx* ctx, long* calls, long* queued, long* cancelled, int reset);
+/* eqf_stats_then_update with VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) made on the device where that saves the frame a host round trip:
+ * while the speculative tail keeps getting cancelled (outlier candidates frame after frame, as with the shipped thresholds) the call queues the statistics,
+ * the decision (candidates ranked absolute outliers first by absErr, then probabilistic ones by probErr, the first max_outliers = (size_t)((1 - featureRetention)
+ * * #features) of them discarded) and the update at once, with the discarded landmarks' measurements masked out; it then removes the discarded landmarks
+ * from the state (removeLandmarkById) and returns their former state indices in removed_idx (capacity: the landmark count before the call). *updated as for
+ * eqf_stats_then_update; when it is 0 the caller runs removeOutliers itself as before. Same results as the reference's erase-then-update order: a landmark
+ * without a measurement can be marginalised before or after the update. */
+int eqf_stats_select_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y_px, int M, double thrAbs, double thrProb, int max_outliers, double meas_var,
+                            int useEquivariantOutput, int discreteCorrection, double* absErr, double* probErr, double* depth2, int* updated, int* removed_idx, int* n_removed);
+/* frames that took the device-side decision, landmarks it discarded */
+int eqf_selection_stats(eqf_ctx* ctx, long* frames, long* discarded, int reset);
 
 /* Gamma of the last update (n doubles) — for parity checks. */
 int eqf_last_gamma(eqf_ctx* ctx, double* out, int cap);

@@ -115,6 +115,43 @@ def test_outlier_rejection_decisions_match():
 
 
 @pytest.mark.parametrize("chart", [COORD_EUCLIDEAN, COORD_INVDEPTH])
+def test_outlier_decision_on_the_device_matches_the_reference_order(chart):
+    """With a fixed initial depth (both shipped dataset configurations) nothing of a frame needs the host between the outlier statistics and the
+    update, and once the speculative tail has been cancelled (an outlier candidate in the frame) the filter queues statistics -> decision on the
+    device (k_select_outliers: VIOFilter.cpp:304-364, the cap of (1 - featureRetention) * #features included) -> update with the discarded
+    landmarks' measurements masked -> removal of those landmarks, with ONE host wait per frame. The reference erases first and updates then;
+    both orders give the same state (an unmeasured landmark can be marginalised before or after the update): frame by frame against the oracle,
+    gross outliers in every frame, features entering and leaving, retention 0.9 so that the cap decides in some frames."""
+    import ctypes as C
+
+    from eqvio_amd.capi import load_eqf_lib
+
+    world = SimWorld(seed=17, num_points=1500, max_features=40, trajectory="wave", noise_px=0.4)
+    settings = sim_settings(chart, useMedianDepth=0, outlierThresholdAbs=6.0, outlierThresholdProb=4.0, featureRetention=0.9, initialPointVariance=0.05)
+    ids0, _ = world.vision(0.0)
+    sensor, ids, p = world.true_state(0.0, ids0)
+    orc = OracleFilter(settings, sensor, ids, p, 0.0)
+    flt = VIOFilter(settings, max_landmarks=64, sensor=sensor, ids=ids, p=p, time=0.0)
+    rng = np.random.default_rng(1)
+    capped = 0
+    for f, (imus, stamp, mid, y) in enumerate(world.frames(30)):
+        y = y.copy()
+        n_bad = 2 + (f % 5)  # (1 - 0.9) * 40 = 4: frames with 5 or 6 gross outliers exceed the cap
+        bad = rng.choice(len(mid), n_bad, replace=False)
+        y.reshape(-1, 2)[bad] += rng.normal(size=(n_bad, 2)) * 25.0
+        capped += n_bad > int((1.0 - 0.9) * len(mid))
+        for s in range(len(imus)):
+            orc.process_imu(imus[s])
+            flt.process_imu(imus[s])
+        orc.process_vision(stamp, world.cam, mid, y)
+        flt.process_vision(stamp, world.cam, mid, y)
+        compare(flt, orc)
+    frames, discarded = C.c_long(), C.c_long()
+    assert load_eqf_lib().eqf_selection_stats(flt.core_handle(), C.byref(frames), C.byref(discarded), 0) == 0
+    assert frames.value >= 20 and discarded.value >= 40 and capped >= 5  # the device took the decision in (almost) every frame
+
+
+@pytest.mark.parametrize("chart", [COORD_EUCLIDEAN, COORD_INVDEPTH])
 def test_template_config_accurate_riccati(chart):
     """20 features, the template's fastRiccati: false (EQVIO_config_template.yaml eqf block):
     one accurate Riccati step per IMU sample, interleaved with the observer steps (VIOFilter.cpp:128-139)."""
