@@ -200,6 +200,8 @@ def load_eqf_lib():
         "eqf_host_wait_stats": (C.c_int, [vp, C.POINTER(C.c_long), c_double_p, C.c_int]),
         "eqf_stats_then_update": (C.c_int, [vp, C.POINTER(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p,
                                   c_double_p, c_int_p]),
+        "eqf_stats_select_update": (C.c_int, [vp, C.POINTER(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, c_double_p,
+                                    c_double_p, c_double_p, c_int_p, c_int_p, c_int_p]),
         "eqf_vision_update": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_int]),
         "eqf_last_gamma": (C.c_int, [vp, c_double_p, C.c_int]),
         "eqf_compute_nees": (C.c_int, [vp, c_double_p, c_int_p, c_double_p, C.c_int, c_double_p]),
