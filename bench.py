@@ -230,7 +230,18 @@ def init_control_group(world_size):
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo")
+    # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."): keep the process's stdout to the one JSON line
+    sys.stdout.flush()
+    saved, null = os.dup(1), os.open(os.devnull, os.O_WRONLY)
+    os.dup2(null, 1)
+    try:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(null)
     return dist
 
 
@@ -269,6 +280,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("EQVIO_BENCH_ONE_DEVICE"):  # test hook: every rank on GPU 0 (rehearsal of the N > 1 launch on a 1-GPU box)
+        local_rank = 0
     backend = HipBackend(local_rank)
     dist = init_control_group(world_size)
     lib = backend.lib
