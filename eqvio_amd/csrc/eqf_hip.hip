@@ -153,7 +153,7 @@ struct eqf_ctx {
     Common* d_common = nullptr;
     ObsStep* d_steps = nullptr;
     double *d_C = nullptr, *d_ytil = nullptr, *d_y = nullptr;
-    int *d_lmidx = nullptr, *d_measof = nullptr, *d_keep = nullptr;
+    int *d_lmidx = nullptr, *d_measof = nullptr;
     double *d_Ebuf = nullptr, *d_Yl = nullptr, *d_Fl = nullptr, *d_PhiB = nullptr; // accurate Riccati (lazily allocated)
     int* d_expinfo = nullptr;
     double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
@@ -165,11 +165,7 @@ struct eqf_ctx {
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int opt_syrk_f32 = 0;                    // EQF_OPT_SYRK_F32
     int* d_perm = nullptr;                   // 2 x (ncap + 2) row permutations of the NEES elimination fallback
-    // landmark bookkeeping staging: a ring of pinned packets, one per eqf_remove_landmarks / eqf_add_landmarks call, so that those calls need not
-    // drain the stream before reusing a buffer (every frame has a host wait behind them; 8 slots cover the <= 4 calls of a frame twice)
-    static constexpr int kRing = 8;
-    int* h_keep_ring = nullptr;    // kRing x Ncap
-    double* h_newp_ring = nullptr; // kRing x 3 Ncap
+    static constexpr int kRing = 8; // pinned packets of the landmark bookkeeping: a ring, so that a flush need not drain the stream before reusing one
     int ring_pos = 0;
     // Deferred landmark bookkeeping: eqf_remove_landmarks / eqf_add_landmarks only record what they do (ids, N and the estimate cache follow at
     // once); flush_reshape applies everything recorded since the last flush with ONE copy + ONE kernel (k_reshape) when the device state is
@@ -599,7 +595,6 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipMalloc(&c->d_y, sizeof(double) * c->mcap));
     HIPCHK(hipMalloc(&c->d_lmidx, sizeof(int) * c->Ncap));
     HIPCHK(hipMalloc(&c->d_measof, sizeof(int) * c->Ncap));
-    HIPCHK(hipMalloc(&c->d_keep, sizeof(int) * c->Ncap));
     HIPCHK(hipMalloc(&c->d_Z, sizeof(double) * (size_t)c->ldz * c->mcap));
     HIPCHK(hipMalloc(&c->d_W, sizeof(double) * (size_t)c->ldz * c->mcap));
     HIPCHK(hipMalloc(&c->d_Linv, sizeof(double) * 2048));
@@ -623,8 +618,6 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     c->hbuf_doubles = (size_t)c->ld * c->ncap; // large enough for a full Sigma transfer
     HIPCHK(hipHostMalloc(&c->h_buf, sizeof(double) * c->hbuf_doubles));
     HIPCHK(hipHostMalloc(&c->h_ibuf, sizeof(int) * 4 * (size_t)c->Ncap));
-    HIPCHK(hipHostMalloc(&c->h_keep_ring, sizeof(int) * eqf_ctx::kRing * (size_t)c->Ncap));
-    HIPCHK(hipHostMalloc(&c->h_newp_ring, sizeof(double) * eqf_ctx::kRing * 3 * (size_t)c->Ncap));
     c->rs_bytes = (sizeof(int) + 4 * sizeof(double)) * (size_t)c->Ncap + 64;
     HIPCHK(hipHostMalloc(&c->h_rs_ring, eqf_ctx::kRing * c->rs_bytes));
     HIPCHK(hipMalloc(&c->d_rs, c->rs_bytes));
@@ -672,7 +665,6 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_y);
     hipFree(c->d_lmidx);
     hipFree(c->d_measof);
-    hipFree(c->d_keep);
     hipFree(c->d_Z);
     hipFree(c->d_W);
     hipFree(c->d_Linv);
@@ -711,8 +703,6 @@ void eqf_destroy(eqf_ctx* c) {
     hipHostFree(c->h_steps);
     hipHostFree(c->h_buf);
     hipHostFree(c->h_ibuf);
-    hipHostFree(c->h_keep_ring);
-    hipHostFree(c->h_newp_ring);
     hipHostFree(c->h_rs_ring);
     hipFree(c->d_rs);
     hipHostFree(c->h_flags);

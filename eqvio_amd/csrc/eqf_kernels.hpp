@@ -2038,8 +2038,6 @@ __global__ void k_gather_landmarks_aos(int N, int Ncap, const double* __restrict
         out[8 * i + 3 + c] = Qq[c * Ncap + i];
     out[8 * i + 7] = Qa[i];
 }
-// removal of landmarks: new index -> old index map `keep` (length Nnew). Sigma_new = Sigma_old[map, map]
-// (removeRows/removeCols, VIO_eqf.cpp:27-45) written to the other buffer.
 // integrateRiccatiStateDiscrete (VIO_eqf.cpp:93-103): A_d = numericalDifferential of a0Discrete (EqFMatrices.cpp:24-41) at 0, central
 // differences with h = cbrt(eps) (Geometry.cpp:25-36). a0Discrete has the arrow structure of A: a landmark's coordinates move only its own
 // three rows; the 21 sensor coordinates move everything. The sensor-level part of the 43 evaluations (nominal + 21 x +-h) is O(1) and done
@@ -2160,35 +2158,11 @@ __global__ void __launch_bounds__(256) k_congruence_normal(int n, int Ncap, int 
     Sout[i + (size_t)j * ld] = (TS)acc;
     Sout[j + (size_t)i * ld] = (TS)acc;
 }
-template <typename TS>
-__global__ void __launch_bounds__(256) k_compact_sigma(int nnew, int ld, const int* __restrict__ keep, const TS* __restrict__ Sin, TS* __restrict__ Sout) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
-    if (r >= nnew)
-        return;
-    const int ro = r < 21 ? r : 21 + 3 * keep[(r - 21) / 3] + (r - 21) % 3;
-    const int co = c < 21 ? c : 21 + 3 * keep[(c - 21) / 3] + (c - 21) % 3;
-    Sout[r + (size_t)c * ld] = Sin[ro + (size_t)co * ld];
-}
-__global__ void k_compact_landmarks(int Nnew, int Ncap, const int* __restrict__ keep, const double* __restrict__ q0i, const double* __restrict__ Qqi,
-                                    const double* __restrict__ Qai, double* __restrict__ q0o, double* __restrict__ Qqo, double* __restrict__ Qao) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Nnew)
-        return;
-    const int o = keep[i];
-    for (int c = 0; c < 3; ++c)
-        q0o[c * Ncap + i] = q0i[c * Ncap + o];
-    for (int c = 0; c < 4; ++c)
-        Qqo[c * Ncap + i] = Qqi[c * Ncap + o];
-    Qao[i] = Qai[o];
-    for (int c = CC_OFF; c < CC_OFF + CC_PLANES; ++c) // chart constants travel with their landmark
-        q0o[(size_t)c * Ncap + i] = q0i[(size_t)c * Ncap + o];
-}
 // Landmark bookkeeping of a frame in ONE pass: removeLandmarkByIndex (VIO_eqf.cpp:172-178) and addNewLandmarks (:225-245) are recorded by the
 // host as a map new landmark -> old landmark (>= 0) or -(t + 1) for the t-th appended landmark, and applied here when the state is next needed:
 // Sigma_new = Sigma_old[map, map] with zero strips and var_t on the diagonal of appended landmarks, the landmark planes gathered / initialised
 // (Q = identity, chart constants of the new origin point), everything written to the other buffers. Pure data movement: the same bits as
-// one k_compact_sigma / k_compact_landmarks / k_scatter_landmarks / k_append_sigma sequence per call.
+// one gather / scatter / append pass per call would give.
 // grid: (ceil(nnew / 256), nnew + ceil(Nnew / 256)); rows blockIdx.y >= nnew handle the landmark planes.
 template <typename TS>
 __global__ void __launch_bounds__(256) k_reshape(int Nnew, int Ncap, int ld, const int* __restrict__ map, const double* __restrict__ newp, const double* __restrict__ newvar,
@@ -2242,17 +2216,6 @@ __global__ void __launch_bounds__(256) k_reshape(int Nnew, int Ncap, int ld, con
         Qqo[3 * Ncap + i] = 0.0;
         Qao[i] = 1.0;
     }
-}
-// append: zero the new strips, put var on the new diagonal (addNewLandmarks, VIO_eqf.cpp:239-244)
-template <typename TS>
-__global__ void __launch_bounds__(256) k_append_sigma(int nold, int nnew, int ld, double var, TS* __restrict__ Sig) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
-    if (r >= nnew || c >= nnew)
-        return;
-    if (r < nold && c < nold)
-        return;
-    Sig[r + (size_t)c * ld] = (r == c) ? var : 0.0;
 }
 template <typename TS>
 __global__ void __launch_bounds__(256) k_set_diag(int n, int ld, const double* __restrict__ diag, TS* __restrict__ Sig) {
