@@ -5,7 +5,8 @@ import pytest
 
 from eqvio_amd.capi import OPT_CHECK_FINITE, EqfCore, EqfError
 from test_gpu_parity import check_sigma, check_state, make_pair
-from util import CHARTS, default_camera, random_imu, random_spd, reasonable_state, settings_for, synth_measurement
+from oracle_binding import OracleFilter
+from util import CHARTS, default_camera, random_imu, random_spd, reasonable_state, rel_fro, settings_for, synth_measurement
 
 pytestmark = pytest.mark.gpu
 
@@ -170,3 +171,82 @@ def test_bad_arguments():
     with pytest.raises(EqfError):
         core.vision_update(cam, np.concatenate([mid, [999]]).astype(np.int32), np.concatenate([y, [1.0, 2.0]]), 1.0, True, False)  # id not in the state
     check_sigma(core, orc)  # nothing of the above changed the state
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_bookkeeping_sequences_match_the_oracle(seed):
+    """Landmark bookkeeping is recorded on the host and applied lazily in one kernel (k_reshape) when the device state is next needed.
+    Random interleavings of remove / add / remove-what-was-just-added / reads / propagation / updates / capacity growth against the oracle,
+    which executes every call at once: Sigma and the landmark arrays must be bit-identical after pure bookkeeping and agree to 1e-9 once
+    arithmetic ran in between."""
+    rng = np.random.default_rng(1000 + seed)
+    chart = CHARTS["invdepth"]
+    settings = settings_for(chart, useDiscreteInnovationLift=0)
+    N0 = 12
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N0)
+    S = np.diag(settings.initial_cov_diag(N0)) + 1e-3 * random_spd(rng, 21 + 3 * N0)
+    orc = OracleFilter(settings)
+    orc.set_eqf(xi0, Xs, ids, q0, Q, S)
+    core = EqfCore(16, chart)  # small on purpose: the sequence outgrows it
+    core.set_state(xi0, Xs, ids, q0, Q)
+    core.set_sigma(S)
+    cam = default_camera()
+    next_id = 1000
+    exact = True  # no arithmetic since the last exact comparison
+    for step in range(120):
+        op = rng.choice(["remove", "add", "add_remove", "read", "propagate", "update", "estimate"], p=[0.2, 0.2, 0.1, 0.15, 0.1, 0.15, 0.1])
+        n_now = core.N
+        if op == "remove" and n_now > 3:
+            k = int(rng.integers(1, min(4, n_now - 2)))
+            idx = np.sort(rng.choice(n_now, k, replace=False))
+            for i in idx[::-1]:
+                orc.remove_landmark_by_index(int(i))
+            core.remove_landmarks(idx)
+        elif op == "add" and n_now < 60:
+            k = int(rng.integers(1, 6))
+            new_ids = np.arange(next_id, next_id + k, dtype=np.int32)
+            next_id += k
+            p = rng.uniform(-1, 1, (k, 3)) + [0, 0, 5]
+            var = float(rng.uniform(0.1, 2.0))
+            orc.add_landmarks(new_ids, p, var)
+            core.add_landmarks(new_ids, p, var)
+        elif op == "add_remove" and 3 < n_now < 60:
+            new_ids = np.arange(next_id, next_id + 3, dtype=np.int32)
+            next_id += 3
+            p = rng.uniform(-1, 1, (3, 3)) + [0, 0, 5]
+            orc.add_landmarks(new_ids, p, 0.5)
+            core.add_landmarks(new_ids, p, 0.5)
+            for i in (n_now + 1, 0):  # one of the landmarks that exist only in the pending record, and an old one
+                orc.remove_landmark_by_index(i)
+            core.remove_landmarks(np.array([0, n_now + 1]))
+        elif op == "read":
+            Sg, So = core.get_sigma(), orc.get_sigma()
+            assert Sg.shape == So.shape
+            if exact:
+                assert np.array_equal(Sg, So)
+                check_state(core, orc, 1e-15)
+            else:
+                assert rel_fro(Sg, So) <= 1e-9
+                check_state(core, orc)
+        elif op == "propagate":
+            imu = random_imu(rng)
+            orc.integrate_riccati_fast(imu, 0.01)
+            core.integrate_riccati_fast(imu, 0.01, settings.input_gain_diag12(), settings.state_gain_diag8())
+            orc.integrate_observer(imu, 0.01, True)
+            core.integrate_observer(imu[None, :], np.array([0.01]), True)
+            exact = False
+        elif op == "update" and n_now > 0:
+            _, _, ids_all, q0_all, Q_all = orc.get_eqf()
+            sub = np.sort(rng.choice(n_now, max(1, n_now // 2), replace=False))
+            mid, y = synth_measurement(rng, cam, ids_all, q0_all, Q_all, noise_px=1.0, subset=sub)
+            orc.vision_update(cam, mid, y)
+            core.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+            exact = False
+        elif op == "estimate":
+            s_g, ids_g, p_g = core.state_estimate()
+            s_o, ids_o, p_o = orc.state_estimate()
+            assert np.array_equal(ids_g, ids_o)
+            assert np.max(np.linalg.norm(p_g - p_o, axis=1) / np.maximum(1.0, np.linalg.norm(p_o, axis=1))) <= (0.0 if exact else 1e-9)
+        assert core.N == len(orc.get_eqf()[2])
+    assert rel_fro(core.get_sigma(), orc.get_sigma()) <= 1e-9
+    check_state(core, orc)
