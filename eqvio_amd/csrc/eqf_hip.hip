@@ -164,6 +164,7 @@ struct eqf_ctx {
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int opt_syrk_f32 = 0;                    // EQF_OPT_SYRK_F32
+    int opt_fused_lift = 0;                  // EQF_OPT_FUSED_LIFT
     int* d_perm = nullptr;                   // 2 x (ncap + 2) row permutations of the NEES elimination fallback
     static constexpr int kRing = 8; // pinned packets of the landmark bookkeeping: a ring, so that a flush need not drain the stream before reusing one
     int ring_pos = 0;
@@ -800,6 +801,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case EQF_OPT_SYRK_F32:
         c->opt_syrk_f32 = value ? 1 : 0;
         return 0;
+    case EQF_OPT_FUSED_LIFT:
+        c->opt_fused_lift = value ? 1 : 0;
+        return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
         return 0;
@@ -1040,7 +1044,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
         return rc == EQF_E_NO_DEVICE ? rc : EQF_E_CAPACITY; // allocation failure at the new size
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_FUSED_UPDATE, c->opt_fused},
                            {EQF_OPT_SPECULATIVE, c->opt_spec}, {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm},
-                           {EQF_OPT_TWO_PHASE, c->opt_two_phase}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead}, {EQF_OPT_SYRK_F32, c->opt_syrk_f32}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_TWO_PHASE, c->opt_two_phase}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead}, {EQF_OPT_SYRK_F32, c->opt_syrk_f32}, {EQF_OPT_FUSED_LIFT, c->opt_fused_lift}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1085,6 +1089,24 @@ static int flush_reshape(eqf_ctx* c) {
     if (identity)
         return 0;
     { int _r = join_observer(c); if (_r) return _r; } // landmark kernels of a stand-alone observer call run on the second stream
+    bool pure_append = knew > 0 && knew <= APPEND_MAX && Nnew - knew == c->dev_N;
+    for (int i = 0; pure_append && i < Nnew; ++i)
+        pure_append = c->pend_map[i] == (i < c->dev_N ? i : -(i - c->dev_N + 1));
+    if (pure_append) { // nothing moves: the new strips and planes are written in place, the numbers travel as kernel arguments
+        AppendArgs aa;
+        for (int t = 0; t < knew; ++t) {
+            aa.p[t][0] = c->pend_p[3 * t], aa.p[t][1] = c->pend_p[3 * t + 1], aa.p[t][2] = c->pend_p[3 * t + 2];
+            aa.var[t] = c->pend_var[t];
+        }
+        {
+            KTimer t(c, KN_MISC);
+            const int nn = 21 + 3 * Nnew;
+            LAUNCH_TS(c, k_append_inplace, dim3(blocks(nn, 256), 3 * knew + 1), dim3(256), c->stream, c->dev_N, knew, c->Ncap, c->ld, aa, (TS*)c->sigma(), c->d_st[c->stcur], c->d_lm[c->lmcur]);
+            HIPCHK(hipGetLastError());
+        }
+        c->dev_N = Nnew;
+        return round_sigma(c);
+    }
     char* slot = c->h_rs_ring + (size_t)(c->ring_pos++ % eqf_ctx::kRing) * c->rs_bytes; // no stream drain: a ring of pinned packets
     const size_t off_p = (sizeof(int) * (size_t)c->Ncap + 15) & ~(size_t)15, off_v = off_p + sizeof(double) * 3 * (size_t)c->Ncap;
     std::memcpy(slot, c->pend_map.data(), sizeof(int) * Nnew);
@@ -1714,7 +1736,7 @@ static bool lookahead_eligible(const eqf_ctx* c, int m) {
     const int NJ = blocks(m, 32);
     return c->opt_lookahead && !c->opt_fused && c->d_pub && NJ >= 3 && NJ <= c->la_njcap;
 }
-static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq) {
+static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq, bool with_lift = false, int discreteCorr = 0, int door_seq = 0) {
     LaArgs a{};
     a.rows = rows;
     a.m = m;
@@ -1737,6 +1759,13 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.spec_seq = spec_seq;
     a.tr_steps = trace_slot(c, TR_STEP0);
     a.dbg = c->d_trace ? c->d_ladbg : nullptr;
+    if (with_lift) { // the vision update: the kernel also lifts the landmarks and rings the doorbell (no k_lift launch)
+        a.lift_N = c->N, a.lift_Ncap = c->Ncap, a.lift_chart = c->chart, a.lift_discrete = discreteCorr;
+        a.lift_q0 = c->q0(), a.lift_Qq = c->Qq(), a.lift_Qa = c->Qa();
+        a.lift_est = c->h_res + 3 * (size_t)c->Ncap, a.lift_gamma_host = c->h_res + 7 * (size_t)c->Ncap;
+        a.lift_flags_host = c->h_resflags, a.lift_done = c->d_door + 2, a.lift_door_host = c->h_door + 1, a.lift_door_seq = door_seq;
+        a.tr_lift = trace_slot(c, TR_LIFT);
+    }
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
     // MAXT = tiles a wave keeps in registers = ceil(NJ / 2)
     // (the two large instantiations feed their operand tiles through an LDS ring and need more than the default 64 KB of dynamic LDS)
@@ -1923,11 +1952,13 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
             return rc;
     } else {
         const bool la = lookahead_eligible(c, m); // one persistent kernel instead of one launch per panel; Gamma complete in d_gamma
-        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq)
+        const bool fl = la && c->opt_early && c->opt_fused_lift; // EQF_OPT_FUSED_LIFT
+        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, fl, discreteCorr, door_seq)
                 : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
         if (rc)
             return rc;
-        if (c->opt_early) { // Gamma, landmark lift, result packet and doorbell BEFORE the covariance update: the host round trip overlaps with it
+        if (c->opt_early && !fl) { // Gamma, landmark lift, result packet and doorbell BEFORE the covariance update: the host round trip overlaps with it
+            // (with EQF_OPT_FUSED_LIFT the look-ahead kernel does this itself: its last T block row lifts and rings)
             rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, la ? nullptr : c->d_gpart);
             if (rc)
                 return rc;

@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void ldl16_inverse_wave(double (&a)[4], double (&out)
     // Linv = blkdiag(chol(D_b)^-1) M : row j -> M[j]/l11 ; row j+1 -> (M[j+1] - (l21/l11) M[j]) / l22
     const bool ok = (p11 > 0.0) && (fma(p11, p22, -p21 * p21) > 0.0);
     if (cq == 0 && check_row && !ok)
-        flags[0] = 1;
+        __hip_atomic_store(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // write-through: the look-ahead kernel's own lift reads it from another workgroup
     const double il11 = fast_rsqrt(ok ? p11 : 1.0);
     const double l21 = ok ? p21 * il11 : 0.0;
     const double il22 = fast_rsqrt(ok ? p22 - l21 * l21 : 1.0);
@@ -2216,6 +2216,46 @@ __global__ void __launch_bounds__(256) k_reshape(int Nnew, int Ncap, int ld, con
         Qqo[3 * Ncap + i] = 0.0;
         Qao[i] = 1.0;
     }
+}
+// k_reshape for the commonest record of all - nothing removed, up to APPEND_MAX landmarks appended (a frame's addNewLandmarks): nothing
+// moves, only the new strips of Sigma (zeros, the variances on the diagonal) and the new landmarks' planes are written, in place, and the few
+// numbers travel as kernel arguments (no copy command). grid: (ceil(nnew / 256), 3 k + 1): row y < 3 k writes column nold + y and row nold + y
+// of Sigma, the last row the landmark planes.
+constexpr int APPEND_MAX = 24;
+struct AppendArgs {
+    double p[APPEND_MAX][3];
+    double var[APPEND_MAX];
+};
+template <typename TS>
+__global__ void __launch_bounds__(256) k_append_inplace(int Nold, int k, int Ncap, int ld, const AppendArgs aa, TS* __restrict__ Sig, double* __restrict__ st, double* __restrict__ lm) {
+    const int nold = 21 + 3 * Nold, nnew = nold + 3 * k;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)blockIdx.y < 3 * k) {
+        if (x >= nnew)
+            return;
+        const int c = nold + blockIdx.y;
+        const TS d = (TS)aa.var[blockIdx.y / 3];
+        Sig[x + (size_t)c * ld] = (x == c) ? d : (TS)0.0;
+        if (x < nold)
+            Sig[c + (size_t)x * ld] = (TS)0.0;
+        return;
+    }
+    if (x >= k)
+        return;
+    const int i = Nold + x;
+    const V3 p{aa.p[x][0], aa.p[x][1], aa.p[x][2]};
+    st[i] = p.x;
+    st[Ncap + i] = p.y;
+    st[2 * Ncap + i] = p.z;
+    double* cc = st + (size_t)CC_OFF * Ncap;
+    st_plane9(cc, Ncap, i, CC_E2I, conv_euc2ind(p));
+    st_plane9(cc, Ncap, i, CC_I2E, conv_ind2euc(p));
+    st_plane9(cc, Ncap, i, CC_R0, ind2euc_r0(p));
+    lm[i] = 1.0;
+    lm[Ncap + i] = 0.0;
+    lm[2 * Ncap + i] = 0.0;
+    lm[3 * Ncap + i] = 0.0;
+    lm[4 * (size_t)Ncap + i] = 1.0;
 }
 template <typename TS>
 __global__ void __launch_bounds__(256) k_set_diag(int n, int ld, const double* __restrict__ diag, TS* __restrict__ Sig) {

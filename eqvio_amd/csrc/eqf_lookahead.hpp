@@ -52,6 +52,15 @@ struct LaArgs {
     int* flags;          // [0] non-positive pivot, [3] stalled
     const int* spec;
     int spec_seq;
+    // the frame's results leave from this kernel (what k_lift does behind the launch chain): the last T block row to finish lifts the
+    // landmarks, fills the pinned result packet and rings the host doorbell
+    int lift_N, lift_Ncap, lift_chart, lift_discrete;
+    const double* lift_q0;
+    double *lift_Qq, *lift_Qa;
+    double *lift_est, *lift_gamma_host; // pinned
+    int *lift_flags_host, *lift_done, *lift_door_host;
+    int lift_door_seq;
+    trace_t* tr_lift;
     trace_t* tr_steps;       // EQF_OPT_TRACE: slot of step 0 (the owner stamps one slot per step), or nullptr
     unsigned long long* dbg; // EQF_OPT_TRACE: per-step stamps inside the owner ([k][8]) and two block rows ([32 + p][8], [64 + p][8]), or nullptr
 };
@@ -556,14 +565,63 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         __syncthreads();
         const int row = row0 + tid;
         if (tid < 32 && row >= m && row < rows - 1)
-            a.gamma[row - m] = ((sZp[tid] + sZp[32 + tid]) + (sZp[64 + tid] + sZp[96 + tid])) + ((sZp[128 + tid] + sZp[160 + tid]) + (sZp[192 + tid] + sZp[224 + tid]));
+            la_st(a.gamma + (row - m), ((sZp[tid] + sZp[32 + tid]) + (sZp[64 + tid] + sZp[96 + tid])) + ((sZp[128 + tid] + sZp[160 + tid]) + (sZp[192 + tid] + sZp[224 + tid])));
+    }
+}
+
+// The end of the frame's device work that the host waits for, run by the T block row that finishes last (every T block row has stored its
+// Gamma rows write-through and counted itself in): X <- Delta X for the landmarks (k_lift's arithmetic: lift_load / lift_landmark), the
+// estimates, Gamma's sensor rows and the status words into the pinned packet, then the doorbell. A failed factorisation (non-positive pivot,
+// stalled wait) lifts nothing, like k_lift. One kernel launch and one kernel boundary less per frame than k_lift behind this kernel, measured
+// neutral for the frame rate (the next frame's first kernel is bound by the host's launch): EQF_OPT_FUSED_LIFT, off by default.
+__device__ __forceinline__ void la_finish(const LaArgs& a) {
+    const int tid = threadIdx.x;
+    if (a.tr_lift && tid == 0)
+        a.tr_lift[0] = wall_clock64();
+    auto ld = [](const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }; // past this XCD's L2: written by other workgroups
+    const int f0 = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), f1 = a.flags[1];
+    const int f3 = __hip_atomic_load(a.flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool failed = f0 != 0 || f3 != 0;
+    for (int i = tid; i < max(a.lift_N, 21); i += LA_T) {
+        const bool lm = i < a.lift_N;
+        const int ic = lm ? i : 0;
+        const double gs = ld(a.gamma + (i < 21 ? i : 0));
+        const double g0 = ld(a.gamma + 21 + 3 * ic), g1 = ld(a.gamma + 21 + 3 * ic + 1), g2 = ld(a.gamma + 21 + 3 * ic + 2);
+        const LiftIn in = lift_load(ic, a.lift_Ncap, a.lift_chart, a.lift_discrete, a.lift_q0, a.lift_Qq, a.lift_Qa);
+        if (!failed) {
+            if (i < 21)
+                a.lift_gamma_host[i] = gs;
+            if (lm)
+                lift_landmark(i, V3{g0, g1, g2}, in, a.lift_N, a.lift_Ncap, a.lift_chart, a.lift_discrete, a.lift_Qq, a.lift_Qa, a.lift_est);
+        }
+    }
+    if (tid == 0) {
+        a.lift_flags_host[0] = f0;
+        a.lift_flags_host[1] = f1;
+        a.lift_flags_host[2] = 0;
+        a.lift_flags_host[3] = f3;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence_system();
+        *reinterpret_cast<volatile int*>(a.lift_door_host) = a.lift_door_seq;
+        if (a.tr_lift)
+            a.tr_lift[1] = wall_clock64();
     }
 }
 
 template <int MAXT, bool RING = false>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
-    if (a.spec && *a.spec == a.spec_seq)
-        return; // cancelled speculative tail
+    if (a.spec && *a.spec == a.spec_seq) { // cancelled speculative tail: say so, ring, done
+        if (a.lift_door_host && blockIdx.x == 0 && threadIdx.x == 0) {
+            a.lift_flags_host[2] = 1;
+            a.lift_flags_host[3] = 0;
+            __threadfence_system();
+            *reinterpret_cast<volatile int*>(a.lift_door_host) = a.lift_door_seq;
+        }
+        return;
+    }
     // static LDS without a ring (constant addresses: 2.6 us per factorisation at N = 200 against the same kernel on dynamic LDS), dynamic
     // (LA_LDS_RING bytes, above the 64 KB a static array may have) with one
     extern __shared__ double la_dyn_smem[];
@@ -579,7 +637,22 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     else
         la_row<MAXT, RING>(a, (int)blockIdx.x, smem, &s_abort, pl);
     if (threadIdx.x == 0 && s_abort)
-        a.flags[3] = 1;
+        __hip_atomic_store(a.flags + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.lift_door_host && (int)blockIdx.x >= a.NJ) { // a T block row (stalled or not) counts itself in; the last one finishes the frame
+        __shared__ int s_last;
+        la_stores_done();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nT = a.NI - a.NJ;
+            const int seen = __hip_atomic_fetch_add(a.lift_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (seen == nT - 1);
+            if (s_last)
+                __hip_atomic_store(a.lift_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_last)
+            la_finish(a);
+    }
 }
 
 } // namespace eqf

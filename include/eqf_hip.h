@@ -60,6 +60,9 @@ enum {
                                   workgroup walks the pivot chain, one workgroup per 32-row block row keeps its tiles in registers and follows one to
                                   two panels behind; hand-offs as write-through tile stores + one sequence-numbered flag per tile, never cleared) when the update has 3 .. 16
                                   panels (32 < M <= 256 measurements); bit-identical W / Sigma to the chain. 0: one launch per panel (k_chol_step) */
+    EQF_OPT_FUSED_LIFT = 14,   /* 1: the look-ahead kernel's last T block row lifts the landmarks, fills the result packet and rings the doorbell (no k_lift launch
+                                  behind it: 4 launches per frame, -2.4 us on the device timeline, bit-identical results); 0 (default): k_lift as a kernel of
+                                  its own. Measured neutral for the frame rate (the frame boundary is bound by the host's launch), so the simpler form is the default */
     EQF_OPT_SYRK_F32 = 13,     /* experiment (the fp32-arithmetic A/B): 1: Sigma -= W W^T multiplies on v_mfma_f32_16x16x4_f32 with the
                                   operands rounded to float (f32 accumulation inside a wave's K slice, fp64 across slices and for the subtraction).
                                   Results then agree with the reference to ~1e-7 only; 0 (default): fp64 MFMA */

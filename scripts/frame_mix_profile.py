@@ -9,6 +9,7 @@ import bench
 from eqvio_amd.capi import OPT_TIMING, PreparedFrames, VIOFilter, load_eqf_lib
 from simworld import SimWorld
 mode = sys.argv[1] if len(sys.argv) > 1 else "shipped"
+opts = [tuple(int(v) for v in a.split("=")) for a in sys.argv[2:]]  # extra arguments "option=value" are set on the core (A/B of eqf_set_option switches)
 lib = load_eqf_lib()
 N = 200
 s = bench.eurocish_settings()
@@ -20,8 +21,10 @@ ids0 = frames[0][2]
 sensor, ids, p = world.true_state(0.0, ids0)
 flt = VIOFilter(s, max_landmarks=N + 64, sensor=sensor, ids=ids, p=p, time=0.0)
 pf = PreparedFrames(world.cam, *bench.flatten_frames(frames))
-flt.run_prepared(pf, 0, 200)
 core = flt.core_handle()
+for o, v in opts:
+    assert lib.eqf_set_option(core, o, v) == 0
+flt.run_prepared(pf, 0, 200)
 lib.eqf_synchronize(core)
 t0 = time.perf_counter(); flt.run_prepared(pf, 200, 300); lib.eqf_synchronize(core); wall = (time.perf_counter() - t0) / 300
 lib.eqf_set_option(core, OPT_TIMING, 1)

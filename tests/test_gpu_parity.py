@@ -560,7 +560,7 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
     instantiation), M < N with a ragged last panel, the 16-panel instantiation, and the two large ones (17 .. 24 and 25 .. 32 panels: N = 300 .. 512,
     the stress configuration N = 500 among them). A second update on the same context
     meets the first one's words in the hand-off buffers (the sequence number tells them apart)."""
-    from eqvio_amd.capi import OPT_LOOKAHEAD
+    from eqvio_amd.capi import OPT_FUSED_LIFT, OPT_LOOKAHEAD
 
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=N + M, useDiscreteInnovationLift=0)
     cam = default_camera()
@@ -568,11 +568,12 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
     rows, m = 2 * M + 21 + 3 * N + 1, 2 * M
     outs = []
     cores = []
-    for la in (0, 1, 1):
+    for la in (0, 1, 1, 2):  # 2: look-ahead kernel that also lifts the landmarks and rings the doorbell (EQF_OPT_FUSED_LIFT)
         c = EqfCore(N, CHARTS["invdepth"])
         c.set_state(xi0, Xs, ids, q0, Q)
         c.set_sigma(S)
-        c.set_option(OPT_LOOKAHEAD, la)
+        c.set_option(OPT_LOOKAHEAD, min(la, 1))
+        c.set_option(OPT_FUSED_LIFT, 1 if la == 2 else 0)
         c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
         outs.append((c.get_sigma(), c.get_state(), c.last_gamma(), c.debug_get_W(rows, m)[m:]))
         cores.append(c)
@@ -583,6 +584,9 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
         for u, v in zip(st1, outs[0][1]):
             assert np.allclose(u, v, rtol=1e-12, atol=1e-13)
     assert np.array_equal(outs[1][2], outs[2][2])  # Gamma is deterministic
+    for a_, b_ in zip(outs[1][1], outs[3][1]):  # the lift inside the kernel is the same arithmetic on the same Gamma
+        assert np.array_equal(a_, b_)
+    assert np.array_equal(outs[1][2], outs[3][2])
     # second frame on every context (propagation in between keeps the problem well posed)
     imu = random_imu(rng)
     y2 = y + rng.normal(size=y.shape) * 0.5
@@ -591,7 +595,7 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
         c.integrate_riccati_fast(imu, 0.05, settings.input_gain_diag12(), settings.state_gain_diag8())
         c.vision_update(cam, mid, y2, settings.measurementNoise**2, True, False)
         S2.append(c.get_sigma())
-    assert rel_fro(S2[1], S2[0]) <= 1e-11 and np.array_equal(S2[1], S2[2])
+    assert rel_fro(S2[1], S2[0]) <= 1e-11 and np.array_equal(S2[1], S2[2]) and np.array_equal(S2[1], S2[3])
     if N <= 60:
         orc.vision_update(cam, mid, y)
         assert rel_fro(outs[1][0], orc.get_sigma()) <= 1e-9

@@ -162,7 +162,7 @@ def test_trace_and_host_statistics():
         assert lib.eqf_host_wait_stats(core, calls, secs, 1) == 0
         assert flt.run_prepared(pf) == nfr
         assert lib.eqf_host_wait_stats(core, calls, secs, 0) == 0
-        assert calls[0] == nfr and secs[0] > 0.0 and calls[1] >= 5 * nfr and secs[1] > 0.0
+        assert calls[0] == nfr and secs[0] > 0.0 and calls[1] >= 4 * nfr and secs[1] > 0.0  # propagation, Z, factorisation (+ lift + doorbell), covariance update
         dev = np.zeros((1024, 48), np.uint64)
         host = np.zeros((1024, 8), np.int64)
         last = C.c_uint()
