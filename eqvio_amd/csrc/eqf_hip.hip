@@ -161,6 +161,7 @@ struct eqf_ctx {
     int* d_pubf = nullptr;
     char *d_puby = nullptr, *d_publ = nullptr;
     int la_njcap = 0, la_seq = 0;
+    bool ring_attr = false; // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the ring instantiations on this context's device
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int opt_syrk_f32 = 0;                    // EQF_OPT_SYRK_F32
@@ -1461,8 +1462,8 @@ static GroupSensor group_inv(const GroupSensor& X) { // VIOGroup::inverse, senso
 int eqf_integrate_riccati_discrete(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
     if (!c || !imu13 || !Qdiag12 || !Pdiag8 || !(dt > 0.0))
         return EQF_E_BAD_ARG;
-    if (c->sig32 || c->chart == EQVIO_COORD_NORMAL)
-        return EQF_E_UNSUPPORTED; // float store: structured fast path only; Normal chart: its input matrix would need M B_e as a third dense term
+    if (c->sig32)
+        return EQF_E_UNSUPPORTED; // float store: structured fast path only
     { int _e = enter(c); if (_e) return _e; }
     const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
     if (!c->d_F)
@@ -1475,6 +1476,16 @@ int eqf_integrate_riccati_discrete(eqf_ctx* c, const double* imu13, double dt, c
     rc = launch_assemble(c, false); // "the last reader of Q" is k_discrete_A below, not k_assemble_AB: the event is recorded there
     if (rc)
         return rc;
+    // Normal chart: A_d,n = M A_d,e M^-1 and B_n = M B_e at the origin (chain rule through the change of coordinates), so the Euclidean
+    // discrete propagation sits between the same two congruences as the continuous ones (riccati_after_assemble); the reference differentiates
+    // a0Discrete numerically in normal coordinates, which agrees to the differencing's own 1e-9
+    const bool normal = c->chart == EQVIO_COORD_NORMAL;
+    static const double kZero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (normal) {
+        rc = normal_congruence(c, -1, dt, nullptr);
+        if (rc)
+            return rc;
+    }
     // sensor-level part of a0Discrete: nominal + 21 x (+h, -h)
     const double h = std::cbrt(2.220446049250313e-16);
     const SensorState xhat = sensor_action(c->X, c->xi0);
@@ -1516,7 +1527,7 @@ int eqf_integrate_riccati_discrete(eqf_ctx* c, const double* imu13, double dt, c
     HIPCHK(hipMemsetAsync(c->d_F, 0, bytes, c->stream));
     HIPCHK(hipMemcpy2DAsync(c->d_F, sizeof(double) * c->ld, c->h_buf, sizeof(double) * 21, sizeof(double) * 21, 21, hipMemcpyHostToDevice, c->stream));
     if (N > 0) {
-        hipLaunchKernelGGL(k_discrete_A, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, c->chart, da, c->q0(), c->Qq(), c->Qa(), c->d_F);
+        hipLaunchKernelGGL(k_discrete_A, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, normal ? (int)EQVIO_COORD_EUCLIDEAN : c->chart, da, c->q0(), c->Qq(), c->Qa(), c->d_F);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_early, c->stream)); // an observer call that follows may overwrite Q from here on (observer_launch)
@@ -1524,7 +1535,7 @@ int eqf_integrate_riccati_discrete(eqf_ctx* c, const double* imu13, double dt, c
     RiccatiArgs ra;
     ra.dt = dt;
     std::memcpy(ra.Qd, Qdiag12, sizeof(ra.Qd));
-    std::memcpy(ra.Pd, Pdiag8, sizeof(ra.Pd));
+    std::memcpy(ra.Pd, normal ? kZero8 : Pdiag8, sizeof(ra.Pd));
     double* Sin = c->d_sigma[c->cur];
     double* Sout = c->d_sigma[1 - c->cur];
     KTimer t(c, KN_DENSE_GEMM);
@@ -1535,6 +1546,11 @@ int eqf_integrate_riccati_discrete(eqf_ctx* c, const double* imu13, double dt, c
     hipLaunchKernelGGL(k_add_noise, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, N, c->Ncap, n, c->ld, ra, c->d_common, c->d_Bl, Sout);
     HIPCHK(hipGetLastError());
     c->cur = 1 - c->cur;
+    if (normal) {
+        rc = normal_congruence(c, +1, dt, Pdiag8);
+        if (rc)
+            return rc;
+    }
     return round_sigma(c);
 }
 
@@ -1769,11 +1785,10 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
     // MAXT = tiles a wave keeps in registers = ceil(NJ / 2)
     // (the two large instantiations feed their operand tiles through an LDS ring and need more than the default 64 KB of dynamic LDS)
-    static bool ring_attr = false;
-    if (!ring_attr) {
+    if (!c->ring_attr) { // per context: the attribute belongs to the device that is current, and a process may drive several
         HIPCHK(hipFuncSetAttribute((const void*)k_chol_lookahead<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LA_LDS_RING));
         HIPCHK(hipFuncSetAttribute((const void*)k_chol_lookahead<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LA_LDS_RING));
-        ring_attr = true;
+        c->ring_attr = true;
     }
     if (a.NJ <= 14)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<7, false>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);

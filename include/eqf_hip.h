@@ -125,7 +125,8 @@ int eqf_integrate_riccati_accurate(eqf_ctx* ctx, const double* imu13, double dt,
 /* VIO_eqf::integrateRiccatiStateDiscrete (VIO_eqf.cpp:93-103): Sigma <- A_d Sigma A_d^T + dt (B Q B^T + P) with A_d = stateMatrixADiscrete
  * (EqFMatrices.cpp:24-41), the central-difference differential (h = cbrt(eps)) of one discrete-lift observer step in error coordinates. A_d has
  * the arrow structure of A: the 43 sensor-level evaluations run on the host, one lane per landmark differentiates its own rows on the device,
- * then two dense fp64 MFMA GEMMs. Euclidean and InvDepth charts (Normal: EQF_E_UNSUPPORTED). The result carries the differencing's rounding
+ * then two dense fp64 MFMA GEMMs. Normal chart: the Euclidean A_d between the two congruences with the closed-form change of coordinates
+ * (A_d,n = M A_d,e M^-1 at the origin). Not with the float Sigma store (EQF_E_UNSUPPORTED). The result carries the differencing's rounding
  * noise (eps / h ~ 4e-11 per unit entry), as the reference's does. */
 int eqf_integrate_riccati_discrete(eqf_ctx* ctx, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8);
 /* VIO_eqf::integrateObserverState (VIO_eqf.cpp:47-60) applied for k consecutive samples
