@@ -190,7 +190,7 @@ def test_filter_grows_past_its_initial_capacity():
     assert len(flt.state_estimate()[1]) > 40
 
 
-@pytest.mark.parametrize("chart", [COORD_EUCLIDEAN, COORD_INVDEPTH])
+@pytest.mark.parametrize("chart", [COORD_EUCLIDEAN, COORD_INVDEPTH, 2])  # 2 = COORD_NORMAL: numerically differentiated twice over in the oracle
 def test_discrete_state_matrix_filter_run(chart):
     """Row a7: useDiscreteStateMatrix (integrateRiccatiStateDiscrete, VIO_eqf.cpp:93-103; the mode the reference's own statistical test runs,
     test_FilterStatistics.cpp:110,132), free running against the oracle's filter. A_d comes from central differences with h = cbrt(eps) on
