@@ -221,6 +221,18 @@ class HipBackend:
         self.lib.eqf_synchronize(flt.core_handle())
         self.torch.cuda.synchronize()
 
+    def spin_up(self, flt, seconds=float(os.environ.get("EQVIO_BENCH_SPIN_UP_S", "0.4"))):
+        """The GPU clocks down while the host builds the synthetic world (seconds of numpy) and takes > 100 ms to come back (measured:
+        tests/run_configs.py config 3 read 1200-1900 instead of 2280 updates/s behind a multi-second idle). A short run, e.g. --steps 20, would
+        time the ramp, not the filter: keep the device busy with the library's own fp64 MFMA micro-benchmark for a moment before the W warm-up
+        frames. Not filter work, not timed, and independent of W."""
+        import ctypes as C
+
+        t = C.c_double()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            self.lib.eqf_mfma_f64_peak(flt.core_handle(), C.byref(t))
+
 
 def init_control_group(world_size):
     """Replicas only: the ranks share NOTHING on the data path. The process group exists for the start/stop barrier and the MAX over the
@@ -259,6 +271,7 @@ def rank_pass(args, rank, world_size, dist, backend, settings=None):
     # tracker / data server hands to the filter) are built once, before the timed region; a step is processIMUData x k +
     # processVisionData on them. The measurement itself still crosses the C-ABI from host memory every frame.
     prepared = backend.prepare(world.cam, *flatten_frames(frames[: args.warmup + args.steps]))
+    backend.spin_up(flt)
     if args.warmup:
         flt.run_prepared(prepared, 0, args.warmup)
     value, elapsed, _ = timed_replica_run(lambda: flt.run_prepared(prepared, args.warmup, args.steps), lambda: backend.sync(flt), args.steps, dist=dist)

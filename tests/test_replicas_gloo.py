@@ -96,6 +96,9 @@ class _CpuStandInBackend:
     def sync(self, flt):
         pass
 
+    def spin_up(self, flt):
+        pass
+
 
 def _bench_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
