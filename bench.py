@@ -259,7 +259,7 @@ def init_control_group(world_size):
 
 def rank_pass(args, rank, world_size, dist, backend, settings=None):
     """One rank's whole job: its own synthetic world (seeded by the rank), its own filter, W warm-up frames, K timed frames between
-    barriers. Returns (aggregate updates/s over all ranks, max-over-ranks seconds, filter, world, frames)."""
+    barriers. Returns (aggregate updates/s over all ranks, max-over-ranks seconds, filter, world, frames, settings, this rank's seconds)."""
     from eqvio_amd.replicas import timed_replica_run
 
     N = args.landmarks
@@ -274,8 +274,43 @@ def rank_pass(args, rank, world_size, dist, backend, settings=None):
     backend.spin_up(flt)
     if args.warmup:
         flt.run_prepared(prepared, 0, args.warmup)
-    value, elapsed, _ = timed_replica_run(lambda: flt.run_prepared(prepared, args.warmup, args.steps), lambda: backend.sync(flt), args.steps, dist=dist)
-    return value, elapsed, flt, world, frames, settings
+    value, elapsed, mine = timed_replica_run(lambda: flt.run_prepared(prepared, args.warmup, args.steps), lambda: backend.sync(flt), args.steps, dist=dist)
+    return value, elapsed, flt, world, frames, settings, mine
+
+
+def load_backend(local_rank):
+    """The product backend, or - test hook, CPU rehearsal of the launch logic only - the class named by EQVIO_BENCH_BACKEND=module:Class
+    (tests/test_replicas_gloo.py passes its oracle-backed stand-in; such a run prints `"data": "stand-in"` and no roofline)."""
+    spec = os.environ.get("EQVIO_BENCH_BACKEND")
+    if not spec:
+        return HipBackend(local_rank), False
+    import importlib
+
+    mod, cls = spec.split(":")
+    return getattr(importlib.import_module(mod), cls)(), True
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (what torch.distributed.run would do: RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1), pass rank 0's one JSON line through, fail if any rank fails."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EQVIO_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write("bench.py --gpus %d: rank exit codes %r\n" % (n, codes))
+        sys.exit(1)
 
 
 def main():
@@ -288,47 +323,59 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-multi-filter", action="store_true")
     ap.add_argument("--no-frame-mix", action="store_true")
+    ap.add_argument("--no-binding", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:  # plain `python bench.py --gpus N`: this process is the launcher
+            return self_launch(args.gpus)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: launched with WORLD_SIZE=%s but --gpus %d: the rank count and --gpus must agree" % (os.environ["WORLD_SIZE"], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("EQVIO_BENCH_ONE_DEVICE"):  # test hook: every rank on GPU 0 (rehearsal of the N > 1 launch on a 1-GPU box)
+    world_size = args.gpus
+    one_device = bool(os.environ.get("EQVIO_BENCH_ONE_DEVICE"))  # test hook: every rank on GPU 0 (rehearsal of the N > 1 launch on a 1-GPU box)
+    if one_device:
         local_rank = 0
-    backend = HipBackend(local_rank)
+    backend, stand_in = load_backend(local_rank)
+    if not stand_in and not one_device:
+        have = backend.torch.cuda.device_count()
+        assert have >= world_size, "bench.py --gpus %d: only %d device(s) visible" % (world_size, have)
     dist = init_control_group(world_size)
-    lib = backend.lib
     N = args.landmarks
 
     def Filter(settings, sensor, ids, p, t):
         return backend.make_filter(settings, N, sensor, ids, p, t)
 
-    value, elapsed, flt, world, frames, settings = rank_pass(args, rank, world_size, dist, backend)
-    cam = world.cam
-    core = flt.core_handle()
-
-    # post-run sanity: the state is finite and Sigma is symmetric positive definite
-    S = flt.get_sigma()
-    assert np.all(np.isfinite(S)) and S.shape[0] == 21 + 3 * N
-    assert np.linalg.eigvalsh(0.5 * (S + S.T)).min() > 0
-
+    value, elapsed, flt, world, frames, settings, mine = rank_pass(args, rank, world_size, dist, backend)
+    per_rank = [mine]
+    if dist is not None:  # every rank's own wall time of the timed region, for the min / max next to the aggregate
+        per_rank = [None] * world_size
+        dist.all_gather_object(per_rank, mine)
     n, m = 21 + 3 * N, 2 * N
     ms_per_step = 1e3 * elapsed / args.steps
     frame_flops = flops_propagate(n) + flops_update(n, m)
-
-    roofline = None
-    if rank == 0 and not args.no_roofline:
-        roofline = measure_roofline(flt, lib, core, cam, frames, args, n, m)
-    cpu = None
-    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(world, frames, settings, N)
-
-    multi = None
-    if rank == 0 and world_size == 1 and not args.no_multi_filter:
-        multi = several_filters_on_one_gpu(settings, N, local_rank, Filter, lib)
-    mix = None
-    if rank == 0 and world_size == 1 and not args.no_frame_mix:
-        mix = frame_mix(N, local_rank, lib)
+    roofline = cpu = multi = mix = binding = None
+    if not stand_in:
+        lib = backend.lib
+        cam = world.cam
+        core = flt.core_handle()
+        # post-run sanity: the state is finite and Sigma is symmetric positive definite
+        S = flt.get_sigma()
+        assert np.all(np.isfinite(S)) and S.shape[0] == 21 + 3 * N
+        assert np.linalg.eigvalsh(0.5 * (S + S.T)).min() > 0
+        if rank == 0 and not args.no_roofline:
+            roofline = measure_roofline(flt, lib, core, cam, frames, args, n, m)
+        if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(world, frames, settings, N)
+        if rank == 0 and world_size == 1 and not args.no_multi_filter:
+            multi = several_filters_on_one_gpu(settings, N, local_rank, Filter, lib)
+        if rank == 0 and world_size == 1 and not args.no_frame_mix:
+            mix = frame_mix(N, local_rank, lib)
+        if rank == 0 and world_size == 1 and not args.no_binding:
+            binding = reference_side_binding(N)
 
     if rank == 0:
         out = {
@@ -343,7 +390,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "stand-in" if stand_in else "synthetic",
             "config": {
                 "workload": f"synthetic 'hover' world, {N} tracked landmarks (state dim {n}, {m} measurement rows), InvDepth chart, fast Riccati, "
                 "IMU 200 Hz / camera 20 Hz (10 observer steps per frame), EuRoC pinhole intrinsics, one independent filter per GPU (replicas)",
@@ -351,6 +398,8 @@ def main():
                 "state_dim": n,
                 "parallelism": f"replicas x{world_size}",
             },
+            "per_rank_updates_per_s": {"min": args.steps / max(per_rank), "max": args.steps / min(per_rank)},
+            "launcher": "self" if os.environ.get("EQVIO_BENCH_SELF_LAUNCHED") else ("external" if "WORLD_SIZE" in os.environ else "single process"),
             "frame_dense_flops": frame_flops,
             "dense_equiv_tflops": frame_flops * value / world_size / 1e12,
             "dense_equiv_frac_of_fp64_mfma_peak": frame_flops * value / world_size / 1e12 / FP64_MFMA_PEAK_TFLOPS,
@@ -363,9 +412,16 @@ def main():
             out["several_filters_one_gpu"] = multi
         if mix is not None:
             out["frame_mix"] = mix
+        if binding is not None:
+            out["reference_side_binding"] = binding
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def reference_side_binding(N):
+    """Filled in by the reference-side VIOFilter binding (tests/integration/VIOFilter_mi355x.cpp); see that function below."""
+    return None
 
 
 def frame_mix(N, device, lib, n_frames=1200, n_warm=200):
@@ -416,42 +472,62 @@ def frame_mix(N, device, lib, n_frames=1200, n_warm=200):
     return out
 
 
-def several_filters_on_one_gpu(settings, N, device, Filter, lib, n_filters=4, n_frames=400, n_warm=100):
-    """"optionally several filters per GPU to fill CUs". A single filter's frame is a latency-bound
-    dependent chain that leaves most CUs idle; R independent filters (one host thread, one eqf_ctx, one stream pair each)
-    overlap on the same GPU. Informational: the headline value stays one filter per GPU, as BASELINE.json's north_star says."""
+def several_filters_on_one_gpu(settings, N, device, Filter, lib, counts=(1, 2, 4, 8, 16), sizes=(50, 200), n_frames=300, n_warm=60):
+    """"optionally several filters per GPU to fill CUs". A single filter's frame is a latency-bound dependent chain that leaves
+    most CUs idle; R independent filters (one host thread, one eqf_ctx, one stream pair each) overlap on the same GPU. The sweep over R at N = 50
+    and N = 200 locates the per-GPU saturation point ahead of the 8-GPU batch (BASELINE config 4 could run several sequences per GPU).
+    Informational: the headline value stays one filter per GPU, as BASELINE.json's north_star says. Each persistent look-ahead kernel needs its
+    workgroups co-resident; `lookahead_fallbacks` counts launches that stalled under the sharing and were redone on the launch chain."""
+    import ctypes as C
     import threading
     import time
 
-    from eqvio_amd.capi import PreparedFrames
+    from eqvio_amd.capi import PreparedFrames, VIOFilter
 
-    flts, work = [], []
-    for r in range(n_filters):
-        world, frames = build_workload(seed=500 + r, n_frames=n_warm + n_frames + 2, N=N)
-        flts.append(make_filter(world, settings, N, device, frames, Filter))
-        work.append(PreparedFrames(world.cam, *flatten_frames(frames[: n_warm + n_frames])))
-    for f, pf in zip(flts, work):
-        f.run_prepared(pf, 0, n_warm)
-        lib.eqf_synchronize(f.core_handle())
-    barrier = threading.Barrier(n_filters + 1)
+    def run_config(Nl, R):
+        flts, work = [], []
+        for r in range(R):
+            world, frames = build_workload(seed=500 + r, n_frames=n_warm + n_frames + 2, N=Nl)
+            flts.append(make_filter(world, settings, Nl, device, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=Nl, device=device, sensor=se, ids=i, p=p, time=t)))
+            work.append(PreparedFrames(world.cam, *flatten_frames(frames[: n_warm + n_frames])))
+        for f, pf in zip(flts, work):
+            f.run_prepared(pf, 0, n_warm)
+            lib.eqf_synchronize(f.core_handle())
+            lib.eqf_lookahead_stats(f.core_handle(), None, None, 1)
+        barrier = threading.Barrier(R + 1)
+        errs = []
 
-    def run(f, pf):
+        def run(f, pf):
+            barrier.wait()
+            try:
+                f.run_prepared(pf, n_warm, n_frames)  # ctypes releases the GIL: the host threads really run in parallel
+                lib.eqf_synchronize(f.core_handle())
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        ths = [threading.Thread(target=run, args=(f, pf)) for f, pf in zip(flts, work)]
+        for t in ths:
+            t.start()
         barrier.wait()
-        f.run_prepared(pf, n_warm, n_frames)  # ctypes releases the GIL: the host threads really run in parallel
-        lib.eqf_synchronize(f.core_handle())
+        t0 = time.perf_counter()
+        for t in ths:
+            t.join()
+        el = time.perf_counter() - t0
+        la, fb = 0, 0
+        for f in flts:
+            a, b = C.c_long(), C.c_long()
+            lib.eqf_lookahead_stats(f.core_handle(), C.byref(a), C.byref(b), 0)
+            la, fb = la + a.value, fb + b.value
+            f.close()
+        out = {"filters": R, "value": R * n_frames / el, "lookahead_launches": la, "lookahead_fallbacks": fb}
+        if errs:
+            out["errors"] = errs
+        return out
 
-    ths = [threading.Thread(target=run, args=(f, pf)) for f, pf in zip(flts, work)]
-    for t in ths:
-        t.start()
-    barrier.wait()
-    t0 = time.perf_counter()
-    for t in ths:
-        t.join()
-    el = time.perf_counter() - t0
-    for f in flts:
-        f.close()
-    return {"filters": n_filters, "frames_each": n_frames, "value": n_filters * n_frames / el, "unit": "updates/s aggregate on one GPU",
-            "note": "informational; independent filters in one process, one host thread + stream pair each"}
+    sweep = {"N%d" % Nl: [run_config(Nl, R) for R in counts] for Nl in sizes}
+    head = next((r for r in sweep.get("N%d" % N, []) if r["filters"] == 4), None) or run_config(N, 4)
+    return {"filters": 4, "frames_each": n_frames, "value": head["value"], "unit": "updates/s aggregate on one GPU", "sweep": sweep,
+            "note": "informational; independent filters in one process, one host thread + stream pair each; sweep = aggregate updates/s for R filters at N = 50 / 200"}
 
 
 def measure_roofline(flt, lib, core, cam, frames, args, n, m):

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_TWO_PHASE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_SYRK_F32, OPT_FUSED_LIFT, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_TWO_PHASE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_SYRK_F32, OPT_FUSED_LIFT, OPT_LA_TIMEOUT_US, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -208,6 +208,7 @@ def load_eqf_lib():
         "eqf_nees_lu_fallbacks": (C.c_int, [vp, C.POINTER(C.c_long)]),
         "eqf_speculation_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
         "eqf_selection_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
+        "eqf_lookahead_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
         "eqf_debug_matrices_AB": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
         "eqf_debug_get_W": (C.c_int, [vp, c_double_p, C.c_int, C.c_int]),
         "eqf_debug_lookahead_stamps": (C.c_int, [vp, C.POINTER(C.c_ulonglong)]),

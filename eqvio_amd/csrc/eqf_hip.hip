@@ -164,11 +164,17 @@ struct eqf_ctx {
     bool ring_attr = false; // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the ring instantiations on this context's device
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
+    long long la_timeout_ticks = LA_TIMEOUT_TICKS; // EQF_OPT_LA_TIMEOUT_US: bound of every device-side wait of the look-ahead kernel (100 MHz ticks)
+    long la_launches = 0, la_fallbacks = 0;  // eqf_lookahead_stats: look-ahead launches; of those, stalled ones that were redone on the launch chain
+    int la_consecutive_stalls = 0;           // three in a row switch the look-ahead kernel off for this context (the GPU is shared with something long-running)
+    int tail_M = 0;                          // measurement count of the update tail in flight (finish_update's retry)
+    bool tail_la = false;                    // ... and whether its factorisation was the look-ahead kernel
     int opt_syrk_f32 = 0;                    // EQF_OPT_SYRK_F32
     int opt_fused_lift = 0;                  // EQF_OPT_FUSED_LIFT
     int* d_perm = nullptr;                   // 2 x (ncap + 2) row permutations of the NEES elimination fallback
     static constexpr int kRing = 8; // pinned packets of the landmark bookkeeping: a ring, so that a flush need not drain the stream before reusing one
     int ring_pos = 0;
+    int ring_inflight = 0; // flushes whose copy may still be queued: reset wherever the host has seen the stream drain past them (sync_ctx, door_wait)
     // Deferred landmark bookkeeping: eqf_remove_landmarks / eqf_add_landmarks only record what they do (ids, N and the estimate cache follow at
     // once); flush_reshape applies everything recorded since the last flush with ONE copy + ONE kernel (k_reshape) when the device state is
     // next needed. A frame's removeOldLandmarks + removeOutliers + addNewLandmarks were 3 copies + 6 launches of host time and three passes over Sigma.
@@ -341,6 +347,7 @@ int sync_ctx(eqf_ctx* c) {
         c->obs_pending = false;
     }
     c->busy_common = c->busy_steps = c->busy_meas = false;
+    c->ring_inflight = 0;
     return 0;
 }
 // Wait for the doorbell `which` to show `seq` (written by the last workgroup of the kernel launched with it, after every
@@ -355,6 +362,7 @@ int door_wait(eqf_ctx* c, int which, int seq) {
         if (*bell == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
             c->busy_common = c->busy_steps = c->busy_meas = false;
+            c->ring_inflight = 0; // the kernel that rang was queued behind every flush of this context
             ++c->wait_calls;
             c->wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (which == 1)
@@ -527,6 +535,8 @@ const char* eqf_error_string(int code) {
         return "no gfx950 (MI355X) HIP device available: the EqF path has no CPU fallback";
     case EQF_E_UNSUPPORTED:
         return "option combination not supported by the device path";
+    case EQF_E_STALLED:
+        return "the look-ahead factorisation stalled and the retry on the launch chain failed as well";
     default:
         return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
@@ -807,6 +817,12 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
+        c->la_consecutive_stalls = 0;
+        return 0;
+    case EQF_OPT_LA_TIMEOUT_US:
+        if (value < 0)
+            return EQF_E_BAD_ARG;
+        c->la_timeout_ticks = 100ll * value; // 100 MHz device wall clock
         return 0;
     case EQF_OPT_TRACE: {
         { int _r = sync_ctx(c); if (_r) return _r; }
@@ -1082,13 +1098,14 @@ static int flush_reshape(eqf_ctx* c) {
     if (!c->reshape_pending)
         return 0;
     HP_SCOPE("abi.flush_reshape");
-    c->reshape_pending = false;
     const int Nnew = (int)c->pend_map.size(), knew = (int)c->pend_var.size();
     bool identity = knew == 0 && Nnew == c->dev_N;
     for (int i = 0; identity && i < Nnew; ++i)
         identity = c->pend_map[i] == i;
-    if (identity)
+    if (identity) {
+        c->reshape_pending = false;
         return 0;
+    }
     { int _r = join_observer(c); if (_r) return _r; } // landmark kernels of a stand-alone observer call run on the second stream
     bool pure_append = knew > 0 && knew <= APPEND_MAX && Nnew - knew == c->dev_N;
     for (int i = 0; pure_append && i < Nnew; ++i)
@@ -1106,8 +1123,18 @@ static int flush_reshape(eqf_ctx* c) {
             HIPCHK(hipGetLastError());
         }
         c->dev_N = Nnew;
+        c->reshape_pending = false; // only now: a failed launch above leaves the recorded bookkeeping in place
         return round_sigma(c);
     }
+    // A slot of the ring is rewritten kRing flushes later. Every host wait of the context (sync_ctx, door_wait) proves that all copies queued
+    // before it have run; only a caller that queues more than kRing flushes with no wait in between (alternating eqf_remove_landmarks /
+    // eqf_add_landmarks with asynchronous Riccati calls) gets here with a slot possibly still unread: drain once.
+    if (c->ring_inflight >= eqf_ctx::kRing) {
+        const int r = sync_ctx(c);
+        if (r)
+            return r;
+    }
+    ++c->ring_inflight;
     char* slot = c->h_rs_ring + (size_t)(c->ring_pos++ % eqf_ctx::kRing) * c->rs_bytes; // no stream drain: a ring of pinned packets
     const size_t off_p = (sizeof(int) * (size_t)c->Ncap + 15) & ~(size_t)15, off_v = off_p + sizeof(double) * 3 * (size_t)c->Ncap;
     std::memcpy(slot, c->pend_map.data(), sizeof(int) * Nnew);
@@ -1129,6 +1156,7 @@ static int flush_reshape(eqf_ctx* c) {
     c->lmcur = 1 - c->lmcur;
     c->stcur = 1 - c->stcur;
     c->dev_N = Nnew;
+    c->reshape_pending = false;
     return knew ? round_sigma(c) : 0; // (EQF_OPT_SIGMA_FP32 = 1 rounds after every store of Sigma: the appended variances)
 }
 
@@ -1762,6 +1790,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     if (++c->la_seq == 0)
         ++c->la_seq;
     a.seq = c->la_seq;
+    a.timeout_ticks = c->la_timeout_ticks;
     a.Z = c->d_Z;
     a.W = c->d_W;
     a.Linv0 = c->d_Linv; // k_build_Z leaves L_0^-1 where step 0 of the launch chain reads it
@@ -1930,6 +1959,7 @@ static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_s
     HIPCHK(hipGetLastError());
     return 0;
 }
+static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain);
 static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq,
                               const MeasFuse* fuse = nullptr) {
     HP_SCOPE("abi.launch_update_tail");
@@ -1961,12 +1991,24 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
         HIPCHK(hipGetLastError());
     }
     host_stamp(c, TH_BUILD_Z_OUT);
+    c->tail_M = M; // what a retry of the factorisation on the launch chain needs to know (finish_update)
+    return launch_factor_tail(c, M, discreteCorr, spec, spec_seq, use_door, door_seq, false);
+}
+// Everything behind k_build_Z: factorisation of Z (look-ahead kernel or launch chain), lift, covariance update. force_chain: the retry after a stalled
+// look-ahead kernel (Z and L_0^-1 are inputs of that kernel only, so the chain can start from them again).
+static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain) {
+    const int n = c->n(), m = 2 * M;
+    const int rows = m + n + 1;
+    int rc = 0;
     if (c->opt_fused) {
         rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, n, c->sigma(), c->d_gamma, true, spec, spec_seq);
         if (rc)
             return rc;
     } else {
-        const bool la = lookahead_eligible(c, m); // one persistent kernel instead of one launch per panel; Gamma complete in d_gamma
+        const bool la = !force_chain && lookahead_eligible(c, m); // one persistent kernel instead of one launch per panel; Gamma complete in d_gamma
+        c->tail_la = la;
+        if (la)
+            ++c->la_launches;
         const bool fl = la && c->opt_early && c->opt_fused_lift; // EQF_OPT_FUSED_LIFT
         rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, fl, discreteCorr, door_seq)
                 : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
@@ -2009,7 +2051,7 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
 }
 // Host part after the wait: the lift kernel wrote Gamma's sensor part, the new estimates / invalid flags (4N) and the status
 // flags straight into the pinned result packet; the sensor part of Delta is lifted here.
-static int finish_update(eqf_ctx* c, int discreteCorr) {
+static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
     HP_SCOPE("abi.finish_update");
     const int N = c->N, n = c->n();
     c->h_flags[0] = c->h_resflags[0];
@@ -2017,11 +2059,32 @@ static int finish_update(eqf_ctx* c, int discreteCorr) {
     // A failed factorisation is reported BEFORE anything of the filter changes: the device kept Sigma and the landmarks (k_lift,
     // k_syrk_sub), the sensor lift below is not applied. (EQF_OPT_FUSED_UPDATE folds the Sigma update into the factorisation steps and
     // cannot offer this; it is off by default.)
+    if (c->h_resflags[3] && !c->h_flags[0] && c->tail_la && !retried) {
+        // A bounded wait of the look-ahead kernel ran out: its workgroups were not all resident within the bound (another process or a long kernel
+        // of this process holds the CUs). Nothing of the filter was modified, and Z / L_0^-1 are inputs of that kernel only: redo the factorisation
+        // on the launch chain (which needs no co-residency), then lift and update Sigma as usual. Three stalls in a row switch the look-ahead
+        // kernel off for this context. EQF_E_STALLED reaches the caller only if the chain fails as well (it cannot stall).
+        ++c->la_fallbacks;
+        if (++c->la_consecutive_stalls >= 3)
+            c->opt_lookahead = 0;
+        HIPCHK(hipMemsetAsync(c->d_flags + 3, 0, sizeof(int), c->stream));
+        const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
+        const int door_seq = (int)(++c->door_seq);
+        int rc = launch_factor_tail(c, c->tail_M, discreteCorr, nullptr, 0, use_door, door_seq, true);
+        if (rc)
+            return rc;
+        rc = use_door ? door_wait(c, 1, door_seq) : sync_ctx(c);
+        if (rc)
+            return rc;
+        return finish_update(c, discreteCorr, true);
+    }
     if (c->h_resflags[3] || c->h_flags[0]) {
         c->est_valid = false;
         c->meas_valid = false;
-        return c->h_resflags[3] ? EQF_E_STALLED : EQF_E_NOT_SPD; // stalled: a bounded wait of the look-ahead kernel ran out (its workgroups were not all resident)
+        return c->h_resflags[3] ? EQF_E_STALLED : EQF_E_NOT_SPD;
     }
+    if (c->tail_la)
+        c->la_consecutive_stalls = 0;
     c->gamma_stale = true;
     c->n_at_update = n;
     c->est_cache.assign(c->h_res + 3 * (size_t)c->Ncap, c->h_res + 3 * (size_t)c->Ncap + 4 * N);
@@ -2243,10 +2306,10 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         ++c->sel_frames;
         if (c->h_sel[c->Ncap] == 0) // a frame without an outlier candidate ends the back-off
             c->spec_backoff = c->spec_backoff_len = 0;
-        *updated = 1;
         rc = finish_update(c, discreteCorr);
         if (rc)
             return rc;
+        *updated = 1;
         std::vector<int> idx;
         for (int i = 0; i < N; ++i)
             if (c->h_sel[i])
@@ -2311,8 +2374,10 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         return 0;
     }
     c->spec_backoff = c->spec_backoff_len = 0;
-    *updated = 1;
-    return finish_update(c, discreteCorr);
+    rc = finish_update(c, discreteCorr);
+    if (rc == 0)
+        *updated = 1;
+    return rc;
 }
 
 int eqf_stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const double* y, int M, double thrAbs, double thrProb, double meas_var, int useEqv,
@@ -2472,6 +2537,18 @@ int eqf_speculation_stats(eqf_ctx* c, long* calls, long* queued, long* cancelled
     *cancelled = c->spec_cancelled;
     if (reset)
         c->spec_calls = c->spec_queued = c->spec_cancelled = 0;
+    return 0;
+}
+
+int eqf_lookahead_stats(eqf_ctx* c, long* launches, long* fallbacks, int reset) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    if (launches)
+        *launches = c->la_launches;
+    if (fallbacks)
+        *fallbacks = c->la_fallbacks;
+    if (reset)
+        c->la_launches = c->la_fallbacks = 0;
     return 0;
 }
 

@@ -41,6 +41,7 @@ constexpr long long LA_TIMEOUT_TICKS = 2000000; // 20 ms at 100 MHz
 
 struct LaArgs {
     int rows, m, ldz, NJ, NI, seq;
+    long long timeout_ticks; // bound of every device-side wait (100 MHz ticks; default LA_TIMEOUT_TICKS)
     const double* Z;     // [S ; T ; y^T] from k_build_Z (plain memory; complete when this kernel starts)
     double* W;           // out, plain: rows >= m receive W = T L^-T and the z row
     const double* Linv0; // L_0^-1, 32 x 32 column-major, from k_build_Z's first-tile elimination
@@ -631,7 +632,7 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (threadIdx.x == 0)
         s_abort = 0;
     __syncthreads();
-    const LaPoll pl{(long long)wall_clock64() + LA_TIMEOUT_TICKS, a.seq, &s_abort};
+    const LaPoll pl{(long long)wall_clock64() + a.timeout_ticks, a.seq, &s_abort};
     if (blockIdx.x == 0)
         la_owner(a, smem, &s_abort, pl);
     else

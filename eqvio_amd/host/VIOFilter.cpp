@@ -39,17 +39,26 @@ std::vector<int> VIOState::getIds() const {
 }
 std::vector<int> VisionMeasurement::getIds() const { return flatIds(); }
 void VisionMeasurement::refreshFlat() const {
+    // camCoordinates is a public std::map (the reference's shape): a caller may change pixel values or swap an interior id without this object
+    // noticing. The cache is therefore trusted only after ONE walk over the map that compares every id and both pixel values (O(M), no allocation;
+    // about as long as the two allocations a rebuild would cost); the first difference rebuilds it.
     const size_t n = camCoordinates.size();
-    if (flatN_ == n && (n == 0 || (flatIds_.front() == camCoordinates.begin()->first && flatIds_.back() == camCoordinates.rbegin()->first)))
-        return;
-    flatIds_.clear();
-    flatY_.clear();
-    flatIds_.reserve(n);
-    flatY_.reserve(2 * n);
+    if (flatN_ == n && flatIds_.size() == n) {
+        size_t j = 0;
+        for (auto it = camCoordinates.begin(); it != camCoordinates.end(); ++it, ++j)
+            if (flatIds_[j] != it->first || flatY_[2 * j] != it->second[0] || flatY_[2 * j + 1] != it->second[1])
+                break;
+        if (j == n)
+            return;
+    }
+    flatIds_.resize(n);
+    flatY_.resize(2 * n);
+    size_t j = 0;
     for (const auto& kv : camCoordinates) {
-        flatIds_.push_back(kv.first);
-        flatY_.push_back(kv.second[0]);
-        flatY_.push_back(kv.second[1]);
+        flatIds_[j] = kv.first;
+        flatY_[2 * j] = kv.second[0];
+        flatY_[2 * j + 1] = kv.second[1];
+        ++j;
     }
     flatN_ = n;
 }
@@ -108,10 +117,13 @@ VIOSensorState unpackSensor(const double* d) {
     s.cameraOffset = unpackPose(d + 16);
     return s;
 }
-void flatten(const VisionMeasurement& m, std::vector<int>& ids, std::vector<double>& y) {
-    ids = m.flatIds();
-    y = m.flatY();
-}
+// the measurement as the two flat arrays the C-ABI takes: one validated view per call (VisionMeasurement::flat), no copies
+struct FlatMeas {
+    const std::vector<int>& ids;
+    const std::vector<double>& y;
+    explicit FlatMeas(const VisionMeasurement& m) : FlatMeas(m.flat()) {}
+    FlatMeas(std::pair<const std::vector<int>*, const std::vector<double>*> v) : ids(*v.first), y(*v.second) {}
+};
 } // namespace
 
 // ---------------------------------------------------------------- VIO_eqf (device backed)
@@ -297,9 +309,9 @@ void VIO_eqf::integrateRiccatiStateFast(const IMUVelocity& imu, const double& dt
 void VIO_eqf::performVisionUpdate(const VisionMeasurement& m, double var, const bool& useEqv, const bool& discreteCorrection) { // :105-135
     if (m.camCoordinates.empty())
         return;
-    std::vector<int> ids;
-    std::vector<double> y;
-    flatten(m, ids, y);
+    const FlatMeas fm(m);
+    const std::vector<int>& ids = fm.ids;
+    const std::vector<double>& y = fm.y;
     check(eqf_vision_update(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), var, useEqv ? 1 : 0, discreteCorrection ? 1 : 0), "eqf_vision_update");
 }
 VIOState VIO_eqf::stateEstimate() const { // :137
@@ -340,17 +352,17 @@ void VIO_eqf::outlierStats(const VisionMeasurement& m, std::vector<double>& absE
     depth2.assign(N, 0.0);
     if (N == 0)
         return;
-    std::vector<int> ids;
-    std::vector<double> y;
-    flatten(m, ids, y);
+    const FlatMeas fm(m);
+    const std::vector<int>& ids = fm.ids;
+    const std::vector<double>& y = fm.y;
     check(eqf_outlier_stats(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), absErr.data(), probErr.data(), depth2.data()), "eqf_outlier_stats");
 }
 void VIO_eqf::stageMeasurement(const VisionMeasurement& m) {
     if (m.camCoordinates.empty() || numLandmarks() == 0)
         return;
-    std::vector<int> ids;
-    std::vector<double> y;
-    flatten(m, ids, y);
+    const FlatMeas fm(m);
+    const std::vector<int>& ids = fm.ids;
+    const std::vector<double>& y = fm.y;
     check(eqf_stage_measurement(ctx, ids.data(), y.data(), (int)ids.size()), "eqf_stage_measurement");
 }
 int VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double thrProb, double var, bool useEqv, bool discreteCorrection, std::vector<double>& absErr,
@@ -359,9 +371,9 @@ int VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double t
     absErr.assign(N, -1.0);
     probErr.assign(N, -1.0);
     depth2.assign(N, 0.0);
-    std::vector<int> ids;
-    std::vector<double> y;
-    flatten(m, ids, y);
+    const FlatMeas fm(m);
+    const std::vector<int>& ids = fm.ids;
+    const std::vector<double>& y = fm.y;
     int updated = 0;
     if (maxOutliers < 0) {
         check(eqf_stats_then_update(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), thrAbs, thrProb, var, useEqv ? 1 : 0, discreteCorrection ? 1 : 0,
@@ -708,8 +720,9 @@ void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std:
     std::vector<Landmark> newLandmarks;
     std::vector<int> have = filterState.ids(); // sorted copy: O(M log N) membership instead of the reference's O(M N) scan
     std::sort(have.begin(), have.end());
-    const std::vector<int>& mids = measurement.flatIds();
-    const std::vector<double>& my = measurement.flatY();
+    const auto flatView = measurement.flat();
+    const std::vector<int>& mids = *flatView.first;
+    const std::vector<double>& my = *flatView.second;
     for (size_t j = 0; j < mids.size(); ++j) {
         const int ccId = mids[j];
         if (!std::binary_search(have.begin(), have.end(), ccId)) {

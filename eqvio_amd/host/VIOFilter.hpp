@@ -114,9 +114,10 @@ struct VisionMeasurement {
     std::map<int, std::array<double, 2>> camCoordinates; // ascending id == the reference's row order
     GICameraPtr cameraPtr;
     std::vector<int> getIds() const;
-    // The same measurement as two flat arrays (ids ascending, pixels u0 v0 u1 v1 ...), the form the C-ABI takes. Built from the map on first use
-    // and rebuilt whenever the map's size or end points differ from what was flattened; code that edits pixel values IN PLACE calls
-    // invalidateFlat(). The replay path builds it once per frame, before the timed region, next to the map itself (eqvio_frames_create).
+    // The same measurement as two flat arrays (ids ascending, pixels u0 v0 u1 v1 ...), the form the C-ABI takes. Every access validates the cached
+    // arrays against the map (all ids, all pixel values: the map is public and may have been edited) and rebuilds them on the first difference;
+    // flat() hands out both arrays after ONE such walk. The replay path builds the cache once per frame, before the timed region (eqvio_frames_create).
+    std::pair<const std::vector<int>*, const std::vector<double>*> flat() const { return refreshFlat(), std::make_pair(&flatIds_, &flatY_); }
     const std::vector<int>& flatIds() const { return refreshFlat(), flatIds_; }
     const std::vector<double>& flatY() const { return refreshFlat(), flatY_; }
     void invalidateFlat() const { flatIds_.clear(), flatY_.clear(), flatN_ = (size_t)-1; }

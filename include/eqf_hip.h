@@ -30,8 +30,10 @@ enum {
     EQF_E_CAPACITY = -4,   /* an output array of the caller is too small; or the device buffers could not be grown (allocation failed) */
     EQF_E_NO_DEVICE = -5,
     EQF_E_UNSUPPORTED = -6, /* option combination not implemented on the device path */
-    EQF_E_STALLED = -7      /* a bounded device-side wait of the look-ahead factorisation ran out (20 ms): its workgroups were not all
-                               resident, e.g. the GPU is oversubscribed by other processes. Nothing was modified except scratch. */
+    EQF_E_STALLED = -7      /* a bounded device-side wait of the look-ahead factorisation ran out (its workgroups were not all resident, e.g. the
+                               GPU is held by another process) AND the automatic retry of the same factorisation on the launch chain failed as
+                               well. A stall alone is not an error: the update is redone on the chain (bit-identical results) and counted, see
+                               eqf_lookahead_stats. Nothing of the filter was modified when this code is returned. */
 };
 
 /* options for eqf_set_option */
@@ -58,8 +60,13 @@ enum {
                                   A and B they need themselves and its observer blocks write the second landmark buffer; 0: k_assemble_AB first */
     EQF_OPT_LOOKAHEAD = 12,    /* 1 (default): the factorisation of [S ; T ; y^T] runs as ONE persistent kernel with a look-ahead schedule (one owner
                                   workgroup walks the pivot chain, one workgroup per 32-row block row keeps its tiles in registers and follows one to
-                                  two panels behind; hand-offs as write-through tile stores + one sequence-numbered flag per tile, never cleared) when the update has 3 .. 16
-                                  panels (32 < M <= 256 measurements); bit-identical W / Sigma to the chain. 0: one launch per panel (k_chol_step) */
+                                  two panels behind; hand-offs as write-through tile stores + one sequence-numbered flag per tile, never cleared) when the update has 3 .. 32
+                                  panels (32 < M <= 512 measurements; 17 .. 32 panels feed their operand tiles through an LDS ring); bit-identical W / Sigma
+                                  to the chain. 0: one launch per panel (k_chol_step). Switched to 0 by the library itself after three stalled launches in
+                                  a row (eqf_lookahead_stats); setting it again re-arms it */
+    EQF_OPT_LA_TIMEOUT_US = 15, /* bound of every device-side wait inside the look-ahead kernel, microseconds of device wall clock; default 20000 (20 ms).
+                                  When it runs out the launch is abandoned and the factorisation redone on the launch chain. 0 makes every look-ahead
+                                  launch stall at its first wait: the test hook for that path */
     EQF_OPT_FUSED_LIFT = 14,   /* 1: the look-ahead kernel's last T block row lifts the landmarks, fills the result packet and rings the doorbell (no k_lift launch
                                   behind it: 4 launches per frame, -2.4 us on the device timeline, bit-identical results); 0 (default): k_lift as a kernel of
                                   its own. Measured neutral for the frame rate (the frame boundary is bound by the host's launch), so the simpler form is the default */
@@ -76,7 +83,7 @@ enum {
 
 const char* eqf_error_string(int code);
 
-/* lifecycle. coordinate_choice: EQVIO_COORD_EUCLIDEAN | EQVIO_COORD_INVDEPTH
+/* lifecycle. coordinate_choice: EQVIO_COORD_EUCLIDEAN | EQVIO_COORD_INVDEPTH | EQVIO_COORD_NORMAL
  * (EqFCoordinateSuite selection, include/eqvio/mathematical/EqFMatrices.h:81-90). */
 /* max_landmarks is the INITIAL capacity, not a limit (the reference has none): eqf_add_landmarks and eqf_set_state grow the device
  * buffers (at least doubling, state and Sigma carried over) when more landmarks arrive. The handle stays valid. */
@@ -168,7 +175,8 @@ int eqf_stage_measurement(eqf_ctx* ctx, const int* ids, const double* y_px, int 
  * which return at their first instruction: nothing is modified, *updated = 0 and the caller continues exactly as without
  * speculation (decide with the returned statistics, remove, eqf_vision_update). Otherwise *updated = 1 and the state is
  * the one eqf_vision_update would have produced (bit-identical). *updated = -1: not applicable, some measurement id is not in
- * the state (nothing was computed). EQF_OPT_SPECULATIVE = 0 turns it into a plain statistics call (*updated = 0). absErr / probErr: -1 for landmarks without a measurement. */
+ * the state (nothing was computed). EQF_OPT_SPECULATIVE = 0 turns it into a plain statistics call (*updated = 0). absErr / probErr: -1 for landmarks without a measurement.
+ * *updated is 1 only when the call returns 0: a failed update (EQF_E_NOT_SPD, EQF_E_NONFINITE) leaves it 0. */
 int eqf_stats_then_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y_px, int M, double thrAbs, double thrProb, double meas_var,
                           int useEquivariantOutput, int discreteCorrection, double* absErr, double* probErr, double* depth2, int* updated);
 
@@ -185,6 +193,9 @@ int eqf_speculation_stats(eqf_ctx* ctx, long* calls, long* queued, long* cancell
  * without a measurement can be marginalised before or after the update. */
 int eqf_stats_select_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y_px, int M, double thrAbs, double thrProb, int max_outliers, double meas_var,
                             int useEquivariantOutput, int discreteCorrection, double* absErr, double* probErr, double* depth2, int* updated, int* removed_idx, int* n_removed);
+/* look-ahead factorisation since the last reset: launches of the persistent kernel; of those, launches whose bounded wait ran out and whose
+ * factorisation was redone on the launch chain (same Z, bit-identical result; three in a row switch EQF_OPT_LOOKAHEAD off for the context). */
+int eqf_lookahead_stats(eqf_ctx* ctx, long* launches, long* fallbacks, int reset);
 /* frames that took the device-side decision, landmarks it discarded */
 int eqf_selection_stats(eqf_ctx* ctx, long* frames, long* discarded, int reset);
 

@@ -1,0 +1,145 @@
+"""The EXACT path bench.py times, in front of the oracle at the benchmarked sizes.
+
+bench.py drives `VIOFilter` (the host mirror) through eqvio_filter_run_prepared -> eqf_stage_measurement + eqf_propagate_fast (k_propagate_main<double, true>: fused
+assembly + observer blocks + measurement staging) + eqf_stats_then_update (k_build_Z<double, true>: measurement fusion + statistics row + speculative cancel,
+k_chol_lookahead, k_lift, k_syrk_sub). The kernel-level tests reach those instantiations at N <= 19 only; here they meet the oracle at N = 200 and N = 500 on
+bench.build_workload's own hover world with bench.eurocish_settings(), through the same C-ABI call bench.py uses, frame by frame (src/VIOFilter.cpp:194-241).
+Also here: the `frame_mix` wave world with the shipped EuRoC thresholds at N ~ 200 (k_select_outliers + masked update + k_reshape at size) and BASELINE
+config 2 (EuRoC-structured settings, sine trajectory, 50 landmarks, >= 100 lockstep frames, promoted from tests/run_configs.py)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from eqvio_amd.capi import PreparedFrames, SimSettings, SimulationDataServer, VIOFilter, load_eqf_lib  # noqa: E402
+from oracle_binding import OracleFilter  # noqa: E402
+from simworld import SimWorld  # noqa: E402
+from test_gpu_filter import compare  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def counters(flt):
+    lib = load_eqf_lib()
+    a, b, c, d, e, f, g = (C.c_long() for _ in range(7))
+    assert lib.eqf_speculation_stats(flt.core_handle(), C.byref(a), C.byref(b), C.byref(c), 0) == 0
+    assert lib.eqf_lookahead_stats(flt.core_handle(), C.byref(d), C.byref(e), 0) == 0
+    assert lib.eqf_selection_stats(flt.core_handle(), C.byref(f), C.byref(g), 0) == 0
+    return dict(calls=a.value, queued=b.value, cancelled=c.value, la_launches=d.value, la_fallbacks=e.value, sel_frames=f.value, sel_discarded=g.value)
+
+
+def run_lockstep(world, frames, settings, N, n_frames, tol=TOL, max_landmarks=None):
+    """bench.rank_pass's filter and input containers; one eqvio_filter_run_prepared call per frame so that the oracle can be compared in between."""
+    mk = lambda s, sensor, ids, p, t: VIOFilter(s, max_landmarks=max_landmarks or N, sensor=sensor, ids=ids, p=p, time=t)  # noqa: E731
+    flt = bench.make_filter(world, settings, N, None, frames, mk)
+    orc = bench.make_filter(world, settings, N, None, frames, lambda s, sensor, ids, p, t: OracleFilter(s, sensor, ids, p, t))
+    prepared = PreparedFrames(world.cam, *bench.flatten_frames(frames[:n_frames]))
+    worst = 0.0
+    for f in range(n_frames):
+        imus, stamp, mid, y = frames[f]
+        assert flt.run_prepared(prepared, f, 1) == 1
+        for s in range(len(imus)):
+            orc.process_imu(imus[s])
+        orc.process_vision(stamp, world.cam, mid, y)
+        assert flt.get_time() == orc.get_time() == stamp
+        compare(flt, orc, tol)
+    return flt, orc, worst
+
+
+def test_headline_path_N200_against_the_oracle():
+    """The workload of the bench line itself (seed of rank 0), 6 frames in lockstep. Every frame must have gone through the one-round-trip path: tail
+    queued speculatively and never cancelled, factorisation on the look-ahead kernel."""
+    N = 200
+    world, frames = bench.build_workload(seed=100, n_frames=7, N=N)
+    flt, orc, _ = run_lockstep(world, frames, bench.eurocish_settings(), N, 6)
+    k = counters(flt)
+    assert k["calls"] == k["queued"] == 6 and k["cancelled"] == 0, k
+    assert k["la_launches"] == 6 and k["la_fallbacks"] == 0, k
+    assert flt.sigma_dim() == 21 + 3 * N
+
+
+def test_headline_path_N500_against_the_oracle():
+    """BASELINE config 3 through the filter (bench.py --landmarks 500): the 32-panel ring instantiation of the look-ahead kernel, two frames."""
+    N = 500
+    world, frames = bench.build_workload(seed=100, n_frames=3, N=N)
+    flt, orc, _ = run_lockstep(world, frames, bench.eurocish_settings(), N, 2)
+    k = counters(flt)
+    assert k["calls"] == k["queued"] == 2 and k["cancelled"] == 0 and k["la_launches"] == 2 and k["la_fallbacks"] == 0, k
+
+
+def test_headline_path_N50_against_the_oracle():
+    """BASELINE config 2's size through the same path (bench.py --landmarks 50): 4 panels, the smallest look-ahead instantiation in use."""
+    N = 50
+    world, frames = bench.build_workload(seed=100, n_frames=13, N=N)
+    flt, orc, _ = run_lockstep(world, frames, bench.eurocish_settings(), N, 12)
+    k = counters(flt)
+    assert k["queued"] == 12 and k["cancelled"] == 0 and k["la_launches"] == 12, k
+
+
+def test_frame_mix_shipped_thresholds_N200_against_the_oracle():
+    """bench.frame_mix's second workload: wave world (about 9 of 200 tracked features change per frame), the shipped EuRoC outlier thresholds / retention /
+    point variance (EQVIO_config_EuRoC_stationary.yaml:26-32). Almost every frame has an outlier candidate: the speculative tail is cancelled, speculation
+    backs off and the frames take statistics -> k_select_outliers -> masked update -> k_reshape, at N ~ 200, in step with the oracle's reference order
+    (src/VIOFilter.cpp:304-364)."""
+    N = 200
+    s = bench.eurocish_settings()
+    s.outlierThresholdAbs, s.outlierThresholdProb, s.featureRetention, s.initialPointVariance = 4.852186665580312, 0.03229809583062128, 0.18594708334486176, 129.90415638150924
+    world = SimWorld(seed=321, num_points=2500, max_features=N, trajectory="wave", noise_px=0.5)
+    frames = list(world.frames(9))
+    ids0 = frames[0][2]
+    sensor, ids, p = world.true_state(0.0, ids0)
+    p = p * (1.0 + 0.05 * np.random.default_rng(7).normal(size=(len(ids), 1)))
+    flt = VIOFilter(s, max_landmarks=N + 120, sensor=sensor, ids=ids, p=p, time=0.0)
+    orc = OracleFilter(s, sensor, ids, p, 0.0)
+    prepared = PreparedFrames(world.cam, *bench.flatten_frames(frames))
+    dims = []
+    for f, (imus, stamp, mid, y) in enumerate(frames[:8]):
+        assert flt.run_prepared(prepared, f, 1) == 1
+        for k_ in range(len(imus)):
+            orc.process_imu(imus[k_])
+        orc.process_vision(stamp, world.cam, mid, y)
+        compare(flt, orc, TOL)
+        dims.append((flt.sigma_dim() - 21) // 3)
+    k = counters(flt)
+    assert k["sel_frames"] >= 3 and k["sel_discarded"] >= 3, k  # the device took the outlier decision at this size
+    assert k["la_launches"] >= 6 and k["la_fallbacks"] == 0, k
+    assert min(dims) >= 100, dims
+
+
+def test_config2_euroc_structured_sine_50_landmarks_lockstep():
+    """BASELINE.json configs[1] stand-in (tests/run_configs.py config 2, promoted): the C++ SimulationDataServer on the sine trajectory, 50 tracked
+    features, the shipped EuRoC settings' structure with simulator-consistent values, the filter adding and dropping landmarks by itself
+    (main_opt-like), >= 100 frames in lockstep with the oracle."""
+    from run_configs import euroc_settings, parity, sim_consistent
+
+    fs = sim_consistent(euroc_settings(), measurementNoise=1.0)
+    sim = SimSettings.defaults(duration=6.0, trajectory="sine", numPoints=4000, wallDistance=3.0, numWalls=6, randomSeed=1, maxFeatures=50, outputNoise=1, inputNoise=0)
+    srv = SimulationDataServer(sim, fs)
+    fs.cameraOffset[:] = srv.camera_offset()
+    s0, ids0, p0 = srv.true_state(0.0, True)
+    flt = VIOFilter(fs, max_landmarks=2 * sim.maxFeatures + 64, sensor=s0, ids=ids0[:0], p=p0[:0], time=0.0)
+    orc = OracleFilter(fs, s0, ids0[:0], p0[:0], 0.0)
+    frames, worst_state, worst_sigma, seen = 0, 0.0, 0.0, set()
+    while srv.next_measurement_type() != srv.NONE:
+        if srv.next_measurement_type() == srv.IMU:
+            imu = srv.get_imu()
+            flt.process_imu(imu)
+            orc.process_imu(imu)
+            continue
+        stamp, ids, y = srv.get_vision()
+        flt.process_vision(stamp, srv.cam, ids, y)
+        orc.process_vision(stamp, srv.cam, ids, y)
+        es, eS = parity(flt, orc)  # asserts identical landmark sets
+        worst_state, worst_sigma = max(worst_state, es), max(worst_sigma, eS)
+        seen |= set(ids.tolist())
+        frames += 1
+    assert frames >= 100 and len(seen) > 60, (frames, len(seen))  # landmarks really entered and left
+    assert worst_state <= TOL and worst_sigma <= TOL, (worst_state, worst_sigma)
+    assert counters(flt)["la_launches"] >= 90

