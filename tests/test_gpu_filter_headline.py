@@ -96,17 +96,31 @@ def test_frame_mix_shipped_thresholds_N200_against_the_oracle():
     ids0 = frames[0][2]
     sensor, ids, p = world.true_state(0.0, ids0)
     p = p * (1.0 + 0.05 * np.random.default_rng(7).normal(size=(len(ids), 1)))
+    from oracle_binding import ARITH_AS_WRITTEN, ARITH_EFFICIENT
+    from run_configs import parity
+
     flt = VIOFilter(s, max_landmarks=N + 120, sensor=sensor, ids=ids, p=p, time=0.0)
+    # Point variance 129.9 against 1.93 px of pixel noise: cond(S) is large and the freshly initialised landmarks move by metres in their first update.
+    # What two fp64 evaluations of the same frame can agree to is measured, not assumed: a second oracle in the other dense arithmetic ("efficient":
+    # Cholesky; the first is "as written": LU inverse, K evaluated twice, VIO_eqf.cpp:116-131). The device is held to max(1e-9, 2 x that floor).
     orc = OracleFilter(s, sensor, ids, p, 0.0)
+    orc2 = OracleFilter(s, sensor, ids, p, 0.0)
+    orc.set_arithmetic(ARITH_AS_WRITTEN)
+    orc2.set_arithmetic(ARITH_EFFICIENT)
     prepared = PreparedFrames(world.cam, *bench.flatten_frames(frames))
-    dims = []
+    dims, worst, worst_floor = [], 0.0, 0.0
     for f, (imus, stamp, mid, y) in enumerate(frames[:8]):
         assert flt.run_prepared(prepared, f, 1) == 1
-        for k_ in range(len(imus)):
-            orc.process_imu(imus[k_])
-        orc.process_vision(stamp, world.cam, mid, y)
-        compare(flt, orc, TOL)
+        for o in (orc, orc2):
+            for k_ in range(len(imus)):
+                o.process_imu(imus[k_])
+            o.process_vision(stamp, world.cam, mid, y)
+        es, eS = parity(flt, orc)  # asserts identical landmark sets: every outlier decision of the device matches the reference order
+        fs_, fS_ = parity(orc2, orc)
+        assert es <= max(TOL, 2.0 * fs_) and eS <= max(TOL, 2.0 * fS_), (f, es, fs_, eS, fS_)
+        worst, worst_floor = max(worst, es, eS), max(worst_floor, fs_, fS_)
         dims.append((flt.sigma_dim() - 21) // 3)
+    assert worst <= 1e-7, (worst, worst_floor)
     k = counters(flt)
     assert k["sel_frames"] >= 3 and k["sel_discarded"] >= 3, k  # the device took the outlier decision at this size
     assert k["la_launches"] >= 6 and k["la_fallbacks"] == 0, k
@@ -124,22 +138,33 @@ def test_config2_euroc_structured_sine_50_landmarks_lockstep():
     srv = SimulationDataServer(sim, fs)
     fs.cameraOffset[:] = srv.camera_offset()
     s0, ids0, p0 = srv.true_state(0.0, True)
+    from oracle_binding import ARITH_AS_WRITTEN, ARITH_EFFICIENT
+
     flt = VIOFilter(fs, max_landmarks=2 * sim.maxFeatures + 64, sensor=s0, ids=ids0[:0], p=p0[:0], time=0.0)
     orc = OracleFilter(fs, s0, ids0[:0], p0[:0], 0.0)
-    frames, worst_state, worst_sigma, seen = 0, 0.0, 0.0, set()
+    orc2 = OracleFilter(fs, s0, ids0[:0], p0[:0], 0.0)  # the other dense arithmetic: what a free-running fp64 filter can agree to after 100+ frames
+    orc.set_arithmetic(ARITH_AS_WRITTEN)
+    orc2.set_arithmetic(ARITH_EFFICIENT)
+    frames, worst_state, worst_sigma, floor_state, floor_sigma, seen = 0, 0.0, 0.0, 0.0, 0.0, set()
     while srv.next_measurement_type() != srv.NONE:
         if srv.next_measurement_type() == srv.IMU:
             imu = srv.get_imu()
             flt.process_imu(imu)
             orc.process_imu(imu)
+            orc2.process_imu(imu)
             continue
         stamp, ids, y = srv.get_vision()
         flt.process_vision(stamp, srv.cam, ids, y)
         orc.process_vision(stamp, srv.cam, ids, y)
+        orc2.process_vision(stamp, srv.cam, ids, y)
         es, eS = parity(flt, orc)  # asserts identical landmark sets
+        fs_, fS_ = parity(orc2, orc)
         worst_state, worst_sigma = max(worst_state, es), max(worst_sigma, eS)
+        floor_state, floor_sigma = max(floor_state, fs_), max(floor_sigma, fS_)
         seen |= set(ids.tolist())
         frames += 1
     assert frames >= 100 and len(seen) > 60, (frames, len(seen))  # landmarks really entered and left
-    assert worst_state <= TOL and worst_sigma <= TOL, (worst_state, worst_sigma)
+    print(f"config 2 stand-in, {frames} frames: device vs oracle state {worst_state:.2e} Sigma {worst_sigma:.2e}; oracle vs oracle {floor_state:.2e} / {floor_sigma:.2e}")
+    assert worst_state <= max(TOL, 2.0 * floor_state) and worst_sigma <= max(TOL, 2.0 * floor_sigma), (worst_state, floor_state, worst_sigma, floor_sigma)
+    assert worst_state <= 1e-8 and worst_sigma <= 1e-9
     assert counters(flt)["la_launches"] >= 90

@@ -47,6 +47,9 @@ def test_fp32_sigma_tracks_fp64(max_features):
     worst = {"sigma": 0.0, "pose": 0.0, "landmarks": 0.0}
     lm_all = []
     frames = 0
+    born = {}  # landmark id -> frame it entered the state
+    by_age = {}  # frames in the state -> worst relative landmark error seen at that age
+    depth_of_worst = (0.0, 0.0, 0)
     while srv.next_measurement_type() != srv.NONE:
         if srv.next_measurement_type() == srv.IMU:
             imu = srv.get_imu()
@@ -74,10 +77,25 @@ def test_fp32_sigma_tracks_fp64(max_features):
         rel = np.linalg.norm(pb - pa, axis=1) / np.maximum(1.0, np.linalg.norm(pa, axis=1))
         lm_all.append(rel)
         worst["landmarks"] = max(worst["landmarks"], float(np.max(rel)))
+        for i_, r_ in zip(ia.tolist(), rel.tolist()):
+            age = frames - born.setdefault(i_, frames)
+            by_age[age] = max(by_age.get(age, 0.0), r_)
+        k_ = int(np.argmax(rel))
+        if rel[k_] > depth_of_worst[0]:
+            depth_of_worst = (float(rel[k_]), float(np.linalg.norm(pa[k_])), frames - born[int(ia[k_])])
     worst["landmarks_median"] = float(np.median(np.concatenate(lm_all)))
-    print(f"fp32-Sigma vs fp64 over {frames} frames, N<={max_features}: {worst}")
+    old = max((v for a_, v in by_age.items() if a_ >= 10), default=0.0)
+    print(f"fp32-Sigma vs fp64 over {frames} frames, N<={max_features}: {worst}; worst landmark error by age (frames in the state): "
+          + ", ".join(f"{a_}: {by_age[a_]:.1e}" for a_ in sorted(by_age) if a_ in (0, 1, 2, 3, 5, 10, 20, 40, 80)) + f"; age >= 10: {old:.1e}; the worst one: rel {depth_of_worst[0]:.1e} "
+          f"at depth {depth_of_worst[1]:.1f} m, age {depth_of_worst[2]}")
     assert frames == 90 and f64.sigma_dim() > 21 + 3 * max_features // 2
-    assert worst["sigma"] <= 1e-4 and worst["pose"] <= 1e-5 and worst["landmarks"] <= 1e-3 and worst["landmarks_median"] <= 1e-5
+    # SURVEY's bounds: Sigma 1e-4, pose 1e-5, landmarks 1e-5. Measured (the print above): with <= 60 features EVERY landmark is within 1e-5 at every age
+    # (worst 8.6e-6); with <= 200 features the median is 6e-6 but the worst landmark reaches 2e-4 - and it is not a young or a distant one (the worst
+    # sample: 8 m deep, 88 frames in the state; the by-age maxima are flat from age 1 to age 80). The float store perturbs Sigma by 1e-5 relative and the
+    # gain distributes that over the landmarks it couples; the tail grows with N, not with age or depth. So: 1e-5 for all landmarks at N <= 60,
+    # 1e-5 for the median and 1e-3 for the worst at N <= 200.
+    assert worst["sigma"] <= 1e-4 and worst["pose"] <= 1e-5 and worst["landmarks_median"] <= 1e-5
+    assert worst["landmarks"] <= (1e-5 if max_features <= 60 else 1e-3)
     assert worst["sigma"] > 1e-9  # the option really changes the arithmetic
 
 

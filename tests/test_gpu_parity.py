@@ -554,12 +554,12 @@ def test_nees_returns_a_number_when_sigma_is_not_numerically_spd():
 @pytest.mark.parametrize("N,M", [(200, 200), (50, 50), (40, 40), (60, 33), (224, 224), (130, 97), (256, 250), (300, 270), (384, 384), (400, 390), (500, 500), (512, 512)])
 def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
     """EQF_OPT_LOOKAHEAD: the factorisation of [S ; T ; y^T] as ONE persistent kernel (owner workgroup on the pivot chain, one workgroup
-    per block row following behind, hand-offs as 16-byte value + sequence words) against one launch per panel. Same tile arithmetic in
+    per block row following behind, hand-offs as write-through 8 KB tiles + one sequence-numbered flag per tile) against one launch per panel. Same tile arithmetic in
     the same order: W and Sigma must not change by a bit; Gamma is summed in another (fixed) order, so it and the lifted state agree to
     rounding. Sizes: 13 panels (the headline), 4, 3 (smallest eligible), a last panel of 2 columns, 14 panels (largest of the small
     instantiation), M < N with a ragged last panel, the 16-panel instantiation, and the two large ones (17 .. 24 and 25 .. 32 panels: N = 300 .. 512,
     the stress configuration N = 500 among them). A second update on the same context
-    meets the first one's words in the hand-off buffers (the sequence number tells them apart)."""
+    meets the first one's tiles and flags in the hand-off buffers (the sequence number in the flags tells them apart)."""
     from eqvio_amd.capi import OPT_FUSED_LIFT, OPT_LOOKAHEAD
 
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=N + M, useDiscreteInnovationLift=0)
