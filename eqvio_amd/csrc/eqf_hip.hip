@@ -161,7 +161,6 @@ struct eqf_ctx {
     int* d_pubf = nullptr;
     char *d_puby = nullptr, *d_publ = nullptr;
     int la_njcap = 0, la_seq = 0;
-    bool ring_attr = false; // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the ring instantiations on this context's device
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     long long la_timeout_ticks = LA_TIMEOUT_TICKS; // EQF_OPT_LA_TIMEOUT_US: bound of every device-side wait of the look-ahead kernel (100 MHz ticks)
@@ -614,9 +613,9 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipMalloc(&c->d_gpart, sizeof(double) * (GAMMA_G + 1) * (size_t)c->ld));
     c->la_njcap = std::min(32, blocks(c->mcap, 32));
     HIPCHK(hipMalloc(&c->d_pub, sizeof(double) * LA_TILE * la_pub_tiles(c->la_njcap)));
-    HIPCHK(hipMalloc(&c->d_pubf, sizeof(int) * la_pub_tiles(c->la_njcap)));
+    HIPCHK(hipMalloc(&c->d_pubf, sizeof(int) * la_pub_flags(c->la_njcap)));
     HIPCHK(hipMalloc(&c->d_puby, 512 * (size_t)c->la_njcap));
-    HIPCHK(hipMemsetAsync(c->d_pubf, 0, sizeof(int) * la_pub_tiles(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
+    HIPCHK(hipMemsetAsync(c->d_pubf, 0, sizeof(int) * la_pub_flags(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
     HIPCHK(hipMemsetAsync(c->d_puby, 0, 512 * (size_t)c->la_njcap, c->stream));
     HIPCHK(hipMalloc(&c->d_publ, 16384 * (size_t)c->la_njcap));
     HIPCHK(hipMemsetAsync(c->d_publ, 0, 16384 * (size_t)c->la_njcap, c->stream));
@@ -1786,7 +1785,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.m = m;
     a.ldz = ldz;
     a.NJ = blocks(m, 32);
-    a.NI = a.NJ + blocks(rows - m, 32);
+    a.NI = (2 * a.NJ - 1) + blocks(rows - m, 16); // the owner + the S half-rows 2 .. 2 NJ - 1 + the T half-rows (16 rows each)
     if (++c->la_seq == 0)
         ++c->la_seq;
     a.seq = c->la_seq;
@@ -1812,21 +1811,11 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
         a.tr_lift = trace_slot(c, TR_LIFT);
     }
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
-    // MAXT = tiles a wave keeps in registers = ceil(NJ / 2)
-    // (the two large instantiations feed their operand tiles through an LDS ring and need more than the default 64 KB of dynamic LDS)
-    if (!c->ring_attr) { // per context: the attribute belongs to the device that is current, and a process may drive several
-        HIPCHK(hipFuncSetAttribute((const void*)k_chol_lookahead<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LA_LDS_RING));
-        HIPCHK(hipFuncSetAttribute((const void*)k_chol_lookahead<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LA_LDS_RING));
-        c->ring_attr = true;
-    }
-    if (a.NJ <= 14)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<7, false>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
-    else if (a.NJ <= 16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8, false>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
-    else if (a.NJ <= 24)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<12, true>), dim3(a.NI), dim3(LA_T), LA_LDS_RING, c->stream, a);
+    // MAXT = tiles a wave keeps in registers = ceil(NJ / 4)
+    if (a.NJ <= 16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<16, true>), dim3(a.NI), dim3(LA_T), LA_LDS_RING, c->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }

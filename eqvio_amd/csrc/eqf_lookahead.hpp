@@ -69,13 +69,19 @@ struct LaArgs {
 // flags: the same indices (one int per tile; U1 / U0 share the flag of U1)
 __device__ __forceinline__ int la_i_linv(const LaArgs& a, int p) { return p; }
 __device__ __forceinline__ int la_i_p(const LaArgs& a, int J, int p) { return a.NJ + p * a.NJ + J; }
-__device__ __forceinline__ int la_i_u(const LaArgs& a, int I, int which) { return a.NJ + a.NJ * a.NJ + 2 * I + which; }
-inline size_t la_pub_tiles(int NJ) { return (size_t)NJ + (size_t)NJ * NJ + 2 * (size_t)NJ; }
+__device__ __forceinline__ int la_i_u(const LaArgs& a, int I, int which) { return a.NJ + a.NJ * a.NJ + 3 * I + which; } // which: 0 U1 = Z(I, I-1), 1 U0 = Z(I, I), 2 U2 = Z(I, I-2)
+inline size_t la_pub_tiles(int NJ) { return (size_t)NJ + (size_t)NJ * NJ + 3 * (size_t)NJ; }
+// flags: one per L_p^-1 | one per (panel p, half-row h) for the factor rows P^(p)_h (a panel's flags are neighbours) | one per (S block row I, half s) for
+// its U1 / U0 hand-off. Half-row h = 2 I + s holds rows 16 h .. 16 h + 15 of S.
+__device__ __forceinline__ int la_f_linv(const LaArgs& a, int p) { return p; }
+__device__ __forceinline__ int la_f_p(const LaArgs& a, int p, int h) { return a.NJ + 2 * a.NJ * p + h; }
+__device__ __forceinline__ int la_f_u(const LaArgs& a, int I, int s) { return a.NJ + 2 * a.NJ * a.NJ + 2 * I + s; }
+inline size_t la_pub_flags(int NJ) { return (size_t)NJ + 2 * (size_t)NJ * NJ + 2 * (size_t)NJ; }
 __device__ __forceinline__ double* la_tile(const LaArgs& a, int idx) { return a.pub + (size_t)LA_TILE * idx; }
 
 __device__ __forceinline__ void la_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } // global_store_dwordx2 sc1
 __device__ __forceinline__ void la_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void la_raise(const LaArgs& a, int idx) { __hip_atomic_store(a.pubf + idx, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void la_raise_f(const LaArgs& a, int fidx) { __hip_atomic_store(a.pubf + fidx, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct LaPoll {
     long long deadline;
     int seq;
@@ -131,13 +137,60 @@ __device__ __forceinline__ void la_operand(const double* __restrict__ tile, int 
 }
 
 // ---- the owner --------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_abort, const LaPoll& pl) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+// Round 3: a dataflow of eight specialised waves, synchronised by monotone LDS counters instead of workgroup barriers, so that no wave ever waits
+// for something it does not need - in particular not for the ~1 us acknowledgement of somebody's write-through stores.
+//   wave 0      pivot: waits for D_(k+1) (cD), eliminates it (LDS + write-through tile of L_(k+1)^-1), announces it (cL), then waits for its own stores
+//               and raises the flag of L_(k+1)^-1 while the post-work runs.
+//   waves 4..7  post-work of step k, one 16 x 16 quadrant each, on the critical path: c = P^(k)_(k+1) = R1 L_k^-T -> sX (cC), D_(k+1) = D' - c c^T -> sD (cD).
+//   waves 2,5,6,7  tail of step k (under the elimination of D_(k+1)): for block row I2 = k + 2 fetch U2 = Z(I2, k), U1 = Z(I2, k+1), U0 = Z(I2, I2) (panels
+//               <= k - 1 applied by the block row itself, except one product, below) and form b = P^(k)_I2 = U2 L_k^-T (round 2: b came from block row I2,
+//               two dependent hand-offs behind L_k^-1, and was the last input to arrive), R1 = U1 - P^(k-1)_I2 b_prev^T - b c^T, D' = U0 - b b^T (cT).
+//               Quadrant 0 runs on wave 2, not on wave 4: waves sit on SIMD (wave % 4), and fp64 MFMAs of a SIMD-mate slow the pivot wave's fp64 VALU chain
+//               (measured: elimination 3.3 -> 4.0 us with 48 tail MFMAs on wave 4); SIMD 0 is left to the pivot wave while it eliminates.
+//   wave 1      publishes c (sX -> write-through tile, waits for the acknowledgement, raises the two half-row flags of P^(k)_(k+1)), then b the same way
+//               (from the LDS copy the tail keeps for the next tail).
+//   wave 3      polls the U flags of the block rows, one after the other, so that a tail finds them checked (a flag poll is ~0.9 us of memory latency
+//               even when the flag has been up for long).
+// The product Z(I, I-1) -= P^(I-3)_I (P^(I-3)_(I-1))^T is left to the owner (r3 below): its second factor is the owner's own b of the step before, and
+// a block row waiting for it closed a cycle b -> block row -> U -> next b of 5.3 us per step (measured).
+// Same products in the same order as round 2 and as the launch chain: W and Sigma+ are bit-identical.
+// relaxed = true: a wait that is not on the critical path sleeps between its looks, so that five spinning waves do not compete with the pivot wave's
+// own LDS traffic (ds_bpermute, operand reads)
+template <bool RELAXED = false> __device__ __forceinline__ bool la_lds_wait(const int* c, int target, const int* s_abort) {
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        if (*(volatile const int*)s_abort)
+            return false;
+        if (RELAXED)
+            __builtin_amdgcn_s_sleep(4);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+__device__ __forceinline__ void la_lds_set(int* c, int v) { // after this wave's LDS stores (LDS operations of a wave execute in order)
+    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0)
+        __hip_atomic_store(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void la_lds_add(int* c) {
+    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0)
+        __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+enum { LC_L = 0, LC_LPUB, LC_T, LC_C, LC_D, LC_B, LC_CCOPIED, LC_BCOPIED, LC_U, LC_COUNT };
+
+__device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_abort, int* cnt, const LaPoll& pl) {
+    // `wave` as a scalar: the role branches become real (scalar) branches. With a vector condition the compiler predicates short blocks instead of
+    // branching around them, and a predicated-off s_sleep still sleeps (measured: every wave took wave 4's nap).
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     double* sLk = smem;                  // L_k^-1, operand layout [r + c CH_LDP]
-    double* sX = smem + 32 * CH_LDP;     // c_k (read by the pre-work), then c_(k+1) (written by the post-work)
-    double* sY = smem + 2 * 32 * CH_LDP; // R1 (written by the pre-work, read by the post-work)
+    double* sX = smem + 32 * CH_LDP;     // c = P^(k)_(k+1): written by the post-work of step k, read by the tail of step k and by wave 1
+    double* sY = smem + 2 * 32 * CH_LDP; // R1 of block row k + 1 (written by the tail of step k - 1, read by the post-work of step k)
     double* sD = smem + 3 * 32 * CH_LDP; // the diagonal tile handed to the elimination
     double* swork = smem + 4 * 32 * CH_LDP;
+    double* sDq = swork + 288;           // 16 x 16: the block (0, 0) of D' on its way from the tail wave 2 to the post-work wave 4 (a slot of swork the elimination does not use)
+    // b of a tail, rows 0 .. 15 / 16 .. 31 in operand layout, parked in the unused rows 32 .. 47 of two of the four operand buffers (leading dimension 48);
+    // the pairs alternate with the parity of the step: tail k reads what tail k - 1 kept
+    auto b_keep = [&](int k, int half) -> double* { return smem + 32 * CH_LDP * ((k & 1) ? 3 * half : 1 + half) + 32; };
     const int NJ = a.NJ;
     {
         double* l0 = la_tile(a, la_i_linv(a, 0));
@@ -147,108 +200,23 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             la_st(l0 + e, v);
         }
         la_stores_done();
-        __syncthreads();
-        if (tid == 0)
-            la_raise(a, la_i_linv(a, 0));
+        __syncthreads(); // the only workgroup barrier of the owner
+        if (tid == 0) {
+            la_raise_f(a, la_f_linv(a, 0));
+            __hip_atomic_store(cnt + LC_L, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(cnt + LC_LPUB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
-    const bool prod = wave >= 4;
-    const int pw = wave & 3, ihU = pw & 1, jhU = pw >> 1;
-    double dacc[4] = {0, 0, 0, 0};
-    for (int k = 0; k + 1 < NJ; ++k) { // this step produces L_(k+1)^-1
-        const int I = k + 1;
-        if (a.tr_steps && tid == 0 && k < 32)
-            a.tr_steps[k] = wall_clock64();
-        if (prod) {
-            // pre-work (runs while wave 0 eliminates D_k): tiles of block row I with the panels <= I-3 applied, panel I-2 applied here
-            if (a.dbg && wave == 4 && lane == 0)
-                a.dbg[8 * k + 0] = wall_clock64();
-            la_wait(a.pubf + la_i_u(a, I, 0), 1, pl);
-            if (k >= 1)
-                la_wait(a.pubf + la_i_p(a, I, k - 1), 1, pl);
-            if (a.dbg && wave == 4 && lane == 0)
-                a.dbg[8 * k + 1] = wall_clock64();
-            double u1[4], u0[4];
-            {
-                const double* t1 = la_tile(a, la_i_u(a, I, 0)) + (16 * ihU + lr) + 32 * (16 * jhU + lk);
-                const double* t0 = la_tile(a, la_i_u(a, I, 1)) + (16 * ihU + lr) + 32 * (16 * jhU + lk);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    u1[q] = t1[128 * q];
-                    u0[q] = t0[128 * q];
-                }
-            }
-            if (k >= 1) {
-                double bi[8], bj[8];
-                const double* bt = la_tile(a, la_i_p(a, I, k - 1));
-                la_operand(bt, ihU, bi);
-                la_operand(bt, jhU, bj);
-                if (a.dbg && wave == 4 && lane == 0)
-                    a.dbg[8 * k + 2] = wall_clock64();
-                d4 r = {0, 0, 0, 0}, d = {0, 0, 0, 0};
-#pragma unroll
-                for (int st = 0; st < 8; ++st) {
-                    const int c = 4 * st + lk;
-                    r = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[16 * jhU + lr + c * CH_LDP], bi[st], r, 0, 0, 0); // b c_k^T
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], bi[st], d, 0, 0, 0);                         // b b^T
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    u1[q] -= r[q];
-                    u0[q] -= d[q];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                dacc[q] = u0[q];
-                sY[16 * ihU + lr + (16 * jhU + lk + 4 * q) * CH_LDP] = u1[q];
-            }
-        }
-        if (a.dbg && lane == 0 && (wave == 4 || wave == 0))
-            a.dbg[8 * k + (wave == 4 ? 3 : 4)] = wall_clock64();
-        __syncthreads(); // B1: L_k^-1 in sLk (wave 0), R1 in sY (waves 4..7)
-        if (*s_abort)
-            return;
-        if (a.dbg && tid == 0)
-            a.dbg[8 * k + 5] = wall_clock64();
-        if (tid == 0 && k >= 1)
-            la_raise(a, la_i_linv(a, k)); // wave 0 stored L_k^-1 and waited for its stores before the barrier
-        if (prod) {
-            // c = P^(k)_I = R1 L_k^-T : sub-tile (ih, ch) = (pw & 1, pw >> 1)
-            const int ih = pw & 1, ch = pw >> 1;
-            d4 acc = {0, 0, 0, 0};
-#pragma unroll
-            for (int st = 0; st < 8; ++st)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLk[16 * ch + lr + (4 * st + lk) * CH_LDP], sY[16 * ih + lr + (4 * st + lk) * CH_LDP], acc, 0, 0, 0);
-            double* ct = la_tile(a, la_i_p(a, I, k));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r_ = 16 * ih + lr, c_ = 16 * ch + lk + 4 * q;
-                sX[r_ + c_ * CH_LDP] = acc[q];
-                la_st(ct + r_ + 32 * c_, acc[q]);
-            }
-        }
-        __syncthreads(); // B1.5: c in sX
-        if (prod) {
-            d4 acc = {0, 0, 0, 0};
-#pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                const int c = 4 * st + lk;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[16 * jhU + lr + c * CH_LDP], sX[16 * ihU + lr + c * CH_LDP], acc, 0, 0, 0);
-            }
-            const int w2 = min(32, a.m - 32 * I); // rows / columns >= w2 of the last diagonal tile are identity padding
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r_ = 16 * ihU + lr, c_ = 16 * jhU + lk + 4 * q;
-                sD[r_ + c_ * CH_LDP] = (r_ >= w2 || c_ >= w2) ? ((r_ == c_) ? 1.0 : 0.0) : dacc[q] - acc[q];
-            }
-            la_stores_done(); // the write-through stores of c have had the product above to complete
-        }
-        __syncthreads(); // B2: D in sD; c written through
-        if (tid == 0)
-            la_raise(a, la_i_p(a, I, k));
-        if (a.dbg && tid == 0)
-            a.dbg[8 * k + 6] = wall_clock64();
-        if (wave == 0) {
+    // ------------------------------------------------------------------------------------------------------------------ wave 0: the pivot chain
+    if (wave == 0) {
+        for (int k = 0; k + 1 < NJ; ++k) {
+            const int I = k + 1;
+            if (a.tr_steps && lane == 0 && k < 32)
+                a.tr_steps[k] = wall_clock64();
+            if (!la_lds_wait(cnt + LC_D, 5 * (k + 1), s_abort)) // the four post-work waves + wave 2, which has read L_k^-1 out of sLk
+                return;
+            if (a.dbg && lane == 0)
+                a.dbg[8 * k + 6] = wall_clock64();
             const int w2 = min(32, a.m - 32 * I);
             double* lt = la_tile(a, la_i_linv(a, I));
             ldl_inverse_tile_put(
@@ -258,92 +226,323 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                     la_st(lt + r + 32 * c, v);
                 },
                 a.flags, swork);
-            la_stores_done(); // the flag of L_(k+1)^-1 goes up right after the next barrier
+            la_lds_set(cnt + LC_L, I + 1); // L_I^-1 complete in sLk: the post-work of step I starts
+            if (a.dbg && lane == 0)
+                a.dbg[8 * I + 4] = wall_clock64();
+            la_stores_done(); // its write-through stores: mostly acknowledged while the elimination ran; the rest under the post-work
+            if (lane == 0)
+                la_raise_f(a, la_f_linv(a, I));
+            la_lds_set(cnt + LC_LPUB, I + 1);
+        }
+        if (a.tr_steps && lane == 0 && NJ - 1 < 32)
+            a.tr_steps[NJ - 1] = wall_clock64();
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------------------------ wave 1: publishes c and b
+    if (wave == 1) {
+        auto publish = [&](const double (&v)[16], int I_, int k_) { // 32 x 32 tile of P^(k_)_I_: write through, wait for the acknowledgement, raise both half-row flags
+            double* t = la_tile(a, la_i_p(a, I_, k_));
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                la_st(t + lane + 64 * i, v[i]);
+            la_stores_done();
+            if (lane < 2)
+                la_raise_f(a, la_f_p(a, k_, 2 * I_ + lane));
+        };
+        for (int k = 0; k + 1 < NJ; ++k) {
+            if (!la_lds_wait<true>(cnt + LC_C, 4 * (k + 1), s_abort))
+                return;
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = lane + 64 * i;
+                v[i] = sX[(e & 31) + (e >> 5) * CH_LDP];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            la_lds_set(cnt + LC_CCOPIED, k + 1);
+            publish(v, k + 1, k);
+            if (k + 2 < NJ) { // b of the same step, ~2 us later
+                if (!la_lds_wait<true>(cnt + LC_B, 2 * (k + 1), s_abort))
+                    return;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { // element (r, c) of b: half r >> 4, kept at [(r & 15) + c CH_LDP]
+                    const int e = lane + 64 * i, r = e & 31, c = e >> 5;
+                    v[i] = b_keep(k, r >> 4)[(r & 15) + c * CH_LDP];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                la_lds_set(cnt + LC_BCOPIED, k + 1);
+                publish(v, k + 2, k);
+            }
+        }
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------------------------ wave 3: polls for the block rows' hand-offs
+    if (wave == 3) {
+        for (int I = 1; I < NJ; ++I) { // both halves of block row I have handed their tiles over: tell the tail waves (bounded like every poll)
+            la_wait(a.pubf + la_f_u(a, I, 0), 2, pl);
+            if (*(volatile int*)s_abort)
+                return;
+            la_lds_set(cnt + LC_U, I);
+        }
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------------------------ waves 2, 4..7: post-work and tail
+    const bool post = wave >= 4;
+    const int pw = wave & 3;
+    const bool tailw = wave == 2 || wave >= 5;
+    const int tq = wave == 2 ? 0 : pw, ihT = tq & 1, jhT = tq >> 1;
+    double dacc[4] = {0, 0, 0, 0};
+    auto put_prepared = [&](const double (&r1)[4], const double (&dp)[4]) { // a tail wave's quadrant of R1 and D' to where the post-work finds them
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sY[16 * ihT + lr + (16 * jhT + lk + 4 * q) * CH_LDP] = r1[q];
+            if (wave == 2)
+                sDq[lr + 16 * (lk + 4 * q)] = dp[q];
+            else
+                dacc[q] = dp[q];
+        }
+    };
+    if (tailw) { // block row 1: no panel to apply
+        if (!la_lds_wait<true>(cnt + LC_U, 1, s_abort))
+            return;
+        const double* t1 = la_tile(a, la_i_u(a, 1, 0)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
+        const double* t0 = la_tile(a, la_i_u(a, 1, 1)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
+        double u1r[4], u0r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u1r[q] = t1[128 * q];
+            u0r[q] = t0[128 * q];
+        }
+        put_prepared(u1r, u0r);
+        la_lds_add(cnt + LC_T);
+    }
+    for (int k = 0; k + 1 < NJ; ++k) { // step k produces D_(k+1)
+        const int I = k + 1;
+        // L_k^-1 as B operand, both column halves, for the two waves that form b in the tail (wave 2: rows 0 .. 15, wave 7: rows 16 .. 31): read from sLk
+        // now, before the elimination of D_(k+1) rewrites it - the pivot wave starts only when wave 2 has counted itself into LC_D as well
+        double lkop[2][8];
+        if (wave == 2) {
+            if (!la_lds_wait(cnt + LC_L, k + 1, s_abort))
+                return;
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int st = 0; st < 8; ++st)
+                    lkop[ch][st] = sLk[16 * ch + lr + (4 * st + lk) * CH_LDP];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            la_lds_add(cnt + LC_D);
+        }
+        if (post) {
+            if (!la_lds_wait(cnt + LC_L, k + 1, s_abort) || !la_lds_wait(cnt + LC_T, 4 * (k + 1), s_abort))
+                return;
+            if (a.dbg && wave == 5 && lane == 0)
+                a.dbg[8 * k + 3] = wall_clock64();
+            if (k >= 1 && !la_lds_wait(cnt + LC_CCOPIED, k, s_abort)) // wave 1 has read the previous c out of sX (it did, 3 us ago)
+                return;
+            if (wave == 7) {
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                    for (int st = 0; st < 8; ++st)
+                        lkop[ch][st] = sLk[16 * ch + lr + (4 * st + lk) * CH_LDP];
+            }
+            const int ih = pw & 1, ch = pw >> 1; // c = P^(k)_I = R1 L_k^-T : sub-tile (ih, ch)
+            if (wave == 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dacc[q] = sDq[lr + 16 * (lk + 4 * q)];
+            }
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLk[16 * ch + lr + (4 * st + lk) * CH_LDP], sY[16 * ih + lr + (4 * st + lk) * CH_LDP], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sX[16 * ih + lr + (16 * ch + lk + 4 * q) * CH_LDP] = acc[q];
+            la_lds_add(cnt + LC_C);
+            if (!la_lds_wait(cnt + LC_C, 4 * (k + 1), s_abort))
+                return;
+            const int ihU = pw & 1, jhU = pw >> 1;
+            d4 acc2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int c = 4 * st + lk;
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[16 * jhU + lr + c * CH_LDP], sX[16 * ihU + lr + c * CH_LDP], acc2, 0, 0, 0);
+            }
+            const int w2 = min(32, a.m - 32 * I); // rows / columns >= w2 of the last diagonal tile are identity padding
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r_ = 16 * ihU + lr, c_ = 16 * jhU + lk + 4 * q;
+                sD[r_ + c_ * CH_LDP] = (r_ >= w2 || c_ >= w2) ? ((r_ == c_) ? 1.0 : 0.0) : dacc[q] - acc2[q];
+            }
+            la_lds_add(cnt + LC_D);
+            if (a.dbg && wave == 5 && lane == 0)
+                a.dbg[8 * k + 5] = wall_clock64();
+            if (wave == 4) // shares SIMD 0 with the pivot wave and has nothing to do until the elimination (~7000 cycles) is over: stay out of its way
+                __builtin_amdgcn_s_sleep(90);
+        }
+        if (tailw && k + 2 < NJ) {
+            // tail: block row I2 = k + 2
+            const int I2 = k + 2;
+            if (!la_lds_wait<true>(cnt + LC_C, 4 * (k + 1), s_abort)) // (wave 2) c complete in sX, every post-work wave done with sY
+                return;
+            if (a.dbg && wave == 5 && lane == 0)
+                a.dbg[8 * k + 0] = wall_clock64();
+            if (!la_lds_wait<true>(cnt + LC_U, I2, s_abort)) // wave 3 saw both U flags of block row I2
+                return;
+            double u2i[8], u1r[4], u0r[4], p3[8];
+            {
+                const double* t1 = la_tile(a, la_i_u(a, I2, 0)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
+                const double* t0 = la_tile(a, la_i_u(a, I2, 1)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u1r[q] = t1[128 * q];
+                    u0r[q] = t0[128 * q];
+                }
+                if (tq == 0 || tq == 3)
+                    la_operand(la_tile(a, la_i_u(a, I2, 2)), ihT, u2i);
+                if (I2 >= 3) // complete before the block row raised its U flags (published at its last panel)
+                    la_operand(la_tile(a, la_i_p(a, I2, I2 - 3)), ihT, p3);
+            }
+            // b = P^(k)_I2 = U2 L_k^-T. Wave 2 forms its rows 0 .. 15, wave 7 its rows 16 .. 31 (the two column halves' accumulators ARE the operand layout:
+            // column 16 ch + lk + 4 q); the triangular L_k^-1 has no columns >= 16 in its rows < 16. The rows are kept in LDS for waves 5 and 6, for the
+            // next tail and for wave 1, which publishes them.
+            double bi[8], bj[8];
+            if (tq == 0 || tq == 3) {
+                d4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    if (st < 4)
+                        b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lkop[0][st], u2i[st], b0, 0, 0, 0);
+                    b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lkop[1][st], u2i[st], b1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bi[q] = b0[q];
+                    bi[4 + q] = b1[q];
+                    bj[q] = b0[q];
+                    bj[4 + q] = b1[q];
+                }
+                if (k >= 2 && !la_lds_wait<true>(cnt + LC_BCOPIED, k - 1, s_abort)) // wave 1 has read what this slot held two steps ago (long since)
+                    return;
+                double* keep = b_keep(k, ihT);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    keep[lr + (lk + 4 * q) * CH_LDP] = b0[q];
+                    keep[lr + (16 + lk + 4 * q) * CH_LDP] = b1[q];
+                }
+                la_lds_add(cnt + LC_B);
+            } else {
+                if (!la_lds_wait<true>(cnt + LC_B, 2 * (k + 1), s_abort)) // both halves of this step's b are in LDS
+                    return;
+                const double *bir = b_keep(k, ihT), *bjr = b_keep(k, jhT);
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    bi[st] = bir[lr + (4 * st + lk) * CH_LDP];
+                    bj[st] = bjr[lr + (4 * st + lk) * CH_LDP];
+                }
+            }
+            if (a.dbg && wave == 5 && lane == 0)
+                a.dbg[8 * k + 1] = wall_clock64();
+            d4 r = {0, 0, 0, 0}, d = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
+            if (I2 >= 3) { // the product the block row left out: P^(I2-3)_I2 (P^(I2-3)_(I2-1))^T, the second factor being the previous tail's b
+                const double* bp = b_keep(k - 1, jhT);
+#pragma unroll
+                for (int st = 0; st < 8; ++st)
+                    r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(bp[lr + (4 * st + lk) * CH_LDP], p3[st], r3, 0, 0, 0);
+            }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int c = 4 * st + lk;
+                r = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[16 * jhT + lr + c * CH_LDP], bi[st], r, 0, 0, 0); // b c^T (c = P^(k)_(k+1), the post-work's)
+                if (tq != 2)                                                                                   // the block (0, 1) of D' is above the diagonal: never read
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], bi[st], d, 0, 0, 0);                      // b b^T
+            }
+            double r1[4], dp[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                r1[q] = (u1r[q] - r3[q]) - r[q];
+                dp[q] = u0r[q] - d[q];
+            }
+            put_prepared(r1, dp);
+            la_lds_add(cnt + LC_T);
+            if (a.dbg && wave == 5 && lane == 0)
+                a.dbg[8 * k + 2] = wall_clock64();
         }
     }
-    __syncthreads();
-    if (tid == 0)
-        la_raise(a, la_i_linv(a, NJ - 1));
-    if (a.tr_steps && tid == 0 && NJ - 1 < 32)
-        a.tr_steps[NJ - 1] = wall_clock64();
 }
 
-// ---- a block row --------------------------------------------------------------------------------------------------------------------
-// RING (the instantiations for 17 .. 32 panels): the P^(p)_J operand tiles of a panel do not travel through registers two at a time (one
-// memory round trip, ~2 us under load, per pair: with up to 16 tiles per wave that round trip, not the MFMA pipe, sets the pace) but through
-// a double-buffered ring in LDS, LA_RC = 8 tiles per half (tile columns 8 c .. 8 c + 7), filled by direct-to-LDS loads (global_load_lds_dwordx4: wave w copies tile w of the
-// chunk, no staging registers) while the previous chunk is multiplied. The destination of such a load is wave-uniform base + lane x 16 bytes,
-// i.e. linear; the k / k+1 bank separation the operand reads need comes from the SOURCE address instead: LDS slot (r', c) of a tile holds
-// element (r' ^ 16 (c & 1), c). Same products in the same order on the same accumulators: bit-identical to the register path.
-constexpr int LA_RC = 8;                                               // tiles per ring half (wave w loads tile w of the chunk)
-constexpr int LA_ROW_DOUBLES = 2 * 32 * CH_LDP + 32 + 256;             // with a ring: sLinv, sPI, sYv, sZp; sT lives in the ring's last tiles
-                                                                       // (dead once P_I exists; the ring's second half is first written after that)
-constexpr size_t LA_LDS_PLAIN = sizeof(double) * (4 * 32 * CH_LDP + LDL_SBUF); // the owner's need (and the rows' without a ring)
-constexpr size_t LA_LDS_RING = sizeof(double) * (LA_ROW_DOUBLES + 2 * LA_RC * LA_TILE);
-static_assert(LA_LDS_RING >= LA_LDS_PLAIN && LA_LDS_RING + 16 <= 160 * 1024, "LDS budget of a row workgroup with the operand ring");
-typedef __attribute__((address_space(3))) void la_lds_ptr;
-
-template <int MAXT, bool RING>
-__device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* smem, int* s_abort, const LaPoll& pl) {
+// ---- a half block row ----------------------------------------------------------------------------------------------------------------
+// One workgroup per 16-ROW half of a block row (round 3; round 2 had one per 32-row block row): half-row h = 2 I + s of S block row I (s = 0 top,
+// 1 bottom), or the t-th 16 rows of T. The trailing update is fp64-MFMA-throughput bound per CU in the early panels (12 tiles x 32 MFMAs of ~100
+// cycles on 4 SIMDs = 4 us per panel for a 32-row block row against an owner step of 4.5 us), so that the late S block rows fell 1-2 panels behind
+// and the owner waited for them from panel 8 on; halving the rows per workgroup halves that time and puts 66 instead of 34 CUs to work at N = 200,
+// 161 instead of 80 at N = 500. It also halves the tiles a wave keeps in registers (4 / 8 instead of 7 / 16): the 17 .. 32-panel instantiation needs
+// neither the LDS operand ring nor spills any more.
+//   wave w: jh = w & 1 is the 16-column half of a tile, jr = w >> 1 the tile column modulo 4; acc[t] = Z(h, J = 4 t + jr)[:, 16 jh .. 16 jh + 15].
+//   A wave's B operand is rows 16 jh .. 16 jh + 15 of P_J, i.e. what ONE half-row (2 J + jh) published: flags are per (panel, half-row).
+//   P^(p)_h = Z(h, p) L_p^-T is formed by waves 0 / 1 (column halves; the zero block of the triangular L_p^-1 skipped).
+template <int MAXT>
+__device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* smem, int* s_abort, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-    double* sLinv = smem;
-    double* sPI = smem + 32 * CH_LDP;
-    double* sYv = smem + 2 * 32 * CH_LDP; // yTilde row of the panel (32)
-    double* sZp = sYv + 32;               // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
-    double* ring = smem + LA_ROW_DOUBLES; // RING: 2 x LA_RC tiles
-    double* sT = RING ? ring + 2 * LA_RC * LA_TILE - 32 * CH_LDP : sZp + 256; // the panel tile in operand layout
+    double* sLinv = smem;                   // L_p^-1, operand layout [r + c CH_LDP]
+    double* sPI = smem + 32 * CH_LDP;       // P_h: 16 rows x 32 columns
+    double* sT = smem + 2 * 32 * CH_LDP;    // the panel tile's 16 rows in operand layout; at the very end the Gamma partial sums
+    double* sYv = smem + 3 * 32 * CH_LDP;   // yTilde row of the panel (32)
+    double* sZp = sYv + 32;                 // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
     const int NJ = a.NJ, m = a.m, rows = a.rows, ldz = a.ldz, seq = a.seq;
-    const bool srow = I < NJ;
-    const int row0 = srow ? 32 * I : m + 32 * (I - NJ);
-    const int ilim = srow ? min(m, row0 + 32) : min(rows, row0 + 32);
+    const bool srow = hidx < 2 * NJ;
+    const int I = hidx >> 1, s = hidx & 1;
+    const int row0 = srow ? 16 * hidx : m + 16 * (hidx - 2 * NJ);
+    const int ilim = srow ? min(m, row0 + 16) : min(rows, row0 + 16);
     const int Jmax = srow ? I : NJ - 1;
-    const bool ylast = (!srow) && (rows - 1 >= row0) && (rows - 1 < row0 + 32); // this block row holds the yTilde row
+    const bool ylast = (!srow) && (rows - 1 >= row0) && (rows - 1 < row0 + 16); // this half-row holds the yTilde row
     const int yloc = rows - 1 - row0;
-    const int g = wave >> 2, wq = wave & 3, ihU = wq & 1, jhU = wq >> 1;
-    const int ri = row0 + 16 * ihU + lr;
+    const int jh = wave & 1, jr = wave >> 1;
+    const int ri = row0 + lr;
     const int ric = min(ri, ilim - 1);
     double acc[MAXT][4];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        const int J = 2 * t + g;
+        const int J = 4 * t + jr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int j = min(32 * J + 16 * jhU + lk + 4 * q, m - 1);
+            const int j = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
             acc[t][q] = (J <= Jmax) ? a.Z[ric + (size_t)j * ldz] : 0.0;
         }
     }
     if (ylast && tid < 32)
         la_put16(a.puby + 16 * (size_t)tid, a.Z[(rows - 1) + (size_t)min(tid, m - 1) * ldz], seq);
-    double gsum = 0.0; // thread (r = tid & 31, h = tid >> 5 < 8): Gamma share of row row0 + r over the columns 4 h .. 4 h + 3 of every panel
-    // S block rows: panels 0 .. I-3 with updates, then the hand-off of U1 / U0, then panel I-2 (b) without updates. T block rows: all panels.
-    const int np = srow ? I - 1 : NJ;
+    double gsum = 0.0; // thread (r = tid & 15, c = tid >> 4): Gamma share of row row0 + r from column c of every panel
+    // S half-rows: panels 0 .. I-3, then the hand-off of U2 / U1 / U0 to the owner, which forms b = P^(I-2)_I and c = P^(I-1)_I itself. ONE product of the
+    // last panel is left to the owner as well: Z(I, I-1) -= P^(I-3)_I (P^(I-3)_(I-1))^T, whose second factor is the owner's own b of the step before -
+    // waiting for it here would close a cycle b -> block row -> U -> next b of 5.3 us per step (measured). T half-rows: all panels.
+    const int np = srow ? max(I - 2, 0) : NJ;
     auto hand_off = [&]() {
-        // to the owner: U1 = Z(I, I-1), U0 = Z(I, I) with the panels <= I-3 applied (all waves of the workgroup call this)
+        // to the owner: rows 16 s .. 16 s + 15 of U2 = Z(I, I-2), U1 = Z(I, I-1) and U0 = Z(I, I) with the panels <= I-3 applied (all waves call this)
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            const int J = 2 * t + g;
-            if (J == I - 1 || J == I) {
-                double* u = la_tile(a, la_i_u(a, I, J == I ? 1 : 0));
+            const int J = 4 * t + jr;
+            if (J >= 0 && J >= I - 2 && J <= I) {
+                double* u = la_tile(a, la_i_u(a, I, J == I ? 1 : (J == I - 1 ? 0 : 2)));
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    la_st(u + (16 * ihU + lr) + 32 * (16 * jhU + lk + 4 * q), acc[t][q]);
+                    la_st(u + (16 * s + lr) + 32 * (16 * jh + lk + 4 * q), acc[t][q]);
             }
         }
         la_stores_done();
         __syncthreads();
         if (tid == 0)
-            la_raise(a, la_i_u(a, I, 0));
+            la_raise_f(a, la_f_u(a, I, s));
     };
     for (int p = 0; p < np; ++p) {
         // laundered once per panel: otherwise the body's address / mask expressions are loop invariant, get hoisted and spilled
         int lrv = lr, lkv = lk;
         asm volatile("" : "+v"(lrv), "+v"(lkv));
-        const bool do_update = srow ? (p <= I - 3) : true;
-        if (srow && p == I - 2)
-            hand_off();
+        const bool do_update = true;
         const int w = min(32, m - 32 * p);
-        // (a) L_p^-1 -> LDS; the panel tile Z(I, p) -> LDS in operand layout (masked like the chain's operand loads); yTilde row of the panel
-        la_wait(a.pubf + la_i_linv(a, p), 1, pl);
+        // (a) L_p^-1 -> LDS; this half-row's part of the panel tile Z(h, p) -> LDS in operand layout (masked like the chain's operand loads); yTilde row
+        la_wait(a.pubf + la_f_linv(a, p), 1, pl);
         {
             const double* lt = la_tile(a, la_i_linv(a, p));
             const double v0 = lt[tid], v1 = lt[tid + LA_T];
@@ -352,11 +551,11 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         }
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
-            if (2 * t + g == p) {
+            if (4 * t + jr == p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int c = 16 * jhU + lk + 4 * q;
-                    sT[16 * ihU + lr + c * CH_LDP] = (ri < ilim && c < w) ? acc[t][q] : 0.0;
+                    const int c = 16 * jh + lk + 4 * q;
+                    sT[lr + c * CH_LDP] = (ri < ilim && c < w) ? acc[t][q] : 0.0;
                 }
             }
         if (!srow && wave == 7 && lane < 32) {
@@ -366,28 +565,30 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         __syncthreads();
         if (*s_abort)
             return;
-        const bool dbg_row = a.dbg && tid == 0 && (I == NJ || I == NJ - 2) && p < 32;
-        unsigned long long* dbr = a.dbg + 8 * ((I == NJ ? 32 : 64) + p);
+        const bool dbg_row = a.dbg && tid == 0 && (hidx == 2 * NJ || hidx == 2 * (NJ - 2)) && p < 32;
+        unsigned long long* dbr = a.dbg + 8 * ((hidx == 2 * NJ ? 32 : 64) + p);
         if (dbg_row)
             dbr[0] = wall_clock64();
-        // (b) P_I = Z(I, p) L_p^-T on waves 0..3 (sub-tile (ih, ch)); z_p partials on waves 4..7
-        if (wave < 4) {
-            const int ih = wave & 1, ch = wave >> 1;
+        // (b) P_h = Z(h, p) L_p^-T on waves 0, 1 (column half ch = wave; L_p^-1 is lower triangular: its columns >= 16 are zero in the rows < 16);
+        //     z_p partials on waves 4..7
+        if (wave < 2) {
+            const int ch = wave;
             d4 pacc = {0, 0, 0, 0};
 #pragma unroll
             for (int st = 0; st < 8; ++st)
-                pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lr + (4 * st + lk) * CH_LDP], sT[16 * ih + lr + (4 * st + lk) * CH_LDP], pacc, 0, 0, 0);
+                if (ch == 1 || st < 4)
+                    pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[16 * ch + lr + (4 * st + lk) * CH_LDP], sT[lr + (4 * st + lk) * CH_LDP], pacc, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                sPI[16 * ih + lr + (16 * ch + lk + 4 * q) * CH_LDP] = pacc[q];
-            if (srow) { // the factor rows leave for the other block rows straight from the accumulators
+                sPI[lr + (16 * ch + lk + 4 * q) * CH_LDP] = pacc[q];
+            if (srow) { // the factor rows leave for the other half-rows straight from the accumulators
                 double* pt = la_tile(a, la_i_p(a, I, p));
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    la_st(pt + (16 * ih + lr) + 32 * (16 * ch + lk + 4 * q), pacc[q]);
+                    la_st(pt + (16 * s + lr) + 32 * (16 * ch + lk + 4 * q), pacc[q]);
                 la_stores_done();
             }
-        } else if (!srow) {
+        } else if (!srow && wave >= 4) {
             // z_p[c] = sum_q yTilde_p[q] L_p^-1[c][q] as 8 partial sums (thread (c, h): q = 4 h .. 4 h + 3), summed in a fixed order by the readers
             const int c = tid & 31, h = (tid >> 5) & 7;
             double z = 0.0;
@@ -397,28 +598,17 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
             sZp[32 * h + c] = z;
         }
         __syncthreads();
-        // (c) P_I: flag for the S block rows; final W rows (+ Gamma) for the T block rows
+        // (c) P_h: flag for the consumers of an S half-row; final W rows (+ Gamma) for a T half-row
         if (srow) {
             if (tid == 0)
-                la_raise(a, la_i_p(a, I, p));
+                la_raise_f(a, la_f_p(a, p, hidx));
         } else {
-            if constexpr (!RING) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int e = tid + h * LA_T;
-                    const int r = e & 31, c = e >> 5;
-                    if (row0 + r < rows && c < w)
-                        a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = sPI[r + c * CH_LDP];
-                }
-            }
-            if (tid < 256) {
-                const int r = tid & 31, h = tid >> 5;
-#pragma unroll
-                for (int c = 4 * h; c < 4 * h + 4; ++c) {
-                    const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
-                    gsum = fma(sPI[r + c * CH_LDP], c < w ? zc : 0.0, gsum);
-                }
-            }
+            const int r = tid & 15, c = tid >> 4;
+            const double pv = sPI[r + c * CH_LDP];
+            if (row0 + r < rows && c < w)
+                a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = pv;
+            const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
+            gsum = fma(pv, c < w ? zc : 0.0, gsum);
         }
         if (dbg_row)
             dbr[1] = wall_clock64();
@@ -427,129 +617,54 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         double aI[8];
 #pragma unroll
         for (int st = 0; st < 8; ++st)
-            aI[st] = sPI[16 * ihU + lr + (4 * st + lk) * CH_LDP];
-        // every P^(p)_J this row needs: flags p NJ + (p+1 .. Jmax) are neighbours -> one polling load per wave
+            aI[st] = sPI[lr + (4 * st + lk) * CH_LDP];
+        // this wave's operands: rows 16 jh .. of P^(p)_J = what half-row 2 J + jh published; lane t watches the flag of tile t. An S half-row's own
+        // P_h (J = I, jh = s) is in LDS; its block above the diagonal (J = I, jh > s) is never used.
         {
-            const int jn = min(Jmax, NJ - 1);
-            const int cnt = (srow ? jn - 1 : jn) - p; // an S block row's own P_I (J = I) is in LDS
-            if (cnt > 0)
-                la_wait(a.pubf + la_i_p(a, p + 1, p), cnt, pl);
+            const int J = 4 * lane + jr;
+            if (lane < MAXT && J > p && J <= Jmax && !(srow && J == I && jh >= s) && !(srow && p == I - 3 && J == I - 1)) {
+                const int* f = a.pubf + la_f_p(a, p, 2 * J + jh);
+                for (;;) {
+                    const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v == pl.seq || !la_retry(pl))
+                        break;
+                }
+            }
+            asm volatile("" ::: "memory");
         }
-        if constexpr (RING) {
-            // chunk cc = the tiles J = 8 cc .. 8 cc + 7 (static: wave w loads tile 8 cc + w, group g multiplies t = 4 cc + u, J = 2 t + g), in ring half
-            // cc & 1; the chunks that hold a tile in (p, Jmax] are walked in order. An S block row's own diagonal tile comes from sPI.
-            // (Measured at N = 500: this two-stage ring 311 us per factorisation; four stages of four tiles with three chunks in flight 328 us:
-            // the round trip is already hidden, the extra barriers are not free.)
-            const int cfirst = (p + 1) >> 3, clast = Jmax >> 3;
-            auto issue = [&](int cc) -> bool {
-                const int J = 8 * cc + wave;
-                if (J <= p || J > Jmax || (srow && J == I))
-                    return false;
-                const double* src = la_tile(a, la_i_p(a, J, p));
-                double* dst = ring + (size_t)((cc & 1) * LA_RC + wave) * LA_TILE;
+        // two tiles per round trip: both operand sets are requested before the first product needs one
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { // 1 KB per instruction: columns 4 i .. 4 i + 3, lane -> (r' = 2 lane & 31, c = 4 i + (lane >> 4))
-                    const int cl = 4 * i + (lane >> 4), rp = (2 * lane) & 31;
-                    __builtin_amdgcn_global_load_lds((const void*)(src + (rp ^ (16 * (cl & 1))) + 32 * cl), (la_lds_ptr*)(dst + 128 * i), 16, 0, 0);
-                }
-                return true;
-            };
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing of this wave may be in flight besides the ring loads counted below
-            issue(cfirst);
+        for (int t0 = 0; t0 < MAXT; t0 += 2) {
+            double bjs[2][8];
 #pragma unroll
-            for (int cc = 0; cc < MAXT / 4; ++cc) {
-                if (cc < cfirst || cc > clast)
-                    continue;
-                const bool nxt = (cc + 1 <= clast) && issue(cc + 1);
-                if (nxt)
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // loads return in order: chunk cc has landed, chunk cc + 1 may still fly
-                else
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                const double* half = ring + (size_t)((cc & 1) * LA_RC) * LA_TILE;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = 4 * cc + u, J = 2 * t + g;
-                    if (J > p && J <= Jmax) {
-                        double bj[8];
-                        if (srow && J == I) {
-#pragma unroll
-                            for (int st = 0; st < 8; ++st)
-                                bj[st] = sPI[16 * jhU + lrv + (4 * st + lkv) * CH_LDP];
-                        } else {
-                            const double* tl = half + (size_t)(2 * u + g) * LA_TILE + ((16 * jhU + lrv) ^ (16 * (lkv & 1))) + 32 * lkv;
-#pragma unroll
-                            for (int st = 0; st < 8; ++st)
-                                bj[st] = tl[128 * st];
-                        }
-                        d4 d = {0, 0, 0, 0};
+            for (int u = 0; u < 2; ++u) {
+                const int J = 4 * (t0 + u) + jr;
+                if (t0 + u < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1)) {
+                    if (srow && J == I && jh == s) { // diagonal block of an S half-row: both operands are P_h
 #pragma unroll
                         for (int st = 0; st < 8; ++st)
-                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], aI[st], d, 0, 0, 0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[t][q] -= d[q];
-                        if (ylast && J == p + 1 && 16 * ihU + lrv == yloc) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jhU + lkv + 4 * q), acc[t][q], seq);
-                        }
-                    }
-                }
-                if (cc + 2 <= clast) { // ring half cc & 1 is refilled by the next iteration's issue: every wave must be done reading it
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
+                            bjs[u][st] = sPI[lrv + (4 * st + lkv) * CH_LDP];
+                    } else
+                        la_operand(la_tile(a, la_i_p(a, J, p)), jh, bjs[u]);
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier(); // sT of the next panel shares the ring's last tiles: every wave is done reading the ring
-            // the W rows of this panel (final since step (b), still in sPI): stored here so that no store is in flight while the ring loads are counted
-            if (!srow) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int e = tid + h * LA_T;
-                    const int r = e & 31, cw = e >> 5;
-                    if (row0 + r < rows && cw < w)
-                        a.W[(row0 + r) + (size_t)(32 * p + cw) * ldz] = sPI[r + cw * CH_LDP];
-                }
-            }
-        } else {
-        // two tiles per round trip: both operand sets are requested before the first product needs one (the loads sit behind branches on
-            // the runtime panel index, which the compiler does not hoist them over by itself)
-    #pragma unroll
-            for (int t0 = 0; t0 < MAXT; t0 += 2) {
-                double bjs[2][8];
-    #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int J = 2 * (t0 + u) + g;
-                    if (t0 + u < MAXT && J > p && J <= Jmax) {
-                        if (J == I) { // diagonal tile of an S block row: both operands are P_I
-    #pragma unroll
-                            for (int st = 0; st < 8; ++st)
-                                bjs[u][st] = sPI[16 * jhU + lrv + (4 * st + lkv) * CH_LDP];
-                        } else
-                            la_operand(la_tile(a, la_i_p(a, J, p)), jhU, bjs[u]);
-                    }
-                }
-    #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int t = (t0 + u < MAXT) ? t0 + u : MAXT - 1;
-                    const int J = 2 * (t0 + u) + g;
-                    if (t0 + u < MAXT && J > p && J <= Jmax) {
-                        d4 d = {0, 0, 0, 0};
-    #pragma unroll
-                        for (int st = 0; st < 8; ++st)
-                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(bjs[u][st], aI[st], d, 0, 0, 0);
-    #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = (t0 + u < MAXT) ? t0 + u : MAXT - 1;
+                const int J = 4 * (t0 + u) + jr;
+                if (t0 + u < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1)) {
+                    d4 d = {0, 0, 0, 0};
+#pragma unroll
+                    for (int st = 0; st < 8; ++st)
+                        d = __builtin_amdgcn_mfma_f64_16x16x4f64(bjs[u][st], aI[st], d, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[t][q] -= d[q];
+                    if (ylast && J == p + 1 && lrv == yloc) {
+                        // the yTilde row of the next panel is final now: publish it for every T half-row's z_(p+1)
+#pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            acc[t][q] -= d[q];
-                        if (ylast && J == p + 1 && 16 * ihU + lrv == yloc) {
-                            // the yTilde row of the next panel is final now: publish it for every T block row's z_(p+1)
-    #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jhU + lkv + 4 * q), acc[t][q], seq);
-                        }
+                            la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jh + lkv + 4 * q), acc[t][q], seq);
                     }
                 }
             }
@@ -557,16 +672,20 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int I, double* sme
         if (dbg_row)
             dbr[2] = wall_clock64();
     }
-    if (srow && I == 1)
-        hand_off(); // block row 1 has no panel of its own to wait for: its two tiles go to the owner as they are
+    if (srow)
+        hand_off(); // after panel I-3 (block rows 1 and 2 have no panel to wait for: their tiles go to the owner as they are)
     if (!srow) {
-        __syncthreads(); // the last panel's readers of sZp are done
-        if (tid < 256)
-            sZp[tid] = gsum; // [h][r]
+        __syncthreads(); // the last panel's readers of sT / sZp are done
+        sT[tid] = gsum;  // [c][r]
         __syncthreads();
         const int row = row0 + tid;
-        if (tid < 32 && row >= m && row < rows - 1)
-            la_st(a.gamma + (row - m), ((sZp[tid] + sZp[32 + tid]) + (sZp[64 + tid] + sZp[96 + tid])) + ((sZp[128 + tid] + sZp[160 + tid]) + (sZp[192 + tid] + sZp[224 + tid])));
+        if (tid < 16 && row >= m && row < rows - 1) {
+            double g = 0.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+                g += sT[tid + 16 * c];
+            la_st(a.gamma + (row - m), g);
+        }
     }
 }
 
@@ -612,7 +731,7 @@ __device__ __forceinline__ void la_finish(const LaArgs& a) {
     }
 }
 
-template <int MAXT, bool RING = false>
+template <int MAXT>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (a.spec && *a.spec == a.spec_seq) { // cancelled speculative tail: say so, ring, done
         if (a.lift_door_host && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -623,28 +742,29 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
         }
         return;
     }
-    // static LDS without a ring (constant addresses: 2.6 us per factorisation at N = 200 against the same kernel on dynamic LDS), dynamic
-    // (LA_LDS_RING bytes, above the 64 KB a static array may have) with one
-    extern __shared__ double la_dyn_smem[];
-    __shared__ double la_st_smem[RING ? 1 : 4 * 32 * CH_LDP + LDL_SBUF];
-    double* smem = RING ? la_dyn_smem : la_st_smem;
-    __shared__ int s_abort;
+    __shared__ double smem[4 * 32 * CH_LDP + LDL_SBUF]; // static LDS: constant addresses (2.6 us per factorisation at N = 200 against dynamic LDS)
+    __shared__ int s_abort, s_cnt[LC_COUNT];
     if (threadIdx.x == 0)
         s_abort = 0;
+    if (threadIdx.x < LC_COUNT)
+        s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const LaPoll pl{(long long)wall_clock64() + a.timeout_ticks, a.seq, &s_abort};
+    // block 0: the owner; blocks 1 .. 2 NJ - 2: the S half-rows h = 2 .. 2 NJ - 1 (block row 0 is the first diagonal tile, eliminated by k_build_Z);
+    // then the T half-rows, numbered on from 2 NJ
+    const int hidx = (int)blockIdx.x + 1;
     if (blockIdx.x == 0)
-        la_owner(a, smem, &s_abort, pl);
+        la_owner(a, smem, &s_abort, s_cnt, pl);
     else
-        la_row<MAXT, RING>(a, (int)blockIdx.x, smem, &s_abort, pl);
+        la_row<MAXT>(a, hidx, smem, &s_abort, pl);
     if (threadIdx.x == 0 && s_abort)
         __hip_atomic_store(a.flags + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.lift_door_host && (int)blockIdx.x >= a.NJ) { // a T block row (stalled or not) counts itself in; the last one finishes the frame
+    if (a.lift_door_host && hidx >= 2 * a.NJ && blockIdx.x != 0) { // a T half-row (stalled or not) counts itself in; the last one finishes the frame
         __shared__ int s_last;
         la_stores_done();
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int nT = a.NI - a.NJ;
+            const int nT = a.NI - (2 * a.NJ - 1);
             const int seen = __hip_atomic_fetch_add(a.lift_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (seen == nT - 1);
             if (s_last)

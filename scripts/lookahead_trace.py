@@ -23,7 +23,7 @@ a = np.median(np.stack(acc), axis=0)
 NJ = (2 * N + 31) // 32
 t0 = a[0, 0]
 print(f"N={N}, {NJ} panels; microseconds from the owner's first stamp (medians over 100 frames)")
-print("owner step k: pre-start  U-arrived  b-arrived  pre-done  elim-done  past-B1  D-handed | step period")
+print("owner step k: tail-start  tiles-in  tail-done  post-start  elim-done  D-written  elim-start | step period   (elim-done of row k = L_k ready; tail of step k prepares block row k + 2)")
 for k in range(NJ - 1):
     r = a[k] - t0
     per = (a[k + 1, 6] - a[k, 6]) if k + 2 < NJ else float("nan")
