@@ -400,3 +400,66 @@ void VIO_eqf::removeInvalidLandmarks() {
     }
     twin.deviceNewer = true;
 }
+
+// ---------------------------------------------------------------- fused entry points (optional; VIOFilter_mi355x.cpp with mi355xFused)
+namespace {
+void flattenMeasurement(const VisionMeasurement& measurement, std::vector<int>& ids, std::vector<double>& px) {
+    ids.clear(), px.clear();
+    for (const auto& [id, y] : measurement.camCoordinates) { // ascending id: the reference's row order
+        ids.push_back(id);
+        px.push_back(y.x());
+        px.push_back(y.y());
+    }
+}
+} // namespace
+void VIO_eqf::propagateFast(const IMUVelocity& meanVelocity, const double& dtTotal, const double (&Qd)[12], const double (&Pd8)[8], const std::vector<IMUVelocity>& samples,
+                            const std::vector<double>& dts, const bool& discreteLift) {
+    eqf_ctx* ctx = ensure(*this);
+    double mean[13];
+    packImu(meanVelocity, mean);
+    std::vector<double> all(13 * samples.size());
+    for (size_t i = 0; i < samples.size(); ++i)
+        packImu(samples[i], &all[13 * i]);
+    check(eqf_propagate_fast(ctx, mean, dtTotal, Qd, Pd8, all.data(), dts.data(), (int)samples.size(), discreteLift ? 1 : 0), "propagateFast");
+    twin.deviceNewer = true;
+}
+void VIO_eqf::stageMeasurement(const VisionMeasurement& measurement) {
+    if (measurement.camCoordinates.empty() || X.id.empty())
+        return;
+    eqf_ctx* ctx = ensure(*this);
+    std::vector<int> ids;
+    std::vector<double> px;
+    flattenMeasurement(measurement, ids, px);
+    check(eqf_stage_measurement(ctx, ids.data(), px.data(), (int)ids.size()), "stageMeasurement");
+}
+int VIO_eqf::statsThenUpdate(const VisionMeasurement& measurement, const double& thrAbs, const double& thrProb, const long& maxOutliers, const double& outputGainVariance,
+                             const bool& useEquivariantOutput, const bool& discreteCorrection, std::vector<double>& absErr, std::vector<double>& probErr) {
+    eqf_ctx* ctx = ensure(*this);
+    const int N = (int)X.id.size();
+    absErr.assign(N, -1.0), probErr.assign(N, -1.0);
+    std::vector<double> depth2(N, 0.0);
+    std::vector<int> ids;
+    std::vector<double> px;
+    flattenMeasurement(measurement, ids, px);
+    const eqvio_camera cam = toEqvioCamera(*measurement.cameraPtr);
+    int updated = 0;
+    if (maxOutliers < 0) {
+        check(eqf_stats_then_update(ctx, &cam, ids.data(), px.data(), (int)ids.size(), thrAbs, thrProb, outputGainVariance, useEquivariantOutput ? 1 : 0, discreteCorrection ? 1 : 0,
+                                    absErr.data(), probErr.data(), depth2.data(), &updated),
+              "statsThenUpdate");
+    } else {
+        std::vector<int> removed(N + 1);
+        int nRemoved = 0;
+        check(eqf_stats_select_update(ctx, &cam, ids.data(), px.data(), (int)ids.size(), thrAbs, thrProb, (int)std::min<long>(maxOutliers, 1 << 30), outputGainVariance,
+                                      useEquivariantOutput ? 1 : 0, discreteCorrection ? 1 : 0, absErr.data(), probErr.data(), depth2.data(), &updated, removed.data(), &nRemoved),
+              "statsSelectUpdate");
+        for (int t = nRemoved - 1; t >= 0; --t) { // the device removed these landmarks (ascending indices): follow on the host containers
+            xi0.cameraLandmarks.erase(xi0.cameraLandmarks.begin() + removed[t]);
+            X.id.erase(X.id.begin() + removed[t]);
+            X.Q.erase(X.Q.begin() + removed[t]);
+        }
+    }
+    if (updated == 1)
+        twin.deviceNewer = true;
+    return updated;
+}

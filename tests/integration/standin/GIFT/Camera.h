@@ -2,6 +2,7 @@
 // distortion coefficients) and the class names the reference instantiates (PinholeCamera: SimulationDataServer.cpp:175,
 // StandardCamera = radtan: ASLDatasetReader.cpp:93, EquidistantCamera: UZHFPVDatasetReader.cpp:102).
 #pragma once
+#include "Eigen/Dense"
 #include <array>
 #include <memory>
 #include <vector>
@@ -15,6 +16,12 @@ class GICamera {
     virtual ~GICamera() = default;
     ImageSize imageSize;
     double fx = 1, fy = 1, cx = 0, cy = 0;
+    // pinhole forms (what VIOFilter::removeOutliers / addNewLandmarks call on the simulator's camera); distorted models: not needed by the driver
+    virtual Eigen::Vector2d projectPoint(const Eigen::Vector3d& p) const { return Eigen::Vector2d(fx * p.x() / p.z() + cx, fy * p.y() / p.z() + cy); }
+    virtual Eigen::Vector3d undistortPoint(const Eigen::Vector2d& y) const {
+        const Eigen::Vector3d b((y.x() - cx) / fx, (y.y() - cy) / fy, 1.0);
+        return b * (1.0 / b.norm());
+    }
 };
 class PinholeCamera : public GICamera {
   public:

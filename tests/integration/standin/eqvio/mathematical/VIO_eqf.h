@@ -51,12 +51,46 @@ struct IMUVelocity {
     Eigen::Vector3d gyr, acc;
     Eigen::Vector3d gyrBiasVel = Eigen::Vector3d::Zero(), accBiasVel = Eigen::Vector3d::Zero();
     constexpr static int CompDim = 12;
+    static IMUVelocity Zero() { return IMUVelocity(); }
+    IMUVelocity operator+(const IMUVelocity& o) const { // src/mathematical/IMUVelocity.cpp:42-50
+        IMUVelocity r;
+        r.stamp = (stamp > 0) ? stamp : o.stamp;
+        r.gyr = gyr + o.gyr, r.acc = acc + o.acc, r.gyrBiasVel = gyrBiasVel + o.gyrBiasVel, r.accBiasVel = accBiasVel + o.accBiasVel;
+        return r;
+    }
+    IMUVelocity operator*(const double& c) const {
+        IMUVelocity r;
+        r.stamp = stamp;
+        r.gyr = gyr * c, r.acc = acc * c, r.gyrBiasVel = gyrBiasVel * c, r.accBiasVel = accBiasVel * c;
+        return r;
+    }
 };
 struct VisionMeasurement {
     double stamp = 0;
     std::map<int, Eigen::Vector2d> camCoordinates;
     GIFT::GICameraPtr cameraPtr;
+    std::vector<int> getIds() const {
+        std::vector<int> ids;
+        for (const auto& kv : camCoordinates) ids.push_back(kv.first);
+        return ids;
+    }
 };
+inline VisionMeasurement operator-(const VisionMeasurement& y1, const VisionMeasurement& y2) { // VisionMeasurement.cpp:58-69: the ids both carry
+    VisionMeasurement d;
+    d.stamp = y1.stamp;
+    d.cameraPtr = y1.cameraPtr;
+    for (const auto& kv : y1.camCoordinates) {
+        const auto it2 = y2.camCoordinates.find(kv.first);
+        if (it2 != y2.camCoordinates.end()) d.camCoordinates[kv.first] = kv.second - it2->second;
+    }
+    return d;
+}
+inline VisionMeasurement measureSystemState(const VIOState& xi, const GIFT::GICameraPtr& cam) { // VIOState.cpp:70-78
+    VisionMeasurement y;
+    y.cameraPtr = cam;
+    for (const Landmark& lm : xi.cameraLandmarks) y.camCoordinates[lm.id] = cam->projectPoint(lm.p);
+    return y;
+}
 struct EqFCoordinateSuite {}; // the reference's struct of function objects; the binding only compares addresses
 extern const EqFCoordinateSuite EqFCoordinateSuite_euclid, EqFCoordinateSuite_invdepth, EqFCoordinateSuite_normal;
 
@@ -106,5 +140,15 @@ struct VIO_eqf {
     // `VIO_eqf{suite, xi0, X, Sigma}` (test/test_FilterStatistics.cpp:40) and copies still work.
     void pull() const;      // device -> host members, if the device is ahead (VIOFilter::viewEqFState() calls it before returning)
     void markHostEdited() { twin.hostEdited = true; } // after code that assigns xi0 / X / Sigma directly (VIOFilter.cpp:33-108)
+    // ---- ADDED for the MI355X binding (3 of 3, optional): the fused entry points of include/eqf_hip.h. A VIOFilter.cpp that calls them
+    // (tests/integration/VIOFilter_mi355x.cpp with settings->mi355xFused) takes ONE host wait per frame; without them every member above still works.
+    // The gain matrices of VIOFilterSettings.h:176-206 are diagonal: the fused members take their distinct values (12 input gains; the 7 sensor 3-blocks + the
+    // per-landmark value of the state gain; the pixel variance) instead of dense (21 + 3N)^2 / (2M)^2 matrices built per frame (3 MB + 1.3 MB at N = 200).
+    void propagateFast(const IMUVelocity& meanVelocity, const double& dtTotal, const double (&inputGainDiag)[12], const double (&stateGainDiag8)[8],
+                       const std::vector<IMUVelocity>& samples, const std::vector<double>& dts, const bool& discreteLift); // eqf_propagate_fast
+    void stageMeasurement(const VisionMeasurement& measurement);                                                                                    // eqf_stage_measurement
+    // eqf_stats_then_update (maxOutliers < 0) / eqf_stats_select_update: returns 1 updated, 0 statistics only (absErr / probErr by state index), -1 not applicable
+    int statsThenUpdate(const VisionMeasurement& measurement, const double& thrAbs, const double& thrProb, const long& maxOutliers, const double& outputGainVariance,
+                        const bool& useEquivariantOutput, const bool& discreteCorrection, std::vector<double>& absErr, std::vector<double>& probErr);
     mutable eqvio_mi355x::DeviceTwin twin;
 };
