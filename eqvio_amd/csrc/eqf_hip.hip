@@ -159,7 +159,7 @@ struct eqf_ctx {
     double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
     double* d_pub = nullptr;                 // look-ahead factorisation: published tiles (la_pub_tiles(NJcap) x 8 KB), their flags, the yTilde rows
     int* d_pubf = nullptr;
-    char *d_puby = nullptr, *d_publ = nullptr;
+    char* d_puby = nullptr;
     int la_njcap = 0, la_seq = 0;
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
@@ -191,6 +191,8 @@ struct eqf_ctx {
     int ldzn = 0;
     double *d_Z = nullptr, *d_W = nullptr, *d_Linv = nullptr, *d_gamma = nullptr, *d_gpart = nullptr, *d_est = nullptr, *d_stats = nullptr, *d_scratch = nullptr, *d_F = nullptr, *d_tmp = nullptr;
     int* d_flags = nullptr;
+    int* d_syrk_order = nullptr;   // k_syrk_sub: block -> tile tables for every tile count nt = 1 .. ntcap (build_syrk_order), table nt at syrk_off[nt]
+    std::vector<int> syrk_off;
     // pinned host staging
     Common* h_common = nullptr;
     ObsStep* h_steps = nullptr;
@@ -577,6 +579,29 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     return EQF_OK;
 }
 // every allocation of a context; on failure the caller destroys the partially built context (eqf_destroy accepts null members)
+// Block -> lower tile of Sigma for k_syrk_sub with nt tiles per side, XCD aware: the tiles are sorted by (super-block of g x g tiles, column, row) with
+// g = sqrt(tiles / 8), the sorted list is cut into 8 equal runs, and run x is dealt to the blocks b = x, x + 8, x + 16 ... (block b runs on XCD b % 8). An XCD
+// then works through about one compact g x g square, column by column: ~2 g row panels of W in its L2 instead of all nt.
+static void build_syrk_order(int nt, int* out) {
+    const int ntiles = nt * (nt + 1) / 2;
+    int g = 1;
+    while ((g + 1) * (g + 1) * 8 <= ntiles)
+        ++g;
+    std::vector<std::pair<long, int>> key;
+    key.reserve(ntiles);
+    for (int bj = 0; bj < nt; ++bj)
+        for (int bi = bj; bi < nt; ++bi)
+            key.push_back({(((long)(bj / g) * 4096 + bi / g) * 4096 + bj) * 4096 + bi, bi | (bj << 16)});
+    std::sort(key.begin(), key.end());
+    const int base = ntiles / 8, rem = ntiles % 8;
+    int start = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int len = base + (x < rem ? 1 : 0);
+        for (int l = 0; l < len; ++l)
+            out[8 * l + x] = key[start + l].second;
+        start += len;
+    }
+}
 static int create_buffers(eqf_ctx* c, int max_landmarks) {
     c->Ncap = roundup(max_landmarks, 16);
     c->ncap = 21 + 3 * c->Ncap;
@@ -617,13 +642,22 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipMalloc(&c->d_puby, 512 * (size_t)c->la_njcap));
     HIPCHK(hipMemsetAsync(c->d_pubf, 0, sizeof(int) * la_pub_flags(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
     HIPCHK(hipMemsetAsync(c->d_puby, 0, 512 * (size_t)c->la_njcap, c->stream));
-    HIPCHK(hipMalloc(&c->d_publ, 16384 * (size_t)c->la_njcap));
-    HIPCHK(hipMemsetAsync(c->d_publ, 0, 16384 * (size_t)c->la_njcap, c->stream));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_flags, sizeof(int) * 4));
     HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(int) * 4, c->stream));
+    {
+        const int ntcap = blocks(c->ncap, 32);
+        c->syrk_off.assign(ntcap + 2, 0);
+        for (int nt = 1; nt <= ntcap; ++nt)
+            c->syrk_off[nt + 1] = c->syrk_off[nt] + nt * (nt + 1) / 2;
+        std::vector<int> all(c->syrk_off[ntcap + 1]);
+        for (int nt = 1; nt <= ntcap; ++nt)
+            build_syrk_order(nt, all.data() + c->syrk_off[nt]);
+        HIPCHK(hipMalloc(&c->d_syrk_order, sizeof(int) * all.size()));
+        HIPCHK(hipMemcpy(c->d_syrk_order, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipHostMalloc(&c->h_common, sizeof(Common)));
     HIPCHK(hipHostMalloc(&c->h_steps, sizeof(ObsStep) * eqf_ctx::kMaxSteps));
     c->hbuf_doubles = (size_t)c->ld * c->ncap; // large enough for a full Sigma transfer
@@ -684,7 +718,6 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_pub);
     hipFree(c->d_pubf);
     hipFree(c->d_puby);
-    hipFree(c->d_publ);
     if (c->d_ladbg)
         hipFree(c->d_ladbg);
     if (c->d_trace)
@@ -693,6 +726,7 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_stats);
     hipFree(c->d_scratch);
     hipFree(c->d_flags);
+    hipFree(c->d_syrk_order);
     if (c->d_Ebuf) {
         hipFree(c->d_Ebuf);
         hipFree(c->d_Yl);
@@ -1796,7 +1830,6 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.pub = c->d_pub;
     a.pubf = c->d_pubf;
     a.puby = c->d_puby;
-    a.publ = c->d_publ;
     a.gamma = c->d_gamma;
     a.flags = c->d_flags;
     a.spec = spec;
@@ -2014,7 +2047,7 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
         const dim3 sg(nt * (nt + 1) / 2), sb(64 * SYRK_NW);
 #define SYRK_LAUNCH(TS_, G_, F_) \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<TS_, G_, F_>), sg, sb, 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (TS_*)c->sigma(), nt, c->d_gamma, spec, spec_seq, G_ ? 1 : 0, c->d_flags, \
-                       trace_slot(c, TR_SYRK))
+                       trace_slot(c, TR_SYRK), c->d_syrk_order + c->syrk_off[nt])
         const bool wg = !(c->opt_early || la);
         if (c->opt_syrk_f32) { // EQF_OPT_SYRK_F32: the fp32-arithmetic A/B (operands rounded to float, f32 MFMA)
             if (c->sig32) { if (wg) SYRK_LAUNCH(float, true, true); else SYRK_LAUNCH(float, false, true); }

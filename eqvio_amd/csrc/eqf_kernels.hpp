@@ -1833,9 +1833,13 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 // launches) overlaps with Sigma -= W W^T instead of leaving the GPU idle after it.
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
 template <typename TS, bool WITH_GAMMA, bool F32 = false>
+// tile_of_block (round 3): which lower tile (bi | bj << 16) block b works on. Workgroups are dealt round robin to the 8 XCDs (block b runs on XCD b % 8) and every
+// XCD has its own L2: with the tiles handed out in plain column order each XCD touched every 32-row panel of W (131 MB fetched for 12 MB of W at N = 500).
+// The table (built on the host, eqf_hip.hip: build_syrk_order) gives XCD x a compact square of the tile triangle and walks it column by column, so that an
+// XCD fetches ~2 sqrt(tiles / 8) row panels of W instead of all of them.
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
                                                   double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma, const int* __restrict__ flags,
-                                                  trace_t* tr) {
+                                                  trace_t* tr, const int* __restrict__ tile_of_block) {
     trace_start(tr);
     const int failed = flags[0] | flags[3]; // requested together with the cancellation word: one round trip
     if (spec && *spec == spec_seq)
@@ -1843,13 +1847,8 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
     if (failed)
         return; // the factorisation failed (see k_lift): Sigma stays as it was
     __shared__ double sred[1024 * SYRK_NW];
-    int b = blockIdx.x;
-    int bj = 0;
-    while (b >= nt - bj) { // column bj holds (nt - bj) lower tiles
-        b -= nt - bj;
-        ++bj;
-    }
-    const int bi = bj + b;
+    const int code = tile_of_block[blockIdx.x];
+    const int bi = code & 0xffff, bj = code >> 16;
     const int i0 = bi * 32, j0 = bj * 32;
     const double* W = Wb + m;
     // with_gamma: the diagonal tiles also produce Gamma[i0 : i0+32] = W[rows] z  (Gamma = K yTilde = W L^-1 yTilde, VIO_eqf.cpp:119)

@@ -48,7 +48,6 @@ struct LaArgs {
     double* pub;         // published tiles (offsets below)
     int* pubf;           // their flags
     char* puby;          // the yTilde row of every panel as 16-byte (value, sequence) words
-    char* publ;          // unused (an experimental variant published L^-1 as 16-byte words here)
     double* gamma;       // out: Gamma[n]
     int* flags;          // [0] non-positive pivot, [3] stalled
     const int* spec;
@@ -85,11 +84,14 @@ __device__ __forceinline__ void la_raise_f(const LaArgs& a, int fidx) { __hip_at
 struct LaPoll {
     long long deadline;
     int seq;
-    int* s_abort;
+    int* s_abort; // [0]: the word every wave acts on; [1]: raised by a poll that ran out of time
 };
+// A poll that runs out of time raises the REQUEST word. In a half-row workgroup thread 0 copies it to the abort word in front of a workgroup barrier and
+// every wave reads the abort word behind that barrier: all waves of the workgroup leave at the same barrier (a wave reading a word that another wave
+// writes at any time could leave one barrier earlier than its neighbours). The owner has no barriers: its waves act on the request word directly.
 __device__ __forceinline__ bool la_retry(const LaPoll& pl) {
     if ((long long)wall_clock64() > pl.deadline) {
-        *pl.s_abort = 1;
+        pl.s_abort[1] = 1;
         return false;
     }
     __builtin_amdgcn_s_sleep(1);
@@ -176,9 +178,10 @@ __device__ __forceinline__ void la_lds_add(int* c) {
     if ((threadIdx.x & 63) == 0)
         __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-enum { LC_L = 0, LC_LPUB, LC_T, LC_C, LC_D, LC_B, LC_CCOPIED, LC_BCOPIED, LC_U, LC_COUNT };
+enum { LC_L = 0, LC_T, LC_C, LC_D, LC_B, LC_CCOPIED, LC_BCOPIED, LC_U, LC_COUNT };
 
-__device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_abort, int* cnt, const LaPoll& pl) {
+__device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_abort_words, int* cnt, const LaPoll& pl) {
+    int* const s_abort = s_abort_words + 1; // the owner has no barriers: its waves act on the request word
     // `wave` as a scalar: the role branches become real (scalar) branches. With a vector condition the compiler predicates short blocks instead of
     // branching around them, and a predicated-off s_sleep still sleeps (measured: every wave took wave 4's nap).
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -204,7 +207,6 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         if (tid == 0) {
             la_raise_f(a, la_f_linv(a, 0));
             __hip_atomic_store(cnt + LC_L, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(cnt + LC_LPUB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     // ------------------------------------------------------------------------------------------------------------------ wave 0: the pivot chain
@@ -232,7 +234,6 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             la_stores_done(); // its write-through stores: mostly acknowledged while the elimination ran; the rest under the post-work
             if (lane == 0)
                 la_raise_f(a, la_f_linv(a, I));
-            la_lds_set(cnt + LC_LPUB, I + 1);
         }
         if (a.tr_steps && lane == 0 && NJ - 1 < 32)
             a.tr_steps[NJ - 1] = wall_clock64();
@@ -562,6 +563,8 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
             const double yv = la_get16(a.puby + 512 * (size_t)p + 16 * (size_t)lane, pl);
             sYv[lane] = lane < w ? yv : 0.0;
         }
+        if (tid == 0 && s_abort[1])
+            s_abort[0] = 1;
         __syncthreads();
         if (*s_abort)
             return;
@@ -743,21 +746,21 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
         return;
     }
     __shared__ double smem[4 * 32 * CH_LDP + LDL_SBUF]; // static LDS: constant addresses (2.6 us per factorisation at N = 200 against dynamic LDS)
-    __shared__ int s_abort, s_cnt[LC_COUNT];
-    if (threadIdx.x == 0)
-        s_abort = 0;
+    __shared__ int s_abort[2], s_cnt[LC_COUNT];
+    if (threadIdx.x < 2)
+        s_abort[threadIdx.x] = 0;
     if (threadIdx.x < LC_COUNT)
         s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const LaPoll pl{(long long)wall_clock64() + a.timeout_ticks, a.seq, &s_abort};
+    const LaPoll pl{(long long)wall_clock64() + a.timeout_ticks, a.seq, s_abort};
     // block 0: the owner; blocks 1 .. 2 NJ - 2: the S half-rows h = 2 .. 2 NJ - 1 (block row 0 is the first diagonal tile, eliminated by k_build_Z);
     // then the T half-rows, numbered on from 2 NJ
     const int hidx = (int)blockIdx.x + 1;
     if (blockIdx.x == 0)
-        la_owner(a, smem, &s_abort, s_cnt, pl);
+        la_owner(a, smem, s_abort, s_cnt, pl);
     else
-        la_row<MAXT>(a, hidx, smem, &s_abort, pl);
-    if (threadIdx.x == 0 && s_abort)
+        la_row<MAXT>(a, hidx, smem, s_abort, pl);
+    if ((threadIdx.x & 63) == 0 && (s_abort[0] | s_abort[1])) // any wave that saw a timeout reports it (the owner's waves return at different times)
         __hip_atomic_store(a.flags + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.lift_door_host && hidx >= 2 * a.NJ && blockIdx.x != 0) { // a T half-row (stalled or not) counts itself in; the last one finishes the frame
         __shared__ int s_last;
