@@ -608,8 +608,10 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
     # HBM-side traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with the
     # same bench command; bench.py cannot run the profiler on itself)
     traffic, traffic_note = None, None
-    try:  # per size: profiles/r02_pmc_traffic.json is written by scripts/pmc_traffic_json.py from the PMC passes of scripts/collect_profiles.sh
-        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+    try:  # per size: profiles/rNN_pmc_traffic.json is written by scripts/pmc_traffic_json.py from the PMC passes of scripts/collect_profiles.sh (newest round wins)
+        import glob
+
+        pmc_all = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
         pmc = pmc_all.get("N%d" % ((n - 21) // 3), {}).get("kernels", {})
         kn = [k_ for k_ in fam[dom][0] if k_ in pmc and launches.get(k_, 0) > 0]
         if kn:

@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/$V
 mkdir -p $OUT
 ST=50; WU=10
 if [ "$NL" -ge 400 ]; then ST=30; WU=5; fi
-BCMD="python $R/bench.py --landmarks $NL --steps $ST --warmup $WU --no-cpu-baseline --no-roofline --no-multi-filter --no-frame-mix"
+BCMD="python $R/bench.py --landmarks $NL --steps $ST --warmup $WU --no-cpu-baseline --no-roofline --no-multi-filter --no-frame-mix --no-binding"
 rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w /tmp/p_m
 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- $BCMD > /tmp/kt.log 2>&1
 DB=$(find /tmp/p_kt -name "*.db" | head -1)
@@ -25,7 +25,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_G
 python $R/scripts/rocpd_pmc.py $(find /tmp/p_m -name "*.db" | head -1) > $OUT/${V}_pmc_mfma.csv
 cd $R
 python scripts/frame_trace.py $NL 2000 > $OUT/${V}_frame_trace.txt 2>&1
-python bench.py --landmarks $NL --steps 2000 --warmup 200 --no-multi-filter > $OUT/${V}_bench.json 2> $OUT/bench.err
+python bench.py --landmarks $NL --steps 2000 --warmup 200 --no-multi-filter --no-binding > $OUT/${V}_bench.json 2> $OUT/bench.err
 if [ "$FULL" = "full" ]; then
   python scripts/host_share.py $NL 6000 > $OUT/${V}_host_share.txt 2>&1
   python scripts/propagate_vs_steps.py > $OUT/${V}_propagate_vs_steps.txt 2>&1
