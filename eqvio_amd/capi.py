@@ -211,6 +211,7 @@ def load_eqf_lib():
         "eqf_lookahead_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
         "eqf_debug_matrices_AB": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
         "eqf_debug_get_W": (C.c_int, [vp, c_double_p, C.c_int, C.c_int]),
+        "eqf_debug_syrk_order": (C.c_int, [C.c_int, c_int_p]),
         "eqf_debug_lookahead_stamps": (C.c_int, [vp, C.POINTER(C.c_ulonglong)]),
         "eqf_debug_matrix_C": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p]),
         "eqf_mfma_f64_peak": (C.c_int, [vp, c_double_p]),

@@ -590,8 +590,13 @@ static void build_syrk_order(int nt, int* out) {
     std::vector<std::pair<long, int>> key;
     key.reserve(ntiles);
     for (int bj = 0; bj < nt; ++bj)
-        for (int bi = bj; bi < nt; ++bi)
-            key.push_back({(((long)(bj / g) * 4096 + bi / g) * 4096 + bj) * 4096 + bi, bi | (bj << 16)});
+        for (int bi = bj; bi < nt; ++bi) {
+            // super-block columns are walked alternately downwards and upwards (boustrophedon), so that a run which crosses from one super-block column
+            // into the next stays in neighbouring super-blocks
+            const int SJ = bj / g, SI = bi / g, SImax = (nt - 1) / g;
+            const int SIk = (SJ & 1) ? SImax - SI : SI;
+            key.push_back({(((long)SJ * 4096 + SIk) * 4096 + bj) * 4096 + bi, bi | (bj << 16)});
+        }
     std::sort(key.begin(), key.end());
     const int base = ntiles / 8, rem = ntiles % 8;
     int start = 0;
@@ -2559,6 +2564,13 @@ int eqf_speculation_stats(eqf_ctx* c, long* calls, long* queued, long* cancelled
     *cancelled = c->spec_cancelled;
     if (reset)
         c->spec_calls = c->spec_queued = c->spec_cancelled = 0;
+    return 0;
+}
+
+int eqf_debug_syrk_order(int nt, int* tile_of_block) {
+    if (nt < 1 || nt > 4095 || !tile_of_block)
+        return EQF_E_BAD_ARG;
+    build_syrk_order(nt, tile_of_block);
     return 0;
 }
 

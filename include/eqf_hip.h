@@ -218,6 +218,9 @@ int eqf_debug_matrices_AB(eqf_ctx* ctx, const double* imu13, double* A_out, doub
 /* the work matrix of the last vision update, column-major rows x cols: rows [2M, 2M + n) hold W = Sigma C^T L^-T, row 2M + n holds z^T = yTilde^T L^-T
  * (Sigma+ = Sigma - W W^T, Gamma = W z); rows < 2M are scratch. For the bit-identity tests of the factorisation variants. */
 int eqf_debug_get_W(eqf_ctx* ctx, double* out, int rows, int cols);
+/* The block -> tile table of the covariance update kernel for nt 32 x 32 tiles per side (host-side, no device needed): tile_of_block[b] = bi | bj << 16, nt (nt + 1) / 2
+ * entries. Blocks are dealt round robin to the 8 XCDs; the table gives every XCD a compact part of the tile triangle. For the test of that property. */
+int eqf_debug_syrk_order(int nt, int* tile_of_block);
 int eqf_debug_matrix_C(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, int useEquivariantOutput, double* C_out, double* ytilde_out);
 
 /* fp64 MFMA micro-benchmark (v_mfma_f64_16x16x4_f64 issue rate): returns achieved TFLOP/s over the whole
