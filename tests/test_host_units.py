@@ -39,5 +39,5 @@ def test_syrk_tile_order_is_a_permutation_and_xcd_compact():
         assert len({(int(a), int(b)) for a, b in zip(bi, bj)}) == ntiles
         if nt >= 20:
             panels = [len(set(bi[x::8].tolist()) | set(bj[x::8].tolist())) for x in range(8)]
-            assert max(panels) <= 0.75 * nt, (nt, panels)  # e.g. nt = 48: <= 36 of 48 panels per XCD (plain order: 48)
+            assert max(panels) <= 0.8 * nt and sum(panels) <= 5.5 * nt, (nt, panels)  # e.g. nt = 48: 18 .. 36 of 48 panels per XCD, 223 in all (plain order: 8 x 48)
             assert abs(len(bi[0::8]) - len(bi[7::8])) <= 1  # equal shares
