@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -163,6 +164,10 @@ struct eqf_ctx {
     int la_njcap = 0, la_seq = 0;
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
+    int opt_sigma_la = 0;                    // EQF_OPT_SIGMA_IN_LOOKAHEAD
+    int cu_count = 256;                      // compute units of the device: what the look-ahead kernel's Sigma workgroups may fill
+    int* d_wflags = nullptr;                 // look-ahead kernel: flags of the T half-rows' W rows, [panel][half-row]
+    long la_sigma_tiles = 0, la_sigma_rest = 0; // eqf_lookahead_stats-style counters: Sigma tiles updated inside the look-ahead kernel / left to k_syrk_sub behind it
     long long la_timeout_ticks = LA_TIMEOUT_TICKS; // EQF_OPT_LA_TIMEOUT_US: bound of every device-side wait of the look-ahead kernel (100 MHz ticks)
     long la_launches = 0, la_fallbacks = 0;  // eqf_lookahead_stats: look-ahead launches; of those, stalled ones that were redone on the launch chain
     int la_consecutive_stalls = 0;           // three in a row switch the look-ahead kernel off for this context (the GPU is shared with something long-running)
@@ -570,10 +575,33 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     eqf_ctx* c = new eqf_ctx();
     c->device = device;
     c->chart = coordinate_choice;
+    c->cu_count = prop.multiProcessorCount;
     const int rc = create_buffers(c, max_landmarks);
     if (rc) { // a failed allocation half way (e.g. the pinned Sigma staging at a large capacity): release what exists
         eqf_destroy(c);
         return rc;
+    }
+    // EQF_OPTIONS="id=value,id=value": options applied to every new context (A/B runs of unchanged callers; a bad entry fails the creation)
+    if (const char* env = std::getenv("EQF_OPTIONS")) {
+        for (const char* q = env; *q;) {
+            char* end = nullptr;
+            const long id = std::strtol(q, &end, 10);
+            if (end == q || *end != '=') {
+                eqf_destroy(c);
+                return EQF_E_BAD_ARG;
+            }
+            q = end + 1;
+            const long v = std::strtol(q, &end, 10);
+            if (end == q || eqf_set_option(c, (int)id, (int)v) != 0) {
+                eqf_destroy(c);
+                return EQF_E_BAD_ARG;
+            }
+            q = (*end == ',') ? end + 1 : end;
+            if (*end && *end != ',') {
+                eqf_destroy(c);
+                return EQF_E_BAD_ARG;
+            }
+        }
     }
     *out = c;
     return EQF_OK;
@@ -647,6 +675,8 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipMalloc(&c->d_puby, 512 * (size_t)c->la_njcap));
     HIPCHK(hipMemsetAsync(c->d_pubf, 0, sizeof(int) * la_pub_flags(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
     HIPCHK(hipMemsetAsync(c->d_puby, 0, 512 * (size_t)c->la_njcap, c->stream));
+    HIPCHK(hipMalloc(&c->d_wflags, sizeof(int) * (size_t)c->la_njcap * blocks(c->ncap + 1, 16)));
+    HIPCHK(hipMemsetAsync(c->d_wflags, 0, sizeof(int) * (size_t)c->la_njcap * blocks(c->ncap + 1, 16), c->stream));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
@@ -723,6 +753,7 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_pub);
     hipFree(c->d_pubf);
     hipFree(c->d_puby);
+    hipFree(c->d_wflags);
     if (c->d_ladbg)
         hipFree(c->d_ladbg);
     if (c->d_trace)
@@ -852,6 +883,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_FUSED_LIFT:
         c->opt_fused_lift = value ? 1 : 0;
+        return 0;
+    case EQF_OPT_SIGMA_IN_LOOKAHEAD:
+        c->opt_sigma_la = value ? 1 : 0;
         return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
@@ -1818,7 +1852,12 @@ static bool lookahead_eligible(const eqf_ctx* c, int m) {
     const int NJ = blocks(m, 32);
     return c->opt_lookahead && !c->opt_fused && c->d_pub && NJ >= 3 && NJ <= c->la_njcap;
 }
-static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq, bool with_lift = false, int discreteCorr = 0, int door_seq = 0) {
+// 16 x 16 quadrants of Sigma a wave of the look-ahead kernel's Sigma workgroups keeps in its accumulators (8 registers each): template argument SQ by panel count
+constexpr int LA_SQ_SMALL = 2, LA_SQ_LARGE = 4;
+// sigma_tiles: nullptr, or out: how many entries of k_syrk_sub's tile table (n / 32 tiles per side) the kernel's Sigma workgroups took (Sigma <- Sigma - W W^T
+// for those tiles is part of this launch; the caller launches k_syrk_sub for the rest, if any)
+static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq, bool with_lift = false, int discreteCorr = 0, int door_seq = 0,
+                            int* sigma_tiles = nullptr) {
     LaArgs a{};
     a.rows = rows;
     a.m = m;
@@ -1848,12 +1887,36 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
         a.lift_flags_host = c->h_resflags, a.lift_done = c->d_door + 2, a.lift_door_host = c->h_door + 1, a.lift_door_seq = door_seq;
         a.tr_lift = trace_slot(c, TR_LIFT);
     }
+    if (sigma_tiles) {
+        // The compute units the factorisation leaves idle take lower tiles of Sigma (la_sigma): all of them if they fit at STW per workgroup, else as many as
+        // fit. Workgroup count a multiple of 8: slot -> table entry keeps the entry's XCD (build_syrk_order).
+        *sigma_tiles = 0;
+        const int n = rows - m - 1, nt = blocks(n, 32), tiles = nt * (nt + 1) / 2;
+        const int sq = a.NJ <= 16 ? LA_SQ_SMALL : LA_SQ_LARGE;
+        const int free8 = (c->cu_count - a.NI) / 8 * 8;
+        if (free8 >= 8) {
+            int spw = blocks(tiles, 2 * free8), nwg, taken; // a workgroup takes 2 spw tiles
+            if (spw <= sq) {
+                nwg = blocks(blocks(tiles, 2 * spw), 8) * 8;
+                taken = tiles;
+            } else {
+                spw = sq;
+                nwg = free8;
+                taken = 2 * spw * nwg;
+            }
+            a.sg_n = n, a.sg_ld = c->ld, a.sg_nwg = nwg, a.sg_spw = spw, a.sg_ntiles = taken;
+            a.sg_sigma = (double*)c->sigma();
+            a.sg_tiles = c->d_syrk_order + c->syrk_off[nt];
+            a.sg_wflags = c->d_wflags;
+            *sigma_tiles = taken;
+        }
+    }
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
     // MAXT = tiles a wave keeps in registers = ceil(NJ / 4)
     if (a.NJ <= 16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, LA_SQ_SMALL>), dim3(a.NI + a.sg_nwg), dim3(LA_T), 0, c->stream, a);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8, LA_SQ_LARGE>), dim3(a.NI + a.sg_nwg), dim3(LA_T), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2037,7 +2100,10 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
         if (la)
             ++c->la_launches;
         const bool fl = la && c->opt_early && c->opt_fused_lift; // EQF_OPT_FUSED_LIFT
-        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, fl, discreteCorr, door_seq)
+        // EQF_OPT_SIGMA_IN_LOOKAHEAD: Sigma <- Sigma - W W^T by the look-ahead kernel's own Sigma workgroups (fp64 store and arithmetic only)
+        int sigma_in_la = 0;
+        const bool sgl = la && c->opt_sigma_la && !c->sig32 && !c->opt_syrk_f32;
+        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, fl, discreteCorr, door_seq, sgl ? &sigma_in_la : nullptr)
                 : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
         if (rc)
             return rc;
@@ -2048,13 +2114,25 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
                 return rc;
         }
         const int nt = blocks(n, 32);
+        const int syrk_tiles = nt * (nt + 1) / 2 - sigma_in_la; // what the look-ahead kernel's Sigma workgroups did not take (the table's tail)
+        c->la_sigma_tiles += sigma_in_la;
+        c->la_sigma_rest += la ? syrk_tiles : 0;
         KTimer t(c, KN_SYRK);
-        const dim3 sg(nt * (nt + 1) / 2), sb(64 * SYRK_NW);
+        const dim3 sg(std::max(syrk_tiles, 1)), sb(64 * SYRK_NW);
 #define SYRK_LAUNCH(TS_, G_, F_) \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<TS_, G_, F_>), sg, sb, 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (TS_*)c->sigma(), nt, c->d_gamma, spec, spec_seq, G_ ? 1 : 0, c->d_flags, \
-                       trace_slot(c, TR_SYRK), c->d_syrk_order + c->syrk_off[nt])
+                       trace_slot(c, TR_SYRK), c->d_syrk_order + c->syrk_off[nt] + sigma_in_la)
         const bool wg = !(c->opt_early || la);
-        if (c->opt_syrk_f32) { // EQF_OPT_SYRK_F32: the fp32-arithmetic A/B (operands rounded to float, f32 MFMA)
+        if (syrk_tiles == 0) {
+            // the whole update was part of the look-ahead kernel
+        } else if (!wg && !c->opt_syrk_f32 && c->opt_sigma_la) { // EQF_OPT_SIGMA_IN_LOOKAHEAD: one accumulation chain per quadrant, the order the look-ahead kernel's Sigma workgroups follow
+            if (c->sig32)
+                hipLaunchKernelGGL(k_syrk_sub_q<float>, sg, dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (float*)c->sigma(), spec, spec_seq, c->d_flags, trace_slot(c, TR_SYRK),
+                                   c->d_syrk_order + c->syrk_off[nt] + sigma_in_la);
+            else
+                hipLaunchKernelGGL(k_syrk_sub_q<double>, sg, dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(), spec, spec_seq, c->d_flags, trace_slot(c, TR_SYRK),
+                                   c->d_syrk_order + c->syrk_off[nt] + sigma_in_la);
+        } else if (c->opt_syrk_f32) { // EQF_OPT_SYRK_F32: the fp32-arithmetic A/B (operands rounded to float, f32 MFMA)
             if (c->sig32) { if (wg) SYRK_LAUNCH(float, true, true); else SYRK_LAUNCH(float, false, true); }
             else { if (wg) SYRK_LAUNCH(double, true, true); else SYRK_LAUNCH(double, false, true); }
         } else {

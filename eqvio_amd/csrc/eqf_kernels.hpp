@@ -1876,6 +1876,84 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
     trace_end(tr);
 }
 
+// K9, round 3: the same update with ONE accumulation chain per 16 x 16 quadrant (a wave owns a quadrant and walks all of K in ascending order; no split of K
+// over waves, no reduction through LDS). This is the order of additions that the look-ahead kernel's Sigma workgroups can follow panel by panel as W
+// appears (eqf_lookahead.hpp: la_sigma), with the result in the accumulator when the last panel arrives - both call syrk_quadrant_panel, so Sigma+ is
+// bit-identical whichever of the two ran. k_syrk_sub above stays for its by-products (Gamma with EQF_OPT_EARLY_LIFT = 0) and the f32-arithmetic experiment.
+//
+// Panel p = the k4-steps 8 p .. 8 p + 7 (columns 32 p .. 32 p + 31 of W) added to the quadrant (rows i0 .. i0 + 15) x (rows j0 .. j0 + 15) of W W^T.
+// Operand order and masks as in mfma_tile32_splitk: a lane's results are C[i0 + (l & 15)][j0 + (l >> 4) + 4 r].
+__device__ __forceinline__ void syrk_quadrant_panel(const double* __restrict__ W, int ldz, int n, int K, int i0, int j0, int p, d4& acc) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int ia = min(i0 + lr, n - 1), ja = min(j0 + lr, n - 1);
+    const double zi = (i0 + lr < n) ? 1.0 : 0.0, zj = (j0 + lr < n) ? 1.0 : 0.0;
+    const int nsteps = (K + 3) >> 2;
+    double pa[8], qa[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int kc = min(4 * (8 * p + s) + lk, K - 1);
+        if (8 * p + s < nsteps) {
+            pa[s] = W[ia + (size_t)kc * ldz];
+            qa[s] = W[ja + (size_t)kc * ldz];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        if (8 * p + s < nsteps) {
+            const double zk = (4 * (8 * p + s) + lk < K) ? 1.0 : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s] * zj, pa[s] * (zi * zk), acc, 0, 0, 0);
+        }
+}
+// the quadrant's entries of Sigma (lower triangle of the diagonal tiles; the strictly lower ones mirrored so that Sigma stays exactly symmetric)
+template <typename TS> __device__ __forceinline__ void syrk_quadrant_load(const TS* __restrict__ Sig, int ld, int n, int i0, int j0, double (&s0)[4]) {
+    const int lane = threadIdx.x & 63, i = i0 + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + (lane >> 4) + 4 * e;
+        s0[e] = (i < n && j < n) ? (double)Sig[i + (size_t)j * ld] : 0.0;
+    }
+}
+template <typename TS> __device__ __forceinline__ void syrk_quadrant_store(TS* __restrict__ Sig, int ld, int n, int i0, int j0, bool diag_tile, const double (&s0)[4], const d4& acc) {
+    const int lane = threadIdx.x & 63, i = i0 + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + (lane >> 4) + 4 * e;
+        if (i < n && j < n && (!diag_tile || i >= j)) {
+            const TS v = (TS)(s0[e] - acc[e]);
+            Sig[i + (size_t)j * ld] = v;
+            if (i != j)
+                Sig[j + (size_t)i * ld] = v;
+        }
+    }
+}
+// one workgroup (4 waves = 4 quadrants) per lower 32 x 32 tile; the quadrant of a diagonal tile that lies strictly above the diagonal is its mirror's
+template <typename TS>
+__global__ void __launch_bounds__(256) k_syrk_sub_q(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, const int* __restrict__ spec, int spec_seq,
+                                                    const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block) {
+    trace_start(tr);
+    const int failed = flags[0] | flags[3];
+    if (spec && *spec == spec_seq)
+        return; // cancelled speculative tail
+    if (failed)
+        return; // the factorisation failed (see k_lift): Sigma stays as it was
+    const int code = tile_of_block[blockIdx.x];
+    const int bi = code & 0xffff, bj = code >> 16;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int qi = wave & 1, qj = wave >> 1;
+    if (bi == bj && qi == 0 && qj == 1)
+        return;
+    const int i0 = 32 * bi + 16 * qi, j0 = 32 * bj + 16 * qj;
+    const double* W = Wb + m;
+    double s0[4];
+    syrk_quadrant_load(Sig, ld, n, i0, j0, s0);
+    d4 acc = {0, 0, 0, 0};
+    const int NJ = (m + 31) >> 5;
+    for (int p = 0; p < NJ; ++p)
+        syrk_quadrant_panel(W, ldz, n, m, i0, j0, p, acc);
+    syrk_quadrant_store(Sig, ld, n, i0, j0, bi == bj, s0, acc);
+    trace_end(tr);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K10: landmark part of X <- Delta * X with Delta lifted from Gamma (liftInnovation / liftInnovationDiscrete,
 // euclid.cpp:36-97, invdepth.cpp:183-253; VIOExp VIOGroup.cpp:273-290; X = Delta * X VIO_eqf.cpp:130).

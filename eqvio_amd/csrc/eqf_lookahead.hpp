@@ -61,6 +61,13 @@ struct LaArgs {
     int *lift_flags_host, *lift_done, *lift_door_host;
     int lift_door_seq;
     trace_t* tr_lift;
+    // Sigma <- Sigma - W W^T under the factorisation (EQF_OPT_SIGMA_IN_LOOKAHEAD; la_sigma below): the workgroups NI .. NI + sg_nwg - 1
+    int sg_n, sg_ld;      // rows and leading dimension of Sigma (sg_n = 0: no Sigma workgroups; the T half-rows then store W with plain stores)
+    int sg_nwg, sg_spw;   // Sigma workgroups and 16 x 16 quadrants per wave (<= the kernel's SQ); a workgroup takes 2 sg_spw tiles
+    int sg_ntiles;        // tiles taken here: entries 0 .. sg_ntiles - 1 of sg_tiles (the rest, if any, is left to a k_syrk_sub_q launch behind this kernel)
+    double* sg_sigma;
+    const int* sg_tiles;  // k_syrk_sub_q's tile table (bi | bj << 16)
+    int* sg_wflags;       // flag of (panel p, T half-row t) at [p NT + t]: the W rows of that half-row for that panel are at the coherence point
     trace_t* tr_steps;       // EQF_OPT_TRACE: slot of step 0 (the owner stamps one slot per step), or nullptr
     unsigned long long* dbg; // EQF_OPT_TRACE: per-step stamps inside the owner ([k][8]) and two block rows ([32 + p][8], [64 + p][8]), or nullptr
 };
@@ -484,7 +491,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 //   A wave's B operand is rows 16 jh .. 16 jh + 15 of P_J, i.e. what ONE half-row (2 J + jh) published: flags are per (panel, half-row).
 //   P^(p)_h = Z(h, p) L_p^-T is formed by waves 0 / 1 (column halves; the zero block of the triangular L_p^-1 skipped).
 template <int MAXT>
-__device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* smem, int* s_abort, const LaPoll& pl) {
+__device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* row_cnt, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     double* sLinv = smem;                   // L_p^-1, operand layout [r + c CH_LDP]
     double* sPI = smem + 32 * CH_LDP;       // P_h: 16 rows x 32 columns
@@ -540,7 +547,6 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         // laundered once per panel: otherwise the body's address / mask expressions are loop invariant, get hoisted and spilled
         int lrv = lr, lkv = lk;
         asm volatile("" : "+v"(lrv), "+v"(lkv));
-        const bool do_update = true;
         const int w = min(32, m - 32 * p);
         // (a) L_p^-1 -> LDS; this half-row's part of the panel tile Z(h, p) -> LDS in operand layout (masked like the chain's operand loads); yTilde row
         la_wait(a.pubf + la_f_linv(a, p), 1, pl);
@@ -608,15 +614,17 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         } else {
             const int r = tid & 15, c = tid >> 4;
             const double pv = sPI[r + c * CH_LDP];
-            if (row0 + r < rows && c < w)
-                a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = pv;
+            if (row0 + r < rows && c < w) {
+                if (a.sg_n) // read by the Sigma workgroups of this launch: write-through, flag at the end of the panel
+                    la_st(a.W + (row0 + r) + (size_t)(32 * p + c) * ldz, pv);
+                else
+                    a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = pv;
+            }
             const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
             gsum = fma(pv, c < w ? zc : 0.0, gsum);
         }
         if (dbg_row)
             dbr[1] = wall_clock64();
-        if (!do_update)
-            continue;
         double aI[8];
 #pragma unroll
         for (int st = 0; st < 8; ++st)
@@ -634,6 +642,12 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
                 }
             }
             asm volatile("" ::: "memory");
+        }
+        const bool dbg_wave = a.dbg && lane == 0 && (hidx == 2 * NJ || hidx == 2 * (NJ - 2)) && p < 32;
+        if (dbg_wave) {
+            atomicMax(dbr + 3, (unsigned long long)wall_clock64());
+            if (wave == 0)
+                dbr[7] = wall_clock64();
         }
         // two tiles per round trip: both operand sets are requested before the first product needs one
 #pragma unroll
@@ -674,6 +688,19 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         }
         if (dbg_row)
             dbr[2] = wall_clock64();
+        if (dbg_wave) {
+            atomicMax(dbr + 4, (unsigned long long)wall_clock64());
+            if (wave == 7)
+                dbr[5] = wall_clock64();
+            if (wave == 3)
+                dbr[6] = wall_clock64();
+        }
+        if (!srow && a.sg_n) {
+            // the W rows of this panel were stored in step (c), a whole trailing update ago: the wait is free. The last wave to pass raises the flag.
+            la_stores_done();
+            if (lane == 0 && __hip_atomic_fetch_add(row_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * p + 7)
+                __hip_atomic_store(a.sg_wflags + (size_t)p * (a.NI - (2 * NJ - 1)) + (hidx - 2 * NJ), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (srow)
         hand_off(); // after panel I-3 (block rows 1 and 2 have no panel to wait for: their tiles go to the owner as they are)
@@ -690,6 +717,469 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
             la_st(a.gamma + (row - m), g);
         }
     }
+}
+
+// ---- a half block row with a look-ahead of its own (17 .. 32 panels) ----------------------------------------------------------------------
+// la_row above walks a panel as wait L_p -> barrier -> P_h -> barrier -> wait P_J -> trailing update, one after the other. With 17 .. 32 panels
+// the trailing update of the early panels is MFMA bound per CU (31 tiles x 16 MFMAs of ~100 cycles on 4 SIMDs = 5.3 us against an owner step of 4.7 us)
+// and the 3.7 us of waits around it are not overlapped with anything: measured 10.5 us per panel at N = 500, the half-rows 40 us behind the owner
+// by panel 8 (profiles/r03_v1_N500_lookahead_trace.txt). Here the panel's NEXT tile goes first: the two waves that own tile Z(h, p + 1) apply panel p
+// to it before anything else, form P_h(p+1) = Z(h, p+1) L_(p+1)^-T with the L_(p+1)^-1 they fetched on the way (the owner is ahead), publish it
+// (S half-rows) and only then turn to their other tiles - while the other six waves are in the trailing update of panel p. One workgroup barrier per
+// panel; P_h, L^-1 and z in LDS are double buffered by panel parity. Same products in the same order per tile: bit-identical to la_row and to the chain.
+template <int MAXT, bool srow>
+__device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* cnt, const LaPoll& pl) {
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int B = 32 * CH_LDP;
+    auto sLinvB = [&](int b) -> double* { return smem + (b & 1) * B; };      // L_p^-1, operand layout [r + c CH_LDP], rows 0 .. 31
+    auto sPIB = [&](int b) -> double* { return smem + (b & 1) * B + 32; };   // P_h(p): 16 rows x 32 columns in the rows 32 .. 47 of the same blocks
+    double* sT = smem + 2 * B;                                               // the next panel tile's 16 rows in operand layout; at the very end the Gamma partial sums
+    auto sZpB = [&](int b) -> double* { return smem + 3 * B + 256 * (b & 1); }; // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
+    int* pair_cnt = cnt;     // the two waves of a look-ahead pair: tile and L^-1 in LDS
+    int* pub_cnt = cnt + 1;  // ... their halves of P_h acknowledged (S half-rows)
+    int* w_cnt = cnt + 2;    // EQF_OPT_SIGMA_IN_LOOKAHEAD: the eight waves' W rows of a panel acknowledged (T half-rows)
+    const int NJ = a.NJ, m = a.m, rows = a.rows, ldz = a.ldz, seq = a.seq;
+    const int I = hidx >> 1, s = hidx & 1;
+    const int row0 = srow ? 16 * hidx : m + 16 * (hidx - 2 * NJ);
+    const int ilim = srow ? min(m, row0 + 16) : min(rows, row0 + 16);
+    const int Jmax = srow ? I : NJ - 1;
+    const bool ylast = (!srow) && (rows - 1 >= row0) && (rows - 1 < row0 + 16); // this half-row holds the yTilde row
+    const int yloc = rows - 1 - row0;
+    const int jh = wave & 1, jr = wave >> 1;
+    const int ri = row0 + lr;
+    const int ric = min(ri, ilim - 1);
+    double acc[MAXT][4];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int J = 4 * t + jr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
+            acc[t][q] = (J <= Jmax) ? a.Z[ric + (size_t)j * ldz] : 0.0;
+        }
+    }
+    if (ylast && tid < 32)
+        la_put16(a.puby + 16 * (size_t)tid, a.Z[(rows - 1) + (size_t)min(tid, m - 1) * ldz], seq);
+    double gsum = 0.0;
+    const int np = srow ? max(I - 2, 0) : NJ; // see la_row
+    auto hand_off = [&]() {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int J = 4 * t + jr;
+            if (J >= 0 && J >= I - 2 && J <= I) {
+                double* u = la_tile(a, la_i_u(a, I, J == I ? 1 : (J == I - 1 ? 0 : 2)));
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    la_st(u + (16 * s + lr) + 32 * (16 * jh + lk + 4 * q), acc[t][q]);
+            }
+        }
+        la_stores_done();
+        __syncthreads();
+        if (tid == 0)
+            la_raise_f(a, la_f_u(a, I, s));
+    };
+    // the panel tile Z(h, q) out of the accumulators into sT, masked like the chain's operand loads (the waves that own it)
+    auto tile_to_lds = [&](int q) {
+        const int wq = min(32, m - 32 * q);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (4 * t + jr == q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 16 * jh + lk + 4 * e;
+                    sT[lr + c * CH_LDP] = (ri < ilim && c < wq) ? acc[t][e] : 0.0;
+                }
+            }
+    };
+    // P_h(q) = Z(h, q) L_q^-T, column half ch, from sT and sLinvB(q) into sPIB(q) (L_q^-1 is lower triangular: its columns >= 16 are zero in the rows < 16)
+    auto form_p = [&](int q, int ch, d4& pacc) {
+        const double* sL = sLinvB(q);
+        pacc = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+            if (ch == 1 || st < 4)
+                pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sL[16 * ch + lr + (4 * st + lk) * CH_LDP], sT[lr + (4 * st + lk) * CH_LDP], pacc, 0, 0, 0);
+        double* sP = sPIB(q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            sP[lr + (16 * ch + lk + 4 * e) * CH_LDP] = pacc[e];
+    };
+    auto publish_p = [&](int q, int ch, const d4& pacc) { // S half-rows: this wave's half of the factor rows, write-through
+        double* pt = la_tile(a, la_i_p(a, I, q));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            la_st(pt + (16 * s + lr) + 32 * (16 * ch + lk + 4 * e), pacc[e]);
+    };
+    // z_q[c] = sum_k yTilde_q[k] L_q^-1[c][k] as 8 partial sums (thread (c, h) of the waves 4 .. 7: k = 4 h .. 4 h + 3), summed in a fixed order by the readers
+    auto z_partials = [&](int q) {
+        const int wq = min(32, m - 32 * q);
+        const int c = tid & 31, h = (tid >> 5) & 7;
+        const double* sL = sLinvB(q);
+        const double ymine = la_get16(a.puby + 512 * (size_t)q + 16 * (size_t)c, pl); // lane: entry c = lane & 31 (one round trip per wave); the four this thread needs come from its neighbours
+        double z = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 4 * h + i;
+            const double yv = fetch_lane(ymine, 4 * k);
+            z = fma(k < wq ? yv : 0.0, sL[c + k * CH_LDP], z);
+        }
+        sZpB(q)[32 * h + c] = z;
+    };
+    if (np > 0) {
+        // prologue: panel 0 the plain way (every thread two entries of L_0^-1; waves 0 / 1 form P_h(0))
+        la_wait(a.pubf + la_f_linv(a, 0), 1, pl);
+        {
+            const double* lt = la_tile(a, la_i_linv(a, 0));
+            const double v0 = lt[tid], v1 = lt[tid + LA_T];
+            double* sL = sLinvB(0);
+            sL[(tid & 31) + (tid >> 5) * CH_LDP] = v0;
+            sL[((tid + LA_T) & 31) + ((tid + LA_T) >> 5) * CH_LDP] = v1;
+        }
+        tile_to_lds(0);
+        __syncthreads();
+        if (wave < 2) {
+            d4 pacc;
+            form_p(0, wave, pacc);
+            if (srow) {
+                publish_p(0, wave, pacc);
+                la_stores_done();
+            }
+        } else if (!srow && wave >= 4)
+            z_partials(0);
+        if (tid == 0 && s_abort[1])
+            s_abort[0] = 1;
+        __syncthreads();
+        if (*s_abort)
+            return;
+        if (srow && tid == 0)
+            la_raise_f(a, la_f_p(a, 0, hidx));
+    }
+    for (int p = 0; p < np; ++p) {
+        int lrv = lr, lkv = lk;
+        asm volatile("" : "+v"(lrv), "+v"(lkv));
+        const int w = min(32, m - 32 * p);
+        const double* sPI = sPIB(p);
+        const bool dbg_row = a.dbg && tid == 0 && (hidx == 2 * NJ || hidx == 2 * (NJ - 2)) && p < 32;
+        unsigned long long* dbr = a.dbg + 8 * ((hidx == 2 * NJ ? 32 : 64) + p);
+        if (dbg_row)
+            dbr[0] = wall_clock64();
+        // (c) final W rows (+ Gamma) of a T half-row
+        if (!srow) {
+            const int r = tid & 15, c = tid >> 4;
+            const double pv = sPI[r + c * CH_LDP];
+            if (row0 + r < rows && c < w) {
+                if (a.sg_n)
+                    la_st(a.W + (row0 + r) + (size_t)(32 * p + c) * ldz, pv);
+                else
+                    a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = pv;
+            }
+            const double* sZp = sZpB(p);
+            const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
+            gsum = fma(pv, c < w ? zc : 0.0, gsum);
+        }
+        if (dbg_row)
+            dbr[1] = wall_clock64();
+        // (d) the trailing update Z(h, J) -= P_h(p) P_J(p)^T; the look-ahead pair first brings the next panel tile forward
+        double aI[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+            aI[st] = sPI[lr + (4 * st + lk) * CH_LDP];
+        const bool ahead = p + 1 < np && jr == ((p + 1) & 3); // this wave owns half of Z(h, p + 1)
+        auto tile_used = [&](int t, int& J) -> bool {
+            J = 4 * t + jr;
+            return t < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1);
+        };
+        // this wave's operands: rows 16 jh .. of P^(p)_J = what half-row 2 J + jh published; lane t watches the flag of tile t, lane 63 of a look-ahead
+        // wave the flag of L_(p+1)^-1
+        {
+            int J;
+            const bool need = tile_used(lane, J) && !(srow && J == I && jh == s);
+            const bool look = ahead && lane == 63;
+            if (need || look) {
+                const int* f = a.pubf + (look ? la_f_linv(a, p + 1) : la_f_p(a, p, 2 * J + jh));
+                for (;;) {
+                    const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v == pl.seq || !la_retry(pl))
+                        break;
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+        const bool dbg_wave = a.dbg && lane == 0 && (hidx == 2 * NJ || hidx == 2 * (NJ - 2)) && p < 32;
+        if (dbg_wave) {
+            atomicMax(dbr + 3, (unsigned long long)wall_clock64());
+            if (wave == 0)
+                dbr[7] = wall_clock64();
+        }
+        auto apply_tile = [&](int t, const double (&bj)[8]) {
+            d4 d = {0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+                d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], aI[st], d, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[t][e] -= d[e];
+        };
+        bool published = false; // (S look-ahead wave) this wave's half of P_h(p+1) is on its way; the flag is due
+        auto flag_when_acknowledged = [&]() {
+            if (srow && ahead && !published) {
+                la_stores_done();
+                if (lane == 0 && __hip_atomic_fetch_add(pub_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2 * p + 1)
+                    la_raise_f(a, la_f_p(a, p + 1, hidx)); // the second of the two halves
+                published = true;
+            }
+        };
+        if (ahead) {
+            // L_(p+1)^-1: this wave's half of the tile (8 entries per lane), and the operand of tile p + 1, in one round trip
+            const double* lt = la_tile(a, la_i_linv(a, p + 1)) + 512 * jh;
+            double lv[8], bj[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                lv[i] = lt[lane + 64 * i];
+            la_operand(la_tile(a, la_i_p(a, p + 1, p)), jh, bj);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t)
+                if (4 * t + jr == p + 1) {
+                    apply_tile(t, bj);
+                    if (ylast && lrv == yloc) {
+                        // the yTilde row of the next panel is final now: publish it for every T half-row's z_(p+1) (the only place: the next panel's tile
+                        // always goes through here; one copy of the store sequence instead of one per tile - 30 registers in la_row)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            la_put16(a.puby + 512 * (size_t)(p + 1) + 16 * (size_t)(16 * jh + lkv + 4 * e), acc[t][e], seq);
+                    }
+                }
+            tile_to_lds(p + 1);
+            double* sL = sLinvB(p + 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 512 * jh + lane + 64 * i;
+                sL[(e & 31) + (e >> 5) * CH_LDP] = lv[i];
+            }
+            la_lds_add(pair_cnt);
+            la_lds_wait(pair_cnt, 2 * (p + 1), s_abort); // the other half of the tile and of L^-1
+            d4 pacc;
+            form_p(p + 1, jh, pacc);
+            if (srow)
+                publish_p(p + 1, jh, pacc);
+        }
+        // the other tiles, two per round trip, double buffered: the next two operand tiles are requested before the products of the current two (a wave's
+        // round trips and its MFMAs alternated before: 4 x (0.9 + 0.7) us per wave and panel at 32 panels)
+        auto load_batch = [&](int t0, double (&bjs)[2][8]) -> bool {
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int J;
+                if (tile_used(t0 + u, J) && !(ahead && J == p + 1)) {
+                    any = true;
+                    if (srow && J == I && jh == s) { // diagonal block of an S half-row: both operands are P_h
+#pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            bjs[u][st] = sPI[lrv + (4 * st + lkv) * CH_LDP];
+                    } else
+                        la_operand(la_tile(a, la_i_p(a, J, p)), jh, bjs[u]);
+                }
+            }
+            return any;
+        };
+        auto apply_batch = [&](int t0, const double (&bjs)[2][8]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = (t0 + u < MAXT) ? t0 + u : MAXT - 1;
+                int J;
+                if (tile_used(t0 + u, J) && !(ahead && J == p + 1))
+                    apply_tile(t, bjs[u]);
+            }
+        };
+        {
+            double bjA[2][8], bjB[2][8];
+            bool any = load_batch(0, bjA);
+#pragma unroll
+            for (int t0 = 0; t0 < MAXT; t0 += 4) {
+                if (t0 + 2 < MAXT)
+                    any |= load_batch(t0 + 2, bjB);
+                if (any)
+                    flag_when_acknowledged(); // under these round trips
+                asm volatile("" ::: "memory");
+                apply_batch(t0, bjA);
+                if (t0 + 4 < MAXT)
+                    any |= load_batch(t0 + 4, bjA);
+                asm volatile("" ::: "memory");
+                if (t0 + 2 < MAXT)
+                    apply_batch(t0 + 2, bjB);
+            }
+        }
+        flag_when_acknowledged(); // a wave without other tiles
+        if (dbg_row)
+            dbr[2] = wall_clock64();
+        if (dbg_wave) {
+            atomicMax(dbr + 4, (unsigned long long)wall_clock64());
+            if (wave == 7)
+                dbr[5] = wall_clock64();
+            if (wave == 3)
+                dbr[6] = wall_clock64();
+        }
+        if (!srow && a.sg_n) {
+            la_stores_done();
+            if (lane == 0 && __hip_atomic_fetch_add(w_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * p + 7)
+                __hip_atomic_store(a.sg_wflags + (size_t)p * (a.NI - (2 * NJ - 1)) + (hidx - 2 * NJ), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (p + 1 < np) {
+            if (!srow && wave >= 4) {
+                la_lds_wait<true>(pair_cnt, 2 * (p + 1), s_abort); // L_(p+1)^-1 is in LDS
+                z_partials(p + 1);
+            }
+            if (tid == 0 && s_abort[1])
+                s_abort[0] = 1;
+            __syncthreads(); // P_h(p+1), z_(p+1) complete; everybody done with sT and with the buffers of parity p - 1
+            if (*s_abort)
+                return;
+        }
+    }
+    if (srow)
+        hand_off();
+    if (!srow) {
+        __syncthreads();
+        sT[tid] = gsum; // [c][r]
+        __syncthreads();
+        const int row = row0 + tid;
+        if (tid < 16 && row >= m && row < rows - 1) {
+            double g = 0.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+                g += sT[tid + 16 * c];
+            la_st(a.gamma + (row - m), g);
+        }
+    }
+}
+
+// ---- Sigma <- Sigma - W W^T under the factorisation -----------------------------------------------------------------------------------
+// Round 3. The covariance update was a kernel of its own behind the factorisation: 14 us of the 106 us frame at N = 200 for 3 us of MFMA work, and the
+// factorisation leaves most of the chip idle (66 workgroups at N = 200). The workgroups NI .. NI + sg_nwg - 1 of this kernel do it on the way: every WAVE
+// owns up to SQ 16 x 16 quadrants of lower 32 x 32 tiles of Sigma, keeps their part of W W^T in its accumulators, and adds panel p's 32 columns of W
+// (syrk_quadrant_panel: 16 operand loads, 8 MFMAs per quadrant) as soon as the T half-rows that hold the tile's rows have flagged their W rows of panel p.
+// When the last panel is in, the accumulator is complete: Sigma+ = Sigma - acc straight from the registers (Sigma's entries were requested at the start).
+// The same accumulation chain as k_syrk_sub_q (eqf_kernels.hpp), which the launch chain uses: bit-identical Sigma+.
+// (First form, dropped: k_syrk_sub's split of K over the 8 waves of a workgroup, one k4-step per wave and panel - 3.5 us of LDS reduction per workgroup
+// behind the last panel, 6 us from the last W row to the last Sigma store.)
+// All or nothing: Sigma is written only when EVERY T half-row has flagged its last panel (a half-row that gave up never does) and no pivot failed.
+// The waits are not bounded by the launch's deadline - a Sigma workgroup that came late finds everything in memory and still has to do its part -
+// but end when flags[3] (stalled) goes up: then nobody writes, and the launch chain redoes the frame with k_syrk_sub_q (eqf_hip.hip: finish_update).
+// They cannot block the factorisation: workgroups are dispatched in block order, the Sigma workgroups come last.
+template <int SQ>
+__device__ __forceinline__ void la_sigma(const LaArgs& a, const int g, int* s_word) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NJ = a.NJ, K = a.m, n = a.sg_n, ldz = a.ldz, NT = a.NI - (2 * NJ - 1), nwg = a.sg_nwg;
+    const double* __restrict__ W = a.W + a.m;
+    // slot r of this workgroup: the two tiles 2 (gg + r nwg), + 1 of k_syrk_sub's table; waves 0 .. 3 the quadrants of the first, 4 .. 7 of the second
+    const int gg = (g + a.NI) % nwg;
+    const int qi = wave & 1, qj = (wave >> 1) & 1;
+    int i0[SQ], j0[SQ];
+    bool diag[SQ];
+#pragma unroll
+    for (int r = 0; r < SQ; ++r) {
+        const int e = 2 * (gg + r * nwg) + (wave >> 2);
+        i0[r] = -1, j0[r] = 0, diag[r] = false;
+        if (r < a.sg_spw && e < a.sg_ntiles) {
+            const int cd = a.sg_tiles[e], bi = cd & 0xffff, bj = cd >> 16;
+            if (!(bi == bj && qi == 0 && qj == 1)) // strictly above the diagonal: its mirror's
+                i0[r] = 32 * bi + 16 * qi, j0[r] = 32 * bj + 16 * qj, diag[r] = bi == bj;
+        }
+    }
+    // wave 0 watches the flags: lane 8 r + 4 h + u: tile h of slot r, T half-row 2 bi + u (u = 0, 1) or 2 bj + u - 2 (u = 2, 3)
+    int my_t = -1;
+    if (lane < 8 * SQ) {
+        const int r = lane >> 3, h = (lane >> 2) & 1, u = lane & 3, e = 2 * (gg + r * nwg) + h;
+        if (r < a.sg_spw && e < a.sg_ntiles) {
+            const int cd = a.sg_tiles[e];
+            my_t = min(2 * (u < 2 ? (cd & 0xffff) : (cd >> 16)) + (u & 1), NT - 1);
+        }
+    }
+    const bool dbg = a.dbg && g == 0 && tid == 0;
+    if (dbg)
+        a.dbg[8 * 95 + 0] = wall_clock64();
+    // s_word[0]: > 0: panels 0 .. s_word[0] - 1 may be read; < 0: give up. s_word[1]: 1: Sigma may be written; < 0: it may not
+    auto watch = [&](const int* f, bool mine, bool relaxed) -> bool { // true: all flags seen. relaxed: a panel's flags may be seen late, only the last panel is on the frame's critical path
+        bool stalled = false;
+        if (mine) {
+            for (;;) {
+                if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq)
+                    break;
+                if (__hip_atomic_load(a.flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    stalled = true;
+                    break;
+                }
+                if (relaxed)
+                    __builtin_amdgcn_s_sleep(64);
+                else
+                    __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        asm volatile("" ::: "memory");
+        return !__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(stalled) != 0));
+    };
+    auto await = [&](const int* word, int target) -> bool {
+        for (;;) {
+            const int v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v < 0)
+                return false;
+            if (v >= target)
+                break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        asm volatile("" ::: "memory");
+        return true;
+    };
+    // the entries of Sigma this wave will update, requested now (nothing in this kernel writes Sigma before the end): at the end they would be a memory
+    // round trip on the frame's critical path
+    double sg0[SQ][4];
+    d4 acc[SQ];
+#pragma unroll
+    for (int r = 0; r < SQ; ++r) {
+        acc[r] = d4{0, 0, 0, 0};
+        if (i0[r] >= 0)
+            syrk_quadrant_load(a.sg_sigma, a.sg_ld, n, i0[r], j0[r], sg0[r]);
+    }
+    for (int p = 0; p < NJ; ++p) {
+        if (wave == 0) {
+            const bool ok = watch(a.sg_wflags + (size_t)p * NT + max(my_t, 0), my_t >= 0, p + 1 < NJ);
+            if (lane == 0)
+                __hip_atomic_store(s_word, ok ? p + 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!ok)
+                return;
+        } else {
+            if (wave == 1 && p == NJ - 1) {
+                // while wave 0 waits for the last panel of this workgroup's tiles: every T half-row through its last panel, no pivot failed?
+                bool ok = true;
+                for (int t0 = 0; t0 < NT && ok; t0 += 64)
+                    ok = watch(a.sg_wflags + (size_t)(NJ - 1) * NT + min(t0 + lane, NT - 1), t0 + lane < NT, false);
+                if (ok && __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                    ok = false; // raised (write-through) by the owner in front of the L_p^-1 it belongs to
+                if (lane == 0)
+                    __hip_atomic_store(s_word + 1, ok ? 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (!await(s_word, p + 1))
+                return;
+        }
+#pragma unroll
+        for (int r = 0; r < SQ; ++r)
+            if (i0[r] >= 0)
+                syrk_quadrant_panel(W, ldz, n, K, i0[r], j0[r], p, acc[r]);
+    }
+    if (dbg)
+        a.dbg[8 * 95 + 1] = wall_clock64();
+    if (!await(s_word + 1, 1)) // wave 1's verdict
+        return;
+    if (dbg)
+        a.dbg[8 * 95 + 2] = wall_clock64();
+#pragma unroll
+    for (int r = 0; r < SQ; ++r)
+        if (i0[r] >= 0)
+            syrk_quadrant_store(a.sg_sigma, a.sg_ld, n, i0[r], j0[r], diag[r], sg0[r], acc[r]);
+    if (dbg)
+        a.dbg[8 * 95 + 3] = wall_clock64();
 }
 
 // The end of the frame's device work that the host waits for, run by the T block row that finishes last (every T block row has stored its
@@ -734,7 +1224,7 @@ __device__ __forceinline__ void la_finish(const LaArgs& a) {
     }
 }
 
-template <int MAXT>
+template <int MAXT, int SQ>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (a.spec && *a.spec == a.spec_seq) { // cancelled speculative tail: say so, ring, done
         if (a.lift_door_host && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -756,10 +1246,19 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     // block 0: the owner; blocks 1 .. 2 NJ - 2: the S half-rows h = 2 .. 2 NJ - 1 (block row 0 is the first diagonal tile, eliminated by k_build_Z);
     // then the T half-rows, numbered on from 2 NJ
     const int hidx = (int)blockIdx.x + 1;
+    if ((int)blockIdx.x >= a.NI) { // a Sigma workgroup: no part in the factorisation, no deadline, nothing to report
+        la_sigma<SQ>(a, (int)blockIdx.x - a.NI, s_cnt);
+        return;
+    }
     if (blockIdx.x == 0)
         la_owner(a, smem, s_abort, s_cnt, pl);
-    else
-        la_row<MAXT>(a, hidx, smem, s_abort, pl);
+    else if (MAXT > 4) { // 17 .. 32 panels: the half-rows with a look-ahead of their own
+        if (hidx < 2 * a.NJ)
+            la_row2<MAXT, true>(a, hidx, smem, s_abort, s_cnt, pl);
+        else
+            la_row2<MAXT, false>(a, hidx, smem, s_abort, s_cnt, pl);
+    } else
+        la_row<MAXT>(a, hidx, smem, s_abort, s_cnt, pl);
     if ((threadIdx.x & 63) == 0 && (s_abort[0] | s_abort[1])) // any wave that saw a timeout reports it (the owner's waves return at different times)
         __hip_atomic_store(a.flags + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.lift_door_host && hidx >= 2 * a.NJ && blockIdx.x != 0) { // a T half-row (stalled or not) counts itself in; the last one finishes the frame

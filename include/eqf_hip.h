@@ -70,6 +70,11 @@ enum {
     EQF_OPT_FUSED_LIFT = 14,   /* 1: the look-ahead kernel's last T block row lifts the landmarks, fills the result packet and rings the doorbell (no k_lift launch
                                   behind it: 4 launches per frame, -2.4 us on the device timeline, bit-identical results); 0 (default): k_lift as a kernel of
                                   its own. Measured neutral for the frame rate (the frame boundary is bound by the host's launch), so the simpler form is the default */
+    EQF_OPT_SIGMA_IN_LOOKAHEAD = 16, /* 1 (default): Sigma <- Sigma - W W^T runs INSIDE the look-ahead kernel: the compute units the factorisation leaves idle
+                                  (190 of 256 at N = 200) each keep the partial sums of a few lower 32 x 32 tiles of Sigma in their accumulators and add panel p's
+                                  columns of W as soon as the T half-rows have flagged them; tiles that do not fit (N = 500) go to a k_syrk_sub launch behind
+                                  the kernel. Bit-identical Sigma; written only if the whole factorisation succeeded. 0: k_syrk_sub for all tiles.
+                                  fp64 Sigma only (EQF_OPT_SIGMA_FP32 = 2 and EQF_OPT_SYRK_F32 keep k_syrk_sub) */
     EQF_OPT_SYRK_F32 = 13,     /* experiment (the fp32-arithmetic A/B): 1: Sigma -= W W^T multiplies on v_mfma_f32_16x16x4_f32 with the
                                   operands rounded to float (f32 accumulation inside a wave's K slice, fp64 across slices and for the subtraction).
                                   Results then agree with the reference to ~1e-7 only; 0 (default): fp64 MFMA */

@@ -29,8 +29,13 @@ for k in range(NJ - 1):
     per = (a[k + 1, 6] - a[k, 6]) if k + 2 < NJ else float("nan")
     print(f"  k={k:2d}  " + "  ".join(f"{v:8.2f}" if a[k, i] > 0 else "       -" for i, v in enumerate(r[:7])) + f" | {per:6.2f}")
 for name, base in (("first T block row", 32), (f"S block row {NJ - 2}", 64)):
-    print(name + ", panel p: L+tile in LDS   P done   updates done")
+    print(name + ", panel p: L+tile in LDS   P done   wave 0: flags seen, updates done | all waves: flags seen, updates done | wave 3, wave 7 done")
     for p in range(NJ):
         if a[base + p, 0] > 0:
             r = a[base + p] - t0
-            print(f"  p={p:2d}  " + "  ".join(f"{v:8.2f}" if a[base + p, i] > 0 else "       -" for i, v in enumerate(r[:3])))
+            cols = [0, 1, 7, 2, 3, 4, 6, 5]
+            print(f"  p={p:2d}  " + "  ".join(f"{r[i]:8.2f}" if a[base + p, i] > 0 else "       -" for i in cols))
+if a[95, 0] > 0:
+    r = a[95] - t0
+    print("Sigma workgroup 0 (EQF_OPT_SIGMA_IN_LOOKAHEAD): start   last panel added   every T half-row done   Sigma tiles written")
+    print("  " + "  ".join(f"{v:8.2f}" for v in r[:4]))

@@ -601,6 +601,42 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
         assert rel_fro(outs[1][0], orc.get_sigma()) <= 1e-9
 
 
+@pytest.mark.parametrize("N,M", [(200, 200), (40, 40), (60, 33), (130, 97), (300, 270), (500, 500)])
+def test_sigma_update_inside_the_lookahead_kernel(N, M):
+    """EQF_OPT_SIGMA_IN_LOOKAHEAD (an experiment, off by default: DESIGN.md section 6): Sigma <- Sigma - W W^T by workgroups of the look-ahead kernel itself, panel by
+    panel as the T half-rows flag their W rows, one accumulation chain per 16 x 16 quadrant. With the option on, the launch chain (EQF_OPT_LOOKAHEAD = 0) runs
+    k_syrk_sub_q, the same chain per quadrant as a kernel of its own: Sigma must not differ by a bit between the two, whether the look-ahead kernel's Sigma
+    workgroups take every tile (N <= 256) or only a part and leave the rest to a k_syrk_sub_q launch behind the kernel (N = 300, 500). Against the default
+    order of additions (k_syrk_sub: K split over 8 waves) the result differs by rounding only."""
+    from eqvio_amd.capi import OPT_LOOKAHEAD, OPT_SIGMA_IN_LOOKAHEAD
+
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=N + M, useDiscreteInnovationLift=0)
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=np.sort(rng.permutation(N)[:M]))
+    imu = random_imu(rng)
+    y2 = y + rng.normal(size=y.shape) * 0.5
+    res = {}
+    for name, la, sg in (("default", 1, 0), ("chain_q", 0, 1), ("inside", 1, 1)):
+        c = EqfCore(N, CHARTS["invdepth"])
+        c.set_state(xi0, Xs, ids, q0, Q)
+        c.set_sigma(S)
+        c.set_option(OPT_LOOKAHEAD, la)
+        c.set_option(OPT_SIGMA_IN_LOOKAHEAD, sg)
+        c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+        S1 = c.get_sigma()
+        c.integrate_riccati_fast(imu, 0.05, settings.input_gain_diag12(), settings.state_gain_diag8())
+        c.vision_update(cam, mid, y2, settings.measurementNoise**2, True, False)  # the flags of the first launch are still in the buffers
+        res[name] = (S1, c.get_sigma(), c.get_state())
+    assert np.array_equal(res["inside"][0], res["chain_q"][0]), np.abs(res["inside"][0] - res["chain_q"][0]).max()
+    # second frame: Gamma of the first is summed in another order by the chain (rounding), so the two filters have parted at the last bit
+    assert rel_fro(res["inside"][1], res["chain_q"][1]) <= 1e-11
+    for k in (0, 1):
+        assert np.array_equal(res["inside"][k], res["inside"][k].T)
+        assert rel_fro(res["inside"][k], res["default"][k]) <= 1e-11
+    for u, v in zip(res["inside"][2], res["chain_q"][2]):
+        assert np.allclose(u, v, rtol=1e-12, atol=1e-13)
+
+
 def test_lookahead_factorisation_soak():
     """The hand-offs of the persistent kernel under repetition: fresh contexts (zeroed buffers, sequence 1) and one context reused
     (every word of the previous launch still in place), every result compared bit by bit with the launch chain's."""
