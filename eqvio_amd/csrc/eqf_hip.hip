@@ -1913,7 +1913,12 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     }
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
     // MAXT = tiles a wave keeps in registers = ceil(NJ / 4)
-    if (a.NJ <= 16)
+    if (a.sg_nwg == 0) { // the default: instantiations without the Sigma role
+        if (a.NJ <= 16)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8, 0>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+    } else if (a.NJ <= 16)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, LA_SQ_SMALL>), dim3(a.NI + a.sg_nwg), dim3(LA_T), 0, c->stream, a);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8, LA_SQ_LARGE>), dim3(a.NI + a.sg_nwg), dim3(LA_T), 0, c->stream, a);

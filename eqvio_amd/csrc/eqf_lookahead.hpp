@@ -61,15 +61,14 @@ struct LaArgs {
     int *lift_flags_host, *lift_done, *lift_door_host;
     int lift_door_seq;
     trace_t* tr_lift;
-    // Sigma <- Sigma - W W^T under the factorisation (EQF_OPT_SIGMA_IN_LOOKAHEAD; la_sigma below): the workgroups NI .. NI + sg_nwg - 1
+    trace_t* tr_steps;       // EQF_OPT_TRACE: slot of step 0 (the owner stamps one slot per step), or nullptr
+    unsigned long long* dbg; // EQF_OPT_TRACE: per-step stamps inside the owner ([k][8]) and two block rows ([32 + p][8], [64 + p][8]), or nullptr    // Sigma <- Sigma - W W^T under the factorisation (EQF_OPT_SIGMA_IN_LOOKAHEAD; la_sigma below): the workgroups NI .. NI + sg_nwg - 1
     int sg_n, sg_ld;      // rows and leading dimension of Sigma (sg_n = 0: no Sigma workgroups; the T half-rows then store W with plain stores)
     int sg_nwg, sg_spw;   // Sigma workgroups and 16 x 16 quadrants per wave (<= the kernel's SQ); a workgroup takes 2 sg_spw tiles
     int sg_ntiles;        // tiles taken here: entries 0 .. sg_ntiles - 1 of sg_tiles (the rest, if any, is left to a k_syrk_sub_q launch behind this kernel)
     double* sg_sigma;
     const int* sg_tiles;  // k_syrk_sub_q's tile table (bi | bj << 16)
     int* sg_wflags;       // flag of (panel p, T half-row t) at [p NT + t]: the W rows of that half-row for that panel are at the coherence point
-    trace_t* tr_steps;       // EQF_OPT_TRACE: slot of step 0 (the owner stamps one slot per step), or nullptr
-    unsigned long long* dbg; // EQF_OPT_TRACE: per-step stamps inside the owner ([k][8]) and two block rows ([32 + p][8], [64 + p][8]), or nullptr
 };
 // tiles: [0, NJ) L_p^-1 | [NJ, NJ + NJ^2) P^(p)_J at p NJ + J (a panel's tiles are neighbours) | then U1, U0 of every S block row
 // flags: the same indices (one int per tile; U1 / U0 share the flag of U1)
@@ -490,7 +489,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 //   wave w: jh = w & 1 is the 16-column half of a tile, jr = w >> 1 the tile column modulo 4; acc[t] = Z(h, J = 4 t + jr)[:, 16 jh .. 16 jh + 15].
 //   A wave's B operand is rows 16 jh .. 16 jh + 15 of P_J, i.e. what ONE half-row (2 J + jh) published: flags are per (panel, half-row).
 //   P^(p)_h = Z(h, p) L_p^-T is formed by waves 0 / 1 (column halves; the zero block of the triangular L_p^-1 skipped).
-template <int MAXT>
+template <int MAXT, bool SG> // SG: the instantiation has Sigma workgroups (EQF_OPT_SIGMA_IN_LOOKAHEAD): the T half-rows publish their W rows
 __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* row_cnt, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     double* sLinv = smem;                   // L_p^-1, operand layout [r + c CH_LDP]
@@ -615,7 +614,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
             const int r = tid & 15, c = tid >> 4;
             const double pv = sPI[r + c * CH_LDP];
             if (row0 + r < rows && c < w) {
-                if (a.sg_n) // read by the Sigma workgroups of this launch: write-through, flag at the end of the panel
+                if (SG && a.sg_n) // read by the Sigma workgroups of this launch: write-through, flag at the end of the panel
                     la_st(a.W + (row0 + r) + (size_t)(32 * p + c) * ldz, pv);
                 else
                     a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = pv;
@@ -642,12 +641,6 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
                 }
             }
             asm volatile("" ::: "memory");
-        }
-        const bool dbg_wave = a.dbg && lane == 0 && (hidx == 2 * NJ || hidx == 2 * (NJ - 2)) && p < 32;
-        if (dbg_wave) {
-            atomicMax(dbr + 3, (unsigned long long)wall_clock64());
-            if (wave == 0)
-                dbr[7] = wall_clock64();
         }
         // two tiles per round trip: both operand sets are requested before the first product needs one
 #pragma unroll
@@ -688,14 +681,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         }
         if (dbg_row)
             dbr[2] = wall_clock64();
-        if (dbg_wave) {
-            atomicMax(dbr + 4, (unsigned long long)wall_clock64());
-            if (wave == 7)
-                dbr[5] = wall_clock64();
-            if (wave == 3)
-                dbr[6] = wall_clock64();
-        }
-        if (!srow && a.sg_n) {
+        if (SG && !srow && a.sg_n) {
             // the W rows of this panel were stored in step (c), a whole trailing update ago: the wait is free. The last wave to pass raises the flag.
             la_stores_done();
             if (lane == 0 && __hip_atomic_fetch_add(row_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * p + 7)
@@ -727,7 +713,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
 // to it before anything else, form P_h(p+1) = Z(h, p+1) L_(p+1)^-T with the L_(p+1)^-1 they fetched on the way (the owner is ahead), publish it
 // (S half-rows) and only then turn to their other tiles - while the other six waves are in the trailing update of panel p. One workgroup barrier per
 // panel; P_h, L^-1 and z in LDS are double buffered by panel parity. Same products in the same order per tile: bit-identical to la_row and to the chain.
-template <int MAXT, bool srow>
+template <int MAXT, bool srow, bool SG>
 __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* cnt, const LaPoll& pl) {
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -869,7 +855,7 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             const int r = tid & 15, c = tid >> 4;
             const double pv = sPI[r + c * CH_LDP];
             if (row0 + r < rows && c < w) {
-                if (a.sg_n)
+                if (SG && a.sg_n)
                     la_st(a.W + (row0 + r) + (size_t)(32 * p + c) * ldz, pv);
                 else
                     a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = pv;
@@ -881,10 +867,6 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         if (dbg_row)
             dbr[1] = wall_clock64();
         // (d) the trailing update Z(h, J) -= P_h(p) P_J(p)^T; the look-ahead pair first brings the next panel tile forward
-        double aI[8];
-#pragma unroll
-        for (int st = 0; st < 8; ++st)
-            aI[st] = sPI[lr + (4 * st + lk) * CH_LDP];
         const bool ahead = p + 1 < np && jr == ((p + 1) & 3); // this wave owns half of Z(h, p + 1)
         auto tile_used = [&](int t, int& J) -> bool {
             J = 4 * t + jr;
@@ -914,9 +896,13 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         }
         auto apply_tile = [&](int t, const double (&bj)[8]) {
             d4 d = {0, 0, 0, 0};
+            // P_h's operand entries are read from LDS again for every tile (index laundered so that the compiler does not keep the 8 doubles in registers
+            // across the tiles: the T half-rows of this instantiation sit at the 256-register limit, and 16 registers decide between 0 and 100+ spills)
+            int la = lrv + lkv * CH_LDP;
+            asm volatile("" : "+v"(la));
 #pragma unroll
             for (int st = 0; st < 8; ++st)
-                d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], aI[st], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], sPI[la + 4 * st * CH_LDP], d, 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 acc[t][e] -= d[e];
@@ -1020,7 +1006,7 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             if (wave == 3)
                 dbr[6] = wall_clock64();
         }
-        if (!srow && a.sg_n) {
+        if (SG && !srow && a.sg_n) {
             la_stores_done();
             if (lane == 0 && __hip_atomic_fetch_add(w_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * p + 7)
                 __hip_atomic_store(a.sg_wflags + (size_t)p * (a.NI - (2 * NJ - 1)) + (hidx - 2 * NJ), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1246,19 +1232,24 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     // block 0: the owner; blocks 1 .. 2 NJ - 2: the S half-rows h = 2 .. 2 NJ - 1 (block row 0 is the first diagonal tile, eliminated by k_build_Z);
     // then the T half-rows, numbered on from 2 NJ
     const int hidx = (int)blockIdx.x + 1;
-    if ((int)blockIdx.x >= a.NI) { // a Sigma workgroup: no part in the factorisation, no deadline, nothing to report
-        la_sigma<SQ>(a, (int)blockIdx.x - a.NI, s_cnt);
-        return;
+    // SQ = 0: an instantiation without the Sigma role (the default). All roles of a kernel share one register allocation: with la_sigma inlined the
+    // half-rows of the 17 .. 32-panel instantiation spilled 14 .. 238 registers depending on SQ, and a call (noinline) costs every role its
+    // argument registers (N = 200: 67 -> 89 us).
+    if constexpr (SQ > 0) {
+        if ((int)blockIdx.x >= a.NI) { // a Sigma workgroup: no part in the factorisation, no deadline, nothing to report
+            la_sigma<SQ>(a, (int)blockIdx.x - a.NI, s_cnt);
+            return;
+        }
     }
     if (blockIdx.x == 0)
         la_owner(a, smem, s_abort, s_cnt, pl);
     else if (MAXT > 4) { // 17 .. 32 panels: the half-rows with a look-ahead of their own
         if (hidx < 2 * a.NJ)
-            la_row2<MAXT, true>(a, hidx, smem, s_abort, s_cnt, pl);
+            la_row2<MAXT, true, (SQ > 0)>(a, hidx, smem, s_abort, s_cnt, pl);
         else
-            la_row2<MAXT, false>(a, hidx, smem, s_abort, s_cnt, pl);
+            la_row2<MAXT, false, (SQ > 0)>(a, hidx, smem, s_abort, s_cnt, pl);
     } else
-        la_row<MAXT>(a, hidx, smem, s_abort, s_cnt, pl);
+        la_row<MAXT, (SQ > 0)>(a, hidx, smem, s_abort, s_cnt, pl);
     if ((threadIdx.x & 63) == 0 && (s_abort[0] | s_abort[1])) // any wave that saw a timeout reports it (the owner's waves return at different times)
         __hip_atomic_store(a.flags + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.lift_door_host && hidx >= 2 * a.NJ && blockIdx.x != 0) { // a T half-row (stalled or not) counts itself in; the last one finishes the frame
