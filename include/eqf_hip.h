@@ -70,10 +70,14 @@ enum {
     EQF_OPT_FUSED_LIFT = 14,   /* 1: the look-ahead kernel's last T block row lifts the landmarks, fills the result packet and rings the doorbell (no k_lift launch
                                   behind it: 4 launches per frame, -2.4 us on the device timeline, bit-identical results); 0 (default): k_lift as a kernel of
                                   its own. Measured neutral for the frame rate (the frame boundary is bound by the host's launch), so the simpler form is the default */
-    EQF_OPT_SIGMA_IN_LOOKAHEAD = 16, /* 1 (default): Sigma <- Sigma - W W^T runs INSIDE the look-ahead kernel: the compute units the factorisation leaves idle
-                                  (190 of 256 at N = 200) each keep the partial sums of a few lower 32 x 32 tiles of Sigma in their accumulators and add panel p's
-                                  columns of W as soon as the T half-rows have flagged them; tiles that do not fit (N = 500) go to a k_syrk_sub launch behind
-                                  the kernel. Bit-identical Sigma; written only if the whole factorisation succeeded. 0: k_syrk_sub for all tiles.
+    EQF_OPT_SIGMA_IN_LOOKAHEAD = 16, /* experiment, 0 (default): Sigma <- Sigma - W W^T is k_syrk_sub behind the factorisation.
+                                  1: it runs INSIDE the look-ahead kernel: workgroups on the compute units the factorisation leaves idle keep the partial
+                                  sums of lower 32 x 32 tiles of Sigma in their accumulators (one accumulation chain per 16 x 16 quadrant and wave) and add
+                                  panel p's columns of W as soon as the T half-rows have flagged them; tiles that do not fit (17 .. 32 panels) go to a
+                                  k_syrk_sub_q launch behind the kernel, and the launch chain uses k_syrk_sub_q as well (same order of additions: bit-identical
+                                  Sigma either way; against the default order it differs by rounding). Sigma is written only if the whole factorisation
+                                  succeeded. Measured slower: at N = 200 the covariance update was already hidden under the host's round trip, and the
+                                  W hand-off slows the half-rows (N = 500: +9 us for publishing, +15 us with the Sigma workgroups running).
                                   fp64 Sigma only (EQF_OPT_SIGMA_FP32 = 2 and EQF_OPT_SYRK_F32 keep k_syrk_sub) */
     EQF_OPT_SYRK_F32 = 13,     /* experiment (the fp32-arithmetic A/B): 1: Sigma -= W W^T multiplies on v_mfma_f32_16x16x4_f32 with the
                                   operands rounded to float (f32 accumulation inside a wave's K slice, fp64 across slices and for the subtraction).
@@ -92,6 +96,9 @@ const char* eqf_error_string(int code);
  * (EqFCoordinateSuite selection, include/eqvio/mathematical/EqFMatrices.h:81-90). */
 /* max_landmarks is the INITIAL capacity, not a limit (the reference has none): eqf_add_landmarks and eqf_set_state grow the device
  * buffers (at least doubling, state and Sigma carried over) when more landmarks arrive. The handle stays valid. */
+/* Environment: EQF_OPTIONS="id=value,id=value" applies eqf_set_option(id, value) to every context created in the process (A/B runs of an unchanged
+ * caller, scripts/ab_bench.sh); a malformed or rejected entry fails the creation with EQF_E_BAD_ARG. The HIP runtime's HIP_FORCE_DEV_KERNARG must stay
+ * at its default (1): with kernel arguments in host memory every launch starts ~3 us later (N = 200: 9.5 k -> 8.2 k updates/s, measured). */
 int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choice);
 void eqf_destroy(eqf_ctx* ctx);
 int eqf_set_option(eqf_ctx* ctx, int option, int value);
