@@ -1198,6 +1198,29 @@ static int flush_reshape(eqf_ctx* c) {
         c->reshape_pending = false; // only now: a failed launch above leaves the recorded bookkeeping in place
         return round_sigma(c);
     }
+    if (Nnew <= RESHAPE_ARG_MAP && knew <= RESHAPE_ARG_NEW && c->Ncap < 32768) {
+        // the record travels as kernel arguments: no copy command in front of the pass (k_reshape_args)
+        ReshapeArgs ra;
+        for (int i = 0; i < Nnew; ++i)
+            ra.map[i] = (short)c->pend_map[i];
+        for (int t = 0; t < knew; ++t) {
+            ra.p[3 * t] = c->pend_p[3 * t], ra.p[3 * t + 1] = c->pend_p[3 * t + 1], ra.p[3 * t + 2] = c->pend_p[3 * t + 2];
+            ra.var[t] = c->pend_var[t];
+        }
+        const int nnew = 21 + 3 * Nnew;
+        {
+            KTimer t(c, KN_MISC);
+            LAUNCH_TS(c, k_reshape_args, dim3(blocks(nnew, 256), nnew + blocks(Nnew, 256)), dim3(256), c->stream, Nnew, c->Ncap, c->ld, ra, (const TS*)c->d_sigma[c->cur],
+                      (TS*)c->d_sigma[1 - c->cur], (const double*)c->d_st[c->stcur], (const double*)c->d_lm[c->lmcur], c->d_st[1 - c->stcur], c->d_lm[1 - c->lmcur]);
+            HIPCHK(hipGetLastError());
+        }
+        c->cur = 1 - c->cur;
+        c->lmcur = 1 - c->lmcur;
+        c->stcur = 1 - c->stcur;
+        c->dev_N = Nnew;
+        c->reshape_pending = false;
+        return knew ? round_sigma(c) : 0;
+    }
     // A slot of the ring is rewritten kRing flushes later. Every host wait of the context (sync_ctx, door_wait) proves that all copies queued
     // before it have run; only a caller that queues more than kRing flushes with no wait in between (alternating eqf_remove_landmarks /
     // eqf_add_landmarks with asynchronous Riccati calls) gets here with a slot possibly still unread: drain once.

@@ -2241,10 +2241,10 @@ __global__ void __launch_bounds__(256) k_congruence_normal(int n, int Ncap, int 
 // (Q = identity, chart constants of the new origin point), everything written to the other buffers. Pure data movement: the same bits as
 // one gather / scatter / append pass per call would give.
 // grid: (ceil(nnew / 256), nnew + ceil(Nnew / 256)); rows blockIdx.y >= nnew handle the landmark planes.
-template <typename TS>
-__global__ void __launch_bounds__(256) k_reshape(int Nnew, int Ncap, int ld, const int* __restrict__ map, const double* __restrict__ newp, const double* __restrict__ newvar,
-                                                 const TS* __restrict__ Sin, TS* __restrict__ Sout, const double* __restrict__ st_in, const double* __restrict__ lm_in,
-                                                 double* __restrict__ st_out, double* __restrict__ lm_out) {
+template <typename TS, typename MapT>
+__device__ __forceinline__ void reshape_body(int Nnew, int Ncap, int ld, const MapT* __restrict__ map, const double* __restrict__ newp, const double* __restrict__ newvar,
+                                             const TS* __restrict__ Sin, TS* __restrict__ Sout, const double* __restrict__ st_in, const double* __restrict__ lm_in,
+                                             double* __restrict__ st_out, double* __restrict__ lm_out) {
     const int nnew = 21 + 3 * Nnew;
     if ((int)blockIdx.y < nnew) {
         const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2293,6 +2293,26 @@ __global__ void __launch_bounds__(256) k_reshape(int Nnew, int Ncap, int ld, con
         Qqo[3 * Ncap + i] = 0.0;
         Qao[i] = 1.0;
     }
+}
+template <typename TS>
+__global__ void __launch_bounds__(256) k_reshape(int Nnew, int Ncap, int ld, const int* __restrict__ map, const double* __restrict__ newp, const double* __restrict__ newvar,
+                                                 const TS* __restrict__ Sin, TS* __restrict__ Sout, const double* __restrict__ st_in, const double* __restrict__ lm_in,
+                                                 double* __restrict__ st_out, double* __restrict__ lm_out) {
+    reshape_body(Nnew, Ncap, ld, map, newp, newvar, Sin, Sout, st_in, lm_in, st_out, lm_out);
+}
+// The same pass with the record in the kernel's argument segment (round 3): a frame of the realistic mix has two of these (old landmarks out before the
+// statistics, outliers out + new landmarks in before the update), and the copy command in front of each was a host call of 4-5 us plus a 4 us blit
+// kernel on the stream. Up to RESHAPE_ARG_MAP landmarks and RESHAPE_ARG_NEW new ones (2.3 KB of arguments); larger records take the copy.
+constexpr int RESHAPE_ARG_MAP = 768, RESHAPE_ARG_NEW = 24;
+struct ReshapeArgs {
+    short map[RESHAPE_ARG_MAP]; // >= 0: old index; -(t + 1): new landmark t
+    double p[RESHAPE_ARG_NEW * 3];
+    double var[RESHAPE_ARG_NEW];
+};
+template <typename TS>
+__global__ void __launch_bounds__(256) k_reshape_args(int Nnew, int Ncap, int ld, const ReshapeArgs ra, const TS* __restrict__ Sin, TS* __restrict__ Sout,
+                                                      const double* __restrict__ st_in, const double* __restrict__ lm_in, double* __restrict__ st_out, double* __restrict__ lm_out) {
+    reshape_body(Nnew, Ncap, ld, ra.map, ra.p, ra.var, Sin, Sout, st_in, lm_in, st_out, lm_out);
 }
 // k_reshape for the commonest record of all - nothing removed, up to APPEND_MAX landmarks appended (a frame's addNewLandmarks): nothing
 // moves, only the new strips of Sigma (zeros, the variances on the diagonal) and the new landmarks' planes are written, in place, and the few
