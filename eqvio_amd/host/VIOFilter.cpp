@@ -718,14 +718,30 @@ VisionMeasurement VIOFilter::getFeaturePredictions(const GICameraPtr& camPtr, co
 }
 void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2) { // :258-278
     std::vector<Landmark> newLandmarks;
-    std::vector<int> have = filterState.ids(); // sorted copy: O(M log N) membership instead of the reference's O(M N) scan
-    std::sort(have.begin(), have.end());
+    // O(M log N) membership instead of the reference's O(M N) scan. The state's ids are usually ascending already (a tracker numbers its features
+    // as they appear, removals keep the order): no copy and no sort then, and one merge pass against the measurement's ascending ids.
+    const std::vector<int>& stateIds = filterState.ids();
+    std::vector<int> sortedCopy;
+    if (!std::is_sorted(stateIds.begin(), stateIds.end())) {
+        sortedCopy = stateIds;
+        std::sort(sortedCopy.begin(), sortedCopy.end());
+    }
+    const std::vector<int>& have = sortedCopy.empty() ? stateIds : sortedCopy;
     const auto flatView = measurement.flat();
     const std::vector<int>& mids = *flatView.first;
     const std::vector<double>& my = *flatView.second;
+    const bool merge = std::is_sorted(mids.begin(), mids.end());
+    size_t h = 0;
     for (size_t j = 0; j < mids.size(); ++j) {
         const int ccId = mids[j];
-        if (!std::binary_search(have.begin(), have.end(), ccId)) {
+        bool known;
+        if (merge) {
+            while (h < have.size() && have[h] < ccId)
+                ++h;
+            known = h < have.size() && have[h] == ccId;
+        } else
+            known = std::binary_search(have.begin(), have.end(), ccId);
+        if (!known) {
             const V3 bearing = measurement.cameraPtr->undistortPoint(my[2 * j], my[2 * j + 1]);
             newLandmarks.emplace_back(Landmark{bearing, ccId});
         }
@@ -741,6 +757,17 @@ void VIOFilter::removeOldLandmarks(const std::vector<int>& measurementIds) { // 
     const std::vector<int>& have = filterState.ids();
     std::vector<int> lost;
     const bool sorted = std::is_sorted(measurementIds.begin(), measurementIds.end()); // ids from a VisionMeasurement are
+    if (sorted && std::is_sorted(have.begin(), have.end())) { // both ascending (the usual case): one merge pass
+        size_t q = 0;
+        for (int i = 0; i < (int)have.size(); ++i) {
+            while (q < measurementIds.size() && measurementIds[q] < have[i])
+                ++q;
+            if (q == measurementIds.size() || measurementIds[q] != have[i])
+                lost.push_back(i);
+        }
+        filterState.removeLandmarksByIndex(lost);
+        return;
+    }
     for (int i = 0; i < (int)have.size(); ++i) {
         const bool found = sorted ? std::binary_search(measurementIds.begin(), measurementIds.end(), have[i])
                                   : std::find(measurementIds.begin(), measurementIds.end(), have[i]) != measurementIds.end();

@@ -642,14 +642,16 @@ def test_lookahead_factorisation_soak():
     (every word of the previous launch still in place), every result compared bit by bit with the launch chain's."""
     from eqvio_amd.capi import OPT_LOOKAHEAD
 
-    for N, M in ((200, 200), (40, 40), (60, 33)):
+    # (300, 270) and (500, 500): the 17 .. 32-panel instantiation, whose half-rows run a look-ahead of their own (la_row2: LDS double buffers by panel parity,
+    # pair counters, flags raised under a later round trip) - fewer repetitions, they are 10 x the work
+    for N, M, reps, fresh in ((200, 200, 61, 20), (40, 40, 61, 20), (60, 33, 61, 20), (300, 270, 25, 8), (500, 500, 25, 8)):
         rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=N + M, useDiscreteInnovationLift=0)
         cam = default_camera()
         mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=np.sort(rng.permutation(N)[:M]))
         ref = None
         kept = EqfCore(N, CHARTS["invdepth"])
-        for it in range(61):
-            c = EqfCore(N, CHARTS["invdepth"]) if it <= 20 else kept
+        for it in range(reps):
+            c = EqfCore(N, CHARTS["invdepth"]) if it <= fresh else kept
             c.set_state(xi0, Xs, ids, q0, Q)
             c.set_sigma(S)
             c.set_option(OPT_LOOKAHEAD, 0 if it == 0 else 1)
