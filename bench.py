@@ -357,7 +357,7 @@ def main():
     n, m = 21 + 3 * N, 2 * N
     ms_per_step = 1e3 * elapsed / args.steps
     frame_flops = flops_propagate(n) + flops_update(n, m)
-    roofline = cpu = multi = mix = binding = None
+    roofline = cpu = multi = mix = binding = factorisation = None
     if not stand_in:
         lib = backend.lib
         cam = world.cam
@@ -366,6 +366,12 @@ def main():
         S = flt.get_sigma()
         assert np.all(np.isfinite(S)) and S.shape[0] == 21 + 3 * N
         assert np.linalg.eigvalsh(0.5 * (S + S.T)).min() > 0
+        # which factorisation the timed frames really ran: look-ahead launches, and how many of them stalled and were redone on the launch chain
+        import ctypes as C
+
+        la_l, la_f = C.c_long(), C.c_long()
+        assert lib.eqf_lookahead_stats(core, C.byref(la_l), C.byref(la_f), 0) == 0
+        factorisation = {"lookahead_launches": la_l.value, "stalled_and_redone_on_the_chain": la_f.value, "frames": args.warmup + args.steps}
         if rank == 0 and not args.no_roofline:
             roofline = measure_roofline(flt, lib, core, cam, frames, args, n, m)
         if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
@@ -404,6 +410,8 @@ def main():
             "dense_equiv_tflops": frame_flops * value / world_size / 1e12,
             "dense_equiv_frac_of_fp64_mfma_peak": frame_flops * value / world_size / 1e12 / FP64_MFMA_PEAK_TFLOPS,
         }
+        if factorisation is not None:
+            out["factorisation"] = factorisation
         if roofline is not None:
             out["roofline"] = roofline
         if cpu is not None:
