@@ -208,6 +208,7 @@ def load_eqf_lib():
         "eqf_nees_lu_fallbacks": (C.c_int, [vp, C.POINTER(C.c_long)]),
         "eqf_speculation_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
         "eqf_selection_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
+        "eqf_output_cov_all": (C.c_int, [vp, P(Camera), c_double_p]),
         "eqf_lookahead_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
         "eqf_debug_matrices_AB": (C.c_int, [vp, c_double_p, c_double_p, c_double_p]),
         "eqf_debug_get_W": (C.c_int, [vp, c_double_p, C.c_int, C.c_int]),
@@ -346,6 +347,12 @@ class EqfCore:
         a, p, d = np.zeros(N), np.zeros(N), np.zeros(N)
         self._chk0(self.lib.eqf_outlier_stats(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), _dp(a), _dp(p), _dp(d)))
         return a, p, d
+
+    def output_cov_all(self, cam):
+        """eqf_output_cov_all: getOutputCovById of every landmark, state order, (N, 2, 2)."""
+        out = np.zeros(4 * self.N)
+        self._chk0(self.lib.eqf_output_cov_all(self.h, C.byref(cam), _dp(out)))
+        return out.reshape(self.N, 2, 2)
 
     def vision_update(self, cam, ids, y, meas_var, use_equivariant=True, discrete=False):
         ids, y = _i32(ids), _f64(y)

@@ -230,6 +230,7 @@ struct eqf_ctx {
     long wait_calls = 0, launch_calls = 0;
     double wait_seconds = 0.0, launch_seconds = 0.0;
     double* h_res = nullptr; // pinned result packet: stats[3 Ncap] | est[4 Ncap] | gamma[32]
+    double* h_ocov = nullptr; // eqf_output_cov_all: pinned, 4 Ncap (allocated on first use)
     int* h_resflags = nullptr;
     int* h_sel = nullptr; // pinned: k_select_outliers' verdict, [0, N) discarded flags, [Ncap] candidates, [Ncap + 1] discarded
     long sel_frames = 0, sel_discarded = 0; // frames that took the device-side outlier decision, landmarks it discarded
@@ -793,6 +794,9 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_meas);
     hipFree(c->d_meas_idx);
     hipHostFree(c->h_res);
+    if (c->h_ocov)
+        hipHostFree(c->h_ocov);
+    c->h_ocov = nullptr;
     hipHostFree(c->h_resflags);
     hipHostFree(c->h_sel);
     hipHostFree(c->h_door);
@@ -1994,6 +1998,23 @@ static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, 
         c->map_N = c->N;
         c->map_all = all;
     }
+    return 0;
+}
+
+int eqf_output_cov_all(eqf_ctx* c, const eqvio_camera* cam, double* out4N) {
+    if (!c || !cam || !out4N || !camera_ok(cam))
+        return EQF_E_BAD_ARG;
+    const int N = c->N;
+    if (N == 0)
+        return 0;
+    { int _e = enter(c); if (_e) return _e; }
+    { int _r = join_observer(c); if (_r) return _r; }
+    if (!c->h_ocov)
+        HIPCHK(hipHostMalloc(&c->h_ocov, sizeof(double) * 4 * (size_t)c->Ncap));
+    LAUNCH_TS(c, k_output_cov, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), c->q0(), c->Qq(), c->Qa(), (const TS*)c->sigma(), c->h_ocov);
+    HIPCHK(hipGetLastError());
+    { int _r = sync_ctx(c); if (_r) return _r; }
+    std::memcpy(out4N, c->h_ocov, sizeof(double) * 4 * N);
     return 0;
 }
 

@@ -814,6 +814,38 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
     out[N + i] = prob_err;
     out[2 * N + i] = norm2(o.qh);
 }
+// VIO_eqf::getOutputCovById (VIO_eqf.cpp:196-211) for every landmark of the state in one pass: out[4 i ..] = C0_i Sigma_ii C0_i^T (row-major 2 x 2) with
+// C0_i = outputMatrixCi at the current estimate (independent of the measured pixel). The reference's removeOutliers (VIOFilter.cpp:304-334) asks for
+// them one id at a time; a binding that keeps the reference's VIOFilter.cpp unchanged fetches all of them on the first call of a frame.
+template <typename TS>
+__global__ void __launch_bounds__(64) k_output_cov(int N, int Ncap, int ld, int chart, Cam cam, const double* __restrict__ q0, const double* __restrict__ Qq,
+                                                   const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const V3 p0 = ld3(q0, Ncap, i);
+    const Qt q = ldq(Qq, Ncap, i);
+    const double a = Qa[i];
+    const M3 r0m = chart == EQVIO_COORD_INVDEPTH ? ld_cc(q0, Ncap, i, CC_R0) : M3{};
+    const MeasOut o = measure_one(chart, cam, p0, q, a, 0.0, 0.0, false, r0m);
+    const int l = 21 + 3 * i;
+    double S[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            S[r][c] = Sig[l + r + (size_t)(l + c) * ld];
+    double CS[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            CS[r][c] = o.c[r * 3 + 0] * S[0][c] + o.c[r * 3 + 1] * S[1][c] + o.c[r * 3 + 2] * S[2][c];
+    out[4 * i + 0] = CS[0][0] * o.c[0] + CS[0][1] * o.c[1] + CS[0][2] * o.c[2];
+    out[4 * i + 1] = CS[0][0] * o.c[3] + CS[0][1] * o.c[4] + CS[0][2] * o.c[5];
+    out[4 * i + 2] = CS[1][0] * o.c[0] + CS[1][1] * o.c[1] + CS[1][2] * o.c[2];
+    out[4 * i + 3] = CS[1][0] * o.c[3] + CS[1][1] * o.c[4] + CS[1][2] * o.c[5];
+}
 template <typename TS>
 __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, int chart, Cam cam, const double* __restrict__ ylm,
                                                       const double* __restrict__ q0, const double* __restrict__ Qq,

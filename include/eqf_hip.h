@@ -158,6 +158,11 @@ int eqf_integrate_observer(eqf_ctx* ctx, const double* imu13_k, const double* dt
  * getMedianSceneDepth (src/VIOFilter.cpp:366-380). Outputs are indexed by STATE landmark index (length N);
  * unmeasured landmarks get -1 in absErr/probErr. */
 int eqf_outlier_stats(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y, int M, double* absErr, double* probErr, double* depth2);
+/* VIO_eqf::getOutputCovById (VIO_eqf.cpp:196-211) for ALL landmarks of the state in one kernel and one host wait: out4N[4 i ..] = C0_i Sigma_ii C0_i^T
+ * (row-major 2 x 2, STATE landmark index i), C0_i = outputMatrixCi at the current estimate - the measured pixel does not enter (the reference's argument y
+ * is [[maybe_unused]]). For a binding that keeps the reference's VIOFilter.cpp unchanged: its removeOutliers asks for one id at a time
+ * (src/VIOFilter.cpp:329); the binding fetches all of them on the first such call after the state changed. */
+int eqf_output_cov_all(eqf_ctx* ctx, const eqvio_camera* cam, double* out4N);
 
 /* VIO_eqf::performVisionUpdate (VIO_eqf.cpp:105-135): yTilde, C, S = C Sigma C^T + R, K = Sigma C^T S^-1,
  * Gamma = K yTilde, X <- Delta * X, Sigma <- Sigma - K C Sigma; R = meas_var * I

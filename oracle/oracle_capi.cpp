@@ -317,6 +317,19 @@ void orc_filter_outlier_stats(void* f, const eqvio_camera* cam, const int* ids, 
     }
 }
 
+// getOutputCovById (VIO_eqf.cpp:196-211) for every landmark of the state, state order, row-major 2 x 2 each: what eqf_output_cov_all returns
+void orc_filter_output_cov_all(void* f, const eqvio_camera* cam, double* out4N) {
+    VIOFilter* vf = (VIOFilter*)f;
+    const int id0 = 0;
+    const double y0[2] = {0.0, 0.0};
+    const VisionMeasurement meas = makeMeasurement(0, cam, &id0, y0, 1); // for its camera pointer only: the pixel does not enter
+    const VIO_eqf& e = vf->filterState;
+    for (size_t i = 0; i < e.X.id.size(); ++i) {
+        const orc::M<2, 2> cov = e.getOutputCovById(e.X.id[i], Vec2{}, meas.cameraPtr);
+        out4N[4 * i + 0] = cov(0, 0), out4N[4 * i + 1] = cov(0, 1), out4N[4 * i + 2] = cov(1, 0), out4N[4 * i + 3] = cov(1, 1);
+    }
+}
+
 // ---- EqF matrices (dense, column-major) for kernel-level parity
 int orc_state_matrix_A(void* f, const double* imu13, double* out, int cap) {
     const VIO_eqf& e = ((VIOFilter*)f)->filterState;

@@ -169,6 +169,7 @@ eqf_ctx* ensure(const VIO_eqf& f, int extra = 0) {
         upload(f, t.ctx);
         t.hostEdited = false;
         t.deviceNewer = false;
+        t.outCovValid = false;
     }
     return t.ctx;
 }
@@ -223,7 +224,7 @@ void VIO_eqf::integrateObserverState(const IMUVelocity& imuVelocity, const doubl
     double imu[13];
     packImu(imuVelocity, imu);
     check(eqf_integrate_observer(ctx, imu, &dt, 1, discreteLift ? 1 : 0), "integrateObserverState");
-    twin.deviceNewer = true;
+    twin.touch();
 }
 void VIO_eqf::integrateRiccatiStateFast(const IMUVelocity& imuVelocity, const double& dt, const Eigen::Matrix<double, 12, 12>& inputGainMatrix,
                                         const Eigen::MatrixXd& stateGainMatrix) {
@@ -232,7 +233,7 @@ void VIO_eqf::integrateRiccatiStateFast(const IMUVelocity& imuVelocity, const do
     packImu(imuVelocity, imu);
     packGains(inputGainMatrix, stateGainMatrix, Qd, Pd8);
     check(eqf_integrate_riccati_fast(ctx, imu, dt, Qd, Pd8), "integrateRiccatiStateFast");
-    twin.deviceNewer = true;
+    twin.touch();
 }
 void VIO_eqf::integrateRiccatiStateAccurate(const IMUVelocity& imuVelocity, const double& dt, const Eigen::Matrix<double, 12, 12>& inputGainMatrix,
                                             const Eigen::MatrixXd& stateGainMatrix) {
@@ -241,7 +242,7 @@ void VIO_eqf::integrateRiccatiStateAccurate(const IMUVelocity& imuVelocity, cons
     packImu(imuVelocity, imu);
     packGains(inputGainMatrix, stateGainMatrix, Qd, Pd8);
     check(eqf_integrate_riccati_accurate(ctx, imu, dt, Qd, Pd8), "integrateRiccatiStateAccurate");
-    twin.deviceNewer = true;
+    twin.touch();
 }
 void VIO_eqf::integrateRiccatiStateDiscrete(const IMUVelocity& imuVelocity, const double& dt, const Eigen::Matrix<double, 12, 12>& inputGainMatrix,
                                             const Eigen::MatrixXd& stateGainMatrix) {
@@ -250,7 +251,7 @@ void VIO_eqf::integrateRiccatiStateDiscrete(const IMUVelocity& imuVelocity, cons
     packImu(imuVelocity, imu);
     packGains(inputGainMatrix, stateGainMatrix, Qd, Pd8);
     check(eqf_integrate_riccati_discrete(ctx, imu, dt, Qd, Pd8), "integrateRiccatiStateDiscrete");
-    twin.deviceNewer = true;
+    twin.touch();
 }
 
 // ---------------------------------------------------------------- vision update (VIO_eqf.cpp:105-135)
@@ -270,7 +271,7 @@ void VIO_eqf::performVisionUpdate(const VisionMeasurement& measurement, const Ei
     // constructOutputGainMatrix (VIOFilterSettings.h:203-206) = measurementNoise^2 * I
     check(eqf_vision_update(ctx, &cam, ids.data(), px.data(), (int)ids.size(), outputGainMatrix(0, 0), useEquivariantOutput ? 1 : 0, discreteCorrection ? 1 : 0),
           "performVisionUpdate");
-    twin.deviceNewer = true;
+    twin.touch();
 }
 
 // ---------------------------------------------------------------- read-outs (VIO_eqf.cpp:137-170, 188-211)
@@ -314,29 +315,27 @@ Eigen::Matrix3d VIO_eqf::getLandmarkCovById(const int& id) const {
     check(eqf_get_sigma_block(ctx, r, r, 3, 3, cov.data()), "getLandmarkCovById");
     return cov;
 }
-Eigen::Matrix2d VIO_eqf::getOutputCovById(const int& id, const Eigen::Vector2d& y, const GIFT::GICameraPtr& camPtr) const {
-    // C0i Sigma_ii C0i^T with C0i = outputMatrixCi (not the equivariant C*). One landmark per call, as the reference's removeOutliers asks
-    // (VIOFilter.cpp:304-334); eqf_outlier_stats is the batched form this repo's own VIOFilter mirror uses instead.
+Eigen::Matrix2d VIO_eqf::getOutputCovById(const int& id, const Eigen::Vector2d&, const GIFT::GICameraPtr& camPtr) const {
+    // C0i Sigma_ii C0i^T with C0i = outputMatrixCi (not the equivariant C*; the pixel does not enter, VIO_eqf.cpp:196-211). The reference's removeOutliers
+    // asks for one landmark per call (VIOFilter.cpp:304-334): one device round trip per landmark made the unchanged VIOFilter.cpp run at 111 frames/s with
+    // 200 landmarks. The first call after the state changed now fetches the covariances of ALL landmarks (eqf_output_cov_all: one kernel, one wait);
+    // the following calls of the frame read the cache. (eqf_outlier_stats is the fused form this repo's own VIOFilter mirror uses instead.)
     eqf_ctx* ctx = ensure(*this);
     const auto it = std::find(X.id.begin(), X.id.end(), id);
     if (it == X.id.end())
         throw std::out_of_range("getOutputCovById: unknown id");
-    const int n = kSensorDim + 3 * (int)X.id.size(), col = kSensorDim + 3 * (int)(it - X.id.begin());
     const eqvio_camera cam = toEqvioCamera(*camPtr);
-    std::vector<double> C(2 * (size_t)n);
-    double ytilde[2];
-    const double px[2] = {y.x(), y.y()};
-    check(eqf_debug_matrix_C(ctx, &cam, &id, px, 1, 0, C.data(), ytilde), "getOutputCovById");
-    const Eigen::Matrix3d S = getLandmarkCovById(id);
+    const double key[10] = {(double)cam.model, cam.fx, cam.fy, cam.cx, cam.cy, cam.dist[0], cam.dist[1], cam.dist[2], cam.dist[3], cam.dist[4]};
+    eqvio_mi355x::DeviceTwin& t = twin;
+    if (!t.outCovValid || t.outCov.size() != 4 * X.id.size() || !std::equal(key, key + 10, t.outCovCam)) {
+        t.outCov.assign(4 * X.id.size(), 0.0);
+        check(eqf_output_cov_all(ctx, &cam, t.outCov.data()), "getOutputCovById");
+        std::copy(key, key + 10, t.outCovCam);
+        t.outCovValid = true;
+    }
+    const double* v = &t.outCov[4 * (size_t)(it - X.id.begin())];
     Eigen::Matrix2d out;
-    for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b) {
-            double acc = 0.0;
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j)
-                    acc += C[a + 2 * (size_t)(col + i)] * S(i, j) * C[b + 2 * (size_t)(col + j)];
-            out(a, b) = acc;
-        }
+    out(0, 0) = v[0], out(0, 1) = v[1], out(1, 0) = v[2], out(1, 1) = v[3];
     return out;
 }
 
@@ -361,7 +360,7 @@ void VIO_eqf::addNewLandmarks(std::vector<Landmark>& newLandmarks, const Eigen::
     xi0.cameraLandmarks.insert(xi0.cameraLandmarks.end(), newLandmarks.begin(), newLandmarks.end());
     X.id.insert(X.id.end(), ids.begin(), ids.end());
     X.Q.resize(X.id.size());
-    twin.deviceNewer = true;
+    twin.touch();
 }
 void VIO_eqf::removeLandmarkByIndex(const int& idx) {
     eqf_ctx* ctx = ensure(*this);
@@ -369,7 +368,7 @@ void VIO_eqf::removeLandmarkByIndex(const int& idx) {
     xi0.cameraLandmarks.erase(xi0.cameraLandmarks.begin() + idx);
     X.id.erase(X.id.begin() + idx);
     X.Q.erase(X.Q.begin() + idx);
-    twin.deviceNewer = true;
+    twin.touch();
 }
 void VIO_eqf::removeLandmarkById(const int& id) {
     const auto it = std::find(X.id.begin(), X.id.end(), id);
@@ -398,7 +397,7 @@ void VIO_eqf::removeInvalidLandmarks() {
         X.Q.resize(keep);
         X.id.resize(keep);
     }
-    twin.deviceNewer = true;
+    twin.touch();
 }
 
 // ---------------------------------------------------------------- fused entry points (optional; VIOFilter_mi355x.cpp with mi355xFused)
@@ -421,7 +420,7 @@ void VIO_eqf::propagateFast(const IMUVelocity& meanVelocity, const double& dtTot
     for (size_t i = 0; i < samples.size(); ++i)
         packImu(samples[i], &all[13 * i]);
     check(eqf_propagate_fast(ctx, mean, dtTotal, Qd, Pd8, all.data(), dts.data(), (int)samples.size(), discreteLift ? 1 : 0), "propagateFast");
-    twin.deviceNewer = true;
+    twin.touch();
 }
 void VIO_eqf::stageMeasurement(const VisionMeasurement& measurement) {
     if (measurement.camCoordinates.empty() || X.id.empty())
@@ -460,6 +459,6 @@ int VIO_eqf::statsThenUpdate(const VisionMeasurement& measurement, const double&
         }
     }
     if (updated == 1)
-        twin.deviceNewer = true;
+        twin.touch();
     return updated;
 }

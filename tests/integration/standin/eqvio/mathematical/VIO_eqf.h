@@ -102,6 +102,12 @@ struct DeviceTwin {
     int chart = -1, capacity = 0;
     bool deviceNewer = false; // Sigma / X / xi0 numbers on the device are ahead of the host members
     bool hostEdited = true;   // the host members were assigned (construction, VIOFilter::setState, ...): upload before the next call
+    // getOutputCovById: the reference's removeOutliers asks for one landmark at a time (VIOFilter.cpp:329); the first call after the state changed fetches
+    // the 2 x 2 output covariances of ALL landmarks in one device call (eqf_output_cov_all), the others are served from here. Not copied with the twin.
+    std::vector<double> outCov;
+    bool outCovValid = false;
+    double outCovCam[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // the camera the cache was computed for
+    void touch() { deviceNewer = true, outCovValid = false; } // every mutating member
     DeviceTwin() = default;
     DeviceTwin(const DeviceTwin& o);
     DeviceTwin& operator=(const DeviceTwin& o);

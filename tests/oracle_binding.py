@@ -60,6 +60,7 @@ def load_oracle():
         "orc_eqf_add_landmarks": (None, [vp, c_int_p, c_double_p, C.c_int, C.c_double]),
         "orc_eqf_compute_nees": (C.c_double, [vp, c_double_p, c_int_p, c_double_p, C.c_int]),
         "orc_filter_outlier_stats": (None, [vp, P(Camera), c_int_p, c_double_p, C.c_int, c_double_p, c_double_p]),
+        "orc_filter_output_cov_all": (None, [vp, P(Camera), c_double_p]),
         "orc_state_matrix_A": (C.c_int, [vp, c_double_p, c_double_p, C.c_int]),
         "orc_input_matrix_B": (C.c_int, [vp, c_double_p, C.c_int]),
         "orc_output_matrix_C": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_int, c_double_p, C.c_int]),
@@ -204,6 +205,12 @@ class OracleFilter:
         a, p = np.zeros(N), np.zeros(N)
         self.lib.orc_filter_outlier_stats(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), _dp(a), _dp(p))
         return a, p
+
+    def output_cov_all(self, cam):
+        N = (self.lib.orc_filter_sigma_dim(self.h) - 21) // 3
+        out = np.zeros(4 * N)
+        self.lib.orc_filter_output_cov_all(self.h, C.byref(cam), _dp(out))
+        return out.reshape(N, 2, 2)
 
     # ---- matrices
     def _n(self):

@@ -245,6 +245,22 @@ def test_outlier_stats(chart):
     np.testing.assert_allclose(d_g, (p_e**2).sum(1), rtol=1e-13)
 
 
+@pytest.mark.parametrize("chart", list(CHARTS))
+@pytest.mark.parametrize("N", [1, 25, 200])
+def test_output_cov_all(chart, N):
+    """eqf_output_cov_all (what a binding with the reference's unchanged VIOFilter.cpp serves getOutputCovById from) against the oracle's
+    getOutputCovById (VIO_eqf.cpp:196-211) for every landmark, after a propagation (Sigma not block diagonal any more)."""
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=40 + N)
+    cam = default_camera()
+    imu = random_imu(rng)
+    core.integrate_riccati_fast(imu, 0.02, settings.input_gain_diag12(), settings.state_gain_diag8())
+    orc.integrate_riccati_fast(imu, 0.02)
+    g, o = core.output_cov_all(cam), orc.output_cov_all(cam)
+    assert g.shape == (N, 2, 2)
+    np.testing.assert_allclose(g, o, rtol=1e-10, atol=1e-12 * np.abs(o).max())
+    assert np.allclose(g, np.transpose(g, (0, 2, 1)), rtol=0, atol=1e-13 * np.abs(g).max())  # v01 and v10 are separate sums
+
+
 def test_update_rejects_unknown_and_unsorted_ids():
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["euclid"], 6, seed=3)
     cam = default_camera()
