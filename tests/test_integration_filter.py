@@ -26,7 +26,7 @@ def test_filter_binding_compiles_and_links():
     used = {ln.split()[-1] for ln in syms.splitlines() if " eqf_" in ln}
     # the member-for-member form needs the VIO_eqf members only; the fused form adds exactly these three (+ the device-side decision variant)
     assert {"eqf_propagate_fast", "eqf_stage_measurement", "eqf_stats_then_update", "eqf_stats_select_update", "eqf_integrate_riccati_fast", "eqf_integrate_observer",
-            "eqf_vision_update", "eqf_get_sigma_block", "eqf_debug_matrix_C"} <= used, used
+            "eqf_vision_update", "eqf_get_sigma_block", "eqf_output_cov_all"} <= used, used
 
 
 def check_against_oracle(states, sigmas, orc_states, orc_sigmas, tol):
