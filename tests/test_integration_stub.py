@@ -40,7 +40,7 @@ def test_binding_compiles_and_links(tmp_path):
     # every member the reference declares forwards to the ABI: these are the entry points the binding pulls from libeqf_hip.so
     assert {"eqf_create", "eqf_destroy", "eqf_set_state", "eqf_get_state", "eqf_set_sigma", "eqf_get_sigma", "eqf_get_sigma_block", "eqf_integrate_observer",
             "eqf_integrate_riccati_fast", "eqf_integrate_riccati_accurate", "eqf_integrate_riccati_discrete", "eqf_vision_update", "eqf_state_estimate",
-            "eqf_compute_nees", "eqf_add_landmarks", "eqf_remove_landmarks", "eqf_remove_invalid_landmarks", "eqf_get_ids", "eqf_debug_matrix_C"} <= used, used
+            "eqf_compute_nees", "eqf_add_landmarks", "eqf_remove_landmarks", "eqf_remove_invalid_landmarks", "eqf_get_ids", "eqf_output_cov_all"} <= used, used
 
 
 def write_records(path, rec):
