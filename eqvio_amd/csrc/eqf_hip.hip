@@ -1422,7 +1422,10 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
     double* Sin = c->d_sigma[c->cur];
     double* Sout = c->d_sigma[1 - c->cur];
     if (!c->opt_dense) {
-        const int nT = blocks(N, PT), nStrip = 0; // the landmark-sensor strips are written by the tile workgroups of column 0
+        const int nT = blocks(N, PT);
+        const bool sym = nT > 16;           // more tiles than fit the chip in one round: lower triangle only, mirrored (k_propagate_main)
+        const int nStrip = sym ? -1 : 0;    // (no strip workgroups either way: the landmark-sensor strips are written by the tile workgroups)
+        const int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
         const int nObs = (obs && obs_k > 0) ? blocks(N, PROP_T) : 0;
         StageArgs sg{};
         if (c->stage_pending) { // one more block copies the staged measurement from the pinned packet to HBM
@@ -1445,7 +1448,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
         }
         KTimer t(c, KN_PROP_MAIN);
         auto launch = [&](auto kern, auto* sin, auto* sout) {
-            hipLaunchKernelGGL(kern, dim3(nT * nT + nStrip + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, sin, sout, c->d_Al, c->d_Bl, nT, nStrip,
+            hipLaunchKernelGGL(kern, dim3(nTiles + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, sin, sout, c->d_Al, c->d_Bl, nT, nStrip,
                                nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa);
         };
         if (c->sig32) {

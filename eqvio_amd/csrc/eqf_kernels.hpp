@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(64) k_observer(const ObsSteps steps_arg, int N
 // inside the workgroups that need it (the tile's 16 i-landmarks; a strip workgroup's 12 landmarks): it costs the same 63
 // loads per landmark a stored G would, and saves a launch.
 // K2b: Sigma' = F Sigma F^T + dt (B Q B^T + P) in arrow form (integrateRiccatiStateFast, VIO_eqf.cpp:62-72).
-// Block roles by blockIdx.x: [0, nT*nT) landmark-landmark tiles of 16x16 landmarks (one 3x3 block per lane),
+// Block roles by blockIdx.x: [0, nT (nT + 1) / 2) lower landmark-landmark tiles of 16x16 landmarks (one 3x3 block per lane, mirrored into the upper triangle),
 // then strip blocks (landmark-sensor 3x21 blocks and their transposes), then one sensor-sensor block.
 constexpr int PT = 16; // landmarks per tile side
 constexpr int PROP_T = 3 * PT * PT; // threads per workgroup of k_propagate_main: one per (row of a 3x3 block, landmark pair)
@@ -374,14 +374,20 @@ struct StageArgs {
 template <typename TS, bool FUSED> // FUSED: fused assembly (FUSED)
 __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
-                                                        const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
+                                                        const double* __restrict__ Bl, int nT, int nStrip /* < 0: lower tiles only */, const ObsSteps obs, int obs_k,
                                                         const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
                                                         trace_t* tr, const FuseArgs fa) {
     trace_start(tr);
     const double dt = ra.dt;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    if (b > nT * nT + nStrip + nObs) {
+    // nStrip < 0 (large N, chosen by the host): only the lower triangle of landmark tiles is computed, the upper one written as its mirror image - half the
+    // tile workgroups (N = 500: 1024 -> 528, one per CU at a time: 45 -> 32 us). Up to 16 tiles per side all tiles fit the chip in one round and the full
+    // form is 1 us faster (the block row's 21 strip columns spread over more workgroups, no strided mirror stores).
+    const bool sym = nStrip < 0;
+    nStrip = 0;
+    const int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
+    if (b > nTiles + nStrip + nObs) {
         // Staging block (eqf_stage_measurement): the coming frame's measurement moves from the pinned host packet to HBM while Sigma
         // is being propagated, so that the update's first kernel finds it next to the state instead of across PCIe.
         for (int t = tid; t < 2 * sg.M; t += PROP_T)
@@ -394,13 +400,13 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         }
         return;
     }
-    if (b > nT * nT + nStrip) {
+    if (b > nTiles + nStrip) {
         // Observer blocks (eqf_propagate_fast): the landmark part of the frame's observer steps rides along with the Sigma
         // propagation. This kernel touches Sigma / Al / Bl only, the assembly kernel before it has already read Q and the
         // statistics kernel after it wants the new Q: in-stream order gives all three, no second stream, no events.
         // With fused assembly the tiles of THIS launch read Q, so the observer blocks write the other (Qq, Qa) buffer (the host
         // flips to it after the launch; q0 and its chart constants live in a buffer of their own and stay where they are).
-        const int i = (b - (nT * nT + nStrip + 1)) * PROP_T + tid;
+        const int i = (b - (nTiles + nStrip + 1)) * PROP_T + tid;
         if (i < N) {
             if (FUSED) {
                 observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, fa.Qqo, fa.Qao);
@@ -418,8 +424,18 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             s_cm[t] = fa.ck.lm[t];
         __syncthreads();
     }
-    if (b < nT * nT) {
-        const int bi = b % nT, bj = b / nT;
+    if (b < nTiles) {
+        // tile (bi, bj), bi >= bj, of the lower triangle in row-major order: b = bi (bi + 1) / 2 + bj
+        int bi = b % nT, bj = b / nT;
+        if (sym) {
+            bi = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+            while (bi * (bi + 1) / 2 > b)
+                --bi;
+            while ((bi + 1) * (bi + 2) / 2 <= b)
+                ++bi;
+            bj = b - bi * (bi + 1) / 2;
+        }
+        const int nb = sym ? bi + 1 : nT; // workgroups of this block row: they share its 21 strip columns
         // per-i arrays: G (63), Fls (36), D (9), Bl (9) ; per-j arrays: Ssj (63), Fls (36), D (9), Bl (9). layout [e][PT]
         double* sGi = sm;
         double* sFi = sGi + 63 * PT;
@@ -441,11 +457,11 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         }
         if (tid < 12 * 21)
             sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
-        // the strip columns this workgroup writes (below): c = bj, bj + nT, ... ; their rows of the sensor blocks go to LDS
-        const int ncol = bj < 21 ? (21 - bj + nT - 1) / nT : 0;
+        // the strip columns this workgroup writes (below): c = bj, bj + nb, ... ; their rows of the sensor blocks go to LDS
+        const int ncol = bj < 21 ? (21 - bj + nb - 1) / nb : 0;
         for (int t = PROP_T - 1 - tid; t < ncol * 33; t += PROP_T) { // taken from the top of the workgroup: the first lanes assemble
             const int m_ = t / 33, e = t % 33;
-            const int c = bj + nT * m_;
+            const int c = bj + nb * m_;
             sSens[t] = e < 21 ? (FUSED ? sensor_Ass_entry(fa.ck, c * 21 + e) : cm->Ass[c * 21 + e]) : (FUSED ? sensor_Bs_entry(fa.ck, c * 12 + (e - 21)) : cm->Bs[c * 12 + (e - 21)]);
         }
         if (FUSED) {
@@ -543,7 +559,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             // outputs per workgroup. Same sums, in the same order, as a separate strip pass would evaluate.
             for (int t = tid; t < PT * 3 * ncol; t += PROP_T) {
                 const int x = t % PT, rc = t / PT;
-                const int r = rc % 3, m_ = rc / 3, c = bj + nT * m_;
+                const int r = rc % 3, m_ = rc / 3, c = bj + nb * m_;
                 const int i = bi * PT + x;
                 if (i < N) {
                     double sacc = 0;
@@ -567,7 +583,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         const int r = tid / (PT * PT), tp = tid % (PT * PT);
         const int ti = tp % PT, tj = tp / PT;
         const int i = bi * PT + ti, j = bj * PT + tj;
-        if (i >= N || j >= N)
+        if (i >= N || j >= N || (sym && bi == bj && i < j)) // (a diagonal tile: the pairs above the diagonal are mirrors too)
             return;
         const int li = 21 + 3 * i, lj = 21 + 3 * j;
         // Sigma_ij
@@ -607,6 +623,8 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             if (i == j && r == c)
                 s += dt * ra.Pd[7];
             Sout[li + r + (size_t)(lj + c) * ld] = s;
+            if (sym && i != j)
+                Sout[lj + c + (size_t)(li + r) * ld] = s; // Sigma'_ji = Sigma'_ij^T: exactly symmetric between landmark blocks, half the tiles
         }
         return;
     }
