@@ -719,9 +719,11 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int B = 32 * CH_LDP;
     auto sLinvB = [&](int b) -> double* { return smem + (b & 1) * B; };      // L_p^-1, operand layout [r + c CH_LDP], rows 0 .. 31
-    auto sPIB = [&](int b) -> double* { return smem + (b & 1) * B + 32; };   // P_h(p): 16 rows x 32 columns in the rows 32 .. 47 of the same blocks
-    double* sT = smem + 2 * B;                                               // the next panel tile's 16 rows in operand layout; at the very end the Gamma partial sums
-    auto sZpB = [&](int b) -> double* { return smem + 3 * B + 256 * (b & 1); }; // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
+    // P_h(p): 16 rows x 32 columns, three buffers (p mod 3: a T half-row stores the W rows of panel p at the top of panel p + 1, while the look-ahead pair
+    // already writes P_h(p + 2)): the rows 32 .. 47 of the two L^-1 blocks and the rows 16 .. 31 of the tile block
+    auto sPIB = [&](int b) -> double* { return (b % 3) < 2 ? smem + (b % 3) * B + 32 : smem + 2 * B + 16; };
+    double* sT = smem + 2 * B;                                               // the next panel tile's 16 rows in operand layout (rows 0 .. 15); at the very end the Gamma partial sums
+    auto sZpB = [&](int b) -> double* { return smem + 3 * B + 256 * (b % 3); }; // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32]), three buffers like P_h
     int* pair_cnt = cnt;     // the two waves of a look-ahead pair: tile and L^-1 in LDS
     int* pub_cnt = cnt + 1;  // ... their halves of P_h acknowledged (S half-rows)
     int* w_cnt = cnt + 2;    // EQF_OPT_SIGMA_IN_LOOKAHEAD: the eight waves' W rows of a panel acknowledged (T half-rows)
@@ -798,11 +800,11 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             la_st(pt + (16 * s + lr) + 32 * (16 * ch + lk + 4 * e), pacc[e]);
     };
     // z_q[c] = sum_k yTilde_q[k] L_q^-1[c][k] as 8 partial sums (thread (c, h) of the waves 4 .. 7: k = 4 h .. 4 h + 3), summed in a fixed order by the readers
-    auto z_partials = [&](int q) {
+    // ymine: entry c = lane & 31 of the yTilde row of panel q (one 16-byte word per lane, one round trip per wave); the four this thread needs come from its neighbours
+    auto z_partials = [&](int q, const double ymine) {
         const int wq = min(32, m - 32 * q);
         const int c = tid & 31, h = (tid >> 5) & 7;
         const double* sL = sLinvB(q);
-        const double ymine = la_get16(a.puby + 512 * (size_t)q + 16 * (size_t)c, pl); // lane: entry c = lane & 31 (one round trip per wave); the four this thread needs come from its neighbours
         double z = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -811,6 +813,20 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             z = fma(k < wq ? yv : 0.0, sL[c + k * CH_LDP], z);
         }
         sZpB(q)[32 * h + c] = z;
+    };
+    auto store_w = [&](int q) {
+        const int wq = min(32, m - 32 * q);
+        const int r = tid & 15, c = tid >> 4;
+        const double pv = sPIB(q)[r + c * CH_LDP];
+        if (row0 + r < rows && c < wq) {
+            if (SG && a.sg_n)
+                la_st(a.W + (row0 + r) + (size_t)(32 * q + c) * ldz, pv);
+            else
+                a.W[(row0 + r) + (size_t)(32 * q + c) * ldz] = pv;
+        }
+        const double* sZp = sZpB(q);
+        const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
+        gsum = fma(pv, c < wq ? zc : 0.0, gsum);
     };
     if (np > 0) {
         // prologue: panel 0 the plain way (every thread two entries of L_0^-1; waves 0 / 1 form P_h(0))
@@ -832,7 +848,7 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
                 la_stores_done();
             }
         } else if (!srow && wave >= 4)
-            z_partials(0);
+            z_partials(0, la_get16(a.puby + 16 * (size_t)(tid & 31), pl));
         if (tid == 0 && s_abort[1])
             s_abort[0] = 1;
         __syncthreads();
@@ -850,20 +866,10 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         unsigned long long* dbr = a.dbg + 8 * ((hidx == 2 * NJ ? 32 : 64) + p);
         if (dbg_row)
             dbr[0] = wall_clock64();
-        // (c) final W rows (+ Gamma) of a T half-row
-        if (!srow) {
-            const int r = tid & 15, c = tid >> 4;
-            const double pv = sPI[r + c * CH_LDP];
-            if (row0 + r < rows && c < w) {
-                if (SG && a.sg_n)
-                    la_st(a.W + (row0 + r) + (size_t)(32 * p + c) * ldz, pv);
-                else
-                    a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = pv;
-            }
-            const double* sZp = sZpB(p);
-            const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
-            gsum = fma(pv, c < w ? zc : 0.0, gsum);
-        }
+        // (c) final W rows (+ Gamma) of a T half-row - of the panel BEFORE this one: z_(p-1) was completed by the barrier that ended panel p - 1, and nothing
+        // waits for W until the very end, so the store costs the critical path of a panel nothing here
+        if (!srow && p > 0)
+            store_w(p - 1);
         if (dbg_row)
             dbr[1] = wall_clock64();
         // (d) the trailing update Z(h, J) -= P_h(p) P_J(p)^T; the look-ahead pair first brings the next panel tile forward
@@ -878,8 +884,21 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             int J;
             const bool need = tile_used(lane, J) && !(srow && J == I && jh == s);
             const bool look = ahead && lane == 63;
-            if (need || look) {
-                const int* f = a.pubf + (look ? la_f_linv(a, p + 1) : la_f_p(a, p, 2 * J + jh));
+            const int* f = a.pubf + (look ? la_f_linv(a, p + 1) : la_f_p(a, p, 2 * (need ? J : 0) + jh));
+            if (!srow && wave >= 4 && p > 0) {
+                // waves 4 .. 7 of a T half-row: the yTilde row of THIS panel (published a panel ago) on the same round trip as the flags, then z_p
+                const char* yp = a.puby + 512 * (size_t)p + 16 * (size_t)(tid & 31);
+                v4i r;
+                for (;;) {
+                    int v = pl.seq;
+                    if (need || look)
+                        v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(yp) : "memory");
+                    if ((v == pl.seq && r.z == pl.seq && r.w == ~pl.seq) || !la_retry(pl))
+                        break;
+                }
+                z_partials(p, __hiloint2double(r.y, r.x));
+            } else if (need || look) {
                 for (;;) {
                     const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (v == pl.seq || !la_retry(pl))
@@ -1006,19 +1025,15 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             if (wave == 3)
                 dbr[6] = wall_clock64();
         }
-        if (SG && !srow && a.sg_n) {
+        if (SG && !srow && a.sg_n && p > 0) { // the W rows of panel p - 1 were stored at the top of this panel
             la_stores_done();
-            if (lane == 0 && __hip_atomic_fetch_add(w_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * p + 7)
-                __hip_atomic_store(a.sg_wflags + (size_t)p * (a.NI - (2 * NJ - 1)) + (hidx - 2 * NJ), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && __hip_atomic_fetch_add(w_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * (p - 1) + 7)
+                __hip_atomic_store(a.sg_wflags + (size_t)(p - 1) * (a.NI - (2 * NJ - 1)) + (hidx - 2 * NJ), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (p + 1 < np) {
-            if (!srow && wave >= 4) {
-                la_lds_wait<true>(pair_cnt, 2 * (p + 1), s_abort); // L_(p+1)^-1 is in LDS
-                z_partials(p + 1);
-            }
             if (tid == 0 && s_abort[1])
                 s_abort[0] = 1;
-            __syncthreads(); // P_h(p+1), z_(p+1) complete; everybody done with sT and with the buffers of parity p - 1
+            __syncthreads(); // P_h(p+1) and z_p complete; everybody done with sT and with the buffers of panel p - 1
             if (*s_abort)
                 return;
         }
@@ -1026,7 +1041,16 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
     if (srow)
         hand_off();
     if (!srow) {
-        __syncthreads();
+        __syncthreads(); // z of the last panel is complete
+        if (np > 0) {
+            store_w(np - 1);
+            if (SG && a.sg_n) {
+                la_stores_done();
+                if (lane == 0 && __hip_atomic_fetch_add(w_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * (np - 1) + 7)
+                    __hip_atomic_store(a.sg_wflags + (size_t)(np - 1) * (a.NI - (2 * NJ - 1)) + (hidx - 2 * NJ), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads(); // the Gamma partial sums below overwrite the third P_h buffer
         sT[tid] = gsum; // [c][r]
         __syncthreads();
         const int row = row0 + tid;
