@@ -1424,7 +1424,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
     if (!c->opt_dense) {
         const int nT = blocks(N, PT);
         const bool sym = nT > 16;           // more tiles than fit the chip in one round: lower triangle only, mirrored (k_propagate_main)
-        const int nStrip = sym ? -1 : 0;    // (no strip workgroups either way: the landmark-sensor strips are written by the tile workgroups)
+        const int nStrip = 0;               // (no strip workgroups: the landmark-sensor strips are written by the tile workgroups)
         const int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
         const int nObs = (obs && obs_k > 0) ? blocks(N, PROP_T) : 0;
         StageArgs sg{};
@@ -1451,17 +1451,25 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
             hipLaunchKernelGGL(kern, dim3(nTiles + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, sin, sout, c->d_Al, c->d_Bl, nT, nStrip,
                                nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa);
         };
+#define PROP_LAUNCH(TS_, F_) \
+    do { \
+        if (sym) \
+            launch(k_propagate_main<TS_, F_, true>, (const TS_*)Sin, (TS_*)Sout); \
+        else \
+            launch(k_propagate_main<TS_, F_, false>, (const TS_*)Sin, (TS_*)Sout); \
+    } while (0)
         if (c->sig32) {
             if (fused)
-                launch(k_propagate_main<float, true>, (const float*)Sin, (float*)Sout);
+                PROP_LAUNCH(float, true);
             else
-                launch(k_propagate_main<float, false>, (const float*)Sin, (float*)Sout);
+                PROP_LAUNCH(float, false);
         } else {
             if (fused)
-                launch(k_propagate_main<double, true>, (const double*)Sin, (double*)Sout);
+                PROP_LAUNCH(double, true);
             else
-                launch(k_propagate_main<double, false>, (const double*)Sin, (double*)Sout);
+                PROP_LAUNCH(double, false);
         }
+#undef PROP_LAUNCH
         HIPCHK(hipGetLastError());
         if (fused && nObs)
             c->lmcur = 1 - c->lmcur;

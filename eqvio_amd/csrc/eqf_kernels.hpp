@@ -371,20 +371,21 @@ struct StageArgs {
     int* idx_d;
 };
 // TS = storage type of Sigma (double, or float for EQF_OPT_SIGMA_FP32 = 2): loads convert to double, stores round.
-template <typename TS, bool FUSED> // FUSED: fused assembly (FUSED)
+template <typename TS, bool FUSED, bool SYM = false> // FUSED: fused assembly; SYM: lower tiles only, mirrored (an instantiation of its own: as a run-time
+                                                      // branch it cost the N = 200 frame 0.6 us)
 __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
-                                                        const double* __restrict__ Bl, int nT, int nStrip /* < 0: lower tiles only */, const ObsSteps obs, int obs_k,
+                                                        const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
                                                         const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
                                                         trace_t* tr, const FuseArgs fa) {
     trace_start(tr);
     const double dt = ra.dt;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    // nStrip < 0 (large N, chosen by the host): only the lower triangle of landmark tiles is computed, the upper one written as its mirror image - half the
+    // SYM (large N, chosen by the host): only the lower triangle of landmark tiles is computed, the upper one written as its mirror image - half the
     // tile workgroups (N = 500: 1024 -> 528, one per CU at a time: 45 -> 32 us). Up to 16 tiles per side all tiles fit the chip in one round and the full
     // form is 1 us faster (the block row's 21 strip columns spread over more workgroups, no strided mirror stores).
-    const bool sym = nStrip < 0;
+    constexpr bool sym = SYM;
     nStrip = 0;
     const int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
     if (b > nTiles + nStrip + nObs) {
@@ -1811,25 +1812,33 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
             acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pb, acc11, 0, 0, 0);
         }
     }
-    double* mine = sred + wave * 1024;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int j = F32 ? 4 * lk + r : lk + 4 * r;
-        mine[lr + 32 * j] = F32 ? (double)fcc00[r] : acc00[r];
-        mine[16 + lr + 32 * j] = F32 ? (double)fcc10[r] : acc10[r];
-        mine[lr + 32 * (16 + j)] = F32 ? (double)fcc01[r] : acc01[r];
-        mine[16 + lr + 32 * (16 + j)] = F32 ? (double)fcc11[r] : acc11[r];
-    }
-    __syncthreads();
+    // The NW partial tiles are summed four at a time through 4 x 1024 doubles of LDS (NW = 8: two rounds; 64 KB for all eight at once allowed two
+    // workgroups per CU, 32 KB allows four). Same additions in the same order as one pass over all of them: sum = 0; sum += (p0 + p1) + (p2 + p3); ...
     TileRed out;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int idx = (tid & 31) + 32 * (((tid & 255) >> 5) + 8 * e); // threads >= 256 (NW = 8) duplicate the first 256
-        double sum = 0.0; // fixed order: deterministic
+    for (int e = 0; e < 4; ++e)
+        out.v[e] = 0.0;
 #pragma unroll
-        for (int q = 0; q < NW; q += 4)
-            sum += (sred[q * 1024 + idx] + sred[(q + 1) * 1024 + idx]) + (sred[(q + 2) * 1024 + idx] + sred[(q + 3) * 1024 + idx]);
-        out.v[e] = sum;
+    for (int q0 = 0; q0 < NW; q0 += 4) {
+        if (q0)
+            __syncthreads(); // the readers of the previous round are done
+        if (wave >= q0 && wave < q0 + 4) {
+            double* mine = sred + (wave - q0) * 1024;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = F32 ? 4 * lk + r : lk + 4 * r;
+                mine[lr + 32 * j] = F32 ? (double)fcc00[r] : acc00[r];
+                mine[16 + lr + 32 * j] = F32 ? (double)fcc10[r] : acc10[r];
+                mine[lr + 32 * (16 + j)] = F32 ? (double)fcc01[r] : acc01[r];
+                mine[16 + lr + 32 * (16 + j)] = F32 ? (double)fcc11[r] : acc11[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = (tid & 31) + 32 * (((tid & 255) >> 5) + 8 * e); // threads >= 256 (NW = 8) duplicate the first 256
+            out.v[e] += (sred[idx] + sred[1024 + idx]) + (sred[2048 + idx] + sred[3072 + idx]); // fixed order: deterministic
+        }
     }
     if (WITH_GEMV) {
         // partial sums: per wave, per lk group (4), rows 0..15 (ga) and 16..31 (gb): reduce 16 partials per row via LDS
@@ -1896,7 +1905,7 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
         return; // cancelled speculative tail
     if (failed)
         return; // the factorisation failed (see k_lift): Sigma stays as it was
-    __shared__ double sred[1024 * SYRK_NW];
+    __shared__ double sred[1024 * 4];
     const int code = tile_of_block[blockIdx.x];
     const int bi = code & 0xffff, bj = code >> 16;
     const int i0 = bi * 32, j0 = bj * 32;
