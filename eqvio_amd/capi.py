@@ -625,6 +625,13 @@ class PreparedFrames:
     def __len__(self):
         return self.lib.eqvio_frames_count(self.h)
 
+    def edit_pixel(self, frame, k, u, v):
+        """eqvio_frames_edit_pixel: write a pixel through the measurement's public map, as a caller of the reference's type may."""
+        self.lib.eqvio_frames_edit_pixel.restype = C.c_int
+        self.lib.eqvio_frames_edit_pixel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+        if self.lib.eqvio_frames_edit_pixel(self.h, frame, k, u, v) != 0:
+            raise IndexError("eqvio_frames_edit_pixel")
+
     def close(self):
         if self.h:
             self.lib.eqvio_frames_destroy(self.h)

@@ -360,7 +360,7 @@ void VIO_eqf::outlierStats(const VisionMeasurement& m, std::vector<double>& absE
 void VIO_eqf::stageMeasurement(const VisionMeasurement& m) {
     if (m.camCoordinates.empty() || numLandmarks() == 0)
         return;
-    const FlatMeas fm(m);
+    const FlatMeas fm(m.flatHint()); // a hint: the device-side copy is checked against the (validated) measurement of the update call
     const std::vector<int>& ids = fm.ids;
     const std::vector<double>& y = fm.y;
     check(eqf_stage_measurement(ctx, ids.data(), y.data(), (int)ids.size()), "eqf_stage_measurement");

@@ -121,6 +121,14 @@ struct VisionMeasurement {
     const std::vector<int>& flatIds() const { return refreshFlat(), flatIds_; }
     const std::vector<double>& flatY() const { return refreshFlat(), flatY_; }
     void invalidateFlat() const { flatIds_.clear(), flatY_.clear(), flatN_ = (size_t)-1; }
+    // The cached arrays WITHOUT the validating walk (built if there are none of the right size): for a consumer that treats them as a hint and checks them
+    // against validated data later - eqf_stage_measurement: the staged copy is compared with the measurement of the update call (eqf_stats_then_update) and
+    // ignored if it differs. Takes the 1.7 us walk over the std::map off the host path between the doorbell and the propagation's launch.
+    std::pair<const std::vector<int>*, const std::vector<double>*> flatHint() const {
+        if (flatN_ != camCoordinates.size() || flatIds_.size() != camCoordinates.size())
+            refreshFlat();
+        return std::make_pair(&flatIds_, &flatY_);
+    }
 
   private:
     void refreshFlat() const;

@@ -227,6 +227,15 @@ eqvio_frames* eqvio_frames_create(const eqvio_camera* cam, int nframes, const in
         return nullptr;
     }
 }
+int eqvio_frames_edit_pixel(eqvio_frames* fr, int frame, int k, double u, double v) {
+    // what a caller holding the reference's VisionMeasurement may do: write into the public std::map, nothing else
+    if (!fr || frame < 0 || (size_t)frame >= fr->meas.size() || k < 0 || (size_t)k >= fr->meas[frame].camCoordinates.size())
+        return -1;
+    auto it = fr->meas[frame].camCoordinates.begin();
+    std::advance(it, k);
+    it->second = {u, v};
+    return 0;
+}
 void eqvio_frames_destroy(eqvio_frames* fr) { delete fr; }
 int eqvio_frames_count(const eqvio_frames* fr) { return fr ? (int)fr->meas.size() : -1; }
 int eqvio_filter_run_prepared(eqvio_filter* f, const eqvio_frames* fr, int first, int count) {

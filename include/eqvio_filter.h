@@ -60,6 +60,11 @@ int eqvio_filter_last_timing(const eqvio_filter* f, double* propagation, double*
 typedef struct eqvio_frames eqvio_frames;
 eqvio_frames* eqvio_frames_create(const eqvio_camera* cam, int nframes, const int* imu_counts, const double* imu13_all, const double* stamps, const int* meas_counts,
                                   const int* ids_all, const double* y_all);
+/* Overwrites the pixel of the k-th feature (ascending id order) of a prepared frame IN PLACE, through the measurement's public map and nothing else - what
+ * a caller of the reference's VisionMeasurement type may do between building a measurement and handing it to the filter. The flat copies the host mirror
+ * caches next to the map are validated against the map before every use that matters (tests/test_gpu_filter.py: an edited frame gives the same state as a
+ * frame built with the new value). Returns 0, or -1 for a bad index. */
+int eqvio_frames_edit_pixel(eqvio_frames* frames, int frame, int k, double u, double v);
 void eqvio_frames_destroy(eqvio_frames* frames);
 int eqvio_frames_count(const eqvio_frames* frames);
 int eqvio_filter_run_prepared(eqvio_filter* f, const eqvio_frames* frames, int first, int count);

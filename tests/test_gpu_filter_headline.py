@@ -168,3 +168,36 @@ def test_config2_euroc_structured_sine_50_landmarks_lockstep():
     assert worst_state <= max(TOL, 2.0 * floor_state) and worst_sigma <= max(TOL, 2.0 * floor_sigma), (worst_state, floor_state, worst_sigma, floor_sigma)
     assert worst_state <= 1e-8 and worst_sigma <= 1e-9
     assert counters(flt)["la_launches"] >= 90
+
+
+def test_measurement_edited_in_place_after_it_was_built():
+    """ADVICE r2 (measurement cache) + round 3: the staging of the measurement ahead of the propagation (eqf_stage_measurement) reads the host mirror's cached
+    flat copy WITHOUT the validating walk over the std::map (a hint; 1.7 us off the host path to the propagation's launch). A caller who writes new pixel
+    values into the public map of an already built VisionMeasurement (eqvio_frames_edit_pixel) must still get exactly what a measurement built with those
+    values gives: the device-side staged copy is compared with the (validated) measurement of the update call and dropped."""
+    N = 60
+    world, frames = bench.build_workload(seed=7, n_frames=6, N=N)
+    settings = bench.eurocish_settings()
+    mk = lambda s, sensor, ids, p, t: VIOFilter(s, max_landmarks=N, sensor=sensor, ids=ids, p=p, time=t)  # noqa: E731
+    edited = [list(f) for f in frames]
+    rng = np.random.default_rng(5)
+    changes = []
+    for f in (2, 3, 4):
+        y = np.array(edited[f][3], dtype=np.float64).reshape(-1, 2).copy()
+        for k in rng.permutation(N)[:5]:
+            y[k] += rng.normal(size=2) * 0.7
+            changes.append((f, int(k), float(y[k, 0]), float(y[k, 1])))
+        edited[f][3] = y.reshape(-1)
+    fresh = bench.make_filter(world, settings, N, None, frames, mk)
+    inplace = bench.make_filter(world, settings, N, None, frames, mk)
+    pf_fresh = PreparedFrames(world.cam, *bench.flatten_frames([tuple(f) for f in edited[:5]]))
+    pf_edit = PreparedFrames(world.cam, *bench.flatten_frames(frames[:5]))  # built (flat copies cached) with the OLD pixels ...
+    for f, k, u, v in changes:
+        pf_edit.edit_pixel(f, k, u, v)  # ... then edited through the map only
+    for f in range(5):
+        assert fresh.run_prepared(pf_fresh, f, 1) == 1 and inplace.run_prepared(pf_edit, f, 1) == 1
+        (sa, ia, pa), (sb, ib, pb) = fresh.state_estimate(), inplace.state_estimate()
+        assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(pa, pb), f
+        assert np.array_equal(fresh.get_sigma(), inplace.get_sigma()), f
+    fresh.close()
+    inplace.close()
