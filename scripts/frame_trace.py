@@ -20,7 +20,8 @@ dev = np.zeros((R, 48), np.uint64); host = np.zeros((R, 8), np.int64); last = C.
 TICK = 0.01  # us per device tick (100 MHz)
 rows = []
 pos = 300
-CH = int(sys.argv[3]) if len(sys.argv) > 3 else 1000  # frames per run_frames call (<= R - 4)
+CH = int(sys.argv[3]) if len(sys.argv) > 3 else min(1000, nfr)  # frames per run_frames call (<= R - 4)
+nsteps = 0
 while pos + CH <= 300 + nfr:
     flt.run_frames(world.cam, *bench.flatten_frames(frames[pos:pos + CH])); pos += CH
     assert lib.eqf_trace_read(core, dev.ctypes.data_as(C.POINTER(C.c_ulonglong)), host.ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(last)) == 0
