@@ -184,6 +184,40 @@ def test_float_storage_round_trip_and_limits():
     assert not np.array_equal(Sg, Sg.astype(np.float32).astype(np.float64))
 
 
+def test_float_storage_large_state():
+    """The float store at N = 300 (19 landmark tiles per side: the propagation kernel's lower-triangle form, the 32-panel look-ahead instantiation): stored
+    floats (mode 2) and the rounding model on the fp64 store (mode 1) stay bit-identical through a propagation and an update, and within float rounding of
+    the fp64 path."""
+    from eqvio_amd.capi import EqfCore
+    from util import CHARTS, default_camera, random_imu, random_spd, reasonable_state, settings_for, synth_measurement
+
+    rng = np.random.default_rng(31)
+    N = 300
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N)
+    S = random_spd(rng, 21 + 3 * N)
+    settings = settings_for(CHARTS["invdepth"])
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=np.sort(rng.permutation(N)[:280]))
+    imu = random_imu(rng)
+    out = []
+    for mode in (0, 1, 2):
+        c = EqfCore(N, CHARTS["invdepth"])
+        c.set_state(xi0, Xs, ids, q0, Q)
+        c.set_sigma(S)
+        c.set_option(OPT_SIGMA_FP32, mode)
+        c.integrate_riccati_fast(imu, 0.02, settings.input_gain_diag12(), settings.state_gain_diag8())
+        S1 = c.get_sigma()
+        c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+        out.append((S1, c.get_sigma(), c.get_state()))
+    for k in (0, 1):
+        assert np.array_equal(out[1][k], out[2][k]), k
+        assert np.array_equal(out[2][k], out[2][k].astype(np.float32).astype(np.float64))
+        assert np.array_equal(out[2][k], out[2][k].T)
+        assert 1e-10 < rel_fro(out[2][k], out[0][k]) <= 1e-5
+    for u, v in zip(out[1][2], out[2][2]):
+        assert np.array_equal(u, v)
+
+
 def test_f32_mfma_syrk_experiment_is_a_rounded_copy_of_the_fp64_update():
     """EQF_OPT_SYRK_F32 (the fp32-ARITHMETIC A/B of DESIGN.md §6, profiles/r02_fp32_ab.json): Sigma -= W W^T on v_mfma_f32_16x16x4_f32 with the
     operands rounded to float. One update from the same state: Sigma agrees with the fp64-MFMA update to float rounding of the products
