@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_TWO_PHASE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_SYRK_F32, OPT_FUSED_LIFT, OPT_LA_TIMEOUT_US, OPT_SIGMA_IN_LOOKAHEAD, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_TWO_PHASE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_SYRK_F32, OPT_FUSED_LIFT, OPT_LA_TIMEOUT_US, OPT_SIGMA_IN_LOOKAHEAD, OPT_Z_IN_LOOKAHEAD, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)

@@ -165,6 +165,10 @@ struct eqf_ctx {
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int opt_sigma_la = 0;                    // EQF_OPT_SIGMA_IN_LOOKAHEAD
+    int opt_zb = 1;                          // EQF_OPT_Z_IN_LOOKAHEAD
+    bool tail_zb = false;                    // the update tail in flight has no Z in memory (built inside the look-ahead kernel): a retry on the chain builds it first
+    double tail_var = 0.0;                   // ... and needs the measurement variance again
+    long zb_launches = 0;
     int cu_count = 256;                      // compute units of the device: what the look-ahead kernel's Sigma workgroups may fill
     int* d_wflags = nullptr;                 // look-ahead kernel: flags of the T half-rows' W rows, [panel][half-row]
     long la_sigma_tiles = 0, la_sigma_rest = 0; // eqf_lookahead_stats-style counters: Sigma tiles updated inside the look-ahead kernel / left to k_syrk_sub behind it
@@ -890,6 +894,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_SIGMA_IN_LOOKAHEAD:
         c->opt_sigma_la = value ? 1 : 0;
+        return 0;
+    case EQF_OPT_Z_IN_LOOKAHEAD:
+        c->opt_zb = value ? 1 : 0;
         return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
@@ -1895,7 +1902,7 @@ constexpr int LA_SQ_SMALL = 2, LA_SQ_LARGE = 4;
 // sigma_tiles: nullptr, or out: how many entries of k_syrk_sub's tile table (n / 32 tiles per side) the kernel's Sigma workgroups took (Sigma <- Sigma - W W^T
 // for those tiles is part of this launch; the caller launches k_syrk_sub for the rest, if any)
 static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq, bool with_lift = false, int discreteCorr = 0, int door_seq = 0,
-                            int* sigma_tiles = nullptr) {
+                            int* sigma_tiles = nullptr, bool zb = false) {
     LaArgs a{};
     a.rows = rows;
     a.m = m;
@@ -1951,7 +1958,12 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     }
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
     // MAXT = tiles a wave keeps in registers = ceil(NJ / 4)
-    if (a.sg_nwg == 0) { // the default: instantiations without the Sigma role
+    if (zb) { // EQF_OPT_Z_IN_LOOKAHEAD: the half-rows build their rows of Z themselves (C, yTilde, index map from the measurement kernel)
+        a.zb_sig = (const double*)c->sigma(), a.zb_ld = c->ld, a.zb_M = m / 2, a.zb_Mcap = c->Ncap, a.zb_var = c->tail_var;
+        a.zb_C = c->d_C, a.zb_ytil = c->d_ytil, a.zb_lmidx = c->d_lmidx, a.zb_linv0 = c->d_Linv;
+        ++c->zb_launches;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0, true>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+    } else if (a.sg_nwg == 0) { // the default: instantiations without the Sigma role
         if (a.NJ <= 16)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
         else
@@ -2109,14 +2121,18 @@ static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_s
     HIPCHK(hipGetLastError());
     return 0;
 }
-static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain);
+static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, bool zb = false);
 static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq,
                               const MeasFuse* fuse = nullptr) {
     HP_SCOPE("abi.launch_update_tail");
     const int n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
     int rc = 0;
-    {
+    // EQF_OPT_Z_IN_LOOKAHEAD: with the C blocks in memory (k_measure / k_outlier_stats ran), fp64 Sigma and 3 .. 16 panels, the look-ahead kernel builds Z itself
+    const bool zb = !fuse && c->opt_zb && !c->sig32 && !c->opt_sigma_la && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
+    c->tail_zb = zb;
+    c->tail_var = meas_var;
+    if (!zb) {
         KTimer t(c, KN_BUILD_Z);
         // one extra grid row eliminates the first diagonal tile of S (no k_chol_first launch in this chain); with measurement fusion
         // the kernel also evaluates C itself, one more grid row computes the outlier statistics and decides about the tail
@@ -2142,11 +2158,11 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
     }
     host_stamp(c, TH_BUILD_Z_OUT);
     c->tail_M = M; // what a retry of the factorisation on the launch chain needs to know (finish_update)
-    return launch_factor_tail(c, M, discreteCorr, spec, spec_seq, use_door, door_seq, false);
+    return launch_factor_tail(c, M, discreteCorr, spec, spec_seq, use_door, door_seq, false, zb);
 }
 // Everything behind k_build_Z: factorisation of Z (look-ahead kernel or launch chain), lift, covariance update. force_chain: the retry after a stalled
 // look-ahead kernel (Z and L_0^-1 are inputs of that kernel only, so the chain can start from them again).
-static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain) {
+static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, bool zb) {
     const int n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
     int rc = 0;
@@ -2163,7 +2179,7 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
         // EQF_OPT_SIGMA_IN_LOOKAHEAD: Sigma <- Sigma - W W^T by the look-ahead kernel's own Sigma workgroups (fp64 store and arithmetic only)
         int sigma_in_la = 0;
         const bool sgl = la && c->opt_sigma_la && !c->sig32 && !c->opt_syrk_f32;
-        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, fl, discreteCorr, door_seq, sgl ? &sigma_in_la : nullptr)
+        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, fl, discreteCorr, door_seq, sgl ? &sigma_in_la : nullptr, zb)
                 : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
         if (rc)
             return rc;
@@ -2235,6 +2251,13 @@ static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
         HIPCHK(hipMemsetAsync(c->d_flags + 3, 0, sizeof(int), c->stream));
         const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
         const int door_seq = (int)(++c->door_seq);
+        if (c->tail_zb) { // the stalled kernel had built Z in its registers: the chain needs it (and L_0^-1) in memory
+            const int n_ = c->n(), M_ = c->tail_M;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_build_Z<double, false>), dim3(blocks(n_ + M_ + 1, 256), blocks(M_, BZ_JB) + 1), dim3(256), 0, c->stream, n_, M_, c->Ncap, c->ld, c->ldz,
+                               c->tail_var, c->d_lmidx, (const double*)c->sigma(), c->d_C, c->d_ytil, c->d_Z, c->d_Linv, c->d_flags, (const int*)nullptr, 0, MeasFuse{}, (trace_t*)nullptr);
+            HIPCHK(hipGetLastError());
+            c->tail_zb = false;
+        }
         int rc = launch_factor_tail(c, c->tail_M, discreteCorr, nullptr, 0, use_door, door_seq, true);
         if (rc)
             return rc;

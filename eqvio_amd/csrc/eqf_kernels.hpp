@@ -1206,6 +1206,32 @@ __global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double
 //  * Grid row 1 computes the per-landmark outlier statistics (VIOFilter.cpp:304-334), writes them to the host packet and, if any
 //    landmark is an outlier candidate, stores spec_seq into *spec_w: this kernel only writes scratch (Z, C), the kernels behind
 //    it compare that word and return at once.
+// The entries of Z = [S ; T ; yTilde^T], written once: k_build_Z stores them, the look-ahead kernel's half-rows can build their own rows from the same
+// expressions (EQF_OPT_Z_IN_LOOKAHEAD), and the results must not differ by a bit.
+// T[t, 2j + a] = Sigma[t, l_j : l_j + 3] C_j[a, :]^T
+__device__ __forceinline__ void bz_T_pair(double s0, double s1, double s2, const double (&cj)[6], double& o0, double& o1) {
+    o0 = s0 * cj[0] + s1 * cj[1] + s2 * cj[2];
+    o1 = s0 * cj[3] + s1 * cj[4] + s2 * cj[5];
+}
+// S[2i + a, 2j + b] = (C_i Sigma[l_i, l_j] C_j^T)[a, b] (+ the measurement variance on the diagonal); sv[3 c + r] = Sigma[l_i + r, l_j + c]
+__device__ __forceinline__ void bz_S_block(const double (&ci)[6], const double (&cj)[6], const double (&sv)[9], bool same_measurement, double meas_var, double (&out)[2][2]) {
+    double CS[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double s0 = sv[3 * c], s1 = sv[3 * c + 1], s2 = sv[3 * c + 2];
+        CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
+        CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            double v = CS[a][0] * cj[3 * bb] + CS[a][1] * cj[3 * bb + 1] + CS[a][2] * cj[3 * bb + 2];
+            if (same_measurement && a == bb)
+                v += meas_var;
+            out[a][bb] = v;
+        }
+}
 constexpr int BZ_JB = 4; // measurements per workgroup of k_build_Z
 struct MeasFuse {
     int enabled;
@@ -1289,22 +1315,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
                 ci[e] = FUSE ? sC16[i * 6 + e] : C[e * Mcap + i];
                 cj2[e] = FUSE ? sC16[jj * 6 + e] : C[e * Mcap + jj];
             }
-            double CS[2][3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double s0 = sv[3 * c], s1 = sv[3 * c + 1], s2 = sv[3 * c + 2];
-                CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
-                CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    double v = CS[a][0] * cj2[3 * bb] + CS[a][1] * cj2[3 * bb + 1] + CS[a][2] * cj2[3 * bb + 2];
-                    if (i == jj && a == bb)
-                        v += meas_var;
-                    blk[a][bb] = v; // identical expression to the S entries written to Z below
-                }
+            bz_S_block(ci, cj2, sv, i == jj, meas_var, blk); // identical expression to the S entries written to Z below
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1400,26 +1411,19 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
         for (int e = 0; e < 6; ++e)
             cj[e] = sCj[q][e];
         if (trow) {
-            Z[m + t + (size_t)(2 * j) * ldz] = sv[q][0] * cj[0] + sv[q][1] * cj[1] + sv[q][2] * cj[2];
-            Z[m + t + (size_t)(2 * j + 1) * ldz] = sv[q][0] * cj[3] + sv[q][1] * cj[4] + sv[q][2] * cj[5];
+            double o0, o1;
+            bz_T_pair(sv[q][0], sv[q][1], sv[q][2], cj, o0, o1);
+            Z[m + t + (size_t)(2 * j) * ldz] = o0;
+            Z[m + t + (size_t)(2 * j + 1) * ldz] = o1;
         } else if (srow) {
             const int i = t - n;
-            double CS[2][3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double s0 = sv[q][3 * c], s1 = sv[q][3 * c + 1], s2 = sv[q][3 * c + 2];
-                CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
-                CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
-            }
+            double blk[2][2];
+            bz_S_block(ci, cj, sv[q], i == j, meas_var, blk);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    double v = CS[a][0] * cj[3 * bb] + CS[a][1] * cj[3 * bb + 1] + CS[a][2] * cj[3 * bb + 2];
-                    if (i == j && a == bb)
-                        v += meas_var;
-                    Z[2 * i + a + (size_t)(2 * j + bb) * ldz] = v;
-                }
+                for (int bb = 0; bb < 2; ++bb)
+                    Z[2 * i + a + (size_t)(2 * j + bb) * ldz] = blk[a][bb];
         } else if (t == n + M) {
             Z[m + n + (size_t)(2 * j) * ldz] = sCj[q][6];
             Z[m + n + (size_t)(2 * j + 1) * ldz] = sCj[q][7];

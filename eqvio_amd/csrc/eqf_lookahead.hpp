@@ -69,6 +69,15 @@ struct LaArgs {
     double* sg_sigma;
     const int* sg_tiles;  // k_syrk_sub_q's tile table (bi | bj << 16)
     int* sg_wflags;       // flag of (panel p, T half-row t) at [p NT + t]: the W rows of that half-row for that panel are at the coherence point
+    // EQF_OPT_Z_IN_LOOKAHEAD (ZB instantiations): no k_build_Z launch in front of this kernel - every half-row builds its own 16 rows of Z = [S ; T ; yTilde^T]
+    // from Sigma and the output blocks C_j (the expressions of k_build_Z: bz_T_pair / bz_S_block), the owner builds and eliminates the first tile
+    const double* zb_sig; // Sigma (fp64), leading dimension zb_ld
+    int zb_ld, zb_M, zb_Mcap;
+    double zb_var;        // measurement variance (diagonal of R)
+    const double* zb_C;   // C blocks, plane e at [e zb_Mcap + j]
+    const double* zb_ytil;
+    const int* zb_lmidx;  // measurement -> state landmark index
+    double* zb_linv0;     // out: L_0^-1 (32 x 32 column-major), for the owner itself
 };
 // tiles: [0, NJ) L_p^-1 | [NJ, NJ + NJ^2) P^(p)_J at p NJ + J (a panel's tiles are neighbours) | then U1, U0 of every S block row
 // flags: the same indices (one int per tile; U1 / U0 share the flag of U1)
@@ -186,6 +195,7 @@ __device__ __forceinline__ void la_lds_add(int* c) {
 }
 enum { LC_L = 0, LC_T, LC_C, LC_D, LC_B, LC_CCOPIED, LC_BCOPIED, LC_U, LC_COUNT };
 
+template <bool ZB>
 __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_abort_words, int* cnt, const LaPoll& pl) {
     int* const s_abort = s_abort_words + 1; // the owner has no barriers: its waves act on the request word
     // `wave` as a scalar: the role branches become real (scalar) branches. With a vector condition the compiler predicates short blocks instead of
@@ -201,10 +211,42 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     // the pairs alternate with the parity of the step: tail k reads what tail k - 1 kept
     auto b_keep = [&](int k, int half) -> double* { return smem + 32 * CH_LDP * ((k & 1) ? 3 * half : 1 + half) + 32; };
     const int NJ = a.NJ;
+    if (ZB) {
+        // the first diagonal tile D_0 = (C Sigma C^T + R)[0:32, 0:32] (k_build_Z's first-tile row: one thread per pair of measurements), eliminated here
+        const int i = tid & 15, jj = (tid >> 4) & 15;
+        const int M = a.zb_M;
+        if (tid < 256) {
+            double blk[2][2] = {{(i == jj) ? 1.0 : 0.0, 0.0}, {0.0, (i == jj) ? 1.0 : 0.0}};
+            if (i < M && jj < M) {
+                const int li = 21 + 3 * a.zb_lmidx[i], lj2 = 21 + 3 * a.zb_lmidx[jj];
+                double sv[9], ci[6], cj2[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        sv[3 * c + r] = a.zb_sig[li + r + (size_t)(lj2 + c) * a.zb_ld];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    ci[e] = a.zb_C[e * a.zb_Mcap + i];
+                    cj2[e] = a.zb_C[e * a.zb_Mcap + jj];
+                }
+                bz_S_block(ci, cj2, sv, i == jj, a.zb_var, blk);
+            }
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+                    sD[2 * i + aa + (2 * jj + bb) * 33] = blk[aa][bb];
+        }
+        __syncthreads();
+        ldl_inverse_tile(sD, 33, min(32, a.m), a.zb_linv0, a.flags, swork); // wave 0; the others wait at the barrier below
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
     {
         double* l0 = la_tile(a, la_i_linv(a, 0));
         for (int e = tid; e < 1024; e += LA_T) {
-            const double v = a.Linv0[e];
+            const double v = ZB ? a.zb_linv0[e] : a.Linv0[e];
             sLk[(e & 31) + (e >> 5) * CH_LDP] = v;
             la_st(l0 + e, v);
         }
@@ -489,7 +531,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 //   wave w: jh = w & 1 is the 16-column half of a tile, jr = w >> 1 the tile column modulo 4; acc[t] = Z(h, J = 4 t + jr)[:, 16 jh .. 16 jh + 15].
 //   A wave's B operand is rows 16 jh .. 16 jh + 15 of P_J, i.e. what ONE half-row (2 J + jh) published: flags are per (panel, half-row).
 //   P^(p)_h = Z(h, p) L_p^-T is formed by waves 0 / 1 (column halves; the zero block of the triangular L_p^-1 skipped).
-template <int MAXT, bool SG> // SG: the instantiation has Sigma workgroups (EQF_OPT_SIGMA_IN_LOOKAHEAD): the T half-rows publish their W rows
+template <int MAXT, bool SG, bool ZB> // SG: the instantiation has Sigma workgroups (EQF_OPT_SIGMA_IN_LOOKAHEAD): the T half-rows publish their W rows; ZB: the rows of Z are built here
 __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* row_cnt, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     double* sLinv = smem;                   // L_p^-1, operand layout [r + c CH_LDP]
@@ -509,17 +551,98 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
     const int ri = row0 + lr;
     const int ric = min(ri, ilim - 1);
     double acc[MAXT][4];
+    if (!ZB) {
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int J = 4 * t + jr;
+        for (int t = 0; t < MAXT; ++t) {
+            const int J = 4 * t + jr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
-            acc[t][q] = (J <= Jmax) ? a.Z[ric + (size_t)j * ldz] : 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const int j = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
+                acc[t][q] = (J <= Jmax) ? a.Z[ric + (size_t)j * ldz] : 0.0;
+            }
         }
+        if (ylast && tid < 32)
+            la_put16(a.puby + 16 * (size_t)tid, a.Z[(rows - 1) + (size_t)min(tid, m - 1) * ldz], seq);
+    } else {
+        // This half-row's 16 rows of Z, built here (no k_build_Z launch, no Z in memory): chunks of 256 columns are evaluated into LDS in a thread mapping
+        // whose Sigma loads are row-coalesced (T: thread = (row, measurement), 3 loads for 2 entries; S: thread = (measurement of the row pair, measurement
+        // of the column pair), one 3 x 3 block of Sigma for 4 entries), then read in the accumulator layout with the clamps of the loads above.
+        constexpr int CW = 256;
+        double* sZ = smem; // [r + 16 c], r < 16, c < CW
+        const int M = a.zb_M, Mcap = a.zb_Mcap, ldS = a.zb_ld, nS = rows - 1 - m;
+        const int ncols = min(m, 32 * (Jmax + 1)); // columns this half-row ever reads
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[t][q] = 0.0;
+        for (int c0 = 0; c0 < ncols; c0 += CW) {
+            const int jend = min(M, (min(ncols, c0 + CW) + 1) / 2);
+            if (srow) {
+                const int i8 = tid & 7, i = 8 * hidx + i8; // measurement of the row pair (2 i, 2 i + 1)
+                if (i < M) {
+                    const int li = 21 + 3 * a.zb_lmidx[i];
+                    double ci[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        ci[e] = a.zb_C[e * Mcap + i];
+                    for (int j = c0 / 2 + (tid >> 3); j < jend; j += LA_T / 8) {
+                        const int lj = 21 + 3 * a.zb_lmidx[j];
+                        double sv[9], cj[6], blk[2][2];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+                                sv[3 * c + r] = a.zb_sig[li + r + (size_t)(lj + c) * ldS];
+#pragma unroll
+                        for (int e = 0; e < 6; ++e)
+                            cj[e] = a.zb_C[e * Mcap + j];
+                        bz_S_block(ci, cj, sv, i == j, a.zb_var, blk);
+#pragma unroll
+                        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                            for (int bb = 0; bb < 2; ++bb)
+                                sZ[(2 * i8 + aa) + 16 * (2 * j + bb - c0)] = blk[aa][bb];
+                    }
+                }
+            } else {
+                const int r = tid & 15, tt = (row0 - m) + r; // row of Sigma / of T; tt == nS: the yTilde row
+                if (tt <= nS) {
+                    for (int j = c0 / 2 + (tid >> 4); j < jend; j += LA_T / 16) {
+                        double o0, o1;
+                        if (tt < nS) {
+                            const int lj = 21 + 3 * a.zb_lmidx[j];
+                            double cj[6];
+#pragma unroll
+                            for (int e = 0; e < 6; ++e)
+                                cj[e] = a.zb_C[e * Mcap + j];
+                            bz_T_pair(a.zb_sig[tt + (size_t)lj * ldS], a.zb_sig[tt + (size_t)(lj + 1) * ldS], a.zb_sig[tt + (size_t)(lj + 2) * ldS], cj, o0, o1);
+                        } else {
+                            o0 = a.zb_ytil[2 * j];
+                            o1 = a.zb_ytil[2 * j + 1];
+                        }
+                        sZ[r + 16 * (2 * j - c0)] = o0;
+                        sZ[r + 16 * (2 * j + 1 - c0)] = o1;
+                    }
+                }
+            }
+            __syncthreads();
+            const int rl = min(lr, ilim - 1 - row0);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int J = 4 * t + jr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
+                    if (J <= Jmax && j >= c0 && j < c0 + CW)
+                        acc[t][q] = sZ[rl + 16 * (j - c0)];
+                }
+            }
+            __syncthreads();
+        }
+        if (ylast && tid < 32)
+            la_put16(a.puby + 16 * (size_t)tid, a.zb_ytil[min(tid, m - 1)], seq);
     }
-    if (ylast && tid < 32)
-        la_put16(a.puby + 16 * (size_t)tid, a.Z[(rows - 1) + (size_t)min(tid, m - 1) * ldz], seq);
     double gsum = 0.0; // thread (r = tid & 15, c = tid >> 4): Gamma share of row row0 + r from column c of every panel
     // S half-rows: panels 0 .. I-3, then the hand-off of U2 / U1 / U0 to the owner, which forms b = P^(I-2)_I and c = P^(I-1)_I itself. ONE product of the
     // last panel is left to the owner as well: Z(I, I-1) -= P^(I-3)_I (P^(I-3)_(I-1))^T, whose second factor is the owner's own b of the step before -
@@ -1234,7 +1357,7 @@ __device__ __forceinline__ void la_finish(const LaArgs& a) {
     }
 }
 
-template <int MAXT, int SQ>
+template <int MAXT, int SQ, bool ZB = false>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (a.spec && *a.spec == a.spec_seq) { // cancelled speculative tail: say so, ring, done
         if (a.lift_door_host && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1266,14 +1389,14 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
         }
     }
     if (blockIdx.x == 0)
-        la_owner(a, smem, s_abort, s_cnt, pl);
+        la_owner<ZB>(a, smem, s_abort, s_cnt, pl);
     else if (MAXT > 4) { // 17 .. 32 panels: the half-rows with a look-ahead of their own
         if (hidx < 2 * a.NJ)
             la_row2<MAXT, true, (SQ > 0)>(a, hidx, smem, s_abort, s_cnt, pl);
         else
             la_row2<MAXT, false, (SQ > 0)>(a, hidx, smem, s_abort, s_cnt, pl);
     } else
-        la_row<MAXT, (SQ > 0)>(a, hidx, smem, s_abort, s_cnt, pl);
+        la_row<MAXT, (SQ > 0), ZB>(a, hidx, smem, s_abort, s_cnt, pl);
     if ((threadIdx.x & 63) == 0 && (s_abort[0] | s_abort[1])) // any wave that saw a timeout reports it (the owner's waves return at different times)
         __hip_atomic_store(a.flags + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.lift_door_host && hidx >= 2 * a.NJ && blockIdx.x != 0) { // a T half-row (stalled or not) counts itself in; the last one finishes the frame

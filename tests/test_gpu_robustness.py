@@ -266,6 +266,48 @@ def test_stalled_lookahead_with_sigma_workgroups_leaves_sigma_alone():
         flt.close()
 
 
+def test_stalled_lookahead_that_built_z_itself_is_redone_on_the_chain():
+    """EQF_OPT_Z_IN_LOOKAHEAD (default, stand-alone update path): the look-ahead kernel builds Z in its registers and there is no k_build_Z launch. A launch
+    that stalls (EQF_OPT_LA_TIMEOUT_US = 0) has left no Z in memory: the retry must build it (k_build_Z from the C blocks of the measurement kernel) before the
+    launch chain runs. Result: bit-identical to a context that never used the look-ahead kernel, with and without the option."""
+    import ctypes as C
+
+    from eqvio_amd.capi import OPT_LA_TIMEOUT_US, OPT_LOOKAHEAD, OPT_Z_IN_LOOKAHEAD, EqfCore
+    from util import CHARTS, default_camera, random_imu, random_spd, reasonable_state, settings_for, synth_measurement
+
+    rng = np.random.default_rng(12)
+    N = 72
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N)
+    S = random_spd(rng, 21 + 3 * N)
+    settings = settings_for(CHARTS["invdepth"])
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=np.sort(rng.permutation(N)[:66]))
+    imu = random_imu(rng)
+    out = {}
+    for name, la, zb, timeout in (("chain", 0, 1, None), ("inside", 1, 1, None), ("build_z", 1, 0, None), ("stalled", 1, 1, 0)):
+        c = EqfCore(N, CHARTS["invdepth"])
+        c.set_state(xi0, Xs, ids, q0, Q)
+        c.set_sigma(S)
+        c.set_option(OPT_LOOKAHEAD, la)
+        c.set_option(OPT_Z_IN_LOOKAHEAD, zb)
+        if timeout is not None:
+            c.set_option(OPT_LA_TIMEOUT_US, timeout)
+        for k in range(2):  # the second frame meets the first one's flags and tiles
+            c.integrate_riccati_fast(imu, 0.01, settings.input_gain_diag12(), settings.state_gain_diag8())
+            c.vision_update(cam, mid, y + 0.1 * k, settings.measurementNoise**2, True, False)
+        a, b = C.c_long(), C.c_long()
+        assert c.lib.eqf_lookahead_stats(c.h, C.byref(a), C.byref(b), 0) == 0
+        out[name] = (c.get_sigma(), c.get_state(), (a.value, b.value))
+    assert out["chain"][2] == (0, 0) and out["inside"][2] == (2, 0) and out["build_z"][2] == (2, 0) and out["stalled"][2] == (2, 2)
+    # one update: W and Sigma+ bit-identical whichever way Z and the factorisation were computed; the second frame starts from states that differ in
+    # the last bit of Gamma's sum (chain / stalled against the look-ahead kernel), so: exact within each family, 1e-11 across
+    assert np.array_equal(out["chain"][0], out["stalled"][0])
+    assert np.array_equal(out["inside"][0], out["build_z"][0])
+    assert np.linalg.norm(out["inside"][0] - out["chain"][0]) <= 1e-11 * np.linalg.norm(out["chain"][0])
+    for u, v in zip(out["chain"][1], out["stalled"][1]):
+        assert np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("N,n_filters", [(200, 4), (200, 8), (500, 4)])
 def test_concurrent_persistent_kernels_stay_on_their_oracles(N, n_filters):
     """several filters, one host thread each, whose persistent look-ahead kernels share the GPU. 4 x N = 500 is 4 x 81 workgroups of
