@@ -729,6 +729,8 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
 }
 
 void eqf_destroy(eqf_ctx* c) {
+    if (c && std::getenv("EQF_DEBUG_STATS"))
+        std::fprintf(stderr, "[eqf_hip] look-ahead launches %ld (stalled %ld), of them with Z built inside %ld\n", c->la_launches, c->la_fallbacks, c->zb_launches);
     if (!c)
         return;
     hipSetDevice(c->device);
@@ -1902,7 +1904,7 @@ constexpr int LA_SQ_SMALL = 2, LA_SQ_LARGE = 4;
 // sigma_tiles: nullptr, or out: how many entries of k_syrk_sub's tile table (n / 32 tiles per side) the kernel's Sigma workgroups took (Sigma <- Sigma - W W^T
 // for those tiles is part of this launch; the caller launches k_syrk_sub for the rest, if any)
 static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq, bool with_lift = false, int discreteCorr = 0, int door_seq = 0,
-                            int* sigma_tiles = nullptr, bool zb = false) {
+                            int* sigma_tiles = nullptr, int zb = 0, const MeasFuse* zb_mf = nullptr) {
     LaArgs a{};
     a.rows = rows;
     a.m = m;
@@ -1958,11 +1960,17 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     }
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
     // MAXT = tiles a wave keeps in registers = ceil(NJ / 4)
-    if (zb) { // EQF_OPT_Z_IN_LOOKAHEAD: the half-rows build their rows of Z themselves (C, yTilde, index map from the measurement kernel)
+    if (zb) { // EQF_OPT_Z_IN_LOOKAHEAD: the half-rows build their rows of Z themselves
         a.zb_sig = (const double*)c->sigma(), a.zb_ld = c->ld, a.zb_M = m / 2, a.zb_Mcap = c->Ncap, a.zb_var = c->tail_var;
         a.zb_C = c->d_C, a.zb_ytil = c->d_ytil, a.zb_lmidx = c->d_lmidx, a.zb_linv0 = c->d_Linv;
+        a.tr_zb = trace_slot(c, TR_BUILD_Z);
         ++c->zb_launches;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0, true>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+        if (zb == 2) { // ... and evaluate the C blocks themselves; one more workgroup for the statistics and the speculation word (the kernel itself does not look at it)
+            a.zb_mf = *zb_mf;
+            a.spec = nullptr;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0, 2>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
+        } else // C, yTilde, index map from the measurement kernel
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0, 1>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     } else if (a.sg_nwg == 0) { // the default: instantiations without the Sigma role
         if (a.NJ <= 16)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
@@ -2121,7 +2129,8 @@ static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_s
     HIPCHK(hipGetLastError());
     return 0;
 }
-static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, bool zb = false);
+static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, int zb = 0,
+                              const MeasFuse* zb_mf = nullptr);
 static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq,
                               const MeasFuse* fuse = nullptr) {
     HP_SCOPE("abi.launch_update_tail");
@@ -2129,8 +2138,10 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
     const int rows = m + n + 1;
     int rc = 0;
     // EQF_OPT_Z_IN_LOOKAHEAD: with the C blocks in memory (k_measure / k_outlier_stats ran), fp64 Sigma and 3 .. 16 panels, the look-ahead kernel builds Z itself
-    const bool zb = !fuse && c->opt_zb && !c->sig32 && !c->opt_sigma_la && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
-    c->tail_zb = zb;
+    // (with measurement fusion - the speculative frame tail - it evaluates the C blocks as well, if the measurement has been staged to HBM: ZB = 2)
+    const bool zb_ok = c->opt_zb && !c->sig32 && !c->opt_sigma_la && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
+    const int zb = !zb_ok ? 0 : (!fuse ? 1 : ((fuse->y == c->d_meas && !c->opt_fused_lift && c->opt_early) ? 2 : 0));
+    c->tail_zb = zb != 0;
     c->tail_var = meas_var;
     if (!zb) {
         KTimer t(c, KN_BUILD_Z);
@@ -2158,11 +2169,11 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
     }
     host_stamp(c, TH_BUILD_Z_OUT);
     c->tail_M = M; // what a retry of the factorisation on the launch chain needs to know (finish_update)
-    return launch_factor_tail(c, M, discreteCorr, spec, spec_seq, use_door, door_seq, false, zb);
+    return launch_factor_tail(c, M, discreteCorr, spec, spec_seq, use_door, door_seq, false, zb, fuse);
 }
 // Everything behind k_build_Z: factorisation of Z (look-ahead kernel or launch chain), lift, covariance update. force_chain: the retry after a stalled
 // look-ahead kernel (Z and L_0^-1 are inputs of that kernel only, so the chain can start from them again).
-static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, bool zb) {
+static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, int zb, const MeasFuse* zb_mf) {
     const int n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
     int rc = 0;
@@ -2179,7 +2190,7 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
         // EQF_OPT_SIGMA_IN_LOOKAHEAD: Sigma <- Sigma - W W^T by the look-ahead kernel's own Sigma workgroups (fp64 store and arithmetic only)
         int sigma_in_la = 0;
         const bool sgl = la && c->opt_sigma_la && !c->sig32 && !c->opt_syrk_f32;
-        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, fl, discreteCorr, door_seq, sgl ? &sigma_in_la : nullptr, zb)
+        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, fl, discreteCorr, door_seq, sgl ? &sigma_in_la : nullptr, zb, zb_mf)
                 : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
         if (rc)
             return rc;

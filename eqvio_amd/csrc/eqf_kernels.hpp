@@ -770,9 +770,10 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
                                                    const double* __restrict__ q0, const double* __restrict__ Qq,
                                                    const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
                                                    double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags,
-                                                   double& abs_err, double& prob_err, bool emit = true) {
+                                                   double& abs_err, double& prob_err, bool emit = true, int i_explicit = -1) {
     // emit: also reset the status flags and write C / yTilde / the index map (false inside k_build_Z, which does both itself)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // i_explicit: the landmark, for a caller whose lanes are not numbered by the grid (the look-ahead kernel's statistics workgroup)
+    const int i = i_explicit >= 0 ? i_explicit : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (emit && i == 0) {
         flags[0] = 0;
         flags[1] = 0;

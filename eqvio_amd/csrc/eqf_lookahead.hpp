@@ -78,6 +78,11 @@ struct LaArgs {
     const double* zb_ytil;
     const int* zb_lmidx;  // measurement -> state landmark index
     double* zb_linv0;     // out: L_0^-1 (32 x 32 column-major), for the owner itself
+    // ZB = 2 (the speculative frame tail, eqf_stats_then_update): no measurement kernel either - every workgroup evaluates the output blocks C_j it needs
+    // (measure_j, one lane per measurement, into LDS), workgroup NI computes the outlier statistics, decides about the tail (speculation word) and
+    // leaves C / yTilde / the index map in memory for a retry; zb_C / zb_ytil / zb_lmidx are not read
+    MeasFuse zb_mf;
+    trace_t* tr_zb; // EQF_OPT_TRACE: k_build_Z's slot - this kernel's start stands for it (the span to step 0 is the prologue that replaces k_build_Z)
 };
 // tiles: [0, NJ) L_p^-1 | [NJ, NJ + NJ^2) P^(p)_J at p NJ + J (a panel's tiles are neighbours) | then U1, U0 of every S block row
 // flags: the same indices (one int per tile; U1 / U0 share the flag of U1)
@@ -195,7 +200,7 @@ __device__ __forceinline__ void la_lds_add(int* c) {
 }
 enum { LC_L = 0, LC_T, LC_C, LC_D, LC_B, LC_CCOPIED, LC_BCOPIED, LC_U, LC_COUNT };
 
-template <bool ZB>
+template <int ZB>
 __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_abort_words, int* cnt, const LaPoll& pl) {
     int* const s_abort = s_abort_words + 1; // the owner has no barriers: its waves act on the request word
     // `wave` as a scalar: the role branches become real (scalar) branches. With a vector condition the compiler predicates short blocks instead of
@@ -212,23 +217,45 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     auto b_keep = [&](int k, int half) -> double* { return smem + 32 * CH_LDP * ((k & 1) ? 3 * half : 1 + half) + 32; };
     const int NJ = a.NJ;
     if (ZB) {
+        if (a.tr_zb && tid == 0)
+            *a.tr_zb = wall_clock64();
         // the first diagonal tile D_0 = (C Sigma C^T + R)[0:32, 0:32] (k_build_Z's first-tile row: one thread per pair of measurements), eliminated here
         const int i = tid & 15, jj = (tid >> 4) & 15;
         const int M = a.zb_M;
+        double* sC16 = sX; // ZB = 2: the C blocks of the first 16 measurements
+        if (ZB == 2) {
+            if (tid == 0) { // this launch's status words start clean (write-through: no dirty line of them may outlive a later write-through set)
+                __hip_atomic_store(a.flags + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.flags + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.flags + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < 16 && tid < M) {
+                int lidx;
+                const MeasOut o = measure_j(a.zb_mf, tid, lidx);
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+                    sC16[tid * 6 + e] = o.c[e];
+            }
+        }
+        double sv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (tid < 256 && i < M && jj < M) { // Sigma's blocks requested before the barrier: in flight while the C blocks are evaluated
+            const int li = 21 + 3 * (ZB == 2 ? a.zb_mf.lmidx[i] : a.zb_lmidx[i]), lj2 = 21 + 3 * (ZB == 2 ? a.zb_mf.lmidx[jj] : a.zb_lmidx[jj]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    sv[3 * c + r] = a.zb_sig[li + r + (size_t)(lj2 + c) * a.zb_ld];
+        }
+        if (ZB == 2)
+            __syncthreads();
         if (tid < 256) {
             double blk[2][2] = {{(i == jj) ? 1.0 : 0.0, 0.0}, {0.0, (i == jj) ? 1.0 : 0.0}};
             if (i < M && jj < M) {
-                const int li = 21 + 3 * a.zb_lmidx[i], lj2 = 21 + 3 * a.zb_lmidx[jj];
-                double sv[9], ci[6], cj2[6];
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        sv[3 * c + r] = a.zb_sig[li + r + (size_t)(lj2 + c) * a.zb_ld];
+                double ci[6], cj2[6];
 #pragma unroll
                 for (int e = 0; e < 6; ++e) {
-                    ci[e] = a.zb_C[e * a.zb_Mcap + i];
-                    cj2[e] = a.zb_C[e * a.zb_Mcap + jj];
+                    ci[e] = ZB == 2 ? sC16[i * 6 + e] : a.zb_C[e * a.zb_Mcap + i];
+                    cj2[e] = ZB == 2 ? sC16[jj * 6 + e] : a.zb_C[e * a.zb_Mcap + jj];
                 }
                 bz_S_block(ci, cj2, sv, i == jj, a.zb_var, blk);
             }
@@ -531,7 +558,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 //   wave w: jh = w & 1 is the 16-column half of a tile, jr = w >> 1 the tile column modulo 4; acc[t] = Z(h, J = 4 t + jr)[:, 16 jh .. 16 jh + 15].
 //   A wave's B operand is rows 16 jh .. 16 jh + 15 of P_J, i.e. what ONE half-row (2 J + jh) published: flags are per (panel, half-row).
 //   P^(p)_h = Z(h, p) L_p^-T is formed by waves 0 / 1 (column halves; the zero block of the triangular L_p^-1 skipped).
-template <int MAXT, bool SG, bool ZB> // SG: the instantiation has Sigma workgroups (EQF_OPT_SIGMA_IN_LOOKAHEAD): the T half-rows publish their W rows; ZB: the rows of Z are built here
+template <int MAXT, bool SG, int ZB> // SG: the instantiation has Sigma workgroups (EQF_OPT_SIGMA_IN_LOOKAHEAD): the T half-rows publish their W rows; ZB: the rows of Z are built here
 __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* row_cnt, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     double* sLinv = smem;                   // L_p^-1, operand layout [r + c CH_LDP]
@@ -569,60 +596,95 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         // of the column pair), one 3 x 3 block of Sigma for 4 entries), then read in the accumulator layout with the clamps of the loads above.
         constexpr int CW = 256;
         double* sZ = smem; // [r + 16 c], r < 16, c < CW
+        double* sC = smem + 16 * CW;               // ZB = 2: C_j and yTilde_j of every measurement, [8 j + e] (M <= 256)
         const int M = a.zb_M, Mcap = a.zb_Mcap, ldS = a.zb_ld, nS = rows - 1 - m;
         const int ncols = min(m, 32 * (Jmax + 1)); // columns this half-row ever reads
+        // A T half-row requests Sigma's entries first, for every measurement of the thread ((row, measurement j = g + 32 k): 3 values): the loads need the
+        // index map only, and are in flight while the C blocks are evaluated (ZB = 2: ~2.5 us)
+        constexpr int KT = 8, KS = 4; // M <= 256
+        const int* lmg = ZB == 2 ? a.zb_mf.lmidx : a.zb_lmidx;
+        const int jmax = min(M, (ncols + 1) / 2); // measurements whose columns this half-row reads
+        double preT[KT][3];
+        const int r16 = tid & 15, tt = (row0 - m) + r16; // T: row of Sigma / of T; tt == nS: the yTilde row
+        const int i8 = tid & 7, iS = 8 * hidx + i8;      // S: measurement of the row pair (2 i, 2 i + 1)
+        if (!srow) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int jj = (tid >> 4) + 32 * k;
+                if (tt < nS && jj < jmax) {
+                    const int lj = 21 + 3 * lmg[jj];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        preT[k][c] = a.zb_sig[tt + (size_t)(lj + c) * ldS];
+                }
+            }
+        }
+        // (the S half-rows request their 3 x 3 blocks chunk by chunk below: 72 more registers across the evaluation of C spill, and they are not the late ones)
+        if (ZB == 2) {
+            for (int jj = tid; jj < M; jj += LA_T) {
+                int lidx;
+                const MeasOut o = measure_j(a.zb_mf, jj, lidx);
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+                    sC[8 * jj + e] = o.c[e];
+                sC[8 * jj + 6] = o.yt[0];
+                sC[8 * jj + 7] = o.yt[1];
+            }
+            __syncthreads();
+        }
+        auto c_of = [&](int jj, double (&cj)[6]) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                cj[e] = ZB == 2 ? sC[8 * jj + e] : a.zb_C[e * Mcap + jj];
+        };
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 acc[t][q] = 0.0;
         for (int c0 = 0; c0 < ncols; c0 += CW) {
-            const int jend = min(M, (min(ncols, c0 + CW) + 1) / 2);
+            const int jbeg = c0 / 2, jend = min(M, (min(ncols, c0 + CW) + 1) / 2);
             if (srow) {
-                const int i8 = tid & 7, i = 8 * hidx + i8; // measurement of the row pair (2 i, 2 i + 1)
-                if (i < M) {
-                    const int li = 21 + 3 * a.zb_lmidx[i];
+                if (iS < M) {
                     double ci[6];
+                    c_of(iS, ci);
 #pragma unroll
-                    for (int e = 0; e < 6; ++e)
-                        ci[e] = a.zb_C[e * Mcap + i];
-                    for (int j = c0 / 2 + (tid >> 3); j < jend; j += LA_T / 8) {
-                        const int lj = 21 + 3 * a.zb_lmidx[j];
-                        double sv[9], cj[6], blk[2][2];
+                    for (int k = 0; k < KS; ++k) {
+                        const int jj = (tid >> 3) + 64 * k;
+                        if (jj >= jbeg && jj < jend) {
+                            double cj[6], blk[2][2], sv[9];
+                            const int li = 21 + 3 * lmg[iS], lj = 21 + 3 * lmg[jj];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c)
+                            for (int c = 0; c < 3; ++c)
 #pragma unroll
-                            for (int r = 0; r < 3; ++r)
-                                sv[3 * c + r] = a.zb_sig[li + r + (size_t)(lj + c) * ldS];
+                                for (int r = 0; r < 3; ++r)
+                                    sv[3 * c + r] = a.zb_sig[li + r + (size_t)(lj + c) * ldS];
+                            c_of(jj, cj);
+                            bz_S_block(ci, cj, sv, iS == jj, a.zb_var, blk);
 #pragma unroll
-                        for (int e = 0; e < 6; ++e)
-                            cj[e] = a.zb_C[e * Mcap + j];
-                        bz_S_block(ci, cj, sv, i == j, a.zb_var, blk);
+                            for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-                        for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                            for (int bb = 0; bb < 2; ++bb)
-                                sZ[(2 * i8 + aa) + 16 * (2 * j + bb - c0)] = blk[aa][bb];
+                                for (int bb = 0; bb < 2; ++bb)
+                                    sZ[(2 * i8 + aa) + 16 * (2 * jj + bb - c0)] = blk[aa][bb];
+                        }
                     }
                 }
-            } else {
-                const int r = tid & 15, tt = (row0 - m) + r; // row of Sigma / of T; tt == nS: the yTilde row
-                if (tt <= nS) {
-                    for (int j = c0 / 2 + (tid >> 4); j < jend; j += LA_T / 16) {
+            } else if (tt <= nS) {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const int jj = (tid >> 4) + 32 * k;
+                    if (jj >= jbeg && jj < jend) {
                         double o0, o1;
                         if (tt < nS) {
-                            const int lj = 21 + 3 * a.zb_lmidx[j];
                             double cj[6];
-#pragma unroll
-                            for (int e = 0; e < 6; ++e)
-                                cj[e] = a.zb_C[e * Mcap + j];
-                            bz_T_pair(a.zb_sig[tt + (size_t)lj * ldS], a.zb_sig[tt + (size_t)(lj + 1) * ldS], a.zb_sig[tt + (size_t)(lj + 2) * ldS], cj, o0, o1);
+                            c_of(jj, cj);
+                            bz_T_pair(preT[k][0], preT[k][1], preT[k][2], cj, o0, o1);
                         } else {
-                            o0 = a.zb_ytil[2 * j];
-                            o1 = a.zb_ytil[2 * j + 1];
+                            o0 = ZB == 2 ? sC[8 * jj + 6] : a.zb_ytil[2 * jj];
+                            o1 = ZB == 2 ? sC[8 * jj + 7] : a.zb_ytil[2 * jj + 1];
                         }
-                        sZ[r + 16 * (2 * j - c0)] = o0;
-                        sZ[r + 16 * (2 * j + 1 - c0)] = o1;
+                        sZ[r16 + 16 * (2 * jj - c0)] = o0;
+                        sZ[r16 + 16 * (2 * jj + 1 - c0)] = o1;
                     }
                 }
             }
@@ -633,15 +695,17 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
                 const int J = 4 * t + jr;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int j = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
-                    if (J <= Jmax && j >= c0 && j < c0 + CW)
-                        acc[t][q] = sZ[rl + 16 * (j - c0)];
+                    const int jc = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
+                    if (J <= Jmax && jc >= c0 && jc < c0 + CW)
+                        acc[t][q] = sZ[rl + 16 * (jc - c0)];
                 }
             }
             __syncthreads();
         }
-        if (ylast && tid < 32)
-            la_put16(a.puby + 16 * (size_t)tid, a.zb_ytil[min(tid, m - 1)], seq);
+        if (ylast && tid < 32) {
+            const int jc = min(tid, m - 1);
+            la_put16(a.puby + 16 * (size_t)tid, ZB == 2 ? sC[8 * (jc >> 1) + 6 + (jc & 1)] : a.zb_ytil[jc], seq);
+        }
     }
     double gsum = 0.0; // thread (r = tid & 15, c = tid >> 4): Gamma share of row row0 + r from column c of every panel
     // S half-rows: panels 0 .. I-3, then the hand-off of U2 / U1 / U0 to the owner, which forms b = P^(I-2)_I and c = P^(I-1)_I itself. ONE product of the
@@ -1315,6 +1379,30 @@ __device__ __forceinline__ void la_sigma(const LaArgs& a, const int g, int* s_wo
         a.dbg[8 * 95 + 3] = wall_clock64();
 }
 
+// ZB = 2: the statistics workgroup (block NI). What k_build_Z's statistics row and its first column of measurement groups do in the speculative frame tail:
+// absErr / probErr / depth^2 per landmark to the pinned packet, the speculation word if a measured landmark is an outlier candidate (the lift and the
+// covariance update behind this kernel then return at once; what this kernel computes is scratch), and C / yTilde / the index map in memory (a retry on the
+// launch chain, or the next call with the same measurement, read them).
+__device__ __forceinline__ void la_stats(const LaArgs& a) {
+    const MeasFuse& mf = a.zb_mf;
+    for (int i = threadIdx.x; i < mf.N; i += LA_T) {
+        double abs_err = -1.0, prob_err = -1.0;
+        outlier_stats_body<double>(mf.N, mf.Ncap, a.zb_ld, mf.chart, mf.cam, mf.ylm, mf.q0, mf.Qq, mf.Qa, a.zb_sig, mf.out, 0, nullptr, nullptr, nullptr, nullptr, abs_err, prob_err, false, i);
+        if (mf.spec_w && abs_err >= 0.0 && (abs_err > mf.thrAbs || prob_err > mf.thrProb)) // the comparisons of VIOFilter.cpp:316-330 (NaN: false)
+            *mf.spec_w = mf.spec_seq;
+    }
+    for (int j = threadIdx.x; j < a.zb_M; j += LA_T) {
+        int lidx;
+        const MeasOut o = measure_j(mf, j, lidx);
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+            mf.C[e * a.zb_Mcap + j] = o.c[e];
+        mf.ytil[2 * j] = o.yt[0];
+        mf.ytil[2 * j + 1] = o.yt[1];
+        mf.lmidx_dev[j] = lidx;
+    }
+}
+
 // The end of the frame's device work that the host waits for, run by the T block row that finishes last (every T block row has stored its
 // Gamma rows write-through and counted itself in): X <- Delta X for the landmarks (k_lift's arithmetic: lift_load / lift_landmark), the
 // estimates, Gamma's sensor rows and the status words into the pinned packet, then the doorbell. A failed factorisation (non-positive pivot,
@@ -1357,7 +1445,7 @@ __device__ __forceinline__ void la_finish(const LaArgs& a) {
     }
 }
 
-template <int MAXT, int SQ, bool ZB = false>
+template <int MAXT, int SQ, int ZB = 0>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (a.spec && *a.spec == a.spec_seq) { // cancelled speculative tail: say so, ring, done
         if (a.lift_door_host && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1382,6 +1470,12 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     // SQ = 0: an instantiation without the Sigma role (the default). All roles of a kernel share one register allocation: with la_sigma inlined the
     // half-rows of the 17 .. 32-panel instantiation spilled 14 .. 238 registers depending on SQ, and a call (noinline) costs every role its
     // argument registers (N = 200: 67 -> 89 us).
+    if constexpr (ZB == 2) {
+        if ((int)blockIdx.x >= a.NI) { // the statistics workgroup
+            la_stats(a);
+            return;
+        }
+    }
     if constexpr (SQ > 0) {
         if ((int)blockIdx.x >= a.NI) { // a Sigma workgroup: no part in the factorisation, no deadline, nothing to report
             la_sigma<SQ>(a, (int)blockIdx.x - a.NI, s_cnt);

@@ -79,9 +79,13 @@ enum {
                                   succeeded. Measured slower: at N = 200 the covariance update was already hidden under the host's round trip, and the
                                   W hand-off slows the half-rows (N = 500: +9 us for publishing, +15 us with the Sigma workgroups running).
                                   fp64 Sigma only (EQF_OPT_SIGMA_FP32 = 2 and EQF_OPT_SYRK_F32 keep k_syrk_sub) */
-    EQF_OPT_Z_IN_LOOKAHEAD = 17, /* 1 (default): where it applies (fp64 Sigma, 3 .. 16 panels, C blocks in memory) there is no k_build_Z launch: the look-ahead kernel's half-rows
-                                  build their own rows of Z = [S ; T ; yTilde^T] and its owner the first tile, from the same expressions (bit-identical W / Sigma);
-                                  a stalled launch builds Z with k_build_Z before the retry on the chain. 0: k_build_Z always */
+    EQF_OPT_Z_IN_LOOKAHEAD = 17, /* 1 (default): where it applies (fp64 Sigma, 3 .. 16 panels) there is no k_build_Z launch: the look-ahead kernel's half-rows build their
+                                  own 16 rows of Z = [S ; T ; yTilde^T] and its owner the first tile, from k_build_Z's expressions (bit-identical W / Sigma). In the
+                                  speculative frame tail (eqf_stats_then_update with the measurement staged by the propagation call) its workgroups evaluate the
+                                  output blocks C_j themselves as well and one more workgroup computes the outlier statistics and the speculation word; after
+                                  eqf_vision_update's measurement kernel they read C from memory. A stalled launch builds Z with k_build_Z before the retry on
+                                  the launch chain. Measured: N = 50 +2.8 %, N = 100 +1.8 %, N = 200 neutral (the kernel's prologue costs what the launch saved).
+                                  0: k_build_Z always */
     EQF_OPT_SYRK_F32 = 13,     /* experiment (the fp32-arithmetic A/B): 1: Sigma -= W W^T multiplies on v_mfma_f32_16x16x4_f32 with the
                                   operands rounded to float (f32 accumulation inside a wave's K slice, fp64 across slices and for the subtraction).
                                   Results then agree with the reference to ~1e-7 only; 0 (default): fp64 MFMA */
