@@ -898,7 +898,7 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         c->opt_sigma_la = value ? 1 : 0;
         return 0;
     case EQF_OPT_Z_IN_LOOKAHEAD:
-        c->opt_zb = value ? 1 : 0;
+        c->opt_zb = value < 0 ? 0 : std::min(value, 2);
         return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
@@ -2140,7 +2140,9 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
     // EQF_OPT_Z_IN_LOOKAHEAD: with the C blocks in memory (k_measure / k_outlier_stats ran), fp64 Sigma and 3 .. 16 panels, the look-ahead kernel builds Z itself
     // (with measurement fusion - the speculative frame tail - it evaluates the C blocks as well, if the measurement has been staged to HBM: ZB = 2)
     const bool zb_ok = c->opt_zb && !c->sig32 && !c->opt_sigma_la && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
-    const int zb = !zb_ok ? 0 : (!fuse ? 1 : ((fuse->y == c->d_meas && !c->opt_fused_lift && c->opt_early) ? 2 : 0));
+    // ZB = 2 up to 8 panels (N <= 128) only: measured +2.8 % at N = 50, +1.8 % at N = 100 and neutral at N = 200, where the tail's first launch then reaches
+    // the GPU late (EQF_OPT_Z_IN_LOOKAHEAD = 2 forces it for every eligible size)
+    const int zb = !zb_ok ? 0 : (!fuse ? 1 : ((fuse->y == c->d_meas && !c->opt_fused_lift && c->opt_early && (blocks(m, 32) <= 8 || c->opt_zb == 2)) ? 2 : 0));
     c->tail_zb = zb != 0;
     c->tail_var = meas_var;
     if (!zb) {

@@ -84,8 +84,9 @@ enum {
                                   speculative frame tail (eqf_stats_then_update with the measurement staged by the propagation call) its workgroups evaluate the
                                   output blocks C_j themselves as well and one more workgroup computes the outlier statistics and the speculation word; after
                                   eqf_vision_update's measurement kernel they read C from memory. A stalled launch builds Z with k_build_Z before the retry on
-                                  the launch chain. Measured: N = 50 +2.8 %, N = 100 +1.8 %, N = 200 neutral (the kernel's prologue costs what the launch saved).
-                                  0: k_build_Z always */
+                                  the launch chain. Measured for the speculative tail: N = 50 +2.8 %, N = 100 +1.8 %, N = 200 neutral (the kernel's prologue costs
+                                  what the launch saved, and the tail's first launch reaches the GPU late), so that form is used up to 8 panels (N <= 128);
+                                  2: for every eligible size. 0: k_build_Z always */
     EQF_OPT_SYRK_F32 = 13,     /* experiment (the fp32-arithmetic A/B): 1: Sigma -= W W^T multiplies on v_mfma_f32_16x16x4_f32 with the
                                   operands rounded to float (f32 accumulation inside a wave's K slice, fp64 across slices and for the subtraction).
                                   Results then agree with the reference to ~1e-7 only; 0 (default): fp64 MFMA */

@@ -201,3 +201,32 @@ def test_measurement_edited_in_place_after_it_was_built():
         assert np.array_equal(fresh.get_sigma(), inplace.get_sigma()), f
     fresh.close()
     inplace.close()
+
+
+@pytest.mark.parametrize("N", [200, 60])
+def test_measurement_and_z_inside_the_lookahead_kernel_change_nothing(N):
+    """EQF_OPT_Z_IN_LOOKAHEAD in the speculative frame tail (bench.py's path): 0 = k_build_Z in front of the look-ahead kernel, 2 = the look-ahead kernel
+    evaluates the C blocks, builds its rows of Z, eliminates the first tile and computes the outlier statistics itself (forced also at N = 200, where the
+    default keeps k_build_Z). Same expressions entry by entry: state, Sigma and the statistics must be identical bit for bit, frame after frame."""
+    from eqvio_amd.capi import OPT_Z_IN_LOOKAHEAD
+
+    lib = load_eqf_lib()
+    world, frames = bench.build_workload(seed=21, n_frames=7, N=N)
+    settings = bench.eurocish_settings()
+    mk = lambda s, sensor, ids, p, t: VIOFilter(s, max_landmarks=N, sensor=sensor, ids=ids, p=p, time=t)  # noqa: E731
+    flts = []
+    for val in (0, 2):
+        f = bench.make_filter(world, settings, N, None, frames, mk)
+        assert lib.eqf_set_option(f.core_handle(), OPT_Z_IN_LOOKAHEAD, val) == 0
+        flts.append(f)
+    pf = PreparedFrames(world.cam, *bench.flatten_frames(frames[:6]))
+    for k in range(6):
+        for f in flts:
+            assert f.run_prepared(pf, k, 1) == 1
+        (sa, ia, pa), (sb, ib, pb) = flts[0].state_estimate(), flts[1].state_estimate()
+        assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(pa, pb), k
+        assert np.array_equal(flts[0].get_sigma(), flts[1].get_sigma()), k
+    ca, cb = counters(flts[0]), counters(flts[1])
+    assert ca["queued"] == cb["queued"] == 6 and ca["cancelled"] == cb["cancelled"] == 0 and cb["la_launches"] == 6 and cb["la_fallbacks"] == 0
+    for f in flts:
+        f.close()
