@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+LIB_DIR = os.environ.get("EQVIO_AMD_LIB_DIR") or os.path.join(_HERE, "lib")  # the override: same-box A/B of two builds (scripts/ab_builds.sh)
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
 OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_TWO_PHASE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_SYRK_F32, OPT_FUSED_LIFT, OPT_LA_TIMEOUT_US, OPT_SIGMA_IN_LOOKAHEAD, OPT_Z_IN_LOOKAHEAD, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 100
@@ -543,6 +543,17 @@ class VIOFilter:
         if N < 0:
             raise RuntimeError("eqvio_filter_get_eqf failed")
         return xi0, Xs, ids[:N].copy(), q0[: 3 * N].reshape(N, 3).copy(), Q[: 5 * N].reshape(N, 5).copy()
+
+    def force_eqf(self, xi0_sensor, X_sensor, ids, q0, Q, Sigma):
+        """Teacher forcing (SURVEY.md section 8(d) "Parity definition"): overwrite (xi0, X, Sigma) of the device context behind viewEqFState() through
+        eqvio_filter_core() + eqf_set_state / eqf_set_sigma, e.g. with the oracle's, so that the next frame starts from exactly the reference's state. The
+        landmark ids must be the filter's own (same set, same order): the host mirror's bookkeeping is not touched."""
+        lib = load_eqf_lib()
+        xi0_sensor, X_sensor, ids, q0, Q = _f64(xi0_sensor), _f64(X_sensor), _i32(ids), _f64(q0), _f64(Q)
+        S = np.asfortranarray(Sigma, dtype=np.float64)
+        core = self.core_handle()
+        if lib.eqf_set_state(core, _dp(xi0_sensor), _dp(X_sensor), _ip(ids), _dp(q0), _dp(Q), len(ids)) != 0 or lib.eqf_set_sigma(core, S.ctypes.data_as(c_double_p), S.shape[0]) != 0:
+            raise RuntimeError("force_eqf: eqf_set_state / eqf_set_sigma failed")
 
     def get_sigma(self):
         n = self.lib.eqvio_filter_sigma_dim(self.h)

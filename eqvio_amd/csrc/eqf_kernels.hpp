@@ -1002,6 +1002,41 @@ template <int J> __device__ __forceinline__ double row_bcast(double v) {
     asm volatile("" : "=v"(old));
     return __builtin_amdgcn_update_dpp(old, v, 0x150 + J, 0xf, 0xf, false);
 }
+// x -= m * (the value x holds in lane J of the lane's own 16-lane row) as ONE instruction, v_fmac_f64_dpp: a v_mov_b64_dpp costs a lone wave ~19 cycles
+// of issue and the FMA behind it ~9 (scripts/ubench/issue.hip). The hardware does not interlock a DPP read behind a VALU write of the same register (2 wait
+// states), the compiler does not see into inline assembly, and an s_nop costs a lone wave a full issue slot: the sequences below are ORDERED so that at
+// least two instructions lie between a write of a register and a DPP read of it, and every block opens with s_nop 1 (the compiler may have copied an operand
+// into its register right in front of the block).
+#define EQF_FNMA_DPP(acc, src, m, lane) "v_fmac_f64_dpp %[" #acc "], -%[" #src "], %[" #m "] row_newbcast:%[" #lane "] row_mask:0xf bank_mask:0xf\n\t"
+#define EQF_MOV_DPP(dst, src, lane) "v_mov_b64_dpp %[" #dst "], %[" #src "] row_newbcast:%[" #lane "] row_mask:0xf bank_mask:0xf\n\t"
+// rank-2 update of five registers with the multipliers (m0, m1) and the pivot rows J0, J0 + 1 (read in place: a pivot row is not modified by its own pair's
+// update, its multipliers are masked to zero)
+template <int J0> __device__ __forceinline__ void ldl_rank2_x5(double& x1, double& x2, double& x3, double& x4, double& x5, double m0, double m1) {
+    asm volatile("s_nop 1\n\t" EQF_FNMA_DPP(x1, x1, m0, j0) EQF_FNMA_DPP(x2, x2, m0, j0) EQF_FNMA_DPP(x3, x3, m0, j0) EQF_FNMA_DPP(x4, x4, m0, j0) EQF_FNMA_DPP(x5, x5, m0, j0)
+                 EQF_FNMA_DPP(x1, x1, m1, j1) EQF_FNMA_DPP(x2, x2, m1, j1) EQF_FNMA_DPP(x3, x3, m1, j1) EQF_FNMA_DPP(x4, x4, m1, j1) EQF_FNMA_DPP(x5, x5, m1, j1)
+                 : [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5)
+                 : [m0] "v"(m0), [m1] "v"(m1), [j0] "n"(J0), [j1] "n"(J0 + 1));
+}
+template <int J0> __device__ __forceinline__ void ldl_rank2_x4(double& x1, double& x2, double& x3, double& x4, double m0, double m1) {
+    asm volatile("s_nop 1\n\t" EQF_FNMA_DPP(x1, x1, m0, j0) EQF_FNMA_DPP(x2, x2, m0, j0) EQF_FNMA_DPP(x3, x3, m0, j0) EQF_FNMA_DPP(x4, x4, m0, j0)
+                 EQF_FNMA_DPP(x1, x1, m1, j1) EQF_FNMA_DPP(x2, x2, m1, j1) EQF_FNMA_DPP(x3, x3, m1, j1) EQF_FNMA_DPP(x4, x4, m1, j1)
+                 : [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4)
+                 : [m0] "v"(m0), [m1] "v"(m1), [j0] "n"(J0), [j1] "n"(J0 + 1));
+}
+// First half of a 4x4 round (pivot rows J0, J0 + 1; second pair J0 + 2, J0 + 3): H = G2 - E Q^T with Q[i][j] = A[J0+2+i][J0+j] = g_j of row J0+2+i, the second
+// pivot block S = H of the rows J0 + 2, J0 + 3, and the first pair's rank-2 update of five registers.
+template <int J0>
+__device__ __forceinline__ void ldl_first_pair(double& h1, double& h2, double& s11, double& s21, double& s22, double g0, double g1, double e1, double e2, double& x1,
+                                               double& x2, double& x3, double& x4, double& x5) {
+    asm volatile("s_nop 1\n\t" EQF_FNMA_DPP(h1, g0, e1, j2) EQF_FNMA_DPP(h2, g0, e1, j3) EQF_FNMA_DPP(h1, g1, e2, j2) EQF_FNMA_DPP(h2, g1, e2, j3)
+                 EQF_FNMA_DPP(x1, x1, e1, j0) EQF_FNMA_DPP(x2, x2, e1, j0)
+                 EQF_MOV_DPP(s11, h1, j2) EQF_MOV_DPP(s21, h1, j3) EQF_MOV_DPP(s22, h2, j3)
+                 EQF_FNMA_DPP(x3, x3, e1, j0) EQF_FNMA_DPP(x4, x4, e1, j0) EQF_FNMA_DPP(x5, x5, e1, j0)
+                 EQF_FNMA_DPP(x1, x1, e2, j1) EQF_FNMA_DPP(x2, x2, e2, j1) EQF_FNMA_DPP(x3, x3, e2, j1) EQF_FNMA_DPP(x4, x4, e2, j1) EQF_FNMA_DPP(x5, x5, e2, j1)
+                 : [h1] "+v"(h1), [h2] "+v"(h2), [s11] "=&v"(s11), [s21] "=&v"(s21), [s22] "=&v"(s22), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4),
+                   [x5] "+v"(x5)
+                 : [g0] "v"(g0), [g1] "v"(g1), [e1] "v"(e1), [e2] "v"(e2), [j0] "n"(J0), [j1] "n"(J0 + 1), [j2] "n"(J0 + 2), [j3] "n"(J0 + 3));
+}
 // odd lanes receive the value of the lane below them (quad_perm [0,0,2,2]); even lanes keep their own
 __device__ __forceinline__ double lane_below_for_odd(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1015,53 +1050,46 @@ template <int L> __device__ __forceinline__ double read_lane(double v) { // wave
 __device__ __forceinline__ double fetch_lane(double v, int byte_addr) { // value held by lane byte_addr / 4
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)));
 }
-// One 2x2-pivot round (pivot rows J, J+1) of the 16x16 block LDL^T below, everything in registers: lane (r, cq) holds
-// A[r][cq + 4k] of the SYMMETRIC partially eliminated tile and M[r][cq + 4k] of M = Lu^-1. The pivot rows reach the lanes
-// by DPP row broadcasts (A[c][J] = A[J][c] sits in lane J of the lane's own 16-lane row), the lane's own multiplier
-// entries A[r][J], A[r][J+1] by ds_bpermute, the pivot block by v_readlane: no LDS traffic in the loop.
-// Software pipelined: the round receives its pivot block / multiplier entries (fetched by the previous round right after
-// that round updated the two columns they live in) and fetches the next round's before finishing its own updates.
-struct PivotIn {
-    double d11, d21, d22, mex, mey;
-};
-template <int J> __device__ __forceinline__ PivotIn ldl16_fetch(const double (&a)[4], int r) {
-    PivotIn p;
-    p.d11 = read_lane<J + 16 * (J & 3)>(a[J >> 2]);
-    p.d21 = read_lane<J + 1 + 16 * (J & 3)>(a[J >> 2]);
-    p.d22 = read_lane<J + 1 + 16 * ((J + 1) & 3)>(a[(J + 1) >> 2]);
-    p.mex = fetch_lane(a[J >> 2], 4 * (r + 16 * (J & 3)));             // A[r][J]
-    p.mey = fetch_lane(a[(J + 1) >> 2], 4 * (r + 16 * ((J + 1) & 3))); // A[r][J+1]
-    return p;
-}
-template <int J> __device__ __forceinline__ PivotIn ldl16_round(double (&a)[4], double (&mm)[4], int r, const PivotIn in) {
-    const double idet = (r > J + 1) ? fast_rcp(fma(in.d11, in.d22, -in.d21 * in.d21)) : 0.0;
-    const double f1 = (in.mex * in.d22 - in.mey * in.d21) * idet; // (A[r][J], A[r][J+1]) * D^-1
-    const double f2 = (in.mey * in.d11 - in.mex * in.d21) * idet;
-    constexpr int kA = (J + 2) >> 2, kB = (J + 3) >> 2; // registers that hold columns J+2, J+3: the next pivot columns
-    a[kA & 3] = fma(-f2, row_bcast<J + 1>(a[kA & 3]), fma(-f1, row_bcast<J>(a[kA & 3]), a[kA & 3]));
-    if (kB != kA)
-        a[kB & 3] = fma(-f2, row_bcast<J + 1>(a[kB & 3]), fma(-f1, row_bcast<J>(a[kB & 3]), a[kB & 3]));
-    PivotIn next = in;
-    if (J + 2 < 16)
-        next = ldl16_fetch<(J + 2 < 16) ? J + 2 : 0>(a, r);
-    // Static pruning (J and k are compile-time): a register of A whose four columns 4k .. 4k+3 are all <= J+1 holds only
-    // eliminated columns (never read again); a register of M whose columns are all > J+1 still holds identity columns on
-    // which the pivot rows J, J+1 of M are zero. On average 4.6 of the 8 registers need the rank-2 update.
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (k != (kA & 3) && k != (kB & 3) && 4 * k + 3 >= J + 2)
-            a[k] = fma(-f2, row_bcast<J + 1>(a[k]), fma(-f1, row_bcast<J>(a[k]), a[k]));
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (4 * k <= J + 1)
-            mm[k] = fma(-f2, row_bcast<J + 1>(mm[k]), fma(-f1, row_bcast<J>(mm[k]), mm[k]));
-    return next;
+// ---- 4x4 pivot blocks (round 4) ---------------------------------------------------------------------------------
+// A single wave issues one instruction per ~4.5 cycles and a dependent fp64 op returns after 11-13 (scripts/ubench/latency.hip: v_fma_f64 11,
+// v_mul_f64 13, v_rcp_f64 19, DPP row broadcast 10, two v_readlane 22, ds_bpermute 75 shader cycles), so a round is bound by BOTH its dependent
+// chain and its instruction count. The 2x2 rounds of rounds 1-3 paid one cross-lane round trip per TWO pivots and were latency bound (~430 cycles
+// for ~48 instructions). A 4x4 round is two 2x2 rounds glued WITHOUT the cross-lane fetch between them: every lane gathers the four pivot-column
+// entries G = A[r, J:J+4] of its row once (ds_bpermute, under the first reciprocal), forms the first pair's multipliers E = G1 P^-1 and the
+// second pair's multiplier sources H = G2 - E Q^T itself; the second pivot block S = R - Q P^-1 Q^T is then simply H of the rows J+2, J+3 (three DPP
+// row broadcasts), F2 = H S^-1. Rank-2 update with (E; pivot rows J, J+1), then rank-2 with (F2; the updated pivot rows J+2, J+3).
+template <int B> __device__ __forceinline__ void ldl16x4_round(double (&a)[4], double (&mm)[4], int r, const int (&gaddr)[4]) {
+    constexpr int J = 4 * B;
+    // P straight from the owning lanes: A[J][J] lane (J, 0), A[J+1][J] lane (J+1, 0), A[J+1][J+1] lane (J+1, 1)
+    const double p11 = read_lane<J>(a[B]), p21 = read_lane<J + 1>(a[B]), p22 = read_lane<J + 1 + 16>(a[B]);
+    const double g0u = fetch_lane(a[B], gaddr[0]), g1u = fetch_lane(a[B], gaddr[1]); // A[r][J], A[r][J+1]
+    const double iP0 = fast_rcp(fma(p11, p22, -p21 * p21));
+    const double iP = (r >= J + 2) ? iP0 : 0.0; // rows of the first pair and above are not touched: their multipliers are zero
+    const double e1 = (g0u * p22 - g1u * p21) * iP, e2 = (g1u * p11 - g0u * p21) * iP; // (A[r][J], A[r][J+1]) P^-1; the numerators form under the reciprocal
+    if (B == 3) { // last block: rows 14, 15 only
+        ldl_rank2_x5<J>(a[3], mm[0], mm[1], mm[2], mm[3], e1, e2);
+        return;
+    }
+    double h1 = fetch_lane(a[B], gaddr[2]), h2 = fetch_lane(a[B], gaddr[3]); // A[r][J+2], A[r][J+3]; become the columns J+2, J+3 after the first pair's update
+    double s11, s21, s22;
+    // Static pruning: registers of A whose columns are all < J hold eliminated columns (register B keeps the pivot blocks for the final scaling and
+    // only needs the first pair's update); registers of M whose columns are all > J + 3 still hold identity columns on which the pivot rows are zero.
+    // That leaves register B of A plus four more: a[B+1 .. 3] and mm[0 .. B].
+    double& x1 = a[(B + 1) & 3]; // the next pivot columns first
+    double& x2 = (B < 2) ? a[(B + 2) & 3] : mm[0];
+    double& x3 = (B < 1) ? a[3] : mm[(B < 2) ? 0 : 1];
+    double& x4 = mm[B];
+    ldl_first_pair<J>(h1, h2, s11, s21, s22, g0u, g1u, e1, e2, x1, x2, x3, x4, a[B]);
+    const double iS0 = fast_rcp(fma(s11, s22, -s21 * s21));
+    const double iS = (r >= J + 4) ? iS0 : 0.0; // rows of the block and above are not touched by the second pair
+    const double f3 = (h1 * s22 - h2 * s21) * iS, f4 = (h2 * s11 - h1 * s21) * iS;
+    ldl_rank2_x4<J + 2>(x1, x2, x3, x4, f3, f4);
 }
 // 16x16 elimination on ONE wave: lane (r = lane & 15, cq = lane >> 4) owns the four entries D[r][cq + 4k], k = 0..3, of the
 // full symmetric tile (identity padding outside the tile) and receives Linv[r][cq + 4k] (0 above the diagonal).
-// Block LDL^T with 2x2 pivots while applying the same row operations to an identity (M = Lu^-1), then
+// Block LDL^T with 2x2 pivots, two pivot pairs per round, while applying the same row operations to an identity (M = Lu^-1), then
 // Linv = blkdiag(chol(D_b)^-1) M. sX: 16 x 17 doubles of LDS, used once after the loop to hand every lane the pivot
-// block of its own row pair (rows stop changing after their own round, so the final tile still holds every pivot block).
+// block of its own row pair (rows stop changing after their own pair's step, so the final tile still holds every pivot block).
 __device__ __forceinline__ void ldl16_inverse_wave(double (&a)[4], double (&out)[4], int* __restrict__ flags, bool check_row, double* __restrict__ sX) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, cq = lane >> 4;
@@ -1069,20 +1097,19 @@ __device__ __forceinline__ void ldl16_inverse_wave(double (&a)[4], double (&out)
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         mm[k] = (r == cq + 4 * k) ? 1.0 : 0.0;
-    PivotIn pv = ldl16_fetch<0>(a, r);
-    pv = ldl16_round<0>(a, mm, r, pv);
-    pv = ldl16_round<2>(a, mm, r, pv);
-    pv = ldl16_round<4>(a, mm, r, pv);
-    pv = ldl16_round<6>(a, mm, r, pv);
-    pv = ldl16_round<8>(a, mm, r, pv);
-    pv = ldl16_round<10>(a, mm, r, pv);
-    pv = ldl16_round<12>(a, mm, r, pv); // the round of rows 14, 15 has no rows left to update
+    const int gaddr[4] = {4 * r, 4 * (r + 16), 4 * (r + 32), 4 * (r + 48)};
+    ldl16x4_round<0>(a, mm, r, gaddr);
+    ldl16x4_round<1>(a, mm, r, gaddr);
+    ldl16x4_round<2>(a, mm, r, gaddr);
+    ldl16x4_round<3>(a, mm, r, gaddr);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         sX[r * 17 + cq + 4 * k] = a[k];
     const int j = r & ~1;
     const double p11 = sX[j * 17 + j], p21 = sX[(j + 1) * 17 + j], p22 = sX[(j + 1) * 17 + j + 1];
-    // Linv = blkdiag(chol(D_b)^-1) M : row j -> M[j]/l11 ; row j+1 -> (M[j+1] - (l21/l11) M[j]) / l22
+    // Linv = blkdiag(chol(D_b)^-1) M : row j -> M[j]/l11 ; row j+1 -> (M[j+1] - (l21/l11) M[j]) / l22. (1/l22 = p11 rsqrt(p11) rsqrt(p11 p22 - p21^2) would make
+    // the two reciprocal square roots independent, ~60 cycles; on the template configuration, cond(S) ~ 1e13, it put Sigma+ 3.5e-9 from the 50-digit truth
+    // instead of 1.4e-9 (tests/test_truth_mp.py): not taken.)
     const bool ok = (p11 > 0.0) && (fma(p11, p22, -p21 * p21) > 0.0);
     if (cq == 0 && check_row && !ok)
         __hip_atomic_store(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // write-through: the look-ahead kernel's own lift reads it from another workgroup
@@ -1094,9 +1121,8 @@ __device__ __forceinline__ void ldl16_inverse_wave(double (&a)[4], double (&out)
     const double s_prev = odd ? -(l21 * il11) * il22 : 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int c = cq + 4 * k;
         const double mprev = lane_below_for_odd(mm[k]);
-        out[k] = (c <= r) ? fma(s_prev, mprev, s_self * mm[k]) : 0.0;
+        out[k] = fma(s_prev, mprev, s_self * mm[k]); // M is lower triangular by construction (row operations on an identity): exact zeros above the diagonal
     }
 }
 // Tile D at sD[r + c*ldd] (lower triangle valid, rows/cols >= w are identity padding, w even). Writes Linv (32x32
@@ -1113,61 +1139,56 @@ __device__ __forceinline__ void ldl_inverse_tile_put(const double* __restrict__ 
     __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
-    double* sA = swork;            // elimination exchange (16 x 18)
-    double* sM = swork + 288;
-    double* sLi11 = swork + 544;   // L11inv[r + c*16]
-    double* sLi11T = sLi11 + 256;  // L11inv[r][c] at [c + r*16]
-    double* sL21 = sLi11T + 256;   // L21[i + p*16]
-    double* sYJ = sL21 + 256;      // Y[p][c] at [c + p*16],  Y = L21 L11inv
-    double* sS22 = sYJ + 256;      // S22 ; later L22inv[i + p*16]
-    double a[4], o[4];
-    // A. first diagonal block
+    double* sA = swork;           // pivot blocks of an elimination (16 x 17)
+    double* sLi11 = swork + 544;  // L11inv[r + c*16]: read back transposed (swork + 288 .. 543 is NOT used here: the look-ahead owner parks a block there)
+    // Everything lives in the "elimination layout": lane (lr, lk) holds X[lr][lk + 4 q], q = 0..3. A product C = I J^T of two 16 x 16 matrices in that
+    // layout needs no data movement at all on fp64 MFMA 16x16x4: step q contracts the columns p = lk + 4 q of BOTH operands (the order of the sum over p is
+    // free), and the result comes back in the same layout. Only Y^T = L11inv^T L21^T needs one operand transposed (one LDS round trip, off the chain).
+    double a[4], d21[4], d22[4], o1[4], o2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = lk + 4 * k;
         a[k] = sD[max(lr, c) + min(lr, c) * ldd]; // symmetric fill from the valid lower triangle
+        d21[k] = sD[16 + lr + c * ldd];
+        d22[k] = sD[16 + max(lr, c) + (16 + min(lr, c)) * ldd];
     }
-    ldl16_inverse_wave(a, o, flags, lr < w, sA);
+    // A. first diagonal block
+    ldl16_inverse_wave(a, o1, flags, lr < w, sA);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        sLi11[lr + (lk + 4 * k) * 16] = o1[k];
+    // B. L21 = D21 L11inv^T ; S22 = D22 - L21 L21^T
+    d4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o1[q], d21[q], acc, 0, 0, 0); // C[i][c] = sum_p I[i][p] J[c][p]: first operand J, second I
+    const d4 l21 = acc;
+    acc = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[q], l21[q], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        a[q] = d22[q] - acc[q]; // Schur complement entry S22[lr][lk + 4 q] (L21 L21^T is symmetric to rounding)
+    // C. second diagonal block
+    ldl16_inverse_wave(a, o2, flags, 16 + lr < w, sA);
+    // D. Y^T = L11inv^T L21^T (I = L11inv^T read back transposed, J = L21), X = -L22inv Y (I = L22inv, J = Y^T)
+    acc = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(l21[q], sLi11[(lk + 4 * q) + lr * 16], acc, 0, 0, 0);
+    const d4 yT = acc;
+    acc = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yT[q], o2[q], acc, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = lk + 4 * k;
-        sLi11[lr + c * 16] = o[k];
-        sLi11T[c + lr * 16] = o[k];
-        put(lr, c, o[k]);
+        put(lr, c, o1[k]);
         put(lr, c + 16, 0.0);
-    }
-    // B. L21 = D21 L11inv^T ; S22 = D22 - L21 L21^T ; Y = L21 L11inv   (fp64 MFMA 16x16x4)
-    {
-        const d4 l21 = mfma16_nt(sD + 16, ldd, sLi11, 16); // I = D21 rows (16 + i), J[c][p] = L11inv[c][p]
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            sL21[lr + (lk + 4 * q) * 16] = l21[q];
-    }
-    {
-        const d4 s = mfma16_nt(sL21, 16, sL21, 16);
-        const d4 y = mfma16_nt(sL21, 16, sLi11T, 16); // J[c][p] = L11inv[p][c]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = lr, j = lk + 4 * q;
-            const double d22 = sD[16 + max(i, j) + (16 + min(i, j)) * ldd];
-            a[q] = d22 - s[q]; // Schur complement entry S22[i][j], j = lk + 4q (L21 L21^T is symmetric to rounding)
-            sYJ[j + i * 16] = y[q];                                // Y[i][j] stored for use as J[c = j][p = i]
-        }
-    }
-    // C. second diagonal block (the lane -> entry mapping of the MFMA result is the elimination's own mapping)
-    ldl16_inverse_wave(a, o, flags, 16 + lr < w, sA);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = lk + 4 * k;
-        sS22[lr + c * 16] = o[k];
-        put(16 + lr, 16 + c, o[k]);
-    }
-    // D. X = -L22inv Y
-    {
-        const d4 x = mfma16_nt(sS22, 16, sYJ, 16); // X[i][c] = sum_p L22inv[i][p] Y[p][c]
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            put(16 + lr, lk + 4 * q, -x[q]);
+        put(16 + lr, c, -acc[k]);
+        put(16 + lr, 16 + c, o2[k]);
     }
 }
 

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cmath>
 #include "../../eqvio_amd/csrc/eqf_kernels.hpp"
 using namespace eqf;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -47,7 +48,7 @@ __global__ void k_empty() {}
 
 int main() {
     double* d_out; long long* d_cyc; int* d_flags; double *d_Z, *d_L;
-    CK(hipMalloc(&d_out, sizeof(double) * 2048 * 256)); CK(hipMalloc(&d_cyc, 64)); CK(hipMalloc(&d_flags, 16)); CK(hipMalloc(&d_Z, 8 * 1024)); CK(hipMalloc(&d_L, 8 * 1024));
+    CK(hipMalloc(&d_out, sizeof(double) * 2048 * 256)); CK(hipMalloc(&d_cyc, 64)); CK(hipMalloc(&d_flags, 16)); CK(hipMemset(d_flags, 0, 16)); CK(hipMalloc(&d_Z, 8 * 1024)); CK(hipMalloc(&d_L, 8 * 1024));
     std::vector<double> hz(1024, 0.0);
     for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) hz[i + 32 * j] = (i == j ? 40.0 : 0.0) + 1.0 / (1 + abs(i - j));
     CK(hipMemcpy(d_Z, hz.data(), 8192, hipMemcpyHostToDevice));
@@ -74,6 +75,15 @@ int main() {
         hipLaunchKernelGGL(k_ldl_cycles, dim3(1), dim3(256), 0, 0, wv[rep], 32, d_Z, d_L, d_flags, d_cyc);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         CK(hipMemcpy(hc, d_cyc, 16, hipMemcpyDeviceToHost));
+        if (rep < 2) { // Linv A Linv^T = I ?
+            std::vector<double> hl(1024); CK(hipMemcpy(hl.data(), d_L, 8192, hipMemcpyDeviceToHost));
+            double worst = 0; long double t[32][32];
+            for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) { long double s = 0; for (int k = 0; k < 32; ++k) s += (long double)hl[i + 32 * k] * hz[k + 32 * j]; t[i][j] = s; }
+            for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) { long double s = 0; for (int k = 0; k < 32; ++k) s += t[i][k] * hl[j + 32 * k]; worst = std::max(worst, (double)fabsl(s - (i == j))); }
+            double up = 0; for (int i = 0; i < 32; ++i) for (int j = i + 1; j < 32; ++j) up = std::max(up, fabs(hl[i + 32 * j]));
+            int hf; CK(hipMemcpy(&hf, d_flags, 4, hipMemcpyDeviceToHost));
+            printf("  check: max |Linv A Linv^T - I| = %.2e, max |upper| = %.2e, flag %d\n", worst, up, hf);
+        }
         printf("ldl_inverse_tile(w=%d): %lld shader cycles, %lld wall ticks (100MHz) = %.2f us ; event span %.2f us -> %.0f cycles/pivot, clock ~%.2f GHz\n", wv[rep], hc[0], hc[1], hc[1] / 100.0, ms * 1e3, hc[0] / 32.0, hc[0] / (hc[1] * 10.0));
     }
     hipLaunchKernelGGL(k_barrier_cycles, dim3(1), dim3(256), 0, 0, 1000, d_cyc, d_out); CK(hipMemcpy(hc, d_cyc, 8, hipMemcpyDeviceToHost));

@@ -12,6 +12,8 @@ from oracle_binding import OracleFilter, se3_log_dist
 from simworld import SimWorld
 from util import CAMERAS, random_imu, random_spd, reasonable_state, rel_fro, settings_for, synth_measurement
 
+from util import teacher_force  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -99,9 +101,11 @@ def test_vision_update_and_nees(discrete):
     assert abs(core.compute_nees(ts, eids, tp) / orc.compute_nees(ts, eids, tp) - 1) <= 1e-8
 
 
-def test_filter_free_running_with_landmark_turnover():
+@pytest.mark.parametrize("teacher_forced", [True, False])
+def test_filter_run_with_landmark_turnover(teacher_forced):
     """The host VIOFilter mirror with coordinateChoice = Normal against the oracle's filter on the wave world (landmarks enter and leave),
-    both lifts as in the template configuration (discrete velocity lift, continuous innovation lift)."""
+    both lifts as in the template configuration (discrete velocity lift, continuous innovation lift). Teacher forced (every frame from the oracle's state;
+    measured 2e-11 / 9e-11) and free running (5e-10 / 1e-10 after 25 frames): flat 1e-9 either way."""
     world = SimWorld(seed=4, num_points=1200, max_features=25, trajectory="wave", noise_px=0.3)
     s = Settings.defaults()
     s.coordinateChoice = COORD_NORMAL
@@ -121,5 +125,7 @@ def test_filter_free_running_with_landmark_turnover():
         s_g, ids_g, p_g = flt.state_estimate()
         s_o, ids_o, p_o = orc.state_estimate()
         assert np.array_equal(ids_g, ids_o)
-        assert np.max(np.abs(s_g - s_o)) <= 1e-8 and np.max(np.abs(p_g - p_o) / np.maximum(1.0, np.abs(p_o))) <= 1e-8
-        assert rel_fro(flt.get_sigma(), orc.get_sigma()) <= 1e-8
+        assert np.max(np.abs(s_g - s_o)) <= 1e-9 and np.max(np.abs(p_g - p_o) / np.maximum(1.0, np.abs(p_o))) <= 1e-9
+        assert rel_fro(flt.get_sigma(), orc.get_sigma()) <= 1e-9
+        if teacher_forced:
+            teacher_force(flt, orc)

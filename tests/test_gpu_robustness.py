@@ -65,7 +65,7 @@ def test_filters_sharing_a_gpu_do_not_interfere():
 
 
 def test_long_free_running_sequence_stays_on_the_oracle():
-    """600 frames (30 s) of landmark turnover, free running: still within 1e-8 of the oracle at the end, Sigma SPD."""
+    """600 frames (30 s) of landmark turnover, free running: within 1e-9 of the oracle every 100 frames (measured: 7e-12 state, 2e-11 Sigma), Sigma SPD."""
     world = SimWorld(seed=31, num_points=3000, max_features=20, trajectory="wave", noise_px=0.3)
     settings = sim_settings(COORD_INVDEPTH)
     ids0, _ = world.vision(0.0)
@@ -81,7 +81,7 @@ def test_long_free_running_sequence_stays_on_the_oracle():
         flt.process_vision(stamp, world.cam, mid, y)
         k += 1
         if k % 100 == 0:
-            compare(flt, orc, tol=1e-8)
+            compare(flt, orc, tol=1e-9)
     S = flt.get_sigma()
     assert np.all(np.isfinite(S)) and np.linalg.eigvalsh(0.5 * (S + S.T)).min() > 0
 

@@ -151,3 +151,12 @@ def rel_fro(a, b):
 
 
 CHARTS = {"euclid": COORD_EUCLIDEAN, "invdepth": COORD_INVDEPTH}
+
+
+def teacher_force(flt, orc):
+    """Reset the device filter to the oracle's (xi0, X, Sigma) (SURVEY.md section 8(d) "Parity definition": teacher-forced parity compares ONE frame's
+    arithmetic at a time; a free-running comparison also measures how the configuration amplifies last-bit differences over the frames before)."""
+    xi0, Xs, ids, q0, Q = orc.get_eqf()
+    _, _, ids_f, _, _ = flt.get_eqf()
+    assert np.array_equal(ids, ids_f), "teacher forcing needs identical landmark bookkeeping"
+    flt.force_eqf(xi0, Xs, ids, q0, Q, orc.get_sigma())
