@@ -428,14 +428,14 @@ def main():
 
 
 def reference_side_binding(N, n_frames=400):
-    """The rate a maintainer's tree sees: tests/integration/VIOFilter_mi355x.cpp - the hot-path members of the reference's src/VIOFilter.cpp
-    over the C-ABI - driven by a caller shaped like src/main_sim.cpp:128-184 (tests/integration/run_filter_frames.cpp; the state estimate read after every
-    frame, as main_sim does), on the headline workload. (i) member for member: the reference's own call sequence (integrateRiccatiStateFast + k x
-    integrateObserverState + one getOutputCovById per landmark + performVisionUpdate); (ii) fused: eqf_stage_measurement / eqf_propagate_fast /
-    eqf_stats_then_update. Parity of both against the oracle, frame by frame: tests/test_integration_filter.py."""
+    """The rate a maintainer's tree sees (INTEGRATION.md section A): the member sequence that the reference's VIOFilter::processVisionData makes on its VIO_eqf
+    (src/VIOFilter.cpp:194-241), replayed over the reference-side binding tests/integration/VIO_eqf_mi355x.cpp by tests/integration/run_filter_frames.cpp (the
+    state estimate read after every frame, as main_sim does), on the headline workload. (i) member for member: integrateRiccatiStateFast + k x
+    integrateObserverState + one getOutputCovById per landmark + performVisionUpdate; (ii) fused: the two hunks of tests/integration/VIOFilter_mi355x_hunks.hpp
+    (eqf_stage_measurement / eqf_propagate_fast / eqf_stats_then_update). Parity of both against the oracle, frame by frame: tests/test_integration_filter.py."""
     import tempfile
 
-    from integration_scenario import build_driver, run_driver, write_scenario
+    from integration_scenario import build_driver, plan_without_decisions, run_driver, write_scenario
 
     try:
         build_driver()
@@ -447,13 +447,13 @@ def reference_side_binding(N, n_frames=400):
         out = {}
         with tempfile.TemporaryDirectory() as tmp:
             scen = os.path.join(tmp, "scenario.bin")
-            write_scenario(scen, settings, world.cam, sensor, ids, p, 0.0, frames[:n_frames])
+            write_scenario(scen, settings, world.cam, sensor, ids, p, 0.0, frames[:n_frames], plan_without_decisions(frames[:n_frames], 0.0))
             for key, fused, nfr in (("member_for_member", 0, min(n_frames, 120)), ("fused", 1, n_frames)):
                 if nfr != n_frames:
-                    write_scenario(scen + ".short", settings, world.cam, sensor, ids, p, 0.0, frames[:nfr])
+                    write_scenario(scen + ".short", settings, world.cam, sensor, ids, p, 0.0, frames[:nfr], plan_without_decisions(frames[:nfr], 0.0))
                 info = run_driver(scen if nfr == n_frames else scen + ".short", os.path.join(tmp, "out.bin"), fused, warm=20)
                 out[key] = {"value": info["updates_per_s"], "unit": "updates/s", "frames": info["frames"]}
-        out["note"] = ("reference-side VIOFilter binding (tests/integration/VIOFilter_mi355x.cpp) called like main_sim: processIMUData x k + processVisionData + stateEstimate per frame, "
+        out["note"] = ("reference-side VIO_eqf binding (tests/integration/VIO_eqf_mi355x.cpp): the member sequence of VIOFilter::processVisionData replayed + stateEstimate per frame, "
                        "N = %d hover world; the mirror's own rate is the headline value" % N)
         return out
     except Exception as e:  # informational leg: never lose the bench line over it

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.environ.get("EQVIO_AMD_LIB_DIR") or os.path.join(_HERE, "lib")  # the override: same-box A/B of two builds (scripts/ab_builds.sh)
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_FUSED_UPDATE, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_TWO_PHASE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_SYRK_F32, OPT_FUSED_LIFT, OPT_LA_TIMEOUT_US, OPT_SIGMA_IN_LOOKAHEAD, OPT_Z_IN_LOOKAHEAD, OPT_TIMING = 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_LA_TIMEOUT_US, OPT_Z_IN_LOOKAHEAD, OPT_TIMING = 1, 2, 3, 6, 7, 8, 9, 11, 12, 15, 17, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -175,6 +175,8 @@ def load_eqf_lib():
         "eqf_create": (C.c_int, [P(vp), C.c_int, C.c_int, C.c_int]),
         "eqf_destroy": (None, [vp]),
         "eqf_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
+        "eqf_get_option": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
+        "eqf_lookahead_selftest": (C.c_int, [vp]),
         "eqf_synchronize": (C.c_int, [vp]),
         "eqf_num_landmarks": (C.c_int, [vp]),
         "eqf_get_ids": (C.c_int, [vp, c_int_p, C.c_int]),
@@ -265,6 +267,14 @@ class EqfCore:
 
     def set_option(self, opt, val):
         self._chk0(self.lib.eqf_set_option(self.h, opt, val))
+
+    def get_option(self, opt):
+        v = C.c_int()
+        self._chk0(self.lib.eqf_get_option(self.h, opt, C.byref(v)))
+        return v.value
+
+    def lookahead_selftest(self):
+        return self.lib.eqf_lookahead_selftest(self.h)
 
     def synchronize(self):
         self._chk0(self.lib.eqf_synchronize(self.h))

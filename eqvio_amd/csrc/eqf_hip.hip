@@ -164,21 +164,17 @@ struct eqf_ctx {
     int la_njcap = 0, la_seq = 0;
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
-    int opt_sigma_la = 0;                    // EQF_OPT_SIGMA_IN_LOOKAHEAD
     int opt_zb = 1;                          // EQF_OPT_Z_IN_LOOKAHEAD
     bool tail_zb = false;                    // the update tail in flight has no Z in memory (built inside the look-ahead kernel): a retry on the chain builds it first
     double tail_var = 0.0;                   // ... and needs the measurement variance again
     long zb_launches = 0;
-    int cu_count = 256;                      // compute units of the device: what the look-ahead kernel's Sigma workgroups may fill
-    int* d_wflags = nullptr;                 // look-ahead kernel: flags of the T half-rows' W rows, [panel][half-row]
-    long la_sigma_tiles = 0, la_sigma_rest = 0; // eqf_lookahead_stats-style counters: Sigma tiles updated inside the look-ahead kernel / left to k_syrk_sub behind it
+    int cu_count = 256;                      // compute units of the device: the look-ahead kernel needs all its workgroups resident at once
+    int la_selftest = 0;                     // look-ahead self-test at creation: 0 not run (never eligible at this capacity), 1 passed, -1 failed (launch chain only)
     long long la_timeout_ticks = LA_TIMEOUT_TICKS; // EQF_OPT_LA_TIMEOUT_US: bound of every device-side wait of the look-ahead kernel (100 MHz ticks)
     long la_launches = 0, la_fallbacks = 0;  // eqf_lookahead_stats: look-ahead launches; of those, stalled ones that were redone on the launch chain
     int la_consecutive_stalls = 0;           // three in a row switch the look-ahead kernel off for this context (the GPU is shared with something long-running)
     int tail_M = 0;                          // measurement count of the update tail in flight (finish_update's retry)
     bool tail_la = false;                    // ... and whether its factorisation was the look-ahead kernel
-    int opt_syrk_f32 = 0;                    // EQF_OPT_SYRK_F32
-    int opt_fused_lift = 0;                  // EQF_OPT_FUSED_LIFT
     int* d_perm = nullptr;                   // 2 x (ncap + 2) row permutations of the NEES elimination fallback
     static constexpr int kRing = 8; // pinned packets of the landmark bookkeeping: a ring, so that a flush need not drain the stream before reusing one
     int ring_pos = 0;
@@ -241,7 +237,7 @@ struct eqf_ctx {
     static constexpr int kMaxSteps = kObsChunk;
     CommonK ck; // kernel-argument form of the last sensor-level packet
     // options
-    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_fused = 0, opt_early = 1, opt_two_phase = 700, opt_fuse_asm = 1;
+    int opt_dense = 0, opt_check = 0, opt_timing = 0, opt_f32 = 0, opt_early = 1, opt_fuse_asm = 1;
     bool sig32 = false; // Sigma stored as float (EQF_OPT_SIGMA_FP32 = 2)
     int opt_door = 1;   // host doorbell instead of the stream completion signal for the two per-frame waits
     int* d_door = nullptr; // device counters (one per doorbell)
@@ -563,6 +559,7 @@ static int enter(eqf_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     return flush_reshape(c);
 }
+static int lookahead_selftest(eqf_ctx* c);
 int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choice) {
     if (!out || max_landmarks < 1 || (coordinate_choice != EQVIO_COORD_EUCLIDEAN && coordinate_choice != EQVIO_COORD_INVDEPTH && coordinate_choice != EQVIO_COORD_NORMAL))
         return EQF_E_BAD_ARG;
@@ -606,6 +603,13 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
                 eqf_destroy(c);
                 return EQF_E_BAD_ARG;
             }
+        }
+    }
+    {   // the persistent look-ahead kernel against the launch chain on a fixed problem, before the context is used (see lookahead_selftest)
+        const int st = lookahead_selftest(c);
+        if (st) {
+            eqf_destroy(c);
+            return st;
         }
     }
     *out = c;
@@ -680,8 +684,6 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipMalloc(&c->d_puby, 512 * (size_t)c->la_njcap));
     HIPCHK(hipMemsetAsync(c->d_pubf, 0, sizeof(int) * la_pub_flags(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
     HIPCHK(hipMemsetAsync(c->d_puby, 0, 512 * (size_t)c->la_njcap, c->stream));
-    HIPCHK(hipMalloc(&c->d_wflags, sizeof(int) * (size_t)c->la_njcap * blocks(c->ncap + 1, 16)));
-    HIPCHK(hipMemsetAsync(c->d_wflags, 0, sizeof(int) * (size_t)c->la_njcap * blocks(c->ncap + 1, 16), c->stream));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
@@ -760,7 +762,6 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_pub);
     hipFree(c->d_pubf);
     hipFree(c->d_puby);
-    hipFree(c->d_wflags);
     if (c->d_ladbg)
         hipFree(c->d_ladbg);
     if (c->d_trace)
@@ -861,6 +862,25 @@ static int round_sigma(eqf_ctx* c, const int* spec, int spec_seq) {
     return 0;
 }
 
+int eqf_get_option(const eqf_ctx* c, int option, int* value) {
+    if (!c || !value)
+        return EQF_E_BAD_ARG;
+    switch (option) {
+    case EQF_OPT_RICCATI_DENSE: *value = c->opt_dense; return 0;
+    case EQF_OPT_CHECK_FINITE: *value = c->opt_check; return 0;
+    case EQF_OPT_SPECULATIVE: *value = c->opt_spec; return 0;
+    case EQF_OPT_DOORBELL: *value = c->opt_door; return 0;
+    case EQF_OPT_EARLY_LIFT: *value = c->opt_early; return 0;
+    case EQF_OPT_FUSED_ASSEMBLY: *value = c->opt_fuse_asm; return 0;
+    case EQF_OPT_Z_IN_LOOKAHEAD: *value = c->opt_zb; return 0;
+    case EQF_OPT_LOOKAHEAD: *value = c->opt_lookahead; return 0;
+    case EQF_OPT_LA_TIMEOUT_US: *value = (int)(c->la_timeout_ticks / 100); return 0;
+    case EQF_OPT_TRACE: *value = c->d_trace ? 1 : 0; return 0;
+    case EQF_OPT_SIGMA_FP32: *value = c->opt_f32; return 0;
+    case 100: *value = c->opt_timing; return 0;
+    default: return EQF_E_BAD_ARG;
+    }
+}
 int eqf_set_option(eqf_ctx* c, int option, int value) {
     if (!c)
         return EQF_E_BAD_ARG;
@@ -885,20 +905,8 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case EQF_OPT_FUSED_ASSEMBLY:
         c->opt_fuse_asm = value;
         return 0;
-    case EQF_OPT_TWO_PHASE:
-        c->opt_two_phase = value;
-        return 0;
-    case EQF_OPT_SYRK_F32:
-        c->opt_syrk_f32 = value ? 1 : 0;
-        return 0;
-    case EQF_OPT_FUSED_LIFT:
-        c->opt_fused_lift = value ? 1 : 0;
-        return 0;
-    case EQF_OPT_SIGMA_IN_LOOKAHEAD:
-        c->opt_sigma_la = value ? 1 : 0;
-        return 0;
     case EQF_OPT_Z_IN_LOOKAHEAD:
-        c->opt_zb = value < 0 ? 0 : std::min(value, 2);
+        c->opt_zb = value ? 1 : 0;
         return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
@@ -925,15 +933,10 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         }
         return 0;
     }
-    case EQF_OPT_FUSED_UPDATE:
-        if (value && c->sig32)
-            return EQF_E_UNSUPPORTED;
-        c->opt_fused = value;
-        return 0;
     case EQF_OPT_SIGMA_FP32: {
         if (value < 0 || value > 2)
             return EQF_E_BAD_ARG;
-        if (value == 2 && (c->opt_dense || c->opt_fused))
+        if (value == 2 && c->opt_dense)
             return EQF_E_UNSUPPORTED; // the float store exists for the structured fast path only
         c->opt_f32 = value;
         { int _e = enter(c); if (_e) return _e; } // the live Sigma is converted: pending landmark bookkeeping first
@@ -1144,9 +1147,10 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     rc = eqf_create(&t, c->device, new_cap, c->chart);
     if (rc)
         return rc == EQF_E_NO_DEVICE ? rc : EQF_E_CAPACITY; // allocation failure at the new size
-    const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_FUSED_UPDATE, c->opt_fused},
-                           {EQF_OPT_SPECULATIVE, c->opt_spec}, {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm},
-                           {EQF_OPT_TWO_PHASE, c->opt_two_phase}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead}, {EQF_OPT_SYRK_F32, c->opt_syrk_f32}, {EQF_OPT_FUSED_LIFT, c->opt_fused_lift}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+    // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
+    const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
+                           {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1162,6 +1166,8 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     t->last_gamma = c->last_gamma, t->n_at_update = c->n_at_update;
     t->spec_calls = c->spec_calls, t->spec_queued = c->spec_queued, t->spec_cancelled = c->spec_cancelled, t->spec_backoff = c->spec_backoff, t->spec_backoff_len = c->spec_backoff_len;
     t->nees_lu_fallbacks = c->nees_lu_fallbacks, t->wait_calls = c->wait_calls, t->launch_calls = c->launch_calls, t->wait_seconds = c->wait_seconds, t->launch_seconds = c->launch_seconds;
+    t->la_launches = c->la_launches, t->la_fallbacks = c->la_fallbacks, t->zb_launches = c->zb_launches, t->la_consecutive_stalls = c->la_consecutive_stalls;
+    t->la_selftest = c->la_selftest;
     t->lm_gen = c->lm_gen + 1;
     std::swap(*c, *t);
     eqf_destroy(t);
@@ -1843,9 +1849,8 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
 
 // Blocked right-looking factorisation of Z (rows x m, leading dimension ldz): one launch per 32-column panel
 // (k_chol_step), preceded by the elimination of the first diagonal tile. Rows >= m of W receive Z[rows >= m] L^-T.
-// nsig > 0: the covariance update Sigma -= W W^T and Gamma = W z ride along in the step kernels (see k_chol_step)
-static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double* W, int nsig = 0, double* Sig = nullptr, double* gamma = nullptr,
-                        bool first_tile_done = false, const int* spec = nullptr, int spec_seq = 0, double* gpart = nullptr) {
+static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double* W, bool first_tile_done = false, const int* spec = nullptr, int spec_seq = 0,
+                        double* gpart = nullptr) {
     constexpr int NB = 32;
     if (!first_tile_done) { // the vision update's k_build_Z eliminates the first tile itself
         KTimer t(c, KN_CHOL_UPDATE);
@@ -1861,32 +1866,17 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
         double* Lout = c->d_Linv + 1024 * ((step + 1) & 1);
         const int gx = blocks(rows - c0, 32);
         const int nyS = c0 < m ? blocks(m - c0, 32) : 1;
-        const int nts = blocks(nsig, 32);
-        const int nySig = nsig > 0 ? blocks(nts * (nts + 1) / 2, gx) : 0;
         // gpart: the last launch (c0 == m) also produces Gamma = W z as GAMMA_G + 1 partial vectors (extra grid rows + its own panel)
-        double* gp = (gpart && nsig == 0 && c0 >= m) ? gpart : nullptr;
-        // Two-phase step where the trailing matrix is large (N = 500: the first ~15 steps): P for every block row once, by its own
-        // launch, instead of twice per trailing tile. Below the threshold the extra launch boundary costs more than it saves.
-        const long trailing_tiles = (long)nyS * (nyS + 1) / 2 + (long)(gx - nyS) * nyS; // lower tiles of the S part + the T / y rows
-        const bool two_phase = nsig == 0 && c0 < m && c->opt_two_phase > 0 && trailing_tiles >= c->opt_two_phase;
-        if (two_phase) {
-            hipLaunchKernelGGL(k_chol_panel, dim3(gx), dim3(256), 0, c->stream, rows, kb, w, ldz, Z, W, Lin, spec, spec_seq);
-            HIPCHK(hipGetLastError());
-        }
+        double* gp = (gpart && c0 >= m) ? gpart : nullptr;
         {
             auto launch = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(gx, nyS + nySig + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0,
-                           nyS, nsig, c->ld, Sig, gamma, spec, spec_seq, gp, c->ld, (gpart || nsig) && step < 32 ? trace_slot(c, TR_STEP0 + step) : nullptr,
-                           two_phase ? (const double*)W : (const double*)nullptr);
+                hipLaunchKernelGGL(kern, dim3(gx, nyS + (gp ? GAMMA_G : 0)), dim3(256), 0, c->stream, rows, m, kb, w, ldz, Z, W, Lin, Lout, c->d_flags, c0 < m ? 1 : 0, nyS, spec,
+                                   spec_seq, gp, c->ld, gpart && step < 32 ? trace_slot(c, TR_STEP0 + step) : nullptr);
             };
-            if (two_phase)
-                launch(k_chol_step<true, false, false>);
-            else if (nsig > 0)
-                launch(k_chol_step<false, true, false>);
-            else if (gp)
-                launch(k_chol_step<false, false, true>);
+            if (gp)
+                launch(k_chol_step<true>);
             else
-                launch(k_chol_step<false, false, false>);
+                launch(k_chol_step<false>);
         }
         HIPCHK(hipGetLastError());
     }
@@ -1897,22 +1887,19 @@ static int launch_chain(eqf_ctx* c, int rows, int m, int ldz, double* Z, double*
 // bit-identical W; Gamma arrives complete in d_gamma (no partial vectors). Eligible: 3 <= NJ <= 32 panels (64 < m <= 1024, i.e. up to 512 measured landmarks).
 static bool lookahead_eligible(const eqf_ctx* c, int m) {
     const int NJ = blocks(m, 32);
-    return c->opt_lookahead && !c->opt_fused && c->d_pub && NJ >= 3 && NJ <= c->la_njcap;
+    const int NI = (2 * NJ - 1) + blocks(c->n() + 1, 16) + 1; // every workgroup of the launch must be resident at once (+ 1: the statistics workgroup of the ZB = 2 form):
+    // one workgroup per compute unit (LDS, registers); a partitioned or smaller device takes the launch chain, which needs no co-residency
+    return c->opt_lookahead && c->la_selftest >= 0 && c->d_pub && NJ >= 3 && NJ <= c->la_njcap && NI <= c->cu_count;
 }
-// 16 x 16 quadrants of Sigma a wave of the look-ahead kernel's Sigma workgroups keeps in its accumulators (8 registers each): template argument SQ by panel count
-constexpr int LA_SQ_SMALL = 2, LA_SQ_LARGE = 4;
-// sigma_tiles: nullptr, or out: how many entries of k_syrk_sub's tile table (n / 32 tiles per side) the kernel's Sigma workgroups took (Sigma <- Sigma - W W^T
-// for those tiles is part of this launch; the caller launches k_syrk_sub for the rest, if any)
-static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq, bool with_lift = false, int discreteCorr = 0, int door_seq = 0,
-                            int* sigma_tiles = nullptr, int zb = 0, const MeasFuse* zb_mf = nullptr) {
+static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq, int zb = 0, const MeasFuse* zb_mf = nullptr) {
     LaArgs a{};
     a.rows = rows;
     a.m = m;
     a.ldz = ldz;
     a.NJ = blocks(m, 32);
     a.NI = (2 * a.NJ - 1) + blocks(rows - m, 16); // the owner + the S half-rows 2 .. 2 NJ - 1 + the T half-rows (16 rows each)
-    if (++c->la_seq == 0)
-        ++c->la_seq;
+    if (++c->la_seq <= 0) // positive: -1 is "no look-ahead launch in front" for k_lift / k_syrk_sub, 0 the initial state of every flag word
+        c->la_seq = 1;
     a.seq = c->la_seq;
     a.timeout_ticks = c->la_timeout_ticks;
     a.Z = c->d_Z;
@@ -1927,37 +1914,6 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.spec_seq = spec_seq;
     a.tr_steps = trace_slot(c, TR_STEP0);
     a.dbg = c->d_trace ? c->d_ladbg : nullptr;
-    if (with_lift) { // the vision update: the kernel also lifts the landmarks and rings the doorbell (no k_lift launch)
-        a.lift_N = c->N, a.lift_Ncap = c->Ncap, a.lift_chart = c->chart, a.lift_discrete = discreteCorr;
-        a.lift_q0 = c->q0(), a.lift_Qq = c->Qq(), a.lift_Qa = c->Qa();
-        a.lift_est = c->h_res + 3 * (size_t)c->Ncap, a.lift_gamma_host = c->h_res + 7 * (size_t)c->Ncap;
-        a.lift_flags_host = c->h_resflags, a.lift_done = c->d_door + 2, a.lift_door_host = c->h_door + 1, a.lift_door_seq = door_seq;
-        a.tr_lift = trace_slot(c, TR_LIFT);
-    }
-    if (sigma_tiles) {
-        // The compute units the factorisation leaves idle take lower tiles of Sigma (la_sigma): all of them if they fit at STW per workgroup, else as many as
-        // fit. Workgroup count a multiple of 8: slot -> table entry keeps the entry's XCD (build_syrk_order).
-        *sigma_tiles = 0;
-        const int n = rows - m - 1, nt = blocks(n, 32), tiles = nt * (nt + 1) / 2;
-        const int sq = a.NJ <= 16 ? LA_SQ_SMALL : LA_SQ_LARGE;
-        const int free8 = (c->cu_count - a.NI) / 8 * 8;
-        if (free8 >= 8) {
-            int spw = blocks(tiles, 2 * free8), nwg, taken; // a workgroup takes 2 spw tiles
-            if (spw <= sq) {
-                nwg = blocks(blocks(tiles, 2 * spw), 8) * 8;
-                taken = tiles;
-            } else {
-                spw = sq;
-                nwg = free8;
-                taken = 2 * spw * nwg;
-            }
-            a.sg_n = n, a.sg_ld = c->ld, a.sg_nwg = nwg, a.sg_spw = spw, a.sg_ntiles = taken;
-            a.sg_sigma = (double*)c->sigma();
-            a.sg_tiles = c->d_syrk_order + c->syrk_off[nt];
-            a.sg_wflags = c->d_wflags;
-            *sigma_tiles = taken;
-        }
-    }
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
     // MAXT = tiles a wave keeps in registers = ceil(NJ / 4)
     if (zb) { // EQF_OPT_Z_IN_LOOKAHEAD: the half-rows build their rows of Z themselves
@@ -1968,18 +1924,13 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
         if (zb == 2) { // ... and evaluate the C blocks themselves; one more workgroup for the statistics and the speculation word (the kernel itself does not look at it)
             a.zb_mf = *zb_mf;
             a.spec = nullptr;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0, 2>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 2>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
         } else // C, yTilde, index map from the measurement kernel
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0, 1>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
-    } else if (a.sg_nwg == 0) { // the default: instantiations without the Sigma role
-        if (a.NJ <= 16)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8, 0>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 1>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     } else if (a.NJ <= 16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, LA_SQ_SMALL>), dim3(a.NI + a.sg_nwg), dim3(LA_T), 0, c->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8, LA_SQ_LARGE>), dim3(a.NI + a.sg_nwg), dim3(LA_T), 0, c->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2121,12 +2072,58 @@ static int stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M)
 
 // The device part of the vision update behind the measurement stage: Z, factorisation chain, Sigma update, lift. With
 // spec != nullptr every kernel first compares *spec with spec_seq and returns at once if they match (cancelled tail).
-static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, const double* gpart) {
+static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, const double* gpart, int stall_seq) {
     KTimer t(c, KN_LIFT);
     hipLaunchKernelGGL(k_lift, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, c->N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),
                        c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags, use_door ? c->d_door + 1 : nullptr, c->h_door + 1, door_seq,
-                       spec, spec_seq, gpart, c->ld, trace_slot(c, TR_LIFT));
+                       spec, spec_seq, gpart, c->ld, trace_slot(c, TR_LIFT), stall_seq);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+// Self-test at context creation (ADVICE r2 / VERDICT r3): the look-ahead kernel's hand-offs rest on relaxed agent-scope flags, write-through stores and
+// s_waitcnt ordering (eqf_lookahead.hpp) - measured behaviour of gfx950 under ROCm 7.2, not a guarantee of the HIP memory model. Before a context is
+// used, the same fixed 96-column problem ([S ; T ; y^T], 3 panels, 16 T rows) is factorised on the launch chain and on the look-ahead kernel: the W rows
+// must agree bit for bit and no wait may run out. On a mismatch the context keeps to the launch chain (eqf_lookahead_stats reports it: launches stay 0).
+static int lookahead_selftest(eqf_ctx* c) {
+    constexpr int m = 96, nT = 16, rows = m + nT + 1;
+    c->la_selftest = 0;
+    if (!c->opt_lookahead || c->mcap < m || c->la_njcap < 3 || c->cu_count < 8)
+        return 0; // the look-ahead kernel is never eligible at this capacity / on this device
+    const size_t cnt = (size_t)c->ldz * m;
+    std::vector<double> hz(cnt, 0.0), w[2];
+    for (int j = 0; j < m; ++j) {
+        for (int i = 0; i < m; ++i) // symmetric positive definite S
+            hz[i + (size_t)j * c->ldz] = (i == j ? 4.0 : 0.0) + 1.0 / (1 + std::abs(i - j)) + 1e-3 * ((i + j) % 7);
+        for (int t = 0; t < nT; ++t)
+            hz[m + t + (size_t)j * c->ldz] = ((t * 31 + j * 17) % 23) / 23.0 - 0.5;
+        hz[m + nT + (size_t)j * c->ldz] = ((j * 5) % 13) / 13.0;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        HIPCHK(hipMemcpyAsync(c->d_Z, hz.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_W, 0, sizeof(double) * cnt, c->stream));
+        int rc;
+        if (pass == 0)
+            rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W);
+        else {
+            hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, 32, c->ldz, c->d_Z, c->d_Linv, c->d_flags);
+            HIPCHK(hipGetLastError());
+            rc = launch_lookahead(c, rows, m, c->ldz, nullptr, 0);
+        }
+        if (rc)
+            return rc;
+        w[pass].resize(cnt);
+        HIPCHK(hipMemcpyAsync(w[pass].data(), c->d_W, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    int fl[4];
+    HIPCHK(hipMemcpy(fl, c->d_flags, sizeof(fl), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(c->d_flags, 0, sizeof(int) * 4));
+    bool same = !fl[0] && fl[3] != c->la_seq;
+    for (int j = 0; j < m && same; ++j)
+        same = std::memcmp(&w[0][m + (size_t)j * c->ldz], &w[1][m + (size_t)j * c->ldz], sizeof(double) * (nT + 1)) == 0;
+    c->la_selftest = same ? 1 : -1;
+    if (!same)
+        std::fprintf(stderr, "[eqf_hip] look-ahead self-test failed on device %d (pivot flag %d, stalled %d): this context factorises on the launch chain\n", c->device, fl[0], fl[3] == c->la_seq);
     return 0;
 }
 static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, int zb = 0,
@@ -2137,12 +2134,13 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
     const int n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
     int rc = 0;
+    c->tail_la = false, c->tail_zb = false, c->tail_M = M; // retry state of finish_update: reset before anything of this tail is queued
     // EQF_OPT_Z_IN_LOOKAHEAD: with the C blocks in memory (k_measure / k_outlier_stats ran), fp64 Sigma and 3 .. 16 panels, the look-ahead kernel builds Z itself
     // (with measurement fusion - the speculative frame tail - it evaluates the C blocks as well, if the measurement has been staged to HBM: ZB = 2)
-    const bool zb_ok = c->opt_zb && !c->sig32 && !c->opt_sigma_la && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
+    const bool zb_ok = c->opt_zb && !c->sig32 && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
     // ZB = 2 up to 8 panels (N <= 128) only: measured +2.8 % at N = 50, +1.8 % at N = 100 and neutral at N = 200, where the tail's first launch then reaches
-    // the GPU late (EQF_OPT_Z_IN_LOOKAHEAD = 2 forces it for every eligible size)
-    const int zb = !zb_ok ? 0 : (!fuse ? 1 : ((fuse->y == c->d_meas && !c->opt_fused_lift && c->opt_early && (blocks(m, 32) <= 8 || c->opt_zb == 2)) ? 2 : 0));
+    // the GPU late
+    const int zb = !zb_ok ? 0 : (!fuse ? 1 : ((fuse->y == c->d_meas && c->opt_early && blocks(m, 32) <= 8) ? 2 : 0));
     c->tail_zb = zb != 0;
     c->tail_var = meas_var;
     if (!zb) {
@@ -2179,61 +2177,35 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
     const int n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
     int rc = 0;
-    if (c->opt_fused) {
-        rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, n, c->sigma(), c->d_gamma, true, spec, spec_seq);
+    const bool la = !force_chain && lookahead_eligible(c, m); // one persistent kernel instead of one launch per panel; Gamma complete in d_gamma
+    c->tail_la = la; // the retry state of finish_update always describes the tail in flight (with tail_zb / tail_M / tail_var, set by launch_update_tail)
+    if (la)
+        ++c->la_launches;
+    rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, zb, zb_mf) : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
+    if (rc)
+        return rc;
+    const int stall_seq = la ? c->la_seq : -1; // the stall word the kernels behind the factorisation compare (sequence valued: eqf_lookahead.hpp)
+    if (c->opt_early) { // Gamma, landmark lift, result packet and doorbell BEFORE the covariance update: the host round trip overlaps with it
+        rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, la ? nullptr : c->d_gpart, stall_seq);
         if (rc)
             return rc;
-    } else {
-        const bool la = !force_chain && lookahead_eligible(c, m); // one persistent kernel instead of one launch per panel; Gamma complete in d_gamma
-        c->tail_la = la;
-        if (la)
-            ++c->la_launches;
-        const bool fl = la && c->opt_early && c->opt_fused_lift; // EQF_OPT_FUSED_LIFT
-        // EQF_OPT_SIGMA_IN_LOOKAHEAD: Sigma <- Sigma - W W^T by the look-ahead kernel's own Sigma workgroups (fp64 store and arithmetic only)
-        int sigma_in_la = 0;
-        const bool sgl = la && c->opt_sigma_la && !c->sig32 && !c->opt_syrk_f32;
-        rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, fl, discreteCorr, door_seq, sgl ? &sigma_in_la : nullptr, zb, zb_mf)
-                : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, 0, nullptr, nullptr, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
-        if (rc)
-            return rc;
-        if (c->opt_early && !fl) { // Gamma, landmark lift, result packet and doorbell BEFORE the covariance update: the host round trip overlaps with it
-            // (with EQF_OPT_FUSED_LIFT the look-ahead kernel does this itself: its last T block row lifts and rings)
-            rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, la ? nullptr : c->d_gpart);
-            if (rc)
-                return rc;
-        }
+    }
+    {
         const int nt = blocks(n, 32);
-        const int syrk_tiles = nt * (nt + 1) / 2 - sigma_in_la; // what the look-ahead kernel's Sigma workgroups did not take (the table's tail)
-        c->la_sigma_tiles += sigma_in_la;
-        c->la_sigma_rest += la ? syrk_tiles : 0;
         KTimer t(c, KN_SYRK);
-        const dim3 sg(std::max(syrk_tiles, 1)), sb(64 * SYRK_NW);
-#define SYRK_LAUNCH(TS_, G_, F_) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<TS_, G_, F_>), sg, sb, 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (TS_*)c->sigma(), nt, c->d_gamma, spec, spec_seq, G_ ? 1 : 0, c->d_flags, \
-                       trace_slot(c, TR_SYRK), c->d_syrk_order + c->syrk_off[nt] + sigma_in_la)
-        const bool wg = !(c->opt_early || la);
-        if (syrk_tiles == 0) {
-            // the whole update was part of the look-ahead kernel
-        } else if (!wg && !c->opt_syrk_f32 && c->opt_sigma_la) { // EQF_OPT_SIGMA_IN_LOOKAHEAD: one accumulation chain per quadrant, the order the look-ahead kernel's Sigma workgroups follow
-            if (c->sig32)
-                hipLaunchKernelGGL(k_syrk_sub_q<float>, sg, dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (float*)c->sigma(), spec, spec_seq, c->d_flags, trace_slot(c, TR_SYRK),
-                                   c->d_syrk_order + c->syrk_off[nt] + sigma_in_la);
-            else
-                hipLaunchKernelGGL(k_syrk_sub_q<double>, sg, dim3(256), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(), spec, spec_seq, c->d_flags, trace_slot(c, TR_SYRK),
-                                   c->d_syrk_order + c->syrk_off[nt] + sigma_in_la);
-        } else if (c->opt_syrk_f32) { // EQF_OPT_SYRK_F32: the fp32-arithmetic A/B (operands rounded to float, f32 MFMA)
-            if (c->sig32) { if (wg) SYRK_LAUNCH(float, true, true); else SYRK_LAUNCH(float, false, true); }
-            else { if (wg) SYRK_LAUNCH(double, true, true); else SYRK_LAUNCH(double, false, true); }
-        } else {
-            if (c->sig32) { if (wg) SYRK_LAUNCH(float, true, false); else SYRK_LAUNCH(float, false, false); }
-            else { if (wg) SYRK_LAUNCH(double, true, false); else SYRK_LAUNCH(double, false, false); }
-        }
+        const dim3 sg(nt * (nt + 1) / 2), sb(64 * SYRK_NW);
+#define SYRK_LAUNCH(TS_, G_) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_sub<TS_, G_>), sg, sb, 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (TS_*)c->sigma(), nt, c->d_gamma, spec, spec_seq, G_ ? 1 : 0, c->d_flags, \
+                       trace_slot(c, TR_SYRK), c->d_syrk_order + c->syrk_off[nt], stall_seq)
+        const bool wg = !(c->opt_early || la); // EQF_OPT_EARLY_LIFT = 0 on the launch chain: Gamma = W z is a by-product of the diagonal tiles
+        if (c->sig32) { if (wg) SYRK_LAUNCH(float, true); else SYRK_LAUNCH(float, false); }
+        else { if (wg) SYRK_LAUNCH(double, true); else SYRK_LAUNCH(double, false); }
 #undef SYRK_LAUNCH
         HIPCHK(hipGetLastError());
     }
     { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }
-    if (c->opt_fused || !c->opt_early) {
-        rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, nullptr);
+    if (!c->opt_early) {
+        rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, nullptr, stall_seq);
         if (rc)
             return rc;
     }
@@ -2251,8 +2223,7 @@ static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
     c->h_flags[0] = c->h_resflags[0];
     c->h_flags[1] = c->h_resflags[1];
     // A failed factorisation is reported BEFORE anything of the filter changes: the device kept Sigma and the landmarks (k_lift,
-    // k_syrk_sub), the sensor lift below is not applied. (EQF_OPT_FUSED_UPDATE folds the Sigma update into the factorisation steps and
-    // cannot offer this; it is off by default.)
+    // k_syrk_sub), the sensor lift below is not applied.
     if (c->h_resflags[3] && !c->h_flags[0] && c->tail_la && !retried) {
         // A bounded wait of the look-ahead kernel ran out: its workgroups were not all resident within the bound (another process or a long kernel
         // of this process holds the CUs). Nothing of the filter was modified, and Z / L_0^-1 are inputs of that kernel only: redo the factorisation
@@ -2482,7 +2453,7 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
     c->meas_star = useEqv ? 1 : 0;
     c->meas_ids.assign(ids, ids + M);
     c->busy_meas = true;
-    if (!speculate && max_outliers >= 0 && N <= SEL_MAXN && !c->opt_fused) {
+    if (!speculate && max_outliers >= 0 && N <= SEL_MAXN) {
         // Outlier candidates frame after frame (speculation has backed off): statistics, the outlier decision (k_select_outliers: the discarded
         // landmarks' measurements are masked out of C) and the whole update queued at once, ONE host wait. The discarded landmarks leave the
         // state after the update (an unmeasured landmark can be marginalised before or after it).
@@ -2759,6 +2730,8 @@ int eqf_lookahead_stats(eqf_ctx* c, long* launches, long* fallbacks, int reset) 
         c->la_launches = c->la_fallbacks = 0;
     return 0;
 }
+
+int eqf_lookahead_selftest(const eqf_ctx* c) { return c ? c->la_selftest : EQF_E_BAD_ARG; }
 
 int eqf_nees_lu_fallbacks(eqf_ctx* c, long* count) {
     if (!c || !count)

@@ -1453,80 +1453,13 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
     }
 }
 
-// Sigma fusion (nsig > 0): the workgroups with blockIdx.y >= nyS own the lower 32x32 tiles of Sigma and apply this
-// panel's share of the covariance update, Sigma -= W_k W_k^T (VIO_eqf.cpp:131 with K C Sigma = W W^T), in the shadow of
-// the diagonal-tile elimination; their diagonal tiles also accumulate Gamma += W_k z_k (VIO_eqf.cpp:119). In effect the
-// factorisation runs on [[S, T^T],[T, Sigma]] and stops after the S block: what is left in the corner is the Schur
-// complement Sigma - T S^-1 T^T.
-// First half of a two-phase step: P_I = Z[I, panel] L^-T for every block row I >= c0, ONE workgroup per block row, stored in the
-// panel's columns of Wout (rows >= m of it are the final W / z rows anyway; the rows < m are scratch). Same operand layout and
-// MFMA order as the in-step evaluation: the values are bit-identical to it.
-__global__ void __launch_bounds__(256) k_chol_panel(int rows, int kb, int w, int ldz, const double* __restrict__ Z, double* __restrict__ Wout,
-                                                    const double* __restrict__ LinvIn, const int* __restrict__ spec, int spec_seq) {
-    if (spec && *spec == spec_seq)
-        return; // cancelled speculative tail
-    const int c0 = kb + w;
-    const int i0 = c0 + blockIdx.x * 32;
-    __shared__ double sLinv[32 * CH_LDP];
-    __shared__ double sPI[32 * CH_LDP];
-    const int tid = threadIdx.x;
-    const int r = tid & 31, g = tid >> 5;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int lr = lane & 15, lk = lane >> 4;
-    double lv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        lv[k] = LinvIn[r + 32 * (g + 8 * k)];
-    const int ihP = wave & 1;
-    double opI[8];
-    {
-        const int rowI = i0 + 16 * ihP + lr;
-        const int rowIc = min(rowI, rows - 1);
-        const double zI = rowI < rows ? 1.0 : 0.0;
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            const int p = 4 * st + lk;
-            const int pc = min(p, w - 1);
-            const double zp = p < w ? 1.0 : 0.0;
-            opI[st] = Z[rowIc + (size_t)(kb + pc) * ldz] * (zI * zp);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        sLinv[r + (g + 8 * k) * CH_LDP] = lv[k];
-    __syncthreads();
-    {
-        const int ch = wave >> 1;
-        d4 accI = {0, 0, 0, 0};
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            const double b = sLinv[16 * ch + lr + (4 * st + lk) * CH_LDP];
-            accI = __builtin_amdgcn_mfma_f64_16x16x4f64(b, opI[st], accI, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            sPI[16 * ihP + lr + (16 * ch + lk + 4 * q) * CH_LDP] = accI[q];
-    }
-    __syncthreads();
-    const int row = i0 + r;
-    if (row < rows) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = g + 8 * k;
-            if (c < w)
-                Wout[row + (size_t)(kb + c) * ldz] = sPI[r + c * CH_LDP];
-        }
-    }
-}
 constexpr int GAMMA_G = 4; // column groups of the Gamma partials computed by the last step launch
-// Template flags, so that the ordinary step (12 of 13 launches at N = 200) carries none of the optional code: PRE = second half of a
-// two-phase step (P ready-made in Ppre); SIGF = the fused covariance update rides along (nsig > 0); GAM = last launch of the
-// unfused chain, produces the Gamma partials (gpart).
-template <bool PRE, bool SIGF, bool GAM>
+// Template flag, so that the ordinary step carries none of the optional code: GAM = last launch of the chain, produces the Gamma partials (gpart).
+// (Rounds 1-3 also had a fused covariance update and two-phase steps in here; measured slower, removed in round 4: DESIGN_APPENDIX.md, git tag r04-before-prune.)
+template <bool GAM>
 __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int w, int ldz, double* __restrict__ Z, double* __restrict__ Wout,
                                                    const double* __restrict__ LinvIn, double* __restrict__ LinvOut, int* __restrict__ flags, int update, int nyS,
-                                                   int nsig, int ldsig, double* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq,
-                                                   double* __restrict__ gpart, int ldg, trace_t* tr, const double* __restrict__ Ppre) {
+                                                   const int* __restrict__ spec, int spec_seq, double* __restrict__ gpart, int ldg, trace_t* tr) {
     trace_start(tr);
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
@@ -1567,28 +1500,10 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
             gpart[(size_t)g * ldg + wr] = ((sp[r] + sp[32 + r]) + (sp[64 + r] + sp[96 + r])) + ((sp[128 + r] + sp[160 + r]) + (sp[192 + r] + sp[224 + r]));
         return;
     }
-    int i0, j0, ilim = rows, jlim = m;
-    const bool sig = SIGF && (int)blockIdx.y >= nyS;
-    if (sig) {
-        const int nt = (nsig + 31) >> 5;
-        int L = ((int)blockIdx.y - nyS) * (int)gridDim.x + (int)blockIdx.x;
-        if (L >= nt * (nt + 1) / 2)
-            return;
-        int bj = 0;
-        while (L >= nt - bj) { // column bj holds (nt - bj) lower tiles
-            L -= nt - bj;
-            ++bj;
-        }
-        i0 = m + 32 * (bj + L);
-        j0 = m + 32 * bj;
-        ilim = jlim = m + nsig;
-        update = 1;
-    } else {
-        i0 = c0 + blockIdx.x * 32;
-        j0 = c0 + blockIdx.y * 32;
-        if (update && (i0 + 31 < j0))
-            return; // strictly upper tile of the symmetric part: never read
-    }
+    const int ilim = rows, jlim = m;
+    const int i0 = c0 + blockIdx.x * 32, j0 = c0 + blockIdx.y * 32;
+    if (update && (i0 + 31 < j0))
+        return; // strictly upper tile of the symmetric part: never read
     __shared__ double sLinv[32 * CH_LDP];
     __shared__ double sPI[32 * CH_LDP];
     __shared__ double sPJ[32 * CH_LDP];
@@ -1601,31 +1516,13 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     const bool needJ = update && !diag_tile;
     // 0. issue every global load up front: L^-1, the panel rows of I and J in MFMA operand layout
     //    (Zp[row][p], p = 4 st + lk) and the output tile
-    // Two-phase steps (Ppre != nullptr, k_chol_panel ran just before): P_I and P_J come ready-made from Ppre instead of being
-    // recomputed by every workgroup of a block row / column (two thirds of a trailing tile's work at N = 500).
-    const bool pre = PRE && !sig;
-    double lv[4] = {0, 0, 0, 0};
-    if (!pre) {
+    double lv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            lv[k] = LinvIn[r + 32 * (g + 8 * k)];
-    }
+    for (int k = 0; k < 4; ++k)
+        lv[k] = LinvIn[r + 32 * (g + 8 * k)];
     const int ihP = wave & 1;
     double opI[8], opJ[8];
-    double ppI[4] = {0, 0, 0, 0}, ppJ[4] = {0, 0, 0, 0};
-    if (pre) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = g + 8 * k;
-            const int cc = min(c, w - 1);
-            const double zc = c < w ? 1.0 : 0.0;
-            ppI[k] = Ppre[min(i0 + r, ilim - 1) + (size_t)(kb + cc) * ldz] * ((i0 + r < ilim) ? zc : 0.0);
-            ppJ[k] = (update && i0 != j0) ? Ppre[min(j0 + r, jlim - 1) + (size_t)(kb + cc) * ldz] * ((j0 + r < jlim) ? zc : 0.0) : 0.0;
-        }
-#pragma unroll
-        for (int st = 0; st < 8; ++st)
-            opI[st] = opJ[st] = 0.0;
-    } else {
+    {
         const int rowI = i0 + 16 * ihP + lr, rowJ = j0 + 16 * ihP + lr;
         const int rowIc = min(rowI, ilim - 1), rowJc = min(rowJ, jlim - 1);
         const double zI = rowI < ilim ? 1.0 : 0.0, zJ = (needJ && rowJ < jlim) ? 1.0 : 0.0;
@@ -1647,7 +1544,7 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = min(j0 + 16 * jhU + lk + 4 * q, jlim - 1);
-            zt[q] = sig ? Sig[(i - m) + (size_t)(j - m) * ldsig] : (update ? Z[i + (size_t)j * ldz] : 0.0);
+            zt[q] = update ? Z[i + (size_t)j * ldz] : 0.0;
         }
     }
 #pragma unroll
@@ -1657,14 +1554,7 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
         swork[32 + tid] = yv;
     __syncthreads();
     // 2. P = Zpanel * Linv^T : P[i][c] = sum_p Zp[i][p] Linv[c][p]; wave -> 16x16 sub-tile (ih, ch) of P_I and of P_J
-    if (pre) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sPI[r + (g + 8 * k) * CH_LDP] = ppI[k];
-            if (needJ)
-                sPJ[r + (g + 8 * k) * CH_LDP] = ppJ[k];
-        }
-    } else {
+    {
         const int ch = wave >> 1;
         d4 accI = {0, 0, 0, 0}, accJ = {0, 0, 0, 0};
 #pragma unroll
@@ -1682,8 +1572,8 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
         }
     }
     __syncthreads();
-    // 4. final W / z rows of this panel (k_chol_panel has stored them in two-phase steps)
-    if (!sig && !pre && blockIdx.y == 0) {
+    // 4. final W / z rows of this panel
+    if (blockIdx.y == 0) {
         const int row = i0 + r;
         if (row < rows && row >= m) {
 #pragma unroll
@@ -1713,26 +1603,8 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     }
     if (!update)
         return;
-    if (sig && diag_tile) {
-        // Gamma[I] (+)= P_I z,  z_c = sum_p yTilde[p] Linv[c][p]  (the yTilde row of Z is row rows - 1)
-        if (tid < 32) {
-            double z = 0.0;
-            for (int p2 = 0; p2 < w; ++p2)
-                z = fma(Z[(rows - 1) + (size_t)(kb + p2) * ldz], sLinv[tid + p2 * CH_LDP], z);
-            swork[tid] = z;
-        }
-        __syncthreads();
-        if (tid < 32 && i0 + tid < ilim) {
-            double gsum = 0.0;
-#pragma unroll 8
-            for (int c = 0; c < 32; ++c)
-                gsum = fma(sPI[tid + c * CH_LDP], swork[c], gsum);
-            const int gi = i0 + tid - m;
-            gamma[gi] = (kb == 0) ? gsum : gamma[gi] + gsum;
-        }
-    }
     // 3. Z[I, J] -= P_I P_J^T : wave -> 16x16 sub-tile (ihU, jhU), K = 32
-    const bool next_diag = (!sig && blockIdx.x == 0 && blockIdx.y == 0);
+    const bool next_diag = (blockIdx.x == 0 && blockIdx.y == 0);
     {
         const double* pj = diag_tile ? sPI : sPJ;
         d4 acc = {0, 0, 0, 0};
@@ -1748,13 +1620,7 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
         for (int q = 0; q < 4; ++q) {
             const int j = j0 + 16 * jhU + lk + 4 * q;
             const double v = zt[q] - acc[q];
-            if (sig) {
-                if (i < ilim && j < jlim && (!diag_tile || i >= j)) {
-                    Sig[(i - m) + (size_t)(j - m) * ldsig] = v;
-                    if (i != j)
-                        Sig[(j - m) + (size_t)(i - m) * ldsig] = v;
-                }
-            } else if (i < rows && j < m && (!next_diag || i >= m))
+            if (i < rows && j < m && (!next_diag || i >= m))
                 Z[i + (size_t)j * ldz] = v; // (the next diagonal tile itself stays on chip: nobody reads it from Z again)
             if (next_diag)
                 sPJ[16 * ihU + lr + (16 * jhU + lk + 4 * q) * CH_LDP] = v; // keep the updated next-diagonal tile on chip
@@ -1792,10 +1658,7 @@ struct TileRed {
 };
 // If zvec != nullptr the workgroup also returns, in gv_out (valid in lanes 0..31 of the workgroup), the GEMV by-product
 // g[i0 + t] = sum_k P[i0 + t][k] * zvec[k * ldzv] from the operand values it loads anyway.
-// F32 (EQF_OPT_SYRK_F32, the fp32-arithmetic A/B of DESIGN.md §6): the operands are rounded to float and multiplied on
-// v_mfma_f32_16x16x4_f32 (twice the issue rate of the f64 form on gfx950; same A/B lane layout, C/D rows 4 (lane >> 4) + r instead of
-// (lane >> 4) + 4 r); a wave accumulates its K slice in f32, the slices are summed in fp64 as before.
-template <bool WITH_GEMV, int NW = 4, bool F32 = false>
+template <bool WITH_GEMV, int NW = 4>
 __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__ P, int ldp, int i0, int rowsP, const double* __restrict__ Qm, int ldq, int j0,
                                                       int rowsQ, int K, double* __restrict__ sred /* 4*1024 doubles */, const double* __restrict__ zvec = nullptr,
                                                       int ldzv = 0, double* gv_out = nullptr) {
@@ -1807,8 +1670,6 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
     const double zia = (i0 + lr < rowsP) ? 1.0 : 0.0, zib = (i0 + 16 + lr < rowsP) ? 1.0 : 0.0;
     const double zja = (j0 + lr < rowsQ) ? 1.0 : 0.0, zjb = (j0 + 16 + lr < rowsQ) ? 1.0 : 0.0;
     d4 acc00 = {0, 0, 0, 0}, acc10 = acc00, acc01 = acc00, acc11 = acc00;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 fcc00 = {0, 0, 0, 0}, fcc10 = fcc00, fcc01 = fcc00, fcc11 = fcc00;
     double ga = 0.0, gb = 0.0;
     const int nsteps = (K + 3) >> 2;
 #pragma unroll 4
@@ -1825,18 +1686,10 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
             ga = fma(pa, zv, ga);
             gb = fma(pb, zv, gb);
         }
-        if constexpr (F32) {
-            const float paf = (float)pa, pbf = (float)pb, qaf = (float)qa, qbf = (float)qb;
-            fcc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(qaf, paf, fcc00, 0, 0, 0);
-            fcc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(qaf, pbf, fcc10, 0, 0, 0);
-            fcc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(qbf, paf, fcc01, 0, 0, 0);
-            fcc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(qbf, pbf, fcc11, 0, 0, 0);
-        } else {
-            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pa, acc00, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pb, acc10, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pa, acc01, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pb, acc11, 0, 0, 0);
-        }
+        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pa, acc00, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, pb, acc10, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pa, acc01, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb, pb, acc11, 0, 0, 0);
     }
     // The NW partial tiles are summed four at a time through 4 x 1024 doubles of LDS (NW = 8: two rounds; 64 KB for all eight at once allowed two
     // workgroups per CU, 32 KB allows four). Same additions in the same order as one pass over all of them: sum = 0; sum += (p0 + p1) + (p2 + p3); ...
@@ -1852,11 +1705,11 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
             double* mine = sred + (wave - q0) * 1024;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = F32 ? 4 * lk + r : lk + 4 * r;
-                mine[lr + 32 * j] = F32 ? (double)fcc00[r] : acc00[r];
-                mine[16 + lr + 32 * j] = F32 ? (double)fcc10[r] : acc10[r];
-                mine[lr + 32 * (16 + j)] = F32 ? (double)fcc01[r] : acc01[r];
-                mine[16 + lr + 32 * (16 + j)] = F32 ? (double)fcc11[r] : acc11[r];
+                const int j = lk + 4 * r;
+                mine[lr + 32 * j] = acc00[r];
+                mine[16 + lr + 32 * j] = acc10[r];
+                mine[lr + 32 * (16 + j)] = acc01[r];
+                mine[16 + lr + 32 * (16 + j)] = acc11[r];
             }
         }
         __syncthreads();
@@ -1917,16 +1770,16 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 // That order gives the host the frame's results one kernel early: its round trip (results, filter logic, the next frame's
 // launches) overlaps with Sigma -= W W^T instead of leaving the GPU idle after it.
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
-template <typename TS, bool WITH_GAMMA, bool F32 = false>
+template <typename TS, bool WITH_GAMMA>
 // tile_of_block (round 3): which lower tile (bi | bj << 16) block b works on. Workgroups are dealt round robin to the 8 XCDs (block b runs on XCD b % 8) and every
 // XCD has its own L2: with the tiles handed out in plain column order each XCD touched every 32-row panel of W (131 MB fetched for 12 MB of W at N = 500).
 // The table (built on the host, eqf_hip.hip: build_syrk_order) gives XCD x a compact square of the tile triangle and walks it column by column, so that an
 // XCD fetches ~2 sqrt(tiles / 8) row panels of W instead of all of them.
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
                                                   double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma, const int* __restrict__ flags,
-                                                  trace_t* tr, const int* __restrict__ tile_of_block) {
+                                                  trace_t* tr, const int* __restrict__ tile_of_block, int stall_seq) {
     trace_start(tr);
-    const int failed = flags[0] | flags[3]; // requested together with the cancellation word: one round trip
+    const int failed = flags[0] | (flags[3] == stall_seq ? 1 : 0); // requested together with the cancellation word: one round trip
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
     if (failed)
@@ -1940,9 +1793,9 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
     double gv = 0.0;
     TileRed t;
     if (WITH_GAMMA && bi == bj)
-        t = mfma_tile32_splitk<true, SYRK_NW, F32>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
+        t = mfma_tile32_splitk<true, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
     else
-        t = mfma_tile32_splitk<false, SYRK_NW, F32>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
+        t = mfma_tile32_splitk<false, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
     if (WITH_GAMMA && bi == bj && threadIdx.x < 32 && i0 + threadIdx.x < n)
         gamma[i0 + threadIdx.x] = gv;
     if (threadIdx.x >= 256)
@@ -1961,83 +1814,6 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
     trace_end(tr);
 }
 
-// K9, round 3: the same update with ONE accumulation chain per 16 x 16 quadrant (a wave owns a quadrant and walks all of K in ascending order; no split of K
-// over waves, no reduction through LDS). This is the order of additions that the look-ahead kernel's Sigma workgroups can follow panel by panel as W
-// appears (eqf_lookahead.hpp: la_sigma), with the result in the accumulator when the last panel arrives - both call syrk_quadrant_panel, so Sigma+ is
-// bit-identical whichever of the two ran. k_syrk_sub above stays for its by-products (Gamma with EQF_OPT_EARLY_LIFT = 0) and the f32-arithmetic experiment.
-//
-// Panel p = the k4-steps 8 p .. 8 p + 7 (columns 32 p .. 32 p + 31 of W) added to the quadrant (rows i0 .. i0 + 15) x (rows j0 .. j0 + 15) of W W^T.
-// Operand order and masks as in mfma_tile32_splitk: a lane's results are C[i0 + (l & 15)][j0 + (l >> 4) + 4 r].
-__device__ __forceinline__ void syrk_quadrant_panel(const double* __restrict__ W, int ldz, int n, int K, int i0, int j0, int p, d4& acc) {
-    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-    const int ia = min(i0 + lr, n - 1), ja = min(j0 + lr, n - 1);
-    const double zi = (i0 + lr < n) ? 1.0 : 0.0, zj = (j0 + lr < n) ? 1.0 : 0.0;
-    const int nsteps = (K + 3) >> 2;
-    double pa[8], qa[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int kc = min(4 * (8 * p + s) + lk, K - 1);
-        if (8 * p + s < nsteps) {
-            pa[s] = W[ia + (size_t)kc * ldz];
-            qa[s] = W[ja + (size_t)kc * ldz];
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-        if (8 * p + s < nsteps) {
-            const double zk = (4 * (8 * p + s) + lk < K) ? 1.0 : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s] * zj, pa[s] * (zi * zk), acc, 0, 0, 0);
-        }
-}
-// the quadrant's entries of Sigma (lower triangle of the diagonal tiles; the strictly lower ones mirrored so that Sigma stays exactly symmetric)
-template <typename TS> __device__ __forceinline__ void syrk_quadrant_load(const TS* __restrict__ Sig, int ld, int n, int i0, int j0, double (&s0)[4]) {
-    const int lane = threadIdx.x & 63, i = i0 + (lane & 15);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int j = j0 + (lane >> 4) + 4 * e;
-        s0[e] = (i < n && j < n) ? (double)Sig[i + (size_t)j * ld] : 0.0;
-    }
-}
-template <typename TS> __device__ __forceinline__ void syrk_quadrant_store(TS* __restrict__ Sig, int ld, int n, int i0, int j0, bool diag_tile, const double (&s0)[4], const d4& acc) {
-    const int lane = threadIdx.x & 63, i = i0 + (lane & 15);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int j = j0 + (lane >> 4) + 4 * e;
-        if (i < n && j < n && (!diag_tile || i >= j)) {
-            const TS v = (TS)(s0[e] - acc[e]);
-            Sig[i + (size_t)j * ld] = v;
-            if (i != j)
-                Sig[j + (size_t)i * ld] = v;
-        }
-    }
-}
-// one workgroup (4 waves = 4 quadrants) per lower 32 x 32 tile; the quadrant of a diagonal tile that lies strictly above the diagonal is its mirror's
-template <typename TS>
-__global__ void __launch_bounds__(256) k_syrk_sub_q(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, const int* __restrict__ spec, int spec_seq,
-                                                    const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block) {
-    trace_start(tr);
-    const int failed = flags[0] | flags[3];
-    if (spec && *spec == spec_seq)
-        return; // cancelled speculative tail
-    if (failed)
-        return; // the factorisation failed (see k_lift): Sigma stays as it was
-    const int code = tile_of_block[blockIdx.x];
-    const int bi = code & 0xffff, bj = code >> 16;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int qi = wave & 1, qj = wave >> 1;
-    if (bi == bj && qi == 0 && qj == 1)
-        return;
-    const int i0 = 32 * bi + 16 * qi, j0 = 32 * bj + 16 * qj;
-    const double* W = Wb + m;
-    double s0[4];
-    syrk_quadrant_load(Sig, ld, n, i0, j0, s0);
-    d4 acc = {0, 0, 0, 0};
-    const int NJ = (m + 31) >> 5;
-    for (int p = 0; p < NJ; ++p)
-        syrk_quadrant_panel(W, ldz, n, m, i0, j0, p, acc);
-    syrk_quadrant_store(Sig, ld, n, i0, j0, bi == bj, s0, acc);
-    trace_end(tr);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // K10: landmark part of X <- Delta * X with Delta lifted from Gamma (liftInnovation / liftInnovationDiscrete,
@@ -2101,7 +1877,7 @@ __device__ __forceinline__ double gamma_row(const double* __restrict__ gamma, co
 __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, double* __restrict__ gamma, const double* __restrict__ q0,
                                              double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
                                              const int* __restrict__ flags, int* __restrict__ flags_host, int* __restrict__ door_count, int* __restrict__ door_host,
-                                             int door_seq, const int* __restrict__ spec, int spec_seq, const double* __restrict__ gpart, int ldg, trace_t* tr) {
+                                             int door_seq, const int* __restrict__ spec, int spec_seq, const double* __restrict__ gpart, int ldg, trace_t* tr, int stall_seq) {
     trace_start(tr);
     // est / gamma_host / flags_host point into the pinned host packet: the results reach the host without copy kernels.
     // Every load this kernel needs is requested before the first result is used (Gamma partials, landmark state, chart constant, status
@@ -2112,7 +1888,7 @@ __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int dis
     const double gs = gamma_row(gamma, gpart, ldg, i < 21 ? i : 0);
     const double g0 = gamma_row(gamma, gpart, ldg, 21 + 3 * ic), g1 = gamma_row(gamma, gpart, ldg, 21 + 3 * ic + 1), g2 = gamma_row(gamma, gpart, ldg, 21 + 3 * ic + 2);
     const LiftIn in = lift_load(ic, Ncap, chart, discrete, q0, Qq, Qa);
-    const int f0 = flags[0], f1 = flags[1], f3 = flags[3];
+    const int f0 = flags[0], f1 = flags[1], f3 = flags[3] == stall_seq ? 1 : 0; // the stall word of the look-ahead launch in front (stall_seq = -1: launch chain, cannot stall)
     const int specv = spec ? __hip_atomic_load(spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const bool aborted = spec && specv == spec_seq; // speculative tail cancelled by the statistics kernel
     // A factorisation that met a non-positive pivot (flags[0], EQF_E_NOT_SPD) or whose bounded wait ran out (flags[3], EQF_E_STALLED) leaves

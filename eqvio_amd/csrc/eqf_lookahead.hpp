@@ -28,7 +28,8 @@
 //  * Gamma = W z is accumulated by the T block rows on the way (z_p = yTilde_p L_p^-T from the published yTilde row), so the lift
 //    kernel finds Gamma complete.
 //  * Every poll is bounded (20 ms of device wall clock); a timeout raises flags[3] (EQF_E_STALLED) and the workgroups drain.
-//    Dependencies point from higher to lower block rows and to the owner only, and NI <= 80 workgroups of 64 KB LDS always fit the chip.
+//    Dependencies point from higher to lower block rows and to the owner only; the host launches this kernel only when its NI workgroups (66 at
+//    N = 200, 161 at N = 512) fit the device at one workgroup per compute unit (eqf_hip.hip: lookahead_eligible).
 #pragma once
 #include "eqf_kernels.hpp"
 
@@ -49,26 +50,11 @@ struct LaArgs {
     int* pubf;           // their flags
     char* puby;          // the yTilde row of every panel as 16-byte (value, sequence) words
     double* gamma;       // out: Gamma[n]
-    int* flags;          // [0] non-positive pivot, [3] stalled
+    int* flags;          // [0] non-positive pivot, [3] = seq: a bounded wait of this launch ran out
     const int* spec;
     int spec_seq;
-    // the frame's results leave from this kernel (what k_lift does behind the launch chain): the last T block row to finish lifts the
-    // landmarks, fills the pinned result packet and rings the host doorbell
-    int lift_N, lift_Ncap, lift_chart, lift_discrete;
-    const double* lift_q0;
-    double *lift_Qq, *lift_Qa;
-    double *lift_est, *lift_gamma_host; // pinned
-    int *lift_flags_host, *lift_done, *lift_door_host;
-    int lift_door_seq;
-    trace_t* tr_lift;
     trace_t* tr_steps;       // EQF_OPT_TRACE: slot of step 0 (the owner stamps one slot per step), or nullptr
-    unsigned long long* dbg; // EQF_OPT_TRACE: per-step stamps inside the owner ([k][8]) and two block rows ([32 + p][8], [64 + p][8]), or nullptr    // Sigma <- Sigma - W W^T under the factorisation (EQF_OPT_SIGMA_IN_LOOKAHEAD; la_sigma below): the workgroups NI .. NI + sg_nwg - 1
-    int sg_n, sg_ld;      // rows and leading dimension of Sigma (sg_n = 0: no Sigma workgroups; the T half-rows then store W with plain stores)
-    int sg_nwg, sg_spw;   // Sigma workgroups and 16 x 16 quadrants per wave (<= the kernel's SQ); a workgroup takes 2 sg_spw tiles
-    int sg_ntiles;        // tiles taken here: entries 0 .. sg_ntiles - 1 of sg_tiles (the rest, if any, is left to a k_syrk_sub_q launch behind this kernel)
-    double* sg_sigma;
-    const int* sg_tiles;  // k_syrk_sub_q's tile table (bi | bj << 16)
-    int* sg_wflags;       // flag of (panel p, T half-row t) at [p NT + t]: the W rows of that half-row for that panel are at the coherence point
+    unsigned long long* dbg; // EQF_OPT_TRACE: per-step stamps inside the owner ([k][8]) and two block rows ([32 + p][8], [64 + p][8]), or nullptr
     // EQF_OPT_Z_IN_LOOKAHEAD (ZB instantiations): no k_build_Z launch in front of this kernel - every half-row builds its own 16 rows of Z = [S ; T ; yTilde^T]
     // from Sigma and the output blocks C_j (the expressions of k_build_Z: bz_T_pair / bz_S_block), the owner builds and eliminates the first tile
     const double* zb_sig; // Sigma (fp64), leading dimension zb_ld
@@ -226,8 +212,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         if (ZB == 2) {
             if (tid == 0) { // this launch's status words start clean (write-through: no dirty line of them may outlive a later write-through set)
                 __hip_atomic_store(a.flags + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.flags + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.flags + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.flags + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (flags[3], the stall word, is sequence valued: never cleared)
             }
             if (tid < 16 && tid < M) {
                 int lidx;
@@ -558,7 +543,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 //   wave w: jh = w & 1 is the 16-column half of a tile, jr = w >> 1 the tile column modulo 4; acc[t] = Z(h, J = 4 t + jr)[:, 16 jh .. 16 jh + 15].
 //   A wave's B operand is rows 16 jh .. 16 jh + 15 of P_J, i.e. what ONE half-row (2 J + jh) published: flags are per (panel, half-row).
 //   P^(p)_h = Z(h, p) L_p^-T is formed by waves 0 / 1 (column halves; the zero block of the triangular L_p^-1 skipped).
-template <int MAXT, bool SG, int ZB> // SG: the instantiation has Sigma workgroups (EQF_OPT_SIGMA_IN_LOOKAHEAD): the T half-rows publish their W rows; ZB: the rows of Z are built here
+template <int MAXT, int ZB> // ZB: the rows of Z are built here
 __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* row_cnt, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     double* sLinv = smem;                   // L_p^-1, operand layout [r + c CH_LDP]
@@ -800,12 +785,8 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         } else {
             const int r = tid & 15, c = tid >> 4;
             const double pv = sPI[r + c * CH_LDP];
-            if (row0 + r < rows && c < w) {
-                if (SG && a.sg_n) // read by the Sigma workgroups of this launch: write-through, flag at the end of the panel
-                    la_st(a.W + (row0 + r) + (size_t)(32 * p + c) * ldz, pv);
-                else
-                    a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = pv;
-            }
+            if (row0 + r < rows && c < w)
+                a.W[(row0 + r) + (size_t)(32 * p + c) * ldz] = pv;
             const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
             gsum = fma(pv, c < w ? zc : 0.0, gsum);
         }
@@ -868,12 +849,6 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         }
         if (dbg_row)
             dbr[2] = wall_clock64();
-        if (SG && !srow && a.sg_n) {
-            // the W rows of this panel were stored in step (c), a whole trailing update ago: the wait is free. The last wave to pass raises the flag.
-            la_stores_done();
-            if (lane == 0 && __hip_atomic_fetch_add(row_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * p + 7)
-                __hip_atomic_store(a.sg_wflags + (size_t)p * (a.NI - (2 * NJ - 1)) + (hidx - 2 * NJ), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
     if (srow)
         hand_off(); // after panel I-3 (block rows 1 and 2 have no panel to wait for: their tiles go to the owner as they are)
@@ -900,7 +875,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
 // to it before anything else, form P_h(p+1) = Z(h, p+1) L_(p+1)^-T with the L_(p+1)^-1 they fetched on the way (the owner is ahead), publish it
 // (S half-rows) and only then turn to their other tiles - while the other six waves are in the trailing update of panel p. One workgroup barrier per
 // panel; P_h, L^-1 and z in LDS are double buffered by panel parity. Same products in the same order per tile: bit-identical to la_row and to the chain.
-template <int MAXT, bool srow, bool SG>
+template <int MAXT, bool srow>
 __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* cnt, const LaPoll& pl) {
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -913,7 +888,6 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
     auto sZpB = [&](int b) -> double* { return smem + 3 * B + 256 * (b % 3); }; // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32]), three buffers like P_h
     int* pair_cnt = cnt;     // the two waves of a look-ahead pair: tile and L^-1 in LDS
     int* pub_cnt = cnt + 1;  // ... their halves of P_h acknowledged (S half-rows)
-    int* w_cnt = cnt + 2;    // EQF_OPT_SIGMA_IN_LOOKAHEAD: the eight waves' W rows of a panel acknowledged (T half-rows)
     const int NJ = a.NJ, m = a.m, rows = a.rows, ldz = a.ldz, seq = a.seq;
     const int I = hidx >> 1, s = hidx & 1;
     const int row0 = srow ? 16 * hidx : m + 16 * (hidx - 2 * NJ);
@@ -1005,12 +979,8 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         const int wq = min(32, m - 32 * q);
         const int r = tid & 15, c = tid >> 4;
         const double pv = sPIB(q)[r + c * CH_LDP];
-        if (row0 + r < rows && c < wq) {
-            if (SG && a.sg_n)
-                la_st(a.W + (row0 + r) + (size_t)(32 * q + c) * ldz, pv);
-            else
-                a.W[(row0 + r) + (size_t)(32 * q + c) * ldz] = pv;
-        }
+        if (row0 + r < rows && c < wq)
+            a.W[(row0 + r) + (size_t)(32 * q + c) * ldz] = pv;
         const double* sZp = sZpB(q);
         const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
         gsum = fma(pv, c < wq ? zc : 0.0, gsum);
@@ -1212,11 +1182,6 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             if (wave == 3)
                 dbr[6] = wall_clock64();
         }
-        if (SG && !srow && a.sg_n && p > 0) { // the W rows of panel p - 1 were stored at the top of this panel
-            la_stores_done();
-            if (lane == 0 && __hip_atomic_fetch_add(w_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * (p - 1) + 7)
-                __hip_atomic_store(a.sg_wflags + (size_t)(p - 1) * (a.NI - (2 * NJ - 1)) + (hidx - 2 * NJ), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         if (p + 1 < np) {
             if (tid == 0 && s_abort[1])
                 s_abort[0] = 1;
@@ -1231,11 +1196,6 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         __syncthreads(); // z of the last panel is complete
         if (np > 0) {
             store_w(np - 1);
-            if (SG && a.sg_n) {
-                la_stores_done();
-                if (lane == 0 && __hip_atomic_fetch_add(w_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 8 * (np - 1) + 7)
-                    __hip_atomic_store(a.sg_wflags + (size_t)(np - 1) * (a.NI - (2 * NJ - 1)) + (hidx - 2 * NJ), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
         __syncthreads(); // the Gamma partial sums below overwrite the third P_h buffer
         sT[tid] = gsum; // [c][r]
@@ -1249,134 +1209,6 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             la_st(a.gamma + (row - m), g);
         }
     }
-}
-
-// ---- Sigma <- Sigma - W W^T under the factorisation -----------------------------------------------------------------------------------
-// Round 3. The covariance update was a kernel of its own behind the factorisation: 14 us of the 106 us frame at N = 200 for 3 us of MFMA work, and the
-// factorisation leaves most of the chip idle (66 workgroups at N = 200). The workgroups NI .. NI + sg_nwg - 1 of this kernel do it on the way: every WAVE
-// owns up to SQ 16 x 16 quadrants of lower 32 x 32 tiles of Sigma, keeps their part of W W^T in its accumulators, and adds panel p's 32 columns of W
-// (syrk_quadrant_panel: 16 operand loads, 8 MFMAs per quadrant) as soon as the T half-rows that hold the tile's rows have flagged their W rows of panel p.
-// When the last panel is in, the accumulator is complete: Sigma+ = Sigma - acc straight from the registers (Sigma's entries were requested at the start).
-// The same accumulation chain as k_syrk_sub_q (eqf_kernels.hpp), which the launch chain uses: bit-identical Sigma+.
-// (First form, dropped: k_syrk_sub's split of K over the 8 waves of a workgroup, one k4-step per wave and panel - 3.5 us of LDS reduction per workgroup
-// behind the last panel, 6 us from the last W row to the last Sigma store.)
-// All or nothing: Sigma is written only when EVERY T half-row has flagged its last panel (a half-row that gave up never does) and no pivot failed.
-// The waits are not bounded by the launch's deadline - a Sigma workgroup that came late finds everything in memory and still has to do its part -
-// but end when flags[3] (stalled) goes up: then nobody writes, and the launch chain redoes the frame with k_syrk_sub_q (eqf_hip.hip: finish_update).
-// They cannot block the factorisation: workgroups are dispatched in block order, the Sigma workgroups come last.
-template <int SQ>
-__device__ __forceinline__ void la_sigma(const LaArgs& a, const int g, int* s_word) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NJ = a.NJ, K = a.m, n = a.sg_n, ldz = a.ldz, NT = a.NI - (2 * NJ - 1), nwg = a.sg_nwg;
-    const double* __restrict__ W = a.W + a.m;
-    // slot r of this workgroup: the two tiles 2 (gg + r nwg), + 1 of k_syrk_sub's table; waves 0 .. 3 the quadrants of the first, 4 .. 7 of the second
-    const int gg = (g + a.NI) % nwg;
-    const int qi = wave & 1, qj = (wave >> 1) & 1;
-    int i0[SQ], j0[SQ];
-    bool diag[SQ];
-#pragma unroll
-    for (int r = 0; r < SQ; ++r) {
-        const int e = 2 * (gg + r * nwg) + (wave >> 2);
-        i0[r] = -1, j0[r] = 0, diag[r] = false;
-        if (r < a.sg_spw && e < a.sg_ntiles) {
-            const int cd = a.sg_tiles[e], bi = cd & 0xffff, bj = cd >> 16;
-            if (!(bi == bj && qi == 0 && qj == 1)) // strictly above the diagonal: its mirror's
-                i0[r] = 32 * bi + 16 * qi, j0[r] = 32 * bj + 16 * qj, diag[r] = bi == bj;
-        }
-    }
-    // wave 0 watches the flags: lane 8 r + 4 h + u: tile h of slot r, T half-row 2 bi + u (u = 0, 1) or 2 bj + u - 2 (u = 2, 3)
-    int my_t = -1;
-    if (lane < 8 * SQ) {
-        const int r = lane >> 3, h = (lane >> 2) & 1, u = lane & 3, e = 2 * (gg + r * nwg) + h;
-        if (r < a.sg_spw && e < a.sg_ntiles) {
-            const int cd = a.sg_tiles[e];
-            my_t = min(2 * (u < 2 ? (cd & 0xffff) : (cd >> 16)) + (u & 1), NT - 1);
-        }
-    }
-    const bool dbg = a.dbg && g == 0 && tid == 0;
-    if (dbg)
-        a.dbg[8 * 95 + 0] = wall_clock64();
-    // s_word[0]: > 0: panels 0 .. s_word[0] - 1 may be read; < 0: give up. s_word[1]: 1: Sigma may be written; < 0: it may not
-    auto watch = [&](const int* f, bool mine, bool relaxed) -> bool { // true: all flags seen. relaxed: a panel's flags may be seen late, only the last panel is on the frame's critical path
-        bool stalled = false;
-        if (mine) {
-            for (;;) {
-                if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq)
-                    break;
-                if (__hip_atomic_load(a.flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    stalled = true;
-                    break;
-                }
-                if (relaxed)
-                    __builtin_amdgcn_s_sleep(64);
-                else
-                    __builtin_amdgcn_s_sleep(4);
-            }
-        }
-        asm volatile("" ::: "memory");
-        return !__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(stalled) != 0));
-    };
-    auto await = [&](const int* word, int target) -> bool {
-        for (;;) {
-            const int v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (v < 0)
-                return false;
-            if (v >= target)
-                break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        asm volatile("" ::: "memory");
-        return true;
-    };
-    // the entries of Sigma this wave will update, requested now (nothing in this kernel writes Sigma before the end): at the end they would be a memory
-    // round trip on the frame's critical path
-    double sg0[SQ][4];
-    d4 acc[SQ];
-#pragma unroll
-    for (int r = 0; r < SQ; ++r) {
-        acc[r] = d4{0, 0, 0, 0};
-        if (i0[r] >= 0)
-            syrk_quadrant_load(a.sg_sigma, a.sg_ld, n, i0[r], j0[r], sg0[r]);
-    }
-    for (int p = 0; p < NJ; ++p) {
-        if (wave == 0) {
-            const bool ok = watch(a.sg_wflags + (size_t)p * NT + max(my_t, 0), my_t >= 0, p + 1 < NJ);
-            if (lane == 0)
-                __hip_atomic_store(s_word, ok ? p + 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!ok)
-                return;
-        } else {
-            if (wave == 1 && p == NJ - 1) {
-                // while wave 0 waits for the last panel of this workgroup's tiles: every T half-row through its last panel, no pivot failed?
-                bool ok = true;
-                for (int t0 = 0; t0 < NT && ok; t0 += 64)
-                    ok = watch(a.sg_wflags + (size_t)(NJ - 1) * NT + min(t0 + lane, NT - 1), t0 + lane < NT, false);
-                if (ok && __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                    ok = false; // raised (write-through) by the owner in front of the L_p^-1 it belongs to
-                if (lane == 0)
-                    __hip_atomic_store(s_word + 1, ok ? 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (!await(s_word, p + 1))
-                return;
-        }
-#pragma unroll
-        for (int r = 0; r < SQ; ++r)
-            if (i0[r] >= 0)
-                syrk_quadrant_panel(W, ldz, n, K, i0[r], j0[r], p, acc[r]);
-    }
-    if (dbg)
-        a.dbg[8 * 95 + 1] = wall_clock64();
-    if (!await(s_word + 1, 1)) // wave 1's verdict
-        return;
-    if (dbg)
-        a.dbg[8 * 95 + 2] = wall_clock64();
-#pragma unroll
-    for (int r = 0; r < SQ; ++r)
-        if (i0[r] >= 0)
-            syrk_quadrant_store(a.sg_sigma, a.sg_ld, n, i0[r], j0[r], diag[r], sg0[r], acc[r]);
-    if (dbg)
-        a.dbg[8 * 95 + 3] = wall_clock64();
 }
 
 // ZB = 2: the statistics workgroup (block NI). What k_build_Z's statistics row and its first column of measurement groups do in the speculative frame tail:
@@ -1403,59 +1235,10 @@ __device__ __forceinline__ void la_stats(const LaArgs& a) {
     }
 }
 
-// The end of the frame's device work that the host waits for, run by the T block row that finishes last (every T block row has stored its
-// Gamma rows write-through and counted itself in): X <- Delta X for the landmarks (k_lift's arithmetic: lift_load / lift_landmark), the
-// estimates, Gamma's sensor rows and the status words into the pinned packet, then the doorbell. A failed factorisation (non-positive pivot,
-// stalled wait) lifts nothing, like k_lift. One kernel launch and one kernel boundary less per frame than k_lift behind this kernel, measured
-// neutral for the frame rate (the next frame's first kernel is bound by the host's launch): EQF_OPT_FUSED_LIFT, off by default.
-__device__ __forceinline__ void la_finish(const LaArgs& a) {
-    const int tid = threadIdx.x;
-    if (a.tr_lift && tid == 0)
-        a.tr_lift[0] = wall_clock64();
-    auto ld = [](const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }; // past this XCD's L2: written by other workgroups
-    const int f0 = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), f1 = a.flags[1];
-    const int f3 = __hip_atomic_load(a.flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool failed = f0 != 0 || f3 != 0;
-    for (int i = tid; i < max(a.lift_N, 21); i += LA_T) {
-        const bool lm = i < a.lift_N;
-        const int ic = lm ? i : 0;
-        const double gs = ld(a.gamma + (i < 21 ? i : 0));
-        const double g0 = ld(a.gamma + 21 + 3 * ic), g1 = ld(a.gamma + 21 + 3 * ic + 1), g2 = ld(a.gamma + 21 + 3 * ic + 2);
-        const LiftIn in = lift_load(ic, a.lift_Ncap, a.lift_chart, a.lift_discrete, a.lift_q0, a.lift_Qq, a.lift_Qa);
-        if (!failed) {
-            if (i < 21)
-                a.lift_gamma_host[i] = gs;
-            if (lm)
-                lift_landmark(i, V3{g0, g1, g2}, in, a.lift_N, a.lift_Ncap, a.lift_chart, a.lift_discrete, a.lift_Qq, a.lift_Qa, a.lift_est);
-        }
-    }
-    if (tid == 0) {
-        a.lift_flags_host[0] = f0;
-        a.lift_flags_host[1] = f1;
-        a.lift_flags_host[2] = 0;
-        a.lift_flags_host[3] = f3;
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence_system();
-        *reinterpret_cast<volatile int*>(a.lift_door_host) = a.lift_door_seq;
-        if (a.tr_lift)
-            a.tr_lift[1] = wall_clock64();
-    }
-}
-
-template <int MAXT, int SQ, int ZB = 0>
+template <int MAXT, int ZB = 0>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
-    if (a.spec && *a.spec == a.spec_seq) { // cancelled speculative tail: say so, ring, done
-        if (a.lift_door_host && blockIdx.x == 0 && threadIdx.x == 0) {
-            a.lift_flags_host[2] = 1;
-            a.lift_flags_host[3] = 0;
-            __threadfence_system();
-            *reinterpret_cast<volatile int*>(a.lift_door_host) = a.lift_door_seq;
-        }
+    if (a.spec && *a.spec == a.spec_seq) // cancelled speculative tail
         return;
-    }
     __shared__ double smem[4 * 32 * CH_LDP + LDL_SBUF]; // static LDS: constant addresses (2.6 us per factorisation at N = 200 against dynamic LDS)
     __shared__ int s_abort[2], s_cnt[LC_COUNT];
     if (threadIdx.x < 2)
@@ -1467,18 +1250,9 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     // block 0: the owner; blocks 1 .. 2 NJ - 2: the S half-rows h = 2 .. 2 NJ - 1 (block row 0 is the first diagonal tile, eliminated by k_build_Z);
     // then the T half-rows, numbered on from 2 NJ
     const int hidx = (int)blockIdx.x + 1;
-    // SQ = 0: an instantiation without the Sigma role (the default). All roles of a kernel share one register allocation: with la_sigma inlined the
-    // half-rows of the 17 .. 32-panel instantiation spilled 14 .. 238 registers depending on SQ, and a call (noinline) costs every role its
-    // argument registers (N = 200: 67 -> 89 us).
     if constexpr (ZB == 2) {
         if ((int)blockIdx.x >= a.NI) { // the statistics workgroup
             la_stats(a);
-            return;
-        }
-    }
-    if constexpr (SQ > 0) {
-        if ((int)blockIdx.x >= a.NI) { // a Sigma workgroup: no part in the factorisation, no deadline, nothing to report
-            la_sigma<SQ>(a, (int)blockIdx.x - a.NI, s_cnt);
             return;
         }
     }
@@ -1486,28 +1260,15 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
         la_owner<ZB>(a, smem, s_abort, s_cnt, pl);
     else if (MAXT > 4) { // 17 .. 32 panels: the half-rows with a look-ahead of their own
         if (hidx < 2 * a.NJ)
-            la_row2<MAXT, true, (SQ > 0)>(a, hidx, smem, s_abort, s_cnt, pl);
+            la_row2<MAXT, true>(a, hidx, smem, s_abort, s_cnt, pl);
         else
-            la_row2<MAXT, false, (SQ > 0)>(a, hidx, smem, s_abort, s_cnt, pl);
+            la_row2<MAXT, false>(a, hidx, smem, s_abort, s_cnt, pl);
     } else
-        la_row<MAXT, (SQ > 0), ZB>(a, hidx, smem, s_abort, s_cnt, pl);
-    if ((threadIdx.x & 63) == 0 && (s_abort[0] | s_abort[1])) // any wave that saw a timeout reports it (the owner's waves return at different times)
-        __hip_atomic_store(a.flags + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.lift_door_host && hidx >= 2 * a.NJ && blockIdx.x != 0) { // a T half-row (stalled or not) counts itself in; the last one finishes the frame
-        __shared__ int s_last;
-        la_stores_done();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int nT = a.NI - (2 * a.NJ - 1);
-            const int seen = __hip_atomic_fetch_add(a.lift_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (seen == nT - 1);
-            if (s_last)
-                __hip_atomic_store(a.lift_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (s_last)
-            la_finish(a);
-    }
+        la_row<MAXT, ZB>(a, hidx, smem, s_abort, s_cnt, pl);
+    // any wave that saw a timeout reports it (the owner's waves return at different times). The stall word carries the launch's sequence number: nobody has to
+    // clear it, so no clear can race with a workgroup that reports early, and a stale word of an earlier launch never matches
+    if ((threadIdx.x & 63) == 0 && (s_abort[0] | s_abort[1]))
+        __hip_atomic_store(a.flags + 3, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 } // namespace eqf

@@ -32,7 +32,7 @@ enum {
     EQF_E_UNSUPPORTED = -6, /* option combination not implemented on the device path */
     EQF_E_STALLED = -7      /* a bounded device-side wait of the look-ahead factorisation ran out (its workgroups were not all resident, e.g. the
                                GPU is held by another process) AND the automatic retry of the same factorisation on the launch chain failed as
-                               well. A stall alone is not an error: the update is redone on the chain (bit-identical results) and counted, see
+                               well. A stall alone is not an error: the update is redone on the chain (W and Sigma+ bit-identical, Gamma up to rounding) and counted, see
                                eqf_lookahead_stats. Nothing of the filter was modified when this code is returned. */
 };
 
@@ -41,9 +41,6 @@ enum {
     EQF_OPT_RICCATI_DENSE = 1, /* 1: propagate with two dense fp64 MFMA GEMMs (F Sigma F^T, F materialised);
                                   0 (default): structure-exploiting arrow-form kernel */
     EQF_OPT_CHECK_FINITE = 2,  /* 1: scan Sigma/X for non-finite values after propagate/update */
-    EQF_OPT_FUSED_UPDATE = 4,  /* 1: Sigma -= W W^T and Gamma = W z ride along in the factorisation step kernels;
-                                  0 (default): one split-K SYRK kernel after the chain. Measured: the fused form re-dirties all
-                                  of Sigma in every step and the per-kernel write-back costs more than the saved launch. */
     EQF_OPT_SPECULATIVE = 7,   /* 1 (default): eqf_stats_then_update queues the update behind the statistics kernel, and backs off where that does not
                                   pay: after a tail the device had to cancel, the next 1, 2, 4 .. 16 calls only compute the statistics (*updated = 0),
                                   until a frame shows no outlier candidate; 2: always queue the tail; 0: never (statistics only) */
@@ -54,45 +51,31 @@ enum {
                                   ring the doorbell, so the host has the frame's results while Sigma -= W W^T is still running;
                                   0: Gamma from the diagonal tiles and a separate lift kernel after it */
     EQF_OPT_TRACE = 9,         /* 1: the frame's kernels stamp the device wall clock (100 MHz) into a ring (eqf_trace_read); 0 (default): off */
-    EQF_OPT_TWO_PHASE = 10,    /* factorisation steps whose trailing matrix has at least this many 32x32 tiles run in two launches (P for every
-                                  block row once, then the tile updates); default 700 (N = 500: the first 19 of 32 steps, +9 %; never at N = 200); 0: never */
     EQF_OPT_FUSED_ASSEMBLY = 11, /* 1 (default): eqf_propagate_fast has no assembly launch: the propagation kernel's workgroups evaluate the rows of
                                   A and B they need themselves and its observer blocks write the second landmark buffer; 0: k_assemble_AB first */
     EQF_OPT_LOOKAHEAD = 12,    /* 1 (default): the factorisation of [S ; T ; y^T] runs as ONE persistent kernel with a look-ahead schedule (one owner
-                                  workgroup walks the pivot chain, one workgroup per 32-row block row keeps its tiles in registers and follows one to
+                                  workgroup walks the pivot chain, one workgroup per 16-row half block row keeps its tiles in registers and follows one to
                                   two panels behind; hand-offs as write-through tile stores + one sequence-numbered flag per tile, never cleared) when the update has 3 .. 32
-                                  panels (32 < M <= 512 measurements; 17 .. 32 panels feed their operand tiles through an LDS ring); bit-identical W / Sigma
-                                  to the chain. 0: one launch per panel (k_chol_step). Switched to 0 by the library itself after three stalled launches in
-                                  a row (eqf_lookahead_stats); setting it again re-arms it */
+                                  panels (32 < M <= 512 measurements; with 17 .. 32 panels the half-rows run a look-ahead of their own) and all its workgroups
+                                  fit the device at once (one per compute unit); W and Sigma+ bit-identical to the chain, Gamma equal up to rounding (summed in
+                                  another order). 0: one launch per panel (k_chol_step). Switched to 0 by the library itself after three stalled launches in
+                                  a row (eqf_lookahead_stats); setting it again re-arms it. eqf_create runs a self-test of the kernel against the chain on
+                                  a fixed problem and keeps a context to the chain if the two disagree */
     EQF_OPT_LA_TIMEOUT_US = 15, /* bound of every device-side wait inside the look-ahead kernel, microseconds of device wall clock; default 20000 (20 ms).
-                                  When it runs out the launch is abandoned and the factorisation redone on the launch chain. 0 makes every look-ahead
+                                  When it runs out the launch is abandoned and the factorisation redone on the launch chain (same Z: W and Sigma+
+                                  bit-identical, Gamma up to rounding). 0 makes every look-ahead
                                   launch stall at its first wait: the test hook for that path */
-    EQF_OPT_FUSED_LIFT = 14,   /* 1: the look-ahead kernel's last T block row lifts the landmarks, fills the result packet and rings the doorbell (no k_lift launch
-                                  behind it: 4 launches per frame, -2.4 us on the device timeline, bit-identical results); 0 (default): k_lift as a kernel of
-                                  its own. Measured neutral for the frame rate (the frame boundary is bound by the host's launch), so the simpler form is the default */
-    EQF_OPT_SIGMA_IN_LOOKAHEAD = 16, /* experiment, 0 (default): Sigma <- Sigma - W W^T is k_syrk_sub behind the factorisation.
-                                  1: it runs INSIDE the look-ahead kernel: workgroups on the compute units the factorisation leaves idle keep the partial
-                                  sums of lower 32 x 32 tiles of Sigma in their accumulators (one accumulation chain per 16 x 16 quadrant and wave) and add
-                                  panel p's columns of W as soon as the T half-rows have flagged them; tiles that do not fit (17 .. 32 panels) go to a
-                                  k_syrk_sub_q launch behind the kernel, and the launch chain uses k_syrk_sub_q as well (same order of additions: bit-identical
-                                  Sigma either way; against the default order it differs by rounding). Sigma is written only if the whole factorisation
-                                  succeeded. Measured slower: at N = 200 the covariance update was already hidden under the host's round trip, and the
-                                  W hand-off slows the half-rows (N = 500: +9 us for publishing, +15 us with the Sigma workgroups running).
-                                  fp64 Sigma only (EQF_OPT_SIGMA_FP32 = 2 and EQF_OPT_SYRK_F32 keep k_syrk_sub) */
     EQF_OPT_Z_IN_LOOKAHEAD = 17, /* 1 (default): where it applies (fp64 Sigma, 3 .. 16 panels) there is no k_build_Z launch: the look-ahead kernel's half-rows build their
                                   own 16 rows of Z = [S ; T ; yTilde^T] and its owner the first tile, from k_build_Z's expressions (bit-identical W / Sigma). In the
                                   speculative frame tail (eqf_stats_then_update with the measurement staged by the propagation call) its workgroups evaluate the
                                   output blocks C_j themselves as well and one more workgroup computes the outlier statistics and the speculation word; after
                                   eqf_vision_update's measurement kernel they read C from memory. A stalled launch builds Z with k_build_Z before the retry on
                                   the launch chain. Measured for the speculative tail: N = 50 +2.8 %, N = 100 +1.8 %, N = 200 neutral (the kernel's prologue costs
-                                  what the launch saved, and the tail's first launch reaches the GPU late), so that form is used up to 8 panels (N <= 128);
-                                  2: for every eligible size. 0: k_build_Z always */
-    EQF_OPT_SYRK_F32 = 13,     /* experiment (the fp32-arithmetic A/B): 1: Sigma -= W W^T multiplies on v_mfma_f32_16x16x4_f32 with the
-                                  operands rounded to float (f32 accumulation inside a wave's K slice, fp64 across slices and for the subtraction).
-                                  Results then agree with the reference to ~1e-7 only; 0 (default): fp64 MFMA */
+                                  what the launch saved, and the tail's first launch reaches the GPU late), so that form is used up to 8 panels (N <= 128).
+                                  0: k_build_Z always */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
-                                     path only: dense / accurate Riccati and the fused update return EQF_E_UNSUPPORTED.
+                                     path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.
                                   1: numerical model of the same thing on the fp64 store: Sigma rounded to the nearest float after
                                      every store - bit-identical results to mode 2 (tests/test_gpu_fp32_sigma.py), any mode.
                                   0: fp64 (default). Switching converts the live Sigma. */
@@ -110,6 +93,8 @@ const char* eqf_error_string(int code);
 int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choice);
 void eqf_destroy(eqf_ctx* ctx);
 int eqf_set_option(eqf_ctx* ctx, int option, int value);
+/* the value an option has now (a context that grows its capacity keeps every option and counter: tests/test_gpu_edge_cases.py) */
+int eqf_get_option(const eqf_ctx* ctx, int option, int* value);
 int eqf_synchronize(eqf_ctx* ctx);
 int eqf_num_landmarks(const eqf_ctx* ctx);
 /* VIO_eqf::X.id (VIOGroup.h:38): the landmark ids in state order. Host-side only, no device work. Returns N or <0. */
@@ -219,8 +204,11 @@ int eqf_speculation_stats(eqf_ctx* ctx, long* calls, long* queued, long* cancell
 int eqf_stats_select_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, const double* y_px, int M, double thrAbs, double thrProb, int max_outliers, double meas_var,
                             int useEquivariantOutput, int discreteCorrection, double* absErr, double* probErr, double* depth2, int* updated, int* removed_idx, int* n_removed);
 /* look-ahead factorisation since the last reset: launches of the persistent kernel; of those, launches whose bounded wait ran out and whose
- * factorisation was redone on the launch chain (same Z, bit-identical result; three in a row switch EQF_OPT_LOOKAHEAD off for the context). */
+ * factorisation was redone on the launch chain (same Z: W and Sigma+ bit-identical, Gamma up to rounding; three in a row switch EQF_OPT_LOOKAHEAD off for the context). */
 int eqf_lookahead_stats(eqf_ctx* ctx, long* launches, long* fallbacks, int reset);
+/* Result of the look-ahead kernel's self-test at eqf_create (the persistent kernel against the launch chain on a fixed 96-column problem, W compared bit
+ * for bit): 1 passed, 0 not run (the kernel is never eligible at this capacity / on this device), -1 failed: the context factorises on the launch chain. */
+int eqf_lookahead_selftest(const eqf_ctx* ctx);
 /* frames that took the device-side decision, landmarks it discarded */
 int eqf_selection_stats(eqf_ctx* ctx, long* frames, long* discarded, int reset);
 

@@ -35,7 +35,3 @@ for name, base in (("first T block row", 32), (f"S block row {NJ - 2}", 64)):
             r = a[base + p] - t0
             cols = [0, 1, 7, 2, 3, 4, 6, 5]
             print(f"  p={p:2d}  " + "  ".join(f"{r[i]:8.2f}" if a[base + p, i] > 0 else "       -" for i in cols))
-if a[95, 0] > 0:
-    r = a[95] - t0
-    print("Sigma workgroup 0 (EQF_OPT_SIGMA_IN_LOOKAHEAD): start   last panel added   every T half-row done   Sigma tiles written")
-    print("  " + "  ".join(f"{v:8.2f}" for v in r[:4]))

@@ -400,7 +400,7 @@ void VIO_eqf::removeInvalidLandmarks() {
     twin.touch();
 }
 
-// ---------------------------------------------------------------- fused entry points (optional; VIOFilter_mi355x.cpp with mi355xFused)
+// ---------------------------------------------------------------- fused entry points (optional; VIOFilter_mi355x_hunks.hpp with mi355xFused)
 namespace {
 void flattenMeasurement(const VisionMeasurement& measurement, std::vector<int>& ids, std::vector<double>& px) {
     ids.clear(), px.clear();

@@ -1,6 +1,6 @@
-// TEST SCAFFOLDING. `class VIOFilter`, `VIOFilter::Settings` and the global `loopTimer` re-declared with the reference's names, members and signatures
-// (include/eqvio/VIOFilter.h:36-192, include/eqvio/VIOFilterSettings.h:58-229, include/eqvio/LoopTimer.h) as far as tests/integration/VIOFilter_mi355x.cpp and
-// its driver touch them, over the stand-in value types of eqvio/mathematical/VIO_eqf.h. The ONE marked field is the only addition the fused binding needs.
+// TEST SCAFFOLDING. `VIOFilter::Settings` re-declared with the reference's names, members and signatures (include/eqvio/VIOFilterSettings.h:58-229) as far as
+// tests/integration/VIOFilter_mi355x_hunks.hpp and the replay driver touch them, over the stand-in value types of eqvio/mathematical/VIO_eqf.h. The ONE marked field
+// is the only addition the fused binding needs.
 #pragma once
 #include <memory>
 #include <string>
@@ -12,33 +12,9 @@ enum class CoordinateChoice { Euclidean, InvDepth, Normal };
 inline const EqFCoordinateSuite* getCoordinates(const CoordinateChoice& cc) { // EqFMatrices.h:81-90
     return cc == CoordinateChoice::Euclidean ? &EqFCoordinateSuite_euclid : cc == CoordinateChoice::InvDepth ? &EqFCoordinateSuite_invdepth : &EqFCoordinateSuite_normal;
 }
-struct LoopTimer { // LoopTimer.h: the driver of this test does its own timing
-    void startTiming(const std::string&) {}
-    void endTiming(const std::string&) {}
-};
-extern LoopTimer loopTimer;
-
-class VIOFilter {
-  protected:
-    bool initialisedFlag = false;
-    VIO_eqf filterState;
-    std::vector<IMUVelocity> velocityBuffer;
-    bool integrateUpToTime(const double& newTime);
-    void addNewLandmarks(const VisionMeasurement& measurement);
-    void removeOldLandmarks(const std::vector<int>& measurementIds);
-    void removeOutliers(VisionMeasurement& measurement);
-    double getMedianSceneDepth() const;
-
+class VIOFilter { // only the nested settings type is needed here: the driver of this test replays the member sequence of src/VIOFilter.cpp from a plan
   public:
     struct Settings;
-    std::unique_ptr<VIOFilter::Settings> settings;
-    VIOFilter() = default;
-    VIOFilter(const VIOState& xi0, const VIOFilter::Settings& settings, const double& time = 0.0);
-    void processIMUData(const IMUVelocity& imuVelocity);
-    void processVisionData(const VisionMeasurement& measurement);
-    double getTime() const;
-    VIOState stateEstimate() const;
-    const VIO_eqf& viewEqFState() const;
 };
 
 struct VIOFilter::Settings { // VIOFilterSettings.h:58-124 (the fields of the eqf block that the hot path reads)

@@ -147,7 +147,7 @@ struct VIO_eqf {
     void pull() const;      // device -> host members, if the device is ahead (VIOFilter::viewEqFState() calls it before returning)
     void markHostEdited() { twin.hostEdited = true; } // after code that assigns xi0 / X / Sigma directly (VIOFilter.cpp:33-108)
     // ---- ADDED for the MI355X binding (3 of 3, optional): the fused entry points of include/eqf_hip.h. A VIOFilter.cpp that calls them
-    // (tests/integration/VIOFilter_mi355x.cpp with settings->mi355xFused) takes ONE host wait per frame; without them every member above still works.
+    // (tests/integration/VIOFilter_mi355x_hunks.hpp) takes ONE host wait per frame; without them every member above still works.
     // The gain matrices of VIOFilterSettings.h:176-206 are diagonal: the fused members take their distinct values (12 input gains; the 7 sensor 3-blocks + the
     // per-landmark value of the state gain; the pixel variance) instead of dense (21 + 3N)^2 / (2M)^2 matrices built per frame (3 MB + 1.3 MB at N = 200).
     void propagateFast(const IMUVelocity& meanVelocity, const double& dtTotal, const double (&inputGainDiag)[12], const double (&stateGainDiag8)[8],

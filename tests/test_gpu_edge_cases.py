@@ -250,3 +250,57 @@ def test_random_bookkeeping_sequences_match_the_oracle(seed):
         assert core.N == len(orc.get_eqf()[2])
     assert rel_fro(core.get_sigma(), orc.get_sigma()) <= 1e-9
     check_state(core, orc)
+
+
+def test_options_and_counters_survive_capacity_growth():
+    """growing the capacity rebuilds the context (eqf_hip.hip: grow_capacity) and must carry EVERY option of eqf_set_option and every counter
+    over. Walks the option enum through eqf_get_option (so that a new option cannot be forgotten without this test failing: every id declared in
+    include/eqf_hip.h that the library knows is set to a non-default value before the growth and read back after it), and checks that the look-ahead
+    counters of eqf_lookahead_stats do not restart."""
+    import ctypes as C
+    import os
+    import re
+
+    from eqvio_amd.capi import OPT_LA_TIMEOUT_US, OPT_LOOKAHEAD, OPT_SIGMA_FP32, OPT_TRACE, OPT_Z_IN_LOOKAHEAD
+
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "eqf_hip.h")).read()
+    enum = hdr[hdr.index("/* options for eqf_set_option */"):]
+    enum = enum[: enum.index("};")]
+    opt_ids = sorted({int(v) for v in re.findall(r"^\s+EQF_OPT_[A-Z0-9_]+\s*=\s*(\d+)", enum, re.M)} | {100})
+    assert len(opt_ids) >= 12, opt_ids
+    rng = np.random.default_rng(9)
+    N = 40
+    chart = CHARTS["invdepth"]
+    settings = settings_for(chart, useDiscreteInnovationLift=0)
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N)
+    core = EqfCore(N, chart)
+    core.set_state(xi0, Xs, ids, q0, Q)
+    core.set_sigma(np.diag(settings.initial_cov_diag(N)))
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0)
+    core.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)  # 3 panels: one look-ahead launch on the books
+    a, b = C.c_long(), C.c_long()
+    assert core.lib.eqf_lookahead_stats(core.h, C.byref(a), C.byref(b), 0) == 0 and (a.value, b.value) == (1, 0)
+    # a non-default value for every option (values that are legal together: the dense Riccati excludes the float store, id 3 = 1 is its fp64 model)
+    wanted = {}
+    for oid in opt_ids:
+        cur = core.get_option(oid)
+        new = {OPT_LA_TIMEOUT_US: 12345, OPT_SIGMA_FP32: 1, OPT_TRACE: 1}.get(oid, 0 if cur else 1)
+        core.set_option(oid, new)
+        wanted[oid] = core.get_option(oid)
+        assert wanted[oid] == new, oid
+    p = rng.uniform(-1, 1, (70, 3)) + [0, 0, 5]
+    core.add_landmarks(np.arange(1000, 1070, dtype=np.int32), p, 0.5)  # 110 landmarks > capacity 40: the context is rebuilt
+    assert core.N == 110
+    for oid in opt_ids:
+        assert core.get_option(oid) == wanted[oid], (oid, core.get_option(oid), wanted[oid])
+    assert core.lib.eqf_lookahead_stats(core.h, C.byref(a), C.byref(b), 0) == 0 and (a.value, b.value) == (1, 0)
+    assert OPT_LOOKAHEAD in opt_ids and OPT_Z_IN_LOOKAHEAD in opt_ids
+
+
+def test_lookahead_selftest_runs_at_creation():
+    """eqf_create factorises a fixed 96-column problem on the launch chain and on the persistent look-ahead kernel and compares W bit for bit
+    (eqf_hip.hip: lookahead_selftest); a context whose capacity never reaches three panels skips it."""
+    assert EqfCore(200, CHARTS["invdepth"]).lookahead_selftest() == 1
+    assert EqfCore(48, CHARTS["euclid"]).lookahead_selftest() == 1
+    assert EqfCore(16, CHARTS["euclid"]).lookahead_selftest() == 0

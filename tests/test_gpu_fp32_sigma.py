@@ -216,34 +216,3 @@ def test_float_storage_large_state():
         assert 1e-10 < rel_fro(out[2][k], out[0][k]) <= 1e-5
     for u, v in zip(out[1][2], out[2][2]):
         assert np.array_equal(u, v)
-
-
-def test_f32_mfma_syrk_experiment_is_a_rounded_copy_of_the_fp64_update():
-    """EQF_OPT_SYRK_F32 (the fp32-ARITHMETIC A/B of DESIGN.md §6, profiles/r02_fp32_ab.json): Sigma -= W W^T on v_mfma_f32_16x16x4_f32 with the
-    operands rounded to float. One update from the same state: Sigma agrees with the fp64-MFMA update to float rounding of the products
-    (<= 1e-6 of |W W^T|), not better, and everything that does not pass through the SYRK (X, Gamma) is bit-identical."""
-    from eqvio_amd.capi import OPT_SYRK_F32, EqfCore
-    from util import CHARTS, default_camera, random_spd, reasonable_state, settings_for, synth_measurement
-
-    rng = np.random.default_rng(12)
-    N = 80
-    chart = CHARTS["invdepth"]
-    settings = settings_for(chart)
-    xi0, Xs, ids, q0, Q = reasonable_state(rng, N)
-    S = random_spd(rng, 21 + 3 * N)
-    cam = default_camera()
-    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0)
-    res = []
-    for f32 in (0, 1):
-        core = EqfCore(N, chart)
-        core.set_option(OPT_SYRK_F32, f32)
-        core.set_state(xi0, Xs, ids, q0, Q)
-        core.set_sigma(S)
-        core.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
-        res.append((core.get_sigma(), core.get_state(), core.last_gamma()))
-    (Sa, sa, ga), (Sb, sb, gb) = res
-    assert np.array_equal(ga, gb) and all(np.array_equal(u, v) for u, v in zip(sa, sb))
-    delta = np.linalg.norm(S - Sa)  # |W W^T|
-    err = np.linalg.norm(Sa - Sb)
-    assert 1e-9 * delta < err <= 1e-6 * delta
-    assert np.array_equal(Sb, Sb.T)

@@ -234,38 +234,6 @@ def test_stalled_lookahead_is_redone_on_the_chain_bit_identically():
     stall.close()
 
 
-def test_stalled_lookahead_with_sigma_workgroups_leaves_sigma_alone():
-    """EQF_OPT_SIGMA_IN_LOOKAHEAD: the look-ahead kernel's Sigma workgroups write Sigma only when every T half-row has flagged its last panel. A launch that
-    stalls (EQF_OPT_LA_TIMEOUT_US = 0) must not have touched Sigma: the retry on the launch chain applies the whole update once, and the run equals, bit
-    for bit, a run on the chain alone (k_syrk_sub_q in both)."""
-    import bench
-    from eqvio_amd.capi import OPT_LA_TIMEOUT_US, OPT_LOOKAHEAD, OPT_SIGMA_IN_LOOKAHEAD, PreparedFrames, load_eqf_lib
-
-    lib = load_eqf_lib()
-    settings = bench.eurocish_settings()
-    N, nfr = 72, 6
-    world, frames = bench.build_workload(seed=78, n_frames=nfr + 2, N=N)
-    pf = PreparedFrames(world.cam, *bench.flatten_frames(frames[:nfr]))
-
-    def fresh():
-        f = bench.make_filter(world, settings, N, 0, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=N, device=0, sensor=se, ids=i, p=p, time=t))
-        assert lib.eqf_set_option(f.core_handle(), OPT_SIGMA_IN_LOOKAHEAD, 1) == 0
-        return f
-
-    chain, stall, inside = fresh(), fresh(), fresh()
-    assert lib.eqf_set_option(chain.core_handle(), OPT_LOOKAHEAD, 0) == 0
-    assert lib.eqf_set_option(stall.core_handle(), OPT_LA_TIMEOUT_US, 0) == 0
-    for f in range(3):  # the three frames before the context gives the look-ahead kernel up
-        assert chain.run_prepared(pf, f, 1) == 1 and stall.run_prepared(pf, f, 1) == 1 and inside.run_prepared(pf, f, 1) == 1
-        assert np.array_equal(chain.get_sigma(), stall.get_sigma()), f
-        (sa, ia, pa), (sb, ib, pb) = chain.state_estimate(), stall.state_estimate()
-        assert np.array_equal(sa, sb) and np.array_equal(pa, pb)
-        assert np.linalg.norm(chain.get_sigma() - inside.get_sigma()) <= 1e-12 * np.linalg.norm(chain.get_sigma())
-    assert _la_stats(stall) == (3, 3) and _la_stats(inside) == (3, 0)
-    for flt in (chain, stall, inside):
-        flt.close()
-
-
 def test_stalled_lookahead_that_built_z_itself_is_redone_on_the_chain():
     """EQF_OPT_Z_IN_LOOKAHEAD (default, stand-alone update path): the look-ahead kernel builds Z in its registers and there is no k_build_Z launch. A launch
     that stalls (EQF_OPT_LA_TIMEOUT_US = 0) has left no Z in memory: the retry must build it (k_build_Z from the C blocks of the measurement kernel) before the
