@@ -324,6 +324,7 @@ def main():
     ap.add_argument("--no-multi-filter", action="store_true")
     ap.add_argument("--no-frame-mix", action="store_true")
     ap.add_argument("--no-binding", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes of the roofline object (three short runs of this script under the profiler)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -374,6 +375,8 @@ def main():
         factorisation = {"lookahead_launches": la_l.value, "stalled_and_redone_on_the_chain": la_f.value, "frames": args.warmup + args.steps}
         if rank == 0 and not args.no_roofline:
             roofline = measure_roofline(flt, lib, core, cam, frames, args, n, m)
+            if not args.no_pmc and world_size == 1 and not stand_in:
+                roofline.update(live_pmc(N, roofline, args.steps / elapsed))
         if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(world, frames, settings, N)
         if rank == 0 and world_size == 1 and not args.no_multi_filter:
@@ -613,21 +616,8 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
     dom_us = fam_time[dom]
     dom_launches = sum(launches.get(kn, 0.0) for kn in fam[dom][0])
     achieved = fam[dom][1] / (dom_us * 1e-6) / 1e12
-    # HBM-side traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with the
-    # same bench command; bench.py cannot run the profiler on itself)
-    traffic, traffic_note = None, None
-    try:  # per size: profiles/rNN_pmc_traffic.json is written by scripts/pmc_traffic_json.py from the PMC passes of scripts/collect_profiles.sh (newest round wins)
-        import glob
-
-        pmc_all = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
-        pmc = pmc_all.get("N%d" % ((n - 21) // 3), {}).get("kernels", {})
-        kn = [k_ for k_ in fam[dom][0] if k_ in pmc and launches.get(k_, 0) > 0]
-        if kn:
-            tot_l = sum(launches[k_] for k_ in kn)
-            traffic = 1024.0 * sum((pmc[k_]["fetch_kib_per_launch"] + pmc[k_]["write_kib_per_launch"]) * launches[k_] for k_ in kn) / tot_l
-            traffic_note = "bytes per launch, FETCH_SIZE + WRITE_SIZE (as reported, uncalibrated for 8 B/lane accesses) from " + pmc_all["N%d" % ((n - 21) // 3)]["source"]
-    except Exception:
-        pass
+    sclk = C.c_double()
+    lib.eqf_mfma_f64_peak_clock(core, C.byref(tpeak), C.byref(sclk))
     return {
         "bound": "mfma",
         "kernel": dom,
@@ -635,15 +625,106 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-        "traffic": traffic,
-        "traffic_note": traffic_note,
+        "traffic": None,  # HBM-side bytes per launch of the dominant kernel: filled in by live_pmc() from a rocprofv3 counter pass of this very build
+        "dominant_kernels": [k_ for k_ in fam[dom][0] if launches.get(k_, 0) > 0],
+        "launches_per_frame_by_kernel": {k_: round(v, 3) for k_, v in launches.items()},
         "launches_per_frame": dom_launches,
         "avg_launch_us": dom_us / max(dom_launches, 1.0),
         "algorithmic_flops_per_launch": fam[dom][1] / max(dom_launches, 1.0),
         "measured_mfma_f64_issue_ceiling_tflops": tpeak.value,
+        "sclk_ghz_during_mfma_ceiling": round(sclk.value, 3),
+        "mfma_ceiling_note": "k_mfma_peak (8 waves per SIMD, 4 independent accumulators each, no memory traffic) while reading the device's own cycle counter against its 100 MHz "
+                             "wall clock: the datasheet's 78.6 TFLOP/s = 1024 SIMDs x 32 flop/clock x 2.4 GHz; at the clock held under this load the same issue rate gives "
+                             "%.1f TFLOP/s, i.e. the measured ceiling is %.0f %% of full issue at that clock (one wave alone issues v_mfma_f64_16x16x4_f64 every 64 cycles = full rate: "
+                             "scripts/ubench/issue.hip)" % (32768 * sclk.value / 1e3, 100.0 * tpeak.value / max(32768 * sclk.value / 1e3, 1e-9)),
         "per_kernel_us_per_frame": {k_: round(v, 2) for k_, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
         "note": "hipEvent spans on the filter's own stream over %d frames of the same workload right after the timed region, one span per launch (the launch chain k_chol_step, when selected, is ONE span over its back-to-back launches divided by their number)" % k,
     }
+
+
+def _pmc_pass(N, counters, steps=40, warmup=10):
+    """One rocprofv3 counter pass over a short run of this script (same build, same workload): {kernel family: {counter: (dispatches, average per dispatch)}}.
+    Counters only (--kernel-trace to attribute them to dispatches, no other trace domain), from /tmp as the guide prescribes."""
+    import glob
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    tmp = tempfile.mkdtemp(prefix="eqvio_pmc_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", tmp, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--landmarks", str(N), "--steps", str(steps),
+               "--warmup", str(warmup), "--no-cpu-baseline", "--no-roofline", "--no-multi-filter", "--no-frame-mix", "--no-binding", "--no-pmc"]
+        subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, timeout=600, check=True)
+        dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+        if not dbs:
+            raise RuntimeError("rocprofv3 wrote no database")
+        cur = sqlite3.connect(dbs[0]).cursor()
+        # a counter has one row per hardware instance and dispatch (32 SQ instances, 8 GRBM): SQ counters are SUMMED over their instances, GRBM_GUI_ACTIVE (the
+        # same interval seen by every instance) is averaged; derived counters (FETCH_SIZE, WRITE_SIZE) come as one row per dispatch
+        rows = cur.execute("""select s.kernel_name, p.name, count(distinct e.event_id), sum(e.value), avg(e.value) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id
+                              join rocpd_kernel_dispatch d on e.event_id = d.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+                              group by s.kernel_name, p.name""").fetchall()
+        out = {}
+        for name, counter, cnt, total, mean in rows:
+            avg = mean if counter.startswith("GRBM") else total / cnt
+            mm = re.search(r"(k_[a-z_A-Z0-9]+?)(?:<|I[A-Za-z0-9_]*E|\(|$)", name.replace("eqf::", ""))
+            if not mm:
+                continue
+            fam = re.sub(r"I[a-zA-Z]?L?[bi]?\d.*$", "", mm.group(1))
+            d, a = out.setdefault(fam, {}).get(counter, (0, 0.0))
+            out[fam][counter] = (d + cnt, (a * d + avg * cnt) / (d + cnt))  # template instantiations of one kernel: averaged by dispatch count
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_pmc(N, roofline, updates_per_s):
+    """The counter half of the roofline object, measured on THIS build in THIS run: three rocprofv3 passes (FETCH_SIZE / WRITE_SIZE cannot share a pass:
+    /opt/skills/guides/MI355X_MICROARCH.md, PMC slots) over 50 frames of the same workload. FETCH_SIZE / WRITE_SIZE arrive in KiB per dispatch. The guide's gfx950
+    correction - FETCH_SIZE reports half the bytes of a wide (16 B per lane) coalesced read - is given as a second figure: these kernels read 8 B per lane (fp64
+    operands in MFMA fragment layout), for which the counter is uncalibrated, so the truth lies between the two."""
+    import shutil
+
+    if shutil.which("rocprofv3") is None:
+        return {"pmc_note": "rocprofv3 not on PATH: no counter pass"}
+    try:
+        fetch = _pmc_pass(N, ["FETCH_SIZE"])
+        write = _pmc_pass(N, ["WRITE_SIZE"])
+        busy = _pmc_pass(N, ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])
+    except Exception as e:  # informational: never lose the bench line over the profiler
+        return {"pmc_note": "counter pass failed: " + repr(e)[:300]}
+    lpf = roofline["launches_per_frame_by_kernel"]
+    dom = roofline["dominant_kernels"]
+
+    def per_launch(table, counter, names):
+        tot = sum(lpf.get(k, 0.0) for k in names if k in table and counter in table[k])
+        return sum(table[k][counter][1] * lpf.get(k, 0.0) for k in names if k in table and counter in table[k]) / tot if tot > 0 else None
+
+    f_dom, w_dom = per_launch(fetch, "FETCH_SIZE", dom), per_launch(write, "WRITE_SIZE", dom)
+    frame_f = sum(fetch[k]["FETCH_SIZE"][1] * lpf[k] for k in lpf if k in fetch and "FETCH_SIZE" in fetch[k]) * 1024.0
+    frame_w = sum(write[k]["WRITE_SIZE"][1] * lpf[k] for k in lpf if k in write and "WRITE_SIZE" in write[k]) * 1024.0
+    out = {}
+    if f_dom is not None and w_dom is not None:
+        out["traffic"] = 1024.0 * (f_dom + w_dom)
+        out["traffic_fetch_x2"] = 1024.0 * (2.0 * f_dom + w_dom)
+    out["hbm_gbps"] = (frame_f + frame_w) * updates_per_s / 1e9
+    out["hbm_gbps_fetch_x2"] = (2.0 * frame_f + frame_w) * updates_per_s / 1e9
+    out["hbm_frac_of_8tbps"] = out["hbm_gbps_fetch_x2"] / 8000.0
+    out["bytes_per_frame_by_kernel"] = {k: round(1024.0 * (fetch.get(k, {}).get("FETCH_SIZE", (0, 0.0))[1] + write.get(k, {}).get("WRITE_SIZE", (0, 0.0))[1]) * lpf[k]) for k in lpf
+                                        if k in fetch or k in write}
+    mb = {}
+    for k in lpf:
+        if k in busy and "SQ_VALU_MFMA_BUSY_CYCLES" in busy[k] and busy[k].get("GRBM_GUI_ACTIVE", (0, 0.0))[1] > 0:
+            mb[k] = round(busy[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (busy[k]["GRBM_GUI_ACTIVE"][1] * 1024.0), 4)  # busy SIMD-cycles over 1024 SIMDs x the kernel's cycles
+    out["mfma_busy_frac_by_kernel"] = mb
+    out["mfma_busy_frac"] = next((mb[k] for k in dom if k in mb), None)
+    out["pmc_note"] = ("rocprofv3 --kernel-trace --pmc, three passes of 50 frames of this workload on this build (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE); "
+                       "traffic = (FETCH_SIZE + WRITE_SIZE) per launch of the dominant kernel as reported, traffic_fetch_x2 with the guide's gfx950 correction for wide reads "
+                       "(these kernels load 8 B per lane: uncalibrated, the truth lies between); hbm_gbps = bytes of every kernel of a frame x the measured frame rate; "
+                       "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES summed over the 32 SQ instances / (GRBM_GUI_ACTIVE x 1024 SIMDs) of the dominant kernel")
+    return out
 
 
 if __name__ == "__main__":

@@ -218,6 +218,7 @@ def load_eqf_lib():
         "eqf_debug_lookahead_stamps": (C.c_int, [vp, C.POINTER(C.c_ulonglong)]),
         "eqf_debug_matrix_C": (C.c_int, [vp, P(Camera), c_int_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p]),
         "eqf_mfma_f64_peak": (C.c_int, [vp, c_double_p]),
+        "eqf_mfma_f64_peak_clock": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "eqf_last_kernel_times": (C.c_int, [vp, c_int_p, P(C.c_float), C.c_int]),
     }
     for name, (res, args) in protos.items():

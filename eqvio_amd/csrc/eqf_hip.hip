@@ -2876,34 +2876,49 @@ int eqf_debug_matrix_C(eqf_ctx* c, const eqvio_camera* cam, const int* ids, cons
     return 0;
 }
 
-int eqf_mfma_f64_peak(eqf_ctx* c, double* tflops) {
+int eqf_mfma_f64_peak_clock(eqf_ctx* c, double* tflops, double* sclk_ghz) {
     if (!c || !tflops)
         return EQF_E_BAD_ARG;
     { int _e = enter(c); if (_e) return _e; }
     const int nblk = 256 * 8, iters = 4096;
     double* d_out = nullptr;
+    unsigned long long* d_clk = nullptr;
     HIPCHK(hipMalloc(&d_out, sizeof(double) * nblk * 256));
+    HIPCHK(hipMalloc(&d_clk, sizeof(unsigned long long) * 2 * (nblk / 64)));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, c->stream, 64, d_out); // warm-up
-    double best = 0;
+    hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, c->stream, 64, d_out, (unsigned long long*)nullptr); // warm-up
+    double best = 0, clock_at_best = 0;
     for (int rep = 0; rep < 5; ++rep) {
         HIPCHK(hipEventRecord(e0, c->stream));
-        hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, c->stream, iters, d_out);
+        hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, c->stream, iters, d_out, d_clk);
         HIPCHK(hipEventRecord(e1, c->stream));
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
         const double flops = (double)nblk * 4 /*waves*/ * iters * 4 /*mfma*/ * (2.0 * 16 * 16 * 4);
-        best = std::max(best, flops / (ms * 1e-3) / 1e12);
+        const double tf = flops / (ms * 1e-3) / 1e12;
+        if (tf > best) {
+            unsigned long long h[2 * (nblk / 64)];
+            HIPCHK(hipMemcpy(h, d_clk, sizeof(h), hipMemcpyDeviceToHost));
+            double cyc = 0, ticks = 0;
+            for (int q = 0; q < nblk / 64; ++q)
+                cyc += (double)h[2 * q], ticks += (double)h[2 * q + 1];
+            best = tf;
+            clock_at_best = ticks > 0 ? cyc / (ticks * 10.0) : 0.0; // cycles / (ticks x 1e-8 s) / 1e9 = GHz
+        }
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     hipFree(d_out);
+    hipFree(d_clk);
     *tflops = best;
+    if (sclk_ghz)
+        *sclk_ghz = clock_at_best;
     return 0;
 }
+int eqf_mfma_f64_peak(eqf_ctx* c, double* tflops) { return eqf_mfma_f64_peak_clock(c, tflops, nullptr); }
 
 int eqf_trace_read(eqf_ctx* c, unsigned long long* device_ticks, long long* host_ns, unsigned* last_frame) {
     if (!c || !device_ticks || !host_ns || !last_frame)

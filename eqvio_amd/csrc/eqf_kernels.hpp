@@ -2714,9 +2714,12 @@ __global__ void __launch_bounds__(1024) k_ge_back(int n, int np, int ldzn, const
 }
 
 // fp64 MFMA issue-rate micro-benchmark: 4 independent accumulators per wave, no memory traffic.
-__global__ void __launch_bounds__(256) k_mfma_peak(int iters, double* __restrict__ out) {
+// clk (optional): the first wave of every 64th block leaves the shader-clock cycles (s_memtime) and the 100 MHz wall-clock ticks it ran for: their ratio is the
+// shader clock the chip held UNDER THIS LOAD (the datasheet peak assumes 2.4 GHz).
+__global__ void __launch_bounds__(256) k_mfma_peak(int iters, double* __restrict__ out, unsigned long long* __restrict__ clk) {
     d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
     const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     for (int i = 0; i < iters; ++i) {
         a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a1, 0, 0, 0);
@@ -2725,6 +2728,10 @@ __global__ void __launch_bounds__(256) k_mfma_peak(int iters, double* __restrict
     }
     const d4 s = a0 + a1 + a2 + a3;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (clk && threadIdx.x == 0 && (blockIdx.x & 63) == 0) {
+        clk[2 * (blockIdx.x >> 6)] = clock64() - c0;
+        clk[2 * (blockIdx.x >> 6) + 1] = wall_clock64() - w0;
+    }
 }
 
 } // namespace eqf

@@ -239,6 +239,9 @@ int eqf_debug_matrix_C(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids, co
 /* fp64 MFMA micro-benchmark (v_mfma_f64_16x16x4_f64 issue rate): returns achieved TFLOP/s over the whole
  * chip; used by bench.py to state the roofline peak it prices against. */
 int eqf_mfma_f64_peak(eqf_ctx* ctx, double* tflops);
+/* the same, and the shader clock the chip held while that kernel ran (device cycle counter over the 100 MHz wall clock, averaged over 32 waves spread
+ * over the grid): the datasheet's 78.6 TFLOP/s are 1024 SIMDs x 32 flop/clock x 2.4 GHz, so tflops / (32768 x sclk) is the issue efficiency at the clock held */
+int eqf_mfma_f64_peak_clock(eqf_ctx* ctx, double* tflops, double* sclk_ghz);
 
 /* per-kernel timing of the last frame's launches on the context's stream (HIP events); fills up to cap
  * (name index, microseconds) pairs; see eqf_kernel_name. Enabled with eqf_set_option(ctx, 100, 1). */

@@ -59,7 +59,7 @@ int main() {
         const int nblk = 2048, iters = 4096; double best = 0;
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(e0);
-            if (which == 0) hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, iters, d_out);
+            if (which == 0) hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, iters, d_out, (unsigned long long*)nullptr);
             else hipLaunchKernelGGL(k_valu_peak, dim3(nblk), dim3(256), 0, 0, iters, d_out);
             hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
             const double flops = which == 0 ? (double)nblk * 4 * iters * 4 * 2048.0 : (double)nblk * 256 * iters * 8 * 2.0;
