@@ -1,5 +1,6 @@
 // See DatasetReplay.hpp.
 #include "DatasetReplay.hpp"
+#include <cctype>
 #include <cmath>
 #include <sstream>
 
@@ -131,6 +132,93 @@ std::vector<StampedPose> TrackReplayServer::groundtruth(const std::string& fileN
         }
     }
     return poses;
+}
+
+namespace {
+// the numbers that follow `key:` in the text (brackets, commas, dashes and line breaks in between are skipped), at most `want`; stops at the next key
+std::vector<double> numbersAfterKey(const std::string& text, size_t from, const std::string& key, size_t want, const std::string& fileName) {
+    size_t at = text.find(key + ":", from);
+    if (at == std::string::npos)
+        throw std::runtime_error("readCameraFile: no key '" + key + "' in " + fileName);
+    at += key.size() + 1;
+    std::vector<double> out;
+    while (at < text.size() && out.size() < want) {
+        const char ch = text[at];
+        if (std::isdigit((unsigned char)ch) || ((ch == '-' || ch == '+' || ch == '.') && at + 1 < text.size() && (std::isdigit((unsigned char)text[at + 1]) || text[at + 1] == '.'))) {
+            size_t used = 0;
+            out.push_back(std::stod(text.substr(at), &used));
+            at += used;
+        } else if (std::isalpha((unsigned char)ch) || ch == '_') {
+            break; // the next key
+        } else
+            ++at;
+    }
+    if (out.size() < want)
+        throw std::runtime_error("readCameraFile: key '" + key + "' of " + fileName + " has " + std::to_string(out.size()) + " numbers, expected " + std::to_string(want));
+    return out;
+}
+Pose poseFromRowMajor(const std::vector<double>& T) { // homogeneous 4 x 4 -> (unit quaternion, translation); the rotation block by Shepperd's method
+    const double m00 = T[0], m01 = T[1], m02 = T[2], m10 = T[4], m11 = T[5], m12 = T[6], m20 = T[8], m21 = T[9], m22 = T[10];
+    const double tr = m00 + m11 + m22;
+    Qt q;
+    if (tr > 0) {
+        const double s = std::sqrt(tr + 1.0) * 2;
+        q = Qt{0.25 * s, (m21 - m12) / s, (m02 - m20) / s, (m10 - m01) / s};
+    } else if (m00 > m11 && m00 > m22) {
+        const double s = std::sqrt(1.0 + m00 - m11 - m22) * 2;
+        q = Qt{(m21 - m12) / s, 0.25 * s, (m01 + m10) / s, (m02 + m20) / s};
+    } else if (m11 > m22) {
+        const double s = std::sqrt(1.0 + m11 - m00 - m22) * 2;
+        q = Qt{(m02 - m20) / s, (m01 + m10) / s, 0.25 * s, (m12 + m21) / s};
+    } else {
+        const double s = std::sqrt(1.0 + m22 - m00 - m11) * 2;
+        q = Qt{(m10 - m01) / s, (m02 + m20) / s, (m12 + m21) / s, 0.25 * s};
+    }
+    return Pose{eqf::q_unit(q), V3{T[3], T[7], T[11]}};
+}
+} // namespace
+
+void readCameraFile(const std::string& fileName, DatasetFormat format, Camera& camera, Pose& cameraOffset) {
+    std::ifstream f(fileName);
+    if (!f)
+        throw std::runtime_error("readCameraFile: cannot open " + fileName);
+    std::stringstream buf;
+    buf << f.rdbuf();
+    const std::string text = buf.str();
+    size_t from = 0;
+    if (format == DatasetFormat::UZHFPV) {
+        from = text.find("cam0:");
+        if (from == std::string::npos)
+            throw std::runtime_error("readCameraFile: no 'cam0' node in " + fileName);
+    }
+    const std::vector<double> res = numbersAfterKey(text, from, "resolution", 2, fileName), K = numbersAfterKey(text, from, "intrinsics", 4, fileName);
+    camera.c = eqvio_camera{};
+    camera.c.width = (int)res[0], camera.c.height = (int)res[1];
+    camera.c.fx = K[0], camera.c.fy = K[1], camera.c.cx = K[2], camera.c.cy = K[3];
+    if (format == DatasetFormat::ASL) {
+        camera.c.model = EQVIO_CAMERA_RADTAN;
+        std::vector<double> d;
+        try {
+            d = numbersAfterKey(text, from, "distortion_coefficients", 5, fileName);
+        } catch (const std::runtime_error&) {
+            d = numbersAfterKey(text, from, "distortion_coefficients", 4, fileName); // EuRoC ships four (k3 = 0)
+        }
+        for (size_t k = 0; k < d.size(); ++k)
+            camera.c.dist[k] = d[k];
+        const size_t tbs = text.find("T_BS:");
+        if (tbs == std::string::npos)
+            throw std::runtime_error("readCameraFile: no key 'T_BS' in " + fileName);
+        cameraOffset = poseFromRowMajor(numbersAfterKey(text, tbs, "data", 16, fileName));
+    } else {
+        camera.c.model = EQVIO_CAMERA_EQUIDISTANT;
+        const std::vector<double> d = numbersAfterKey(text, from, "distortion_coeffs", 4, fileName);
+        for (size_t k = 0; k < 4; ++k)
+            camera.c.dist[k] = d[k];
+        const Pose imuInCamera = poseFromRowMajor(numbersAfterKey(text, from, "T_cam_imu", 16, fileName));
+        const Qt Ri = eqf::q_inv(imuInCamera.R);
+        const V3 xi = eqf::q_rot(Ri, imuInCamera.x);
+        cameraOffset = Pose{Ri, V3{-xi.x, -xi.y, -xi.z}};
+    }
 }
 
 } // namespace eqvio_amd

@@ -42,4 +42,13 @@ class TrackReplayServer {
     static std::vector<StampedPose> groundtruth(const std::string& fileName, DatasetFormat format);
 };
 
+// The camera file of a dataset (main_opt.cpp:114-147: intrinsics for the measurement's camera, extrinsics into settings.cameraOffset), the subset of YAML the two
+// readers consume - yaml-cpp is not in this image, so the few keys are picked out of the text directly:
+//   ASL / EuRoC  mav0/cam0/sensor.yaml (ASLDatasetReader.cpp:76-101): resolution [w, h], intrinsics [fu, fv, cu, cv], distortion_coefficients [k1, k2, p1, p2 (, k3)]
+//                -> radial-tangential camera; T_BS: data: [16 numbers, row major] = the pose of the camera w.r.t. the IMU, used as it is
+//   UZH-FPV      camchain-imucam-*.yaml (UZHFPVDatasetReader.cpp:78-115), under cam0: resolution, intrinsics, distortion_coeffs [4] -> equidistant camera;
+//                T_cam_imu: four rows of four = the pose of the IMU w.r.t. the camera, INVERTED for the offset
+// Throws std::runtime_error on a missing key or a short list.
+void readCameraFile(const std::string& fileName, DatasetFormat format, Camera& camera, Pose& cameraOffset);
+
 } // namespace eqvio_amd

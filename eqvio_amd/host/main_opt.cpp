@@ -13,15 +13,16 @@
 using namespace eqvio_amd;
 
 static void usage() {
-    std::puts("usage: eqvio_opt --imu FILE --features FILE [--format asl|uzhfpv] [--groundtruth FILE] [--dumpMeasurements] [--camera fx fy cx cy width height]\n"
-              "                 [--distortion radtan k1 k2 p1 p2 k3 | --distortion equidistant k1 k2 k3 k4]\n"
+    std::puts("usage: eqvio_opt --imu FILE --features FILE [--format asl|uzhfpv] [--groundtruth FILE] [--dumpMeasurements] [--dumpStates FILE] [--printCamera]\n"
+              "                 [--cameraFile sensor.yaml | camchain.yaml]   (intrinsics, distortion and camera offset from the dataset's own file, main_opt.cpp:114-147)\n"
+              "                 [--camera fx fy cx cy width height] [--distortion radtan k1 k2 p1 p2 k3 | --distortion equidistant k1 k2 k3 k4]\n"
               "                 [--cameraOffset qw qx qy qz x y z] [--cameraLag S] [--start S] [--stop S] [--output DIR] [--sigmaFP32] [--quiet]\n"
               "                 [--<eqf setting> VALUE ...]   (names of VIOFilter::Settings, e.g. --fastRiccati 1 --coordinateChoice InvDepth)");
 }
 
 int main(int argc, char** argv) {
     VIOFilter::Settings fs;
-    std::string imuName, featName, gtName, outputDir;
+    std::string imuName, featName, gtName, outputDir, cameraFileName, statesName;
     DatasetFormat format = DatasetFormat::ASL;
     auto cam = std::make_shared<Camera>();
     cam->c.fx = 458.654; // intrinsics.yaml:7 (EuRoC cam0)
@@ -31,7 +32,7 @@ int main(int argc, char** argv) {
     cam->c.width = 752;
     cam->c.height = 480;
     double cameraLag = 0, startTime = -1, stopTime = -1;
-    bool quiet = false, dump = false, sigmaFP32 = false;
+    bool quiet = false, dump = false, sigmaFP32 = false, printCamera = false;
     try {
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -43,6 +44,8 @@ int main(int argc, char** argv) {
             if (a == "--imu") imuName = val();
             else if (a == "--features") featName = val();
             else if (a == "--groundtruth") gtName = val();
+            else if (a == "--cameraFile") cameraFileName = val();
+            else if (a == "--dumpStates") statesName = val();
             else if (a == "--format") {
                 const std::string f = val();
                 if (f == "asl") format = DatasetFormat::ASL;
@@ -79,6 +82,7 @@ int main(int argc, char** argv) {
             else if (a == "--quiet") quiet = true;
             else if (a == "--sigmaFP32") sigmaFP32 = true;
             else if (a == "--dumpMeasurements") dump = true;
+            else if (a == "--printCamera") printCamera = true;
             else if (!parseFilterFlag(a, val, fs)) {
                 usage();
                 return a == "--help" ? 0 : 2;
@@ -87,6 +91,14 @@ int main(int argc, char** argv) {
         if (imuName.empty() || featName.empty()) {
             usage();
             return 2;
+        }
+        if (!cameraFileName.empty()) // after the flags: --format decides which layout the file has (main_opt.cpp:114-147)
+            readCameraFile(cameraFileName, format, *cam, fs.cameraOffset);
+        if (printCamera) { // host-only: the camera and the camera offset as the run would use them (model fx fy cx cy width height k1..k5 | qw qx qy qz x y z)
+            std::printf("camera %d %.17g %.17g %.17g %.17g %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", cam->c.model, cam->c.fx, cam->c.fy, cam->c.cx,
+                        cam->c.cy, cam->c.width, cam->c.height, cam->c.dist[0], cam->c.dist[1], cam->c.dist[2], cam->c.dist[3], cam->c.dist[4], fs.cameraOffset.R.w, fs.cameraOffset.R.x,
+                        fs.cameraOffset.R.y, fs.cameraOffset.R.z, fs.cameraOffset.x.x, fs.cameraOffset.x.y, fs.cameraOffset.x.z);
+            return 0;
         }
         TrackReplayServer dataServer(imuName, featName, format, cam, cameraLag);
         if (dump) { // host-only: print the merged measurement stream as parsed (no filter, no device)
@@ -123,6 +135,11 @@ int main(int argc, char** argv) {
         std::unique_ptr<VIOWriter> vioWriter;
         if (!outputDir.empty())
             vioWriter = std::make_unique<VIOWriter>(outputDir);
+        // --dumpStates: the state estimate after every vision measurement at FULL precision (%.17g; the writer's files carry 6 digits), one line per frame:
+        // time, the 23 numbers of the sensor state (bias, pose wxyz + xyz, velocity, camera offset), N, then id x y z per landmark. For parity tests.
+        std::FILE* statesFile = statesName.empty() ? nullptr : std::fopen(statesName.c_str(), "w");
+        if (!statesName.empty() && !statesFile)
+            throw std::runtime_error("cannot open " + statesName);
         int imuDataCounter = 0, visionDataCounter = 0;
         const auto loopStartTime = std::chrono::steady_clock::now();
         while (true) {
@@ -142,6 +159,19 @@ int main(int argc, char** argv) {
                 ++visionDataCounter;
                 loopTimer.startTiming("write output");
                 const VIOState estimatedState = filter.stateEstimate();
+                if (statesFile) {
+                    const VIOSensorState& se = estimatedState.sensor;
+                    std::fprintf(statesFile, "%.17g", filter.getTime());
+                    const double sv[23] = {se.inputBias[0], se.inputBias[1], se.inputBias[2], se.inputBias[3], se.inputBias[4], se.inputBias[5], se.pose.R.w, se.pose.R.x, se.pose.R.y,
+                                           se.pose.R.z, se.pose.x.x, se.pose.x.y, se.pose.x.z, se.velocity.x, se.velocity.y, se.velocity.z, se.cameraOffset.R.w, se.cameraOffset.R.x,
+                                           se.cameraOffset.R.y, se.cameraOffset.R.z, se.cameraOffset.x.x, se.cameraOffset.x.y, se.cameraOffset.x.z};
+                    for (const double v : sv)
+                        std::fprintf(statesFile, " %.17g", v);
+                    std::fprintf(statesFile, " %zu", estimatedState.cameraLandmarks.size());
+                    for (const Landmark& lm : estimatedState.cameraLandmarks)
+                        std::fprintf(statesFile, " %d %.17g %.17g %.17g", lm.id, lm.p.x, lm.p.y, lm.p.z);
+                    std::fprintf(statesFile, "\n");
+                }
                 if (vioWriter) {
                     vioWriter->writeStates(filter.getTime(), estimatedState);
                     vioWriter->writeFeatures(measData);
@@ -160,6 +190,8 @@ int main(int argc, char** argv) {
                 break;
         }
         const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - loopStartTime).count();
+        if (statesFile)
+            std::fclose(statesFile);
         std::cout << "Processed " << imuDataCounter << " IMU and " << visionDataCounter << " vision measurements.\n"
                   << "Time taken: " << elapsed << " seconds." << std::endl;
         const VIOState est = filter.stateEstimate();
