@@ -278,6 +278,85 @@ def rank_pass(args, rank, world_size, dist, backend, settings=None):
     return value, elapsed, flt, world, frames, settings, mine
 
 
+BATCH8 = [dict(trajectory=tr, maxFeatures=mf, seed=k) for k, (mf, tr) in enumerate((mf, tr) for mf in (40, 200) for tr in ("wave", "square", "sine", "line"))]
+
+
+def batch8_sequence(q, duration=60.0):
+    """Sequence q of BASELINE.json configs[3] ("batch of 8 EuRoC MH/V sequences, one filter instance per GPU") as SURVEY.md section 8(d) spells it out for a box without the
+    datasets: the C++ SimulationDataServer (the reference's simulator restated, eqvio_amd/host/VIOSimulator.cpp) on trajectory BATCH8[q], 60 s at 200 Hz IMU / 20 Hz camera,
+    pixel noise on, the EuRoC configuration's structure with simulator-consistent values (eqvio_amd/configs.py). Returns (settings, camera, initial sensor state, frames)."""
+    from eqvio_amd.capi import SimSettings, SimulationDataServer
+    from eqvio_amd.configs import euroc_settings, sim_consistent
+
+    spec = BATCH8[q]
+    fs = sim_consistent(euroc_settings(), measurementNoise=1.0)
+    sim = SimSettings.defaults(duration=duration, trajectory=spec["trajectory"], numPoints=8000, wallDistance=3.0, numWalls=6, randomSeed=spec["seed"], maxFeatures=spec["maxFeatures"],
+                               outputNoise=1, inputNoise=0)
+    srv = SimulationDataServer(sim, fs)
+    fs.cameraOffset[:] = srv.camera_offset()
+    s0, _, _ = srv.true_state(0.0, True)
+    frames, imus = [], []
+    while srv.next_measurement_type() != srv.NONE:
+        if srv.next_measurement_type() == srv.IMU:
+            imus.append(srv.get_imu())
+            continue
+        stamp, ids, y = srv.get_vision()
+        frames.append((np.array(imus).reshape(-1, 13), stamp, ids, y))
+        imus = []
+    return fs, srv.cam, s0, frames
+
+
+def batch8(args, rank, world_size, dist, backend, stand_in, one_device):
+    """`bench.py --gpus N --config batch8`: the 8 sequences are shared out over the N ranks (rank r takes q = r, r + N, ...), one filter per sequence (main_opt-like: it starts
+    without landmarks and adds / drops them itself), the input containers built before the timed region. value = vision updates of the whole batch / the slowest rank's time:
+    total work is fixed, so this line is "scaling": "strong". Parity of two of the sequences against the oracle: tests/test_gpu_batch8.py."""
+    from eqvio_amd.capi import VIOFilter
+
+    mine_q = list(range(rank, len(BATCH8), world_size))
+    jobs = []
+    for q in mine_q:
+        fs, cam, s0, frames = batch8_sequence(q)
+        flt = VIOFilter(fs, max_landmarks=2 * BATCH8[q]["maxFeatures"] + 64, device=backend.local_rank if not stand_in else 0, sensor=s0, ids=np.zeros(0, np.int32), p=np.zeros((0, 3)), time=0.0)
+        jobs.append((q, flt, backend.prepare(cam, *flatten_frames(frames)), len(frames)))
+    if not stand_in and jobs:
+        backend.spin_up(jobs[0][1])
+    for _, flt, _, _ in jobs:
+        backend.sync(flt)
+    if dist is not None:
+        dist.barrier()
+    per_seq = {}
+    t0 = time.perf_counter()
+    for q, flt, prepared, nfr in jobs:
+        t1 = time.perf_counter()
+        done = flt.run_prepared(prepared, 0, nfr)
+        backend.sync(flt)
+        assert done == nfr, (q, done, nfr)
+        per_seq[q] = {"frames": nfr, "seconds": time.perf_counter() - t1, "final_landmarks": (flt.sigma_dim() - 21) // 3}
+    mine = time.perf_counter() - t0
+    gathered = [(mine, per_seq)]
+    if dist is not None:
+        gathered = [None] * world_size
+        dist.all_gather_object(gathered, (mine, per_seq))
+        dist.barrier()
+    if rank == 0:
+        slowest = max(g[0] for g in gathered)
+        seqs = {q: v for g in gathered for q, v in g[1].items()}
+        total = sum(v["frames"] for v in seqs.values())
+        rates = [v["frames"] / v["seconds"] for v in seqs.values()]
+        print(json.dumps({
+            "metric": "EqF vision updates/sec, batch of 8 sequences", "value": total / slowest, "unit": "updates/s", "n_gpus": world_size, "steps": total, "warmup": 0,
+            "ms_per_step": 1e3 * slowest / total, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "stand-in" if stand_in else "synthetic",
+            "config": {"workload": "BASELINE.json configs[3] stand-in: 8 simulated sequences (wave / square / sine / line x maxFeatures 40 / 200, seeds 0-7, 60 s, 200 Hz IMU, 20 Hz camera), "
+                                   "EuRoC-structured settings, one filter per sequence, sequences shared out over the ranks" + (" (every rank on GPU 0: EQVIO_BENCH_ONE_DEVICE)" if one_device else ""),
+                       "parallelism": f"replicas x{world_size}"},
+            "per_rank_seconds": {"min": min(g[0] for g in gathered), "max": slowest},
+            "per_sequence_updates_per_s": {"min": min(rates), "max": max(rates)},
+            "sequences": {str(q): dict(BATCH8[q], **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in seqs[q].items()}) for q in sorted(seqs)},
+        }))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def load_backend(local_rank):
     """The product backend, or - test hook, CPU rehearsal of the launch logic only - the class named by EQVIO_BENCH_BACKEND=module:Class
     (tests/test_replicas_gloo.py passes its oracle-backed stand-in; such a run prints `"data": "stand-in"` and no roofline)."""
@@ -325,6 +404,9 @@ def main():
     ap.add_argument("--no-frame-mix", action="store_true")
     ap.add_argument("--no-binding", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes of the roofline object (three short runs of this script under the profiler)")
+    ap.add_argument("--config", default="headline", choices=["headline", "batch8"],
+                    help="batch8: BASELINE.json configs[3] - a batch of 8 sequences (trajectories wave / square / sine / line x maxFeatures 40 / 200, seeds 0-7, 60 s each) "
+                         "shared out over the ranks, one filter per sequence; --steps / --warmup / --landmarks are ignored")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -345,6 +427,8 @@ def main():
         have = backend.torch.cuda.device_count()
         assert have >= world_size, "bench.py --gpus %d: only %d device(s) visible" % (world_size, have)
     dist = init_control_group(world_size)
+    if args.config == "batch8":
+        return batch8(args, rank, world_size, dist, backend, stand_in, one_device)
     N = args.landmarks
 
     def Filter(settings, sensor, ids, p, t):
