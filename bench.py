@@ -648,9 +648,24 @@ def several_filters_on_one_gpu(settings, N, device, Filter, lib, counts=(1, 2, 4
         return out
 
     sweep = {"N%d" % Nl: [run_config(Nl, R) for R in counts] for Nl in sizes}
-    head = next((r for r in sweep.get("N%d" % N, []) if r["filters"] == 4), None) or run_config(N, 4)
-    return {"filters": 4, "frames_each": n_frames, "value": head["value"], "unit": "updates/s aggregate on one GPU", "sweep": sweep,
-            "note": "informational; independent filters in one process, one host thread + stream pair each; sweep = aggregate updates/s for R filters at N = 50 / 200"}
+    # the same with one PROCESS per filter (the reference-compatible mode: its LoopTimer is a global, include/eqvio/LoopTimer.h:95): scripts/multi_process.py
+    procs = None
+    try:
+        import subprocess
+
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "multi_process.py"), str(N), "1500", "1,2,3,4,6"], capture_output=True, text=True, timeout=600, check=True)
+        procs = {int(k): v for k, v in json.loads(res.stdout.strip().splitlines()[-1])["aggregate_updates_per_s"].items()}
+    except Exception as e:  # noqa: BLE001
+        procs = {"error": repr(e)[:200]}
+    threads_best = max(sweep.get("N%d" % N, [{"value": 0.0, "filters": 0}]), key=lambda r: r["value"])
+    best_p = max(((v, k) for k, v in procs.items() if isinstance(k, int)), default=(0.0, 0))
+    return {"filters": best_p[1] if best_p[0] > threads_best["value"] else threads_best["filters"], "frames_each": n_frames, "value": max(best_p[0], threads_best["value"]),
+            "unit": "updates/s aggregate on one GPU", "sweep": sweep, "one_process_per_filter_N%d" % N: procs,
+            "note": "informational; sweep = aggregate updates/s for R independent filters as R threads of one process (one context + one stream each) at N = 50 / 200; "
+                    "one_process_per_filter = the same as R processes. Three things bound it (DESIGN.md section 7, profiles/r04_multi_*): a stream is one of the runtime's "
+                    "GPU_MAX_HW_QUEUES = 4 hardware queues (round 3's second stream per context halved that: saturation at two filters); a look-ahead kernel needs its 66 workgroups "
+                    "(N = 200) resident at once, one per compute unit, so three fit a 256-CU device (launches are booked against the CUs inside a process); and in ONE process the "
+                    "launch path of the HIP runtime serialises the host threads (the kernel trace at four threads shows the GPU idle 40 % of the time)"}
 
 
 def measure_roofline(flt, lib, core, cam, frames, args, n, m):

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -169,6 +171,7 @@ struct eqf_ctx {
     double tail_var = 0.0;                   // ... and needs the measurement variance again
     long zb_launches = 0;
     int cu_count = 256;                      // compute units of the device: the look-ahead kernel needs all its workgroups resident at once
+    int la_cus_held = 0;                     // compute units this context has booked for a look-ahead launch in flight (la_book / la_release)
     int la_selftest = 0;                     // look-ahead self-test at creation: 0 not run (never eligible at this capacity), 1 passed, -1 failed (launch chain only)
     long long la_timeout_ticks = LA_TIMEOUT_TICKS; // EQF_OPT_LA_TIMEOUT_US: bound of every device-side wait of the look-ahead kernel (100 MHz ticks)
     long la_launches = 0, la_fallbacks = 0;  // eqf_lookahead_stats: look-ahead launches; of those, stalled ones that were redone on the launch chain
@@ -341,6 +344,33 @@ int spin_stream(hipStream_t st) {
         }
     }
 }
+// Several filters on one GPU (one context each, any threads of this process): the look-ahead kernel needs ALL its workgroups resident at once, one per compute
+// unit (66 at N = 200), and waits for them inside the kernel. Three such launches fit a 256-CU device; a fourth one's workgroups would trickle in as the
+// others leave and every kernel involved crawls (measured: 3 filters 22.5 k updates/s aggregate, 4 filters 15 k). The launches are therefore BOOKED against
+// the device's compute units: a context whose launch does not fit waits on the host until an earlier one has rung its doorbell. One filter never waits.
+namespace {
+std::mutex la_gate_mutex;
+std::condition_variable la_gate_cv;
+int la_cus_booked[64] = {0}; // per device
+} // namespace
+static void la_release(eqf_ctx* c) {
+    if (!c->la_cus_held)
+        return;
+    {
+        std::lock_guard<std::mutex> g(la_gate_mutex);
+        la_cus_booked[c->device & 63] -= c->la_cus_held;
+    }
+    c->la_cus_held = 0;
+    la_gate_cv.notify_all();
+}
+static void la_book(eqf_ctx* c, int workgroups) {
+    la_release(c);
+    std::unique_lock<std::mutex> g(la_gate_mutex);
+    int& booked = la_cus_booked[c->device & 63];
+    la_gate_cv.wait(g, [&] { return booked == 0 || booked + workgroups <= c->cu_count; });
+    booked += workgroups;
+    c->la_cus_held = workgroups;
+}
 int sync_ctx(eqf_ctx* c) {
     {
         int r = spin_stream(c->stream);
@@ -355,6 +385,7 @@ int sync_ctx(eqf_ctx* c) {
     }
     c->busy_common = c->busy_steps = c->busy_meas = false;
     c->ring_inflight = 0;
+    la_release(c);
     return 0;
 }
 // Wait for the doorbell `which` to show `seq` (written by the last workgroup of the kernel launched with it, after every
@@ -372,8 +403,10 @@ int door_wait(eqf_ctx* c, int which, int seq) {
             c->ring_inflight = 0; // the kernel that rang was queued behind every flush of this context
             ++c->wait_calls;
             c->wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (which == 1)
+            if (which == 1) {
                 host_stamp(c, TH_DOOR);
+                la_release(c); // the lift kernel rang: the look-ahead kernel in front of it has left the compute units
+            }
             return 0;
         }
         if ((it & 0xfff) == 0 || spins_after_done) {
@@ -651,7 +684,8 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     c->mcap = 2 * c->Ncap;
     c->ldz = pick_ld(c->mcap + c->ncap + 1);
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    // (the second stream is created by the first stand-alone eqf_integrate_observer call: a stream is a hardware queue, the runtime hands out GPU_MAX_HW_QUEUES = 4 of them per
+    //  process by default, and streams that share a queue run one after the other - with two streams per context a GPU saturated at TWO filters)
     HIPCHK(hipEventCreateWithFlags(&c->ev_assembled, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_observer, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming));
@@ -731,6 +765,8 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
 }
 
 void eqf_destroy(eqf_ctx* c) {
+    if (c)
+        la_release(c);
     if (c && std::getenv("EQF_DEBUG_STATS"))
         std::fprintf(stderr, "[eqf_hip] look-ahead launches %ld (stalled %ld), of them with Z built inside %ld\n", c->la_launches, c->la_fallbacks, c->zb_launches);
     if (!c)
@@ -1759,6 +1795,8 @@ static void observer_host_steps(eqf_ctx* c, const double* imu13_k, const double*
 static int observer_launch(eqf_ctx* c, const ObsSteps& steps_arg, int chunk) {
     if (c->N == 0)
         return 0;
+    if (!c->stream2)
+        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     if (c->obs_pending)
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_observer, 0));
     if (!c->ev_assembled_early)
@@ -2179,8 +2217,10 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
     int rc = 0;
     const bool la = !force_chain && lookahead_eligible(c, m); // one persistent kernel instead of one launch per panel; Gamma complete in d_gamma
     c->tail_la = la; // the retry state of finish_update always describes the tail in flight (with tail_zb / tail_M / tail_var, set by launch_update_tail)
-    if (la)
+    if (la) {
         ++c->la_launches;
+        la_book(c, (2 * blocks(m, 32) - 1) + blocks(rows - m, 16) + 1);
+    }
     rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, zb, zb_mf) : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
     if (rc)
         return rc;
