@@ -1058,11 +1058,31 @@ __device__ __forceinline__ double fetch_lane(double v, int byte_addr) { // value
 // entries G = A[r, J:J+4] of its row once (ds_bpermute, under the first reciprocal), forms the first pair's multipliers E = G1 P^-1 and the
 // second pair's multiplier sources H = G2 - E Q^T itself; the second pivot block S = R - Q P^-1 Q^T is then simply H of the rows J+2, J+3 (three DPP
 // row broadcasts), F2 = H S^-1. Rank-2 update with (E; pivot rows J, J+1), then rank-2 with (F2; the updated pivot rows J+2, J+3).
+// every lane (r, *) receives the values v of the lanes (r, 0), (r, 1), (r, 2), (r, 3): the gfx950 pair v_permlane32_swap + v_permlane16_swap (VALU). ds_bpermute does the
+// same through the LDS crossbar at the same issue cost (14 cycles per instruction for a lone wave against ~8 per swap + copy) - but in the look-ahead kernel's owner the
+// other waves' operand reads queue in front of it: the elimination took 2.6 us alone and 2.95 us under the tail's LDS traffic (profiles/r04_*_lookahead_trace.txt).
+typedef unsigned ldl_v2u __attribute__((ext_vector_type(2)));
+template <bool FOUR> __device__ __forceinline__ void row_allgather(double v, double& g0, double& g1, double& g2, double& g3) {
+    const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+    const ldl_v2u h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false); // .x = rows [0, 1, 0, 1], .y = rows [2, 3, 2, 3]
+    const ldl_v2u l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const ldl_v2u h01 = __builtin_amdgcn_permlane16_swap(h32.x, h32.x, false, false); // .x = row 0 everywhere, .y = row 1
+    const ldl_v2u l01 = __builtin_amdgcn_permlane16_swap(l32.x, l32.x, false, false);
+    g0 = __hiloint2double((int)h01.x, (int)l01.x);
+    g1 = __hiloint2double((int)h01.y, (int)l01.y);
+    if (FOUR) {
+        const ldl_v2u h23 = __builtin_amdgcn_permlane16_swap(h32.y, h32.y, false, false);
+        const ldl_v2u l23 = __builtin_amdgcn_permlane16_swap(l32.y, l32.y, false, false);
+        g2 = __hiloint2double((int)h23.x, (int)l23.x);
+        g3 = __hiloint2double((int)h23.y, (int)l23.y);
+    }
+}
 template <int B> __device__ __forceinline__ void ldl16x4_round(double (&a)[4], double (&mm)[4], int r, const int (&gaddr)[4]) {
     constexpr int J = 4 * B;
     // P straight from the owning lanes: A[J][J] lane (J, 0), A[J+1][J] lane (J+1, 0), A[J+1][J+1] lane (J+1, 1)
     const double p11 = read_lane<J>(a[B]), p21 = read_lane<J + 1>(a[B]), p22 = read_lane<J + 1 + 16>(a[B]);
-    const double g0u = fetch_lane(a[B], gaddr[0]), g1u = fetch_lane(a[B], gaddr[1]); // A[r][J], A[r][J+1]
+    double g0u, g1u, h1 = 0.0, h2 = 0.0; // A[r][J], A[r][J+1]; A[r][J+2], A[r][J+3] (which become the columns J+2, J+3 after the first pair's update)
+    row_allgather<(B < 3)>(a[B], g0u, g1u, h1, h2);
     const double iP0 = fast_rcp(fma(p11, p22, -p21 * p21));
     const double iP = (r >= J + 2) ? iP0 : 0.0; // rows of the first pair and above are not touched: their multipliers are zero
     const double e1 = (g0u * p22 - g1u * p21) * iP, e2 = (g1u * p11 - g0u * p21) * iP; // (A[r][J], A[r][J+1]) P^-1; the numerators form under the reciprocal
@@ -1070,7 +1090,6 @@ template <int B> __device__ __forceinline__ void ldl16x4_round(double (&a)[4], d
         ldl_rank2_x5<J>(a[3], mm[0], mm[1], mm[2], mm[3], e1, e2);
         return;
     }
-    double h1 = fetch_lane(a[B], gaddr[2]), h2 = fetch_lane(a[B], gaddr[3]); // A[r][J+2], A[r][J+3]; become the columns J+2, J+3 after the first pair's update
     double s11, s21, s22;
     // Static pruning: registers of A whose columns are all < J hold eliminated columns (register B keeps the pivot blocks for the final scaling and
     // only needs the first pair's update); registers of M whose columns are all > J + 3 still hold identity columns on which the pivot rows are zero.

@@ -280,20 +280,30 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             if (a.dbg && lane == 0)
                 a.dbg[8 * k + 6] = wall_clock64();
             const int w2 = min(32, a.m - 32 * I);
-            double* lt = la_tile(a, la_i_linv(a, I));
-            ldl_inverse_tile_put(
-                sD, CH_LDP, w2,
-                [sLk, lt](int r, int c, double v) {
-                    sLk[r + c * CH_LDP] = v;
-                    la_st(lt + r + 32 * c, v);
-                },
-                a.flags, swork);
-            la_lds_set(cnt + LC_L, I + 1); // L_I^-1 complete in sLk: the post-work of step I starts
-            if (a.dbg && lane == 0)
-                a.dbg[8 * I + 4] = wall_clock64();
-            la_stores_done(); // its write-through stores: mostly acknowledged while the elimination ran; the rest under the post-work
-            if (lane == 0)
-                la_raise_f(a, la_f_linv(a, I));
+            // Round 4: L_I^-1 leaves this wave through LDS only. Its 64 write-through stores (address arithmetic + store: ~0.3 us of a lone wave's issue slots
+            // at the end of every elimination) are wave 3's now, which idles between two hand-off polls. Only the LAST tile, which the T half-rows are waiting
+            // for and behind which nothing of the owner runs, is still published from here.
+            if (I + 1 < NJ) {
+                ldl_inverse_tile_put(sD, CH_LDP, w2, [sLk](int r, int c, double v) { sLk[r + c * CH_LDP] = v; }, a.flags, swork);
+                la_lds_set(cnt + LC_L, I + 1); // L_I^-1 complete in sLk: the post-work of step I starts
+                if (a.dbg && lane == 0)
+                    a.dbg[8 * I + 4] = wall_clock64();
+            } else {
+                double* lt = la_tile(a, la_i_linv(a, I));
+                ldl_inverse_tile_put(
+                    sD, CH_LDP, w2,
+                    [sLk, lt](int r, int c, double v) {
+                        sLk[r + c * CH_LDP] = v;
+                        la_st(lt + r + 32 * c, v);
+                    },
+                    a.flags, swork);
+                la_lds_set(cnt + LC_L, I + 1);
+                if (a.dbg && lane == 0)
+                    a.dbg[8 * I + 4] = wall_clock64();
+                la_stores_done();
+                if (lane == 0)
+                    la_raise_f(a, la_f_linv(a, I));
+            }
         }
         if (a.tr_steps && lane == 0 && NJ - 1 < 32)
             a.tr_steps[NJ - 1] = wall_clock64();
@@ -338,12 +348,41 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         return;
     }
     // ------------------------------------------------------------------------------------------------------------------ wave 3: polls for the block rows' hand-offs
+    // ... and, round 4, publishes L_1^-1 .. L_(NJ-2)^-1 out of sLk (the pivot wave keeps its issue slots for the elimination). The two jobs alternate in the order
+    // the data appears: L_k^-1 is complete ~2 us before block row k + 2 hands its tiles over (which needs L_(k-1)^-1 and earlier ones only: no cycle), and the next
+    // L^-1 another ~2.5 us later. The flag of L_k^-1 is the first link of the chain L -> block row -> U -> tail, so it goes up as soon as its stores are acknowledged.
     if (wave == 3) {
-        for (int I = 1; I < NJ; ++I) { // both halves of block row I have handed their tiles over: tell the tail waves (bounded like every poll)
+        auto wait_u = [&](int I) { // both halves of block row I have handed their tiles over: tell the tail waves (bounded like every poll)
             la_wait(a.pubf + la_f_u(a, I, 0), 2, pl);
             if (*(volatile int*)s_abort)
-                return;
+                return false;
             la_lds_set(cnt + LC_U, I);
+            return true;
+        };
+        if (!wait_u(1) || (NJ > 2 && !wait_u(2)))
+            return;
+        for (int k = 1; k + 1 < NJ; ++k) {
+            if (k + 2 <= NJ - 1 || k <= NJ - 2) {
+                if (k <= NJ - 2) {
+                    if (!la_lds_wait<true>(cnt + LC_L, k + 1, s_abort)) // relaxed: a tight LDS poll for ~2 us would compete with the pivot wave's own LDS traffic
+                        return;
+                    double v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int e = lane + 64 * i;
+                        v[i] = sLk[(e & 31) + (e >> 5) * CH_LDP];
+                    }
+                    double* t = la_tile(a, la_i_linv(a, k));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        la_st(t + lane + 64 * i, v[i]);
+                    la_stores_done();
+                    if (lane == 0)
+                        la_raise_f(a, la_f_linv(a, k));
+                }
+                if (k + 2 < NJ && !wait_u(k + 2))
+                    return;
+            }
         }
         return;
     }
