@@ -1150,12 +1150,12 @@ __device__ __forceinline__ void ldl16_inverse_wave(double (&a)[4], double (&out)
 constexpr int LDL_SBUF = 7 * 256 + 32;
 // The result leaves through put(r, c, v) (every entry of the 32x32 factor exactly once, zeros above the diagonal blocks included):
 // ldl_inverse_tile stores it column-major to global memory, the look-ahead kernel keeps it in LDS and publishes it.
-template <typename Put>
-__device__ __forceinline__ void ldl_inverse_tile_put(const double* __restrict__ sD, int ldd, int w, Put put, int* __restrict__ flags, double* __restrict__ swork) {
-    if (threadIdx.x >= 64)
-        return;
-    // this wave is the critical path of the whole frame: win the issue arbitration against co-resident workgroups
-    __builtin_amdgcn_s_setprio(3);
+// The core works on registers: D11 arrives in `a` (elimination layout, symmetric fill, identity padding), D21 / D22 are fetched by `rest(d21, d22)` only
+// when the first diagonal block has been inverted (the look-ahead owner's pivot wave forms D11 itself and receives the other two blocks from its neighbours about
+// a microsecond later), and the blocks of the factor stay with the caller: o1 = Linv[0:16, 0:16], o2 = Linv[16:32, 16:32], xl = Linv[16:32, 0:16].
+template <typename Rest, typename Put>
+__device__ __forceinline__ void ldl_inverse_tile_regs(double (&a)[4], Rest rest, int w, Put put, int* __restrict__ flags, double* __restrict__ swork, double (&o1)[4],
+                                                      double (&o2)[4], double (&xl)[4]) {
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
     double* sA = swork;           // pivot blocks of an elimination (16 x 17)
@@ -1163,19 +1163,13 @@ __device__ __forceinline__ void ldl_inverse_tile_put(const double* __restrict__ 
     // Everything lives in the "elimination layout": lane (lr, lk) holds X[lr][lk + 4 q], q = 0..3. A product C = I J^T of two 16 x 16 matrices in that
     // layout needs no data movement at all on fp64 MFMA 16x16x4: step q contracts the columns p = lk + 4 q of BOTH operands (the order of the sum over p is
     // free), and the result comes back in the same layout. Only Y^T = L11inv^T L21^T needs one operand transposed (one LDS round trip, off the chain).
-    double a[4], d21[4], d22[4], o1[4], o2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = lk + 4 * k;
-        a[k] = sD[max(lr, c) + min(lr, c) * ldd]; // symmetric fill from the valid lower triangle
-        d21[k] = sD[16 + lr + c * ldd];
-        d22[k] = sD[16 + max(lr, c) + (16 + min(lr, c)) * ldd];
-    }
+    double d21[4], d22[4];
     // A. first diagonal block
     ldl16_inverse_wave(a, o1, flags, lr < w, sA);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         sLi11[lr + (lk + 4 * k) * 16] = o1[k];
+    rest(d21, d22);
     // B. L21 = D21 L11inv^T ; S22 = D22 - L21 L21^T
     d4 acc = {0, 0, 0, 0};
 #pragma unroll
@@ -1204,11 +1198,39 @@ __device__ __forceinline__ void ldl_inverse_tile_put(const double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = lk + 4 * k;
+        xl[k] = -acc[k];
         put(lr, c, o1[k]);
         put(lr, c + 16, 0.0);
-        put(16 + lr, c, -acc[k]);
+        put(16 + lr, c, xl[k]);
         put(16 + lr, 16 + c, o2[k]);
     }
+}
+template <typename Put>
+__device__ __forceinline__ void ldl_inverse_tile_put(const double* __restrict__ sD, int ldd, int w, Put put, int* __restrict__ flags, double* __restrict__ swork) {
+    if (threadIdx.x >= 64)
+        return;
+    // this wave is the critical path of the whole frame: win the issue arbitration against co-resident workgroups
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    double a[4], d21r[4], d22r[4], o1[4], o2[4], xl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { // all of the tile requested up front
+        const int c = lk + 4 * k;
+        a[k] = sD[max(lr, c) + min(lr, c) * ldd]; // symmetric fill from the valid lower triangle
+        d21r[k] = sD[16 + lr + c * ldd];
+        d22r[k] = sD[16 + max(lr, c) + (16 + min(lr, c)) * ldd];
+    }
+    ldl_inverse_tile_regs(
+        a,
+        [&](double (&d21)[4], double (&d22)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d21[k] = d21r[k];
+                d22[k] = d22r[k];
+            }
+        },
+        w, put, flags, swork, o1, o2, xl);
 }
 
 __device__ __forceinline__ void ldl_inverse_tile(const double* __restrict__ sD, int ldd, int w, double* __restrict__ LinvOut, int* __restrict__ flags,

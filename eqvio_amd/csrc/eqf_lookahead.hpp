@@ -179,12 +179,12 @@ __device__ __forceinline__ void la_lds_set(int* c, int v) { // after this wave's
     if ((threadIdx.x & 63) == 0)
         __hip_atomic_store(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void la_lds_add(int* c) {
+__device__ __forceinline__ void la_lds_add(int* c, int by = 1) {
     asm volatile("" ::: "memory");
     if ((threadIdx.x & 63) == 0)
-        __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(c, by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-enum { LC_L = 0, LC_T, LC_C, LC_D, LC_B, LC_CCOPIED, LC_BCOPIED, LC_U, LC_COUNT };
+enum { LC_L = 0, LC_T, LC_C, LC_D, LC_B, LC_CCOPIED, LC_BCOPIED, LC_U, LC_LCOPIED, LC_COUNT };
 
 template <int ZB>
 __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_abort_words, int* cnt, const LaPoll& pl) {
@@ -270,33 +270,100 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         }
     }
     // ------------------------------------------------------------------------------------------------------------------ wave 0: the pivot chain
+    // Round 4 (second half): the pivot wave forms the block it needs FIRST itself. D_(k+1)[0:16, 0:16] = D'_00 - c_0 c_0^T with c_0 = R1[0:16, :] L_k^-T is 20
+    // register-operand MFMAs on the blocks of L_k^-1 this wave still holds from its last elimination (elimination layout: no data movement, result in place,
+    // ~0.55 us), against ~1.3 us for the four-wave post-work with its two LDS hand-offs and the read-back of the tile. The rows 16 .. 31 of c and the blocks
+    // (1, 0), (1, 1) of D_(k+1) are still waves 5 / 7's: they arrive in sD while the first 16 x 16 block is being eliminated. Same products in the same order as
+    // before (the zero block of the triangular L_k^-1 skipped): W stays bit-identical to the launch chain.
     if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3); // this wave is the critical path of the whole frame
+        double o1[4], o2[4], xl[4];    // L_k^-1: blocks (0, 0), (1, 1), (1, 0) in elimination layout, lane (lr, lk) holds X[lr][lk + 4 q]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o1[q] = sLk[lr + (lk + 4 * q) * CH_LDP];
+            xl[q] = sLk[16 + lr + (lk + 4 * q) * CH_LDP];
+            o2[q] = sLk[16 + lr + (16 + lk + 4 * q) * CH_LDP];
+        }
         for (int k = 0; k + 1 < NJ; ++k) {
             const int I = k + 1;
             if (a.tr_steps && lane == 0 && k < 32)
                 a.tr_steps[k] = wall_clock64();
-            if (!la_lds_wait(cnt + LC_D, 5 * (k + 1), s_abort)) // the four post-work waves + wave 2, which has read L_k^-1 out of sLk
+            // R1 and D'_00 of block row k + 1 (the tail of step k - 1 left them in sY / sDq); sX free: the tail of step k - 1 and wave 1 have read c^(k-1)
+            if (!la_lds_wait(cnt + LC_T, 4 * (k + 1), s_abort) || (k >= 1 && !la_lds_wait(cnt + LC_CCOPIED, k, s_abort)))
                 return;
             if (a.dbg && lane == 0)
+                a.dbg[8 * k + 3] = wall_clock64();
+            double r11[4], r12[4], dq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = lk + 4 * q;
+                r11[q] = sY[lr + c * CH_LDP];
+                r12[q] = sY[lr + (16 + c) * CH_LDP];
+                dq[q] = sDq[max(lr, c) + 16 * min(lr, c)]; // symmetric fill from the lower triangle, as the tile read-back did
+            }
+            d4 c11 = {0, 0, 0, 0}, c12 = {0, 0, 0, 0}, cc = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(o1[q], r11[q], c11, 0, 0, 0); // C = I J^T: first operand J
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                c12 = __builtin_amdgcn_mfma_f64_16x16x4f64(xl[q], r11[q], c12, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                c12 = __builtin_amdgcn_mfma_f64_16x16x4f64(o2[q], r12[q], c12, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { // rows 0 .. 15 of c = P^(k)_(k+1) for waves 5 / 7 (blocks (1, 0), (1, 1) of D), the tail of step k and wave 1
+                sX[lr + (lk + 4 * q) * CH_LDP] = c11[q];
+                sX[lr + (16 + lk + 4 * q) * CH_LDP] = c12[q];
+            }
+            la_lds_add(cnt + LC_C, 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                cc = __builtin_amdgcn_mfma_f64_16x16x4f64(c11[q], c11[q], cc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                cc = __builtin_amdgcn_mfma_f64_16x16x4f64(c12[q], c12[q], cc, 0, 0, 0);
+            const int w2 = min(32, a.m - 32 * I); // rows / columns >= w2 of the last diagonal tile are identity padding
+            double d11[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = lk + 4 * q;
+                d11[q] = (lr >= w2 || c >= w2) ? ((lr == c) ? 1.0 : 0.0) : dq[q] - cc[q];
+            }
+            if (a.dbg && lane == 0)
                 a.dbg[8 * k + 6] = wall_clock64();
-            const int w2 = min(32, a.m - 32 * I);
-            // Round 4: L_I^-1 leaves this wave through LDS only. Its 64 write-through stores (address arithmetic + store: ~0.3 us of a lone wave's issue slots
-            // at the end of every elimination) are wave 3's now, which idles between two hand-off polls. Only the LAST tile, which the T half-rows are waiting
-            // for and behind which nothing of the owner runs, is still published from here.
+            bool gone = false;
+            auto rest = [&](double (&d21)[4], double (&d22)[4]) {
+                // waves 5 / 7 have written the blocks (1, 0) / (1, 1) of D_(k+1) to sD; they, wave 2 and wave 3 have read L_k^-1 out of sLk (rewritten below)
+                if (!la_lds_wait(cnt + LC_D, 3 * (k + 1), s_abort) || (k >= 1 && !la_lds_wait(cnt + LC_LCOPIED, k, s_abort)))
+                    gone = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = lk + 4 * q;
+                    d21[q] = sD[16 + lr + c * CH_LDP];
+                    d22[q] = sD[16 + max(lr, c) + (16 + min(lr, c)) * CH_LDP];
+                }
+            };
+            // Round 4: L_I^-1 leaves this wave through LDS only; wave 3 publishes it. Only the LAST tile, which the T half-rows are waiting for and behind
+            // which nothing of the owner runs, is still published from here.
             if (I + 1 < NJ) {
-                ldl_inverse_tile_put(sD, CH_LDP, w2, [sLk](int r, int c, double v) { sLk[r + c * CH_LDP] = v; }, a.flags, swork);
-                la_lds_set(cnt + LC_L, I + 1); // L_I^-1 complete in sLk: the post-work of step I starts
+                ldl_inverse_tile_regs(d11, rest, w2, [sLk](int r, int c, double v) { sLk[r + c * CH_LDP] = v; }, a.flags, swork, o1, o2, xl);
+                if (gone)
+                    return;
+                la_lds_set(cnt + LC_L, I + 1); // L_I^-1 complete in sLk
                 if (a.dbg && lane == 0)
                     a.dbg[8 * I + 4] = wall_clock64();
             } else {
                 double* lt = la_tile(a, la_i_linv(a, I));
-                ldl_inverse_tile_put(
-                    sD, CH_LDP, w2,
+                ldl_inverse_tile_regs(
+                    d11, rest, w2,
                     [sLk, lt](int r, int c, double v) {
                         sLk[r + c * CH_LDP] = v;
                         la_st(lt + r + 32 * c, v);
                     },
-                    a.flags, swork);
+                    a.flags, swork, o1, o2, xl);
+                if (gone)
+                    return;
                 la_lds_set(cnt + LC_L, I + 1);
                 if (a.dbg && lane == 0)
                     a.dbg[8 * I + 4] = wall_clock64();
@@ -372,6 +439,8 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                         const int e = lane + 64 * i;
                         v[i] = sLk[(e & 31) + (e >> 5) * CH_LDP];
                     }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    la_lds_set(cnt + LC_LCOPIED, k); // the pivot wave may overwrite sLk
                     double* t = la_tile(a, la_i_linv(a, k));
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
@@ -387,9 +456,11 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         return;
     }
     // ------------------------------------------------------------------------------------------------------------------ waves 2, 4..7: post-work and tail
-    const bool post = wave >= 4;
+    const bool post = wave == 5 || wave == 7; // rows 16 .. 31 of c and the blocks (1, 0) / (1, 1) of D_(k+1); rows 0 .. 15 and the block (0, 0) are the pivot wave's
     const int pw = wave & 3;
     const bool tailw = wave == 2 || wave >= 5;
+    if (wave == 4) // round 3's fourth post-work wave: nothing left to do (kept in the launch: 512 threads = the half-rows' workgroup size)
+        return;
     const int tq = wave == 2 ? 0 : pw, ihT = tq & 1, jhT = tq >> 1;
     double dacc[4] = {0, 0, 0, 0};
     auto put_prepared = [&](const double (&r1)[4], const double (&dp)[4]) { // a tail wave's quadrant of R1 and D' to where the post-work finds them
@@ -419,7 +490,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     for (int k = 0; k + 1 < NJ; ++k) { // step k produces D_(k+1)
         const int I = k + 1;
         // L_k^-1 as B operand, both column halves, for the two waves that form b in the tail (wave 2: rows 0 .. 15, wave 7: rows 16 .. 31): read from sLk
-        // now, before the elimination of D_(k+1) rewrites it - the pivot wave starts only when wave 2 has counted itself into LC_D as well
+        // now, before the elimination of D_(k+1) rewrites it - the pivot wave writes L_(k+1)^-1 only when wave 2 has counted itself into LC_D as well
         double lkop[2][8];
         if (wave == 2) {
             if (!la_lds_wait(cnt + LC_L, k + 1, s_abort))
@@ -435,8 +506,6 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         if (post) {
             if (!la_lds_wait(cnt + LC_L, k + 1, s_abort) || !la_lds_wait(cnt + LC_T, 4 * (k + 1), s_abort))
                 return;
-            if (a.dbg && wave == 5 && lane == 0)
-                a.dbg[8 * k + 3] = wall_clock64();
             if (k >= 1 && !la_lds_wait(cnt + LC_CCOPIED, k, s_abort)) // wave 1 has read the previous c out of sX (it did, 3 us ago)
                 return;
             if (wave == 7) {
@@ -446,40 +515,34 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                     for (int st = 0; st < 8; ++st)
                         lkop[ch][st] = sLk[16 * ch + lr + (4 * st + lk) * CH_LDP];
             }
-            const int ih = pw & 1, ch = pw >> 1; // c = P^(k)_I = R1 L_k^-T : sub-tile (ih, ch)
-            if (wave == 4) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    dacc[q] = sDq[lr + 16 * (lk + 4 * q)];
-            }
+            const int ch = pw >> 1; // c = P^(k)_I = R1 L_k^-T : sub-tile (1, ch)
             d4 acc = {0, 0, 0, 0};
 #pragma unroll
             for (int st = 0; st < 8; ++st)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLk[16 * ch + lr + (4 * st + lk) * CH_LDP], sY[16 * ih + lr + (4 * st + lk) * CH_LDP], acc, 0, 0, 0);
+                if (ch == 1 || st < 4) // the triangular L_k^-1 has no columns >= 16 in its rows < 16
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sLk[16 * ch + lr + (4 * st + lk) * CH_LDP], sY[16 + lr + (4 * st + lk) * CH_LDP], acc, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                sX[16 * ih + lr + (16 * ch + lk + 4 * q) * CH_LDP] = acc[q];
+                sX[16 + lr + (16 * ch + lk + 4 * q) * CH_LDP] = acc[q];
             la_lds_add(cnt + LC_C);
             if (!la_lds_wait(cnt + LC_C, 4 * (k + 1), s_abort))
                 return;
-            const int ihU = pw & 1, jhU = pw >> 1;
+            const int jhU = pw >> 1; // the block (1, jhU) of D_(k+1)
             d4 acc2 = {0, 0, 0, 0};
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 const int c = 4 * st + lk;
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[16 * jhU + lr + c * CH_LDP], sX[16 * ihU + lr + c * CH_LDP], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[16 * jhU + lr + c * CH_LDP], sX[16 + lr + c * CH_LDP], acc2, 0, 0, 0);
             }
             const int w2 = min(32, a.m - 32 * I); // rows / columns >= w2 of the last diagonal tile are identity padding
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r_ = 16 * ihU + lr, c_ = 16 * jhU + lk + 4 * q;
+                const int r_ = 16 + lr, c_ = 16 * jhU + lk + 4 * q;
                 sD[r_ + c_ * CH_LDP] = (r_ >= w2 || c_ >= w2) ? ((r_ == c_) ? 1.0 : 0.0) : dacc[q] - acc2[q];
             }
             la_lds_add(cnt + LC_D);
             if (a.dbg && wave == 5 && lane == 0)
                 a.dbg[8 * k + 5] = wall_clock64();
-            if (wave == 4) // shares SIMD 0 with the pivot wave and has nothing to do until the elimination (~7000 cycles) is over: stay out of its way
-                __builtin_amdgcn_s_sleep(90);
         }
         if (tailw && k + 2 < NJ) {
             // tail: block row I2 = k + 2
@@ -490,7 +553,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 a.dbg[8 * k + 0] = wall_clock64();
             if (!la_lds_wait<true>(cnt + LC_U, I2, s_abort)) // wave 3 saw both U flags of block row I2
                 return;
-            double u2i[8], u1r[4], u0r[4], p3[8];
+            double u2i[8], u1r[4], u0r[4], p3[8], p3t[8];
             {
                 const double* t1 = la_tile(a, la_i_u(a, I2, 0)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
                 const double* t0 = la_tile(a, la_i_u(a, I2, 1)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
@@ -501,8 +564,11 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 }
                 if (tq == 0 || tq == 3)
                     la_operand(la_tile(a, la_i_u(a, I2, 2)), ihT, u2i);
-                if (I2 >= 3) // complete before the block row raised its U flags (published at its last panel)
+                if (I2 >= 3) { // complete before the block row raised its U flags (published at its last panel)
                     la_operand(la_tile(a, la_i_p(a, I2, I2 - 3)), ihT, p3);
+                    if (tq == 1)
+                        la_operand(la_tile(a, la_i_p(a, I2, I2 - 3)), 0, p3t);
+                }
             }
             // b = P^(k)_I2 = U2 L_k^-T. Wave 2 forms its rows 0 .. 15, wave 7 its rows 16 .. 31 (the two column halves' accumulators ARE the operand layout:
             // column 16 ch + lk + 4 q); the triangular L_k^-1 has no columns >= 16 in its rows < 16. The rows are kept in LDS for waves 5 and 6, for the
@@ -557,6 +623,18 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 r = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[16 * jhT + lr + c * CH_LDP], bi[st], r, 0, 0, 0); // b c^T (c = P^(k)_(k+1), the post-work's)
                 if (tq != 2)                                                                                   // the block (0, 1) of D' is above the diagonal: never read
                     d = __builtin_amdgcn_mfma_f64_16x16x4f64(bj[st], bi[st], d, 0, 0, 0);                      // b b^T
+            }
+            if (tq == 1 && I2 >= 3) {
+                // Round 4: the block (1, 0) of the diagonal tile misses its product of the block row's last panel as well, P^(I2-3)_bottom (P^(I2-3)_top)^T: the
+                // bottom half-row would have to wait for the top one's factor rows (store acknowledgement + flag poll + load, ~2 us in the middle of the
+                // loop L -> block row -> U -> tail that bounds the owner's step); the owner has both halves of that tile in hand anyway
+                d4 e = {0, 0, 0, 0};
+#pragma unroll
+                for (int st = 0; st < 8; ++st)
+                    e = __builtin_amdgcn_mfma_f64_16x16x4f64(p3t[st], p3[st], e, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    u0r[q] -= e[q];
             }
             double r1[4], dp[4];
 #pragma unroll
@@ -839,7 +917,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         // P_h (J = I, jh = s) is in LDS; its block above the diagonal (J = I, jh > s) is never used.
         {
             const int J = 4 * lane + jr;
-            if (lane < MAXT && J > p && J <= Jmax && !(srow && J == I && jh >= s) && !(srow && p == I - 3 && J == I - 1)) {
+            if (lane < MAXT && J > p && J <= Jmax && !(srow && J == I && jh >= s) && !(srow && p == I - 3 && J >= I - 1)) {
                 const int* f = a.pubf + la_f_p(a, p, 2 * J + jh);
                 for (;;) {
                     const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -856,7 +934,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int J = 4 * (t0 + u) + jr;
-                if (t0 + u < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1)) {
+                if (t0 + u < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1) && !(srow && p == I - 3 && J == I && jh < s)) {
                     if (srow && J == I && jh == s) { // diagonal block of an S half-row: both operands are P_h
 #pragma unroll
                         for (int st = 0; st < 8; ++st)
@@ -869,7 +947,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
             for (int u = 0; u < 2; ++u) {
                 const int t = (t0 + u < MAXT) ? t0 + u : MAXT - 1;
                 const int J = 4 * (t0 + u) + jr;
-                if (t0 + u < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1)) {
+                if (t0 + u < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1) && !(srow && p == I - 3 && J == I && jh < s)) {
                     d4 d = {0, 0, 0, 0};
 #pragma unroll
                     for (int st = 0; st < 8; ++st)
@@ -1072,7 +1150,7 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         const bool ahead = p + 1 < np && jr == ((p + 1) & 3); // this wave owns half of Z(h, p + 1)
         auto tile_used = [&](int t, int& J) -> bool {
             J = 4 * t + jr;
-            return t < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1);
+            return t < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1) && !(srow && p == I - 3 && J == I && jh < s);
         };
         // this wave's operands: rows 16 jh .. of P^(p)_J = what half-row 2 J + jh published; lane t watches the flag of tile t, lane 63 of a look-ahead
         // wave the flag of L_(p+1)^-1
