@@ -2136,32 +2136,46 @@ static int lookahead_selftest(eqf_ctx* c) {
             hz[m + t + (size_t)j * c->ldz] = ((t * 31 + j * 17) % 23) / 23.0 - 0.5;
         hz[m + nT + (size_t)j * c->ldz] = ((j * 5) % 13) / 13.0;
     }
-    for (int pass = 0; pass < 2; ++pass) {
-        HIPCHK(hipMemcpyAsync(c->d_Z, hz.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemsetAsync(c->d_W, 0, sizeof(double) * cnt, c->stream));
-        int rc;
-        if (pass == 0)
-            rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W);
-        else {
-            hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, 32, c->ldz, c->d_Z, c->d_Linv, c->d_flags);
-            HIPCHK(hipGetLastError());
-            rc = launch_lookahead(c, rows, m, c->ldz, nullptr, 0);
+    // A launch that STALLS (its workgroups were not all resident within the bound: other contexts are being created on the same device, or share it) says nothing about
+    // the kernel: it is repeated a few times, and if the device stays busy the test counts as not run - the look-ahead kernel stays enabled, every launch of it is
+    // bounded and redone on the chain when it stalls (finish_update)
+    int fl[4] = {0, 0, 0, 0};
+    bool stalled = false;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        for (int pass = (attempt == 0 ? 0 : 1); pass < 2; ++pass) {
+            HIPCHK(hipMemcpyAsync(c->d_Z, hz.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemsetAsync(c->d_W, 0, sizeof(double) * cnt, c->stream));
+            int rc;
+            if (pass == 0)
+                rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W);
+            else {
+                hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, 32, c->ldz, c->d_Z, c->d_Linv, c->d_flags);
+                HIPCHK(hipGetLastError());
+                rc = launch_lookahead(c, rows, m, c->ldz, nullptr, 0);
+            }
+            if (rc)
+                return rc;
+            w[pass].resize(cnt);
+            HIPCHK(hipMemcpyAsync(w[pass].data(), c->d_W, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            la_release(c);
         }
-        if (rc)
-            return rc;
-        w[pass].resize(cnt);
-        HIPCHK(hipMemcpyAsync(w[pass].data(), c->d_W, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(fl, c->d_flags, sizeof(fl), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(c->d_flags, 0, sizeof(int) * 4));
+        stalled = fl[3] == c->la_seq;
+        if (!stalled)
+            break;
     }
-    int fl[4];
-    HIPCHK(hipMemcpy(fl, c->d_flags, sizeof(fl), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(c->d_flags, 0, sizeof(int) * 4));
-    bool same = !fl[0] && fl[3] != c->la_seq;
+    if (stalled) {
+        std::fprintf(stderr, "[eqf_hip] look-ahead self-test could not run on device %d (the launch stalled four times: the device is busy); not counted as a failure\n", c->device);
+        return 0; // la_selftest stays 0
+    }
+    bool same = !fl[0];
     for (int j = 0; j < m && same; ++j)
         same = std::memcmp(&w[0][m + (size_t)j * c->ldz], &w[1][m + (size_t)j * c->ldz], sizeof(double) * (nT + 1)) == 0;
     c->la_selftest = same ? 1 : -1;
     if (!same)
-        std::fprintf(stderr, "[eqf_hip] look-ahead self-test failed on device %d (pivot flag %d, stalled %d): this context factorises on the launch chain\n", c->device, fl[0], fl[3] == c->la_seq);
+        std::fprintf(stderr, "[eqf_hip] look-ahead self-test failed on device %d (pivot flag %d): this context factorises on the launch chain\n", c->device, fl[0]);
     return 0;
 }
 static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, int zb = 0,

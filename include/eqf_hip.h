@@ -207,7 +207,9 @@ int eqf_stats_select_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* id
  * factorisation was redone on the launch chain (same Z: W and Sigma+ bit-identical, Gamma up to rounding; three in a row switch EQF_OPT_LOOKAHEAD off for the context). */
 int eqf_lookahead_stats(eqf_ctx* ctx, long* launches, long* fallbacks, int reset);
 /* Result of the look-ahead kernel's self-test at eqf_create (the persistent kernel against the launch chain on a fixed 96-column problem, W compared bit
- * for bit): 1 passed, 0 not run (the kernel is never eligible at this capacity / on this device), -1 failed: the context factorises on the launch chain. */
+ * for bit): 1 passed, 0 not run (the kernel is never eligible at this capacity / on this device, or its launch stalled four times because the device was busy -
+ * e.g. eight processes creating contexts on one device at once: a stall says nothing about the kernel, and every later launch is bounded and redone on the chain
+ * if it stalls), -1 failed (W differed): the context factorises on the launch chain. */
 int eqf_lookahead_selftest(const eqf_ctx* ctx);
 /* frames that took the device-side decision, landmarks it discarded */
 int eqf_selection_stats(eqf_ctx* ctx, long* frames, long* discarded, int reset);
