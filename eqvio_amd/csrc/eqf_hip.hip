@@ -167,6 +167,7 @@ struct eqf_ctx {
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int opt_zb = 1;                          // EQF_OPT_Z_IN_LOOKAHEAD
+    int opt_la_split = 1;                    // EQF_OPT_LA_SPLIT_ROWS
     bool tail_zb = false;                    // the update tail in flight has no Z in memory (built inside the look-ahead kernel): a retry on the chain builds it first
     double tail_var = 0.0;                   // ... and needs the measurement variance again
     long zb_launches = 0;
@@ -909,6 +910,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_EARLY_LIFT: *value = c->opt_early; return 0;
     case EQF_OPT_FUSED_ASSEMBLY: *value = c->opt_fuse_asm; return 0;
     case EQF_OPT_Z_IN_LOOKAHEAD: *value = c->opt_zb; return 0;
+    case EQF_OPT_LA_SPLIT_ROWS: *value = c->opt_la_split; return 0;
     case EQF_OPT_LOOKAHEAD: *value = c->opt_lookahead; return 0;
     case EQF_OPT_LA_TIMEOUT_US: *value = (int)(c->la_timeout_ticks / 100); return 0;
     case EQF_OPT_TRACE: *value = c->d_trace ? 1 : 0; return 0;
@@ -943,6 +945,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_Z_IN_LOOKAHEAD:
         c->opt_zb = value ? 1 : 0;
+        return 0;
+    case EQF_OPT_LA_SPLIT_ROWS:
+        c->opt_la_split = value ? 1 : 0;
         return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
@@ -1186,7 +1191,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1929,6 +1934,13 @@ static bool lookahead_eligible(const eqf_ctx* c, int m) {
     // one workgroup per compute unit (LDS, registers); a partitioned or smaller device takes the launch chain, which needs no co-residency
     return c->opt_lookahead && c->la_selftest >= 0 && c->d_pub && NJ >= 3 && NJ <= c->la_njcap && NI <= c->cu_count;
 }
+// Workgroups of a look-ahead launch. With more than 16 panels the half-rows of the block rows >= 16 are split over two workgroups each (la_row2, round 4) where the
+// device has the compute units for it: owner + S half-rows + T half-rows (+ 2 per split block row).
+constexpr int LA_SPLIT_FROM = 16;
+static int la_split_extra(const eqf_ctx* c, int NJ, int base) {
+    const int extra = NJ > LA_SPLIT_FROM + 1 ? 2 * (NJ - LA_SPLIT_FROM) : 0;
+    return (c->opt_la_split && base + extra <= c->cu_count) ? extra : 0;
+}
 static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spec, int spec_seq, int zb = 0, const MeasFuse* zb_mf = nullptr) {
     LaArgs a{};
     a.rows = rows;
@@ -1936,6 +1948,8 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.ldz = ldz;
     a.NJ = blocks(m, 32);
     a.NI = (2 * a.NJ - 1) + blocks(rows - m, 16); // the owner + the S half-rows 2 .. 2 NJ - 1 + the T half-rows (16 rows each)
+    const int extra = zb ? 0 : la_split_extra(c, a.NJ, a.NI);
+    a.split_from = extra ? LA_SPLIT_FROM : a.NJ;
     if (++c->la_seq <= 0) // positive: -1 is "no look-ahead launch in front" for k_lift / k_syrk_sub, 0 the initial state of every flag word
         c->la_seq = 1;
     a.seq = c->la_seq;
@@ -1968,7 +1982,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     } else if (a.NJ <= 16)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8>), dim3(a.NI + extra), dim3(LA_T), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2233,7 +2247,8 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
     c->tail_la = la; // the retry state of finish_update always describes the tail in flight (with tail_zb / tail_M / tail_var, set by launch_update_tail)
     if (la) {
         ++c->la_launches;
-        la_book(c, (2 * blocks(m, 32) - 1) + blocks(rows - m, 16) + 1);
+        const int base = (2 * blocks(m, 32) - 1) + blocks(rows - m, 16);
+        la_book(c, base + 1 + la_split_extra(c, blocks(m, 32), base));
     }
     rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, zb, zb_mf) : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
     if (rc)

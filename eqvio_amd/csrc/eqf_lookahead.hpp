@@ -42,6 +42,7 @@ constexpr long long LA_TIMEOUT_TICKS = 2000000; // 20 ms at 100 MHz
 
 struct LaArgs {
     int rows, m, ldz, NJ, NI, seq;
+    int split_from;          // S block rows I >= split_from are held by TWO workgroups per half-row (la_row2: Jlo, partA); >= NJ: none
     long long timeout_ticks; // bound of every device-side wait (100 MHz ticks; default LA_TIMEOUT_TICKS)
     const double* Z;     // [S ; T ; y^T] from k_build_Z (plain memory; complete when this kernel starts)
     double* W;           // out, plain: rows >= m receive W = T L^-T and the z row
@@ -993,7 +994,13 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
 // (S half-rows) and only then turn to their other tiles - while the other six waves are in the trailing update of panel p. One workgroup barrier per
 // panel; P_h, L^-1 and z in LDS are double buffered by panel parity. Same products in the same order per tile: bit-identical to la_row and to the chain.
 template <int MAXT, bool srow>
-__device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* cnt, const LaPoll& pl) {
+// Round 4, N > 256: an S half-row of a LATE block row (I >= a.split_from) holds up to 32 tiles, and the trailing update of the early panels is MFMA-issue bound on its
+// compute unit (8 tiles per wave: 5.3 us per panel against an owner step of 4.4): those rows handed their tiles over late and the owner's steps were 4.3 - 8.7 us
+// (profiles/r04_v2_N500_lookahead_trace.txt). Their tile columns are split over TWO workgroups: part A (partA) holds the tiles 0 .. Jlo - 1, forms and publishes the factor
+// rows P_h(p) of the panels p < Jlo and leaves; part B holds the tiles Jlo .. I, takes P_h(p) for p < Jlo from memory like any other operand (no barrier, no LDS: its waves
+// walk those panels independently), and is an ordinary half-row from panel Jlo - 1 on. Same products in the same order per tile. Jlo: a multiple of 4, <= I - 2 (the three
+// tiles handed to the owner are part B's).
+__device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* cnt, const LaPoll& pl, const int Jlo = 0, const bool partA = false) {
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int B = 32 * CH_LDP;
@@ -1009,7 +1016,9 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
     const int I = hidx >> 1, s = hidx & 1;
     const int row0 = srow ? 16 * hidx : m + 16 * (hidx - 2 * NJ);
     const int ilim = srow ? min(m, row0 + 16) : min(rows, row0 + 16);
-    const int Jmax = srow ? I : NJ - 1;
+    const int Jmax = srow ? (partA ? Jlo - 1 : I) : NJ - 1;
+    const int Jfirst = (srow && !partA) ? Jlo : 0;
+    const bool partB = srow && !partA && Jlo > 0;
     const bool ylast = (!srow) && (rows - 1 >= row0) && (rows - 1 < row0 + 16); // this half-row holds the yTilde row
     const int yloc = rows - 1 - row0;
     const int jh = wave & 1, jr = wave >> 1;
@@ -1022,13 +1031,13 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
-            acc[t][q] = (J <= Jmax) ? a.Z[ric + (size_t)j * ldz] : 0.0;
+            acc[t][q] = (J <= Jmax && J >= Jfirst) ? a.Z[ric + (size_t)j * ldz] : 0.0;
         }
     }
     if (ylast && tid < 32)
         la_put16(a.puby + 16 * (size_t)tid, a.Z[(rows - 1) + (size_t)min(tid, m - 1) * ldz], seq);
     double gsum = 0.0;
-    const int np = srow ? max(I - 2, 0) : NJ; // see la_row
+    const int np = srow ? (partA ? Jlo : max(I - 2, 0)) : NJ; // see la_row
     auto hand_off = [&]() {
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
@@ -1102,7 +1111,75 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
         gsum = fma(pv, c < wq ? zc : 0.0, gsum);
     };
-    if (np > 0) {
+    if (partB) {
+        // part B of a split half-row: the panels 0 .. Jlo - 2 on its own tiles, every wave by itself
+        for (int p = 0; p + 1 < Jlo; ++p) {
+            {
+                // lane t watches the flag of tile t's operand, lane 62 the flag of this half-row's own factor rows (formed by part A)
+                const int J = 4 * lane + jr;
+                const bool need = lane < MAXT && J >= Jlo && J <= I && !(J == I && jh >= s);
+                if (need || lane == 62) {
+                    const int* f = a.pubf + la_f_p(a, p, need ? 2 * J + jh : hidx);
+                    for (;;) {
+                        const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v == pl.seq || !la_retry(pl))
+                            break;
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+            double aI[8];
+            la_operand(la_tile(a, la_i_p(a, I, p)), s, aI);
+#pragma unroll
+            for (int t0 = 0; t0 < MAXT; t0 += 2) {
+                double bjs[2][8];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int J = 4 * (t0 + u) + jr;
+                    if (t0 + u < MAXT && J >= Jlo && J <= I && !(J == I && jh > s)) {
+                        if (J == I && jh == s) { // diagonal block: both operands are this half-row's factor rows
+#pragma unroll
+                            for (int st = 0; st < 8; ++st)
+                                bjs[u][st] = aI[st];
+                        } else
+                            la_operand(la_tile(a, la_i_p(a, J, p)), jh, bjs[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = (t0 + u < MAXT) ? t0 + u : MAXT - 1;
+                    const int J = 4 * (t0 + u) + jr;
+                    if (t0 + u < MAXT && J >= Jlo && J <= I && !(J == I && jh > s)) {
+                        d4 d = {0, 0, 0, 0};
+#pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(bjs[u][st], aI[st], d, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[t][e] -= d[e];
+                    }
+                }
+            }
+        }
+        // P_h(Jlo - 1), the last one part A forms, into the LDS buffer where the loop below expects this half-row's factor rows; the counters of the look-ahead
+        // pairs start where a half-row that had walked the panels 0 .. Jlo - 2 itself would have them
+        la_wait(a.pubf + la_f_p(a, Jlo - 1, hidx), 1, pl);
+        {
+            const double* pt = la_tile(a, la_i_p(a, I, Jlo - 1));
+            double* sP = sPIB(Jlo - 1);
+            const int r = tid & 15, c = tid >> 4;
+            sP[r + c * CH_LDP] = pt[(16 * s + r) + 32 * c];
+        }
+        if (tid == 0) {
+            pair_cnt[0] = 2 * (Jlo - 1);
+            pub_cnt[0] = 2 * (Jlo - 1);
+            if (s_abort[1])
+                s_abort[0] = 1;
+        }
+        __syncthreads();
+        if (*s_abort)
+            return;
+    } else if (np > 0) {
         // prologue: panel 0 the plain way (every thread two entries of L_0^-1; waves 0 / 1 form P_h(0))
         la_wait(a.pubf + la_f_linv(a, 0), 1, pl);
         {
@@ -1131,7 +1208,7 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         if (srow && tid == 0)
             la_raise_f(a, la_f_p(a, 0, hidx));
     }
-    for (int p = 0; p < np; ++p) {
+    for (int p = partB ? Jlo - 1 : 0; p < np; ++p) {
         int lrv = lr, lkv = lk;
         asm volatile("" : "+v"(lrv), "+v"(lkv));
         const int w = min(32, m - 32 * p);
@@ -1307,7 +1384,7 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
                 return;
         }
     }
-    if (srow)
+    if (srow && !partA)
         hand_off();
     if (!srow) {
         __syncthreads(); // z of the last panel is complete
@@ -1376,9 +1453,14 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (blockIdx.x == 0)
         la_owner<ZB>(a, smem, s_abort, s_cnt, pl);
     else if (MAXT > 4) { // 17 .. 32 panels: the half-rows with a look-ahead of their own
-        if (hidx < 2 * a.NJ)
-            la_row2<MAXT, true>(a, hidx, smem, s_abort, s_cnt, pl);
-        else
+        const int nbase = a.NI; // owner + S half-rows + T half-rows; behind them the parts A of the split half-rows (block rows >= split_from, two halves each)
+        if ((int)blockIdx.x >= nbase) {
+            const int e = (int)blockIdx.x - nbase, I = a.split_from + (e >> 1);
+            la_row2<MAXT, true>(a, 2 * I + (e & 1), smem, s_abort, s_cnt, pl, 4 * ((I + 5) >> 3), true);
+        } else if (hidx < 2 * a.NJ) {
+            const int I = hidx >> 1;
+            la_row2<MAXT, true>(a, hidx, smem, s_abort, s_cnt, pl, I >= a.split_from ? 4 * ((I + 5) >> 3) : 0, false);
+        } else
             la_row2<MAXT, false>(a, hidx, smem, s_abort, s_cnt, pl);
     } else
         la_row<MAXT, ZB>(a, hidx, smem, s_abort, s_cnt, pl);

@@ -73,6 +73,11 @@ enum {
                                   the launch chain. Measured for the speculative tail: N = 50 +2.8 %, N = 100 +1.8 %, N = 200 neutral (the kernel's prologue costs
                                   what the launch saved, and the tail's first launch reaches the GPU late), so that form is used up to 8 panels (N <= 128).
                                   0: k_build_Z always */
+    EQF_OPT_LA_SPLIT_ROWS = 18, /* 1 (default): with more than 17 panels (N > 272) the look-ahead kernel holds the S half-rows of the block rows >= 16 with TWO workgroups
+                                  each (tile columns split: 8 instead of up to 16 MFMA chains per wave and panel in the early panels, where the trailing update is
+                                  MFMA-issue bound per compute unit and those rows handed their tiles to the owner late), if the device has the compute units for the
+                                  larger launch (N = 500: 191 instead of 159 workgroups). Same products in the same order per tile: bit-identical. 0: one workgroup
+                                  per half-row */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.
