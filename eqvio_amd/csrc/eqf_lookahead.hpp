@@ -31,6 +31,7 @@
 //    Dependencies point from higher to lower block rows and to the owner only; the host launches this kernel only when its NI workgroups (66 at
 //    N = 200, 161 at N = 512) fit the device at one workgroup per compute unit (eqf_hip.hip: lookahead_eligible).
 #pragma once
+#include <type_traits>
 #include "eqf_kernels.hpp"
 
 namespace eqf {
@@ -1320,51 +1321,70 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             if (srow)
                 publish_p(p + 1, jh, pacc);
         }
-        // the other tiles, two per round trip, double buffered: the next two operand tiles are requested before the products of the current two (a wave's
-        // round trips and its MFMAs alternated before: 4 x (0.9 + 0.7) us per wave and panel at 32 panels)
-        auto load_batch = [&](int t0, double (&bjs)[2][8]) -> bool {
-            bool any = false;
+        // The other tiles, from the last one down, ONE per step, the operands of the next requested before the products of the current. Round 4: the requests are
+        // unconditional (a tile below the wave's range is a valid address of the same buffer, requested once per panel and never used), so that the number of loads
+        // in flight is known at compile time and the wait in front of a tile's products is vmcnt(16): two tiles stay in flight - with requests under run-time conditions the compiler waited
+        // for ALL loads in front of every tile (the prefetch bought nothing), and the factor rows P_h were re-read from LDS two entries at a time between the
+        // MFMAs (4 exposed LDS round trips per tile: ~150 cycles per MFMA and SIMD where 64 is the issue rate). P_h's operand now stays in 16 registers for
+        // the panel (the operand buffers: 3 x 16 registers instead of 4 x 16). A wave's tiles are contiguous in t: what is left out sits at the ends of its range.
+        int tlo = MAXT, thi = -1;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+        for (int t = 0; t < MAXT; ++t) {
+            int J;
+            if (tile_used(t, J) && !(ahead && J == p + 1)) {
+                tlo = min(tlo, t);
+                thi = max(thi, t);
+            }
+        }
+        if (thi >= 0) {
+            double aI[8], bq0[8], bq1[8], bq2[8]; // two tiles requested ahead of the one whose products run (a round trip is ~1 us, a tile's 8 MFMAs 0.2 us, two waves share a SIMD)
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+                aI[st] = sPI[lrv + (4 * st + lkv) * CH_LDP];
+            bool done = false;
+            // (one buffer per t mod 3, chosen at compile time: an array of three indexed by t % 3 went to scratch)
+            auto step = [&](auto TT, double (&cur)[8], double (&nxt)[8], double (&nxt2)[8]) {
+                constexpr int t = decltype(TT)::value;
+                if (done || t > thi)
+                    return;
+                if (t == thi) {
+                    la_operand(la_tile(a, la_i_p(a, 4 * t + jr, p)), jh, cur);
+                    if (t > 0)
+                        la_operand(la_tile(a, la_i_p(a, 4 * (t > 0 ? t - 1 : 0) + jr, p)), jh, nxt);
+                }
+                if (t > 1)
+                    la_operand(la_tile(a, la_i_p(a, 4 * (t > 1 ? t - 2 : 0) + jr, p)), jh, nxt2);
+                flag_when_acknowledged(); // under these round trips (once)
                 int J;
-                if (tile_used(t0 + u, J) && !(ahead && J == p + 1)) {
-                    any = true;
-                    if (srow && J == I && jh == s) { // diagonal block of an S half-row: both operands are P_h
+                if (tile_used(t, J) && !(ahead && J == p + 1)) {
+                    d4 d = {0, 0, 0, 0};
+                    if (srow && J == I && jh == s) { // diagonal block of an S half-row: both operands are P_h (its published copy may not have landed yet)
 #pragma unroll
                         for (int st = 0; st < 8; ++st)
-                            bjs[u][st] = sPI[lrv + (4 * st + lkv) * CH_LDP];
-                    } else
-                        la_operand(la_tile(a, la_i_p(a, J, p)), jh, bjs[u]);
+                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[st], aI[st], d, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            d = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[st], aI[st], d, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[t][e] -= d[e];
                 }
+                if (t == tlo)
+                    done = true;
+            };
+            // tile t in buffer t mod 3: (7 -> 1), (6 -> 0), (5 -> 2), ...
+            if constexpr (MAXT > 4) {
+                step(std::integral_constant<int, 7>{}, bq1, bq0, bq2);
+                step(std::integral_constant<int, 6>{}, bq0, bq2, bq1);
+                step(std::integral_constant<int, 5>{}, bq2, bq1, bq0);
+                step(std::integral_constant<int, 4>{}, bq1, bq0, bq2);
             }
-            return any;
-        };
-        auto apply_batch = [&](int t0, const double (&bjs)[2][8]) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = (t0 + u < MAXT) ? t0 + u : MAXT - 1;
-                int J;
-                if (tile_used(t0 + u, J) && !(ahead && J == p + 1))
-                    apply_tile(t, bjs[u]);
-            }
-        };
-        {
-            double bjA[2][8], bjB[2][8];
-            bool any = load_batch(0, bjA);
-#pragma unroll
-            for (int t0 = 0; t0 < MAXT; t0 += 4) {
-                if (t0 + 2 < MAXT)
-                    any |= load_batch(t0 + 2, bjB);
-                if (any)
-                    flag_when_acknowledged(); // under these round trips
-                asm volatile("" ::: "memory");
-                apply_batch(t0, bjA);
-                if (t0 + 4 < MAXT)
-                    any |= load_batch(t0 + 4, bjA);
-                asm volatile("" ::: "memory");
-                if (t0 + 2 < MAXT)
-                    apply_batch(t0 + 2, bjB);
-            }
+            step(std::integral_constant<int, 3>{}, bq0, bq2, bq1);
+            step(std::integral_constant<int, 2>{}, bq2, bq1, bq0);
+            step(std::integral_constant<int, 1>{}, bq1, bq0, bq2);
+            step(std::integral_constant<int, 0>{}, bq0, bq2, bq1);
         }
         flag_when_acknowledged(); // a wave without other tiles
         if (dbg_row)
