@@ -168,6 +168,14 @@ struct eqf_ctx {
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int opt_zb = 1;                          // EQF_OPT_Z_IN_LOOKAHEAD
     int opt_la_split = 1;                    // EQF_OPT_LA_SPLIT_ROWS
+    int opt_measure_prop = 1;                // EQF_OPT_MEASURE_IN_PROPAGATE
+    // ... its state: what the propagation kernel's observer blocks evaluated the output blocks with (camera and C / C* of the LAST update call stand in for the
+    // coming one's; the update call checks), for which staged measurement
+    bool pred_valid = false, me_valid = false;
+    Cam pred_cam{}, me_cam{};
+    int pred_star = 0, me_star = 0, me_M = 0;
+    unsigned long me_gen = 0;
+    long me_used = 0;
     bool tail_zb = false;                    // the update tail in flight has no Z in memory (built inside the look-ahead kernel): a retry on the chain builds it first
     double tail_var = 0.0;                   // ... and needs the measurement variance again
     long zb_launches = 0;
@@ -911,6 +919,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_FUSED_ASSEMBLY: *value = c->opt_fuse_asm; return 0;
     case EQF_OPT_Z_IN_LOOKAHEAD: *value = c->opt_zb; return 0;
     case EQF_OPT_LA_SPLIT_ROWS: *value = c->opt_la_split; return 0;
+    case EQF_OPT_MEASURE_IN_PROPAGATE: *value = c->opt_measure_prop; return 0;
     case EQF_OPT_LOOKAHEAD: *value = c->opt_lookahead; return 0;
     case EQF_OPT_LA_TIMEOUT_US: *value = (int)(c->la_timeout_ticks / 100); return 0;
     case EQF_OPT_TRACE: *value = c->d_trace ? 1 : 0; return 0;
@@ -948,6 +957,10 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_LA_SPLIT_ROWS:
         c->opt_la_split = value ? 1 : 0;
+        return 0;
+    case EQF_OPT_MEASURE_IN_PROPAGATE:
+        c->opt_measure_prop = value ? 1 : 0;
+        c->me_valid = false;
         return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
@@ -1191,7 +1204,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1209,6 +1222,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     t->nees_lu_fallbacks = c->nees_lu_fallbacks, t->wait_calls = c->wait_calls, t->launch_calls = c->launch_calls, t->wait_seconds = c->wait_seconds, t->launch_seconds = c->launch_seconds;
     t->la_launches = c->la_launches, t->la_fallbacks = c->la_fallbacks, t->zb_launches = c->zb_launches, t->la_consecutive_stalls = c->la_consecutive_stalls;
     t->la_selftest = c->la_selftest;
+    t->me_used = c->me_used, t->pred_valid = c->pred_valid, t->pred_cam = c->pred_cam, t->pred_star = c->pred_star;
     t->lm_gen = c->lm_gen + 1;
     std::swap(*c, *t);
     eqf_destroy(t);
@@ -1502,10 +1516,18 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
             fa.Qqo = other, fa.Qao = other + 4 * (size_t)c->Ncap;
             fa.ck = c->ck;
         }
+        // EQF_OPT_MEASURE_IN_PROPAGATE: the observer blocks evaluate the output blocks of the staged measurement with the camera / output choice of the last update call
+        MeasEval me{};
+        c->me_valid = false;
+        if (c->opt_measure_prop && fused && nObs && sg.M > 0 && c->pred_valid && !c->sig32 && !c->opt_f32 && c->opt_zb && !c->opt_check) {
+            me.on = 1, me.star = c->pred_star, me.Mcap = c->Ncap, me.cam = c->pred_cam;
+            me.ylm = c->h_ylm, me.C = c->d_C, me.ytil = c->d_ytil, me.lmidx_dev = c->d_lmidx;
+            c->me_valid = true, c->me_cam = c->pred_cam, c->me_star = c->pred_star, c->me_M = sg.M, c->me_gen = c->staged_gen;
+        }
         KTimer t(c, KN_PROP_MAIN);
         auto launch = [&](auto kern, auto* sin, auto* sout) {
             hipLaunchKernelGGL(kern, dim3(nTiles + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, sin, sout, c->d_Al, c->d_Bl, nT, nStrip,
-                               nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa);
+                               nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa, me);
         };
 #define PROP_LAUNCH(TS_, F_) \
     do { \
@@ -1977,6 +1999,10 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
             a.zb_mf = *zb_mf;
             a.spec = nullptr;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 2>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
+        } else if (zb == 3) { // C, yTilde, index map from the propagation kernel's observer blocks; the statistics workgroup as above
+            a.zb_mf = *zb_mf;
+            a.spec = nullptr;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 3>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
         } else // C, yTilde, index map from the measurement kernel
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 1>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
     } else if (a.NJ <= 16)
@@ -2206,7 +2232,17 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
     const bool zb_ok = c->opt_zb && !c->sig32 && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
     // ZB = 2 up to 8 panels (N <= 128) only: measured +2.8 % at N = 50, +1.8 % at N = 100 and neutral at N = 200, where the tail's first launch then reaches
     // the GPU late
-    const int zb = !zb_ok ? 0 : (!fuse ? 1 : ((fuse->y == c->d_meas && c->opt_early && blocks(m, 32) <= 8) ? 2 : 0));
+    // ZB = 3 (round 4, up to 16 panels): the propagation kernel's observer blocks have evaluated the output blocks of THIS measurement (staged, same landmark set) with
+    // the camera and output choice this call asks for: the look-ahead kernel builds Z from them and one more workgroup computes the statistics
+    auto same_cam = [](const Cam& x, const Cam& y) {
+        return x.fx == y.fx && x.fy == y.fy && x.cx == y.cx && x.cy == y.cy && x.model == y.model && std::equal(x.d, x.d + 5, y.d);
+    };
+    const bool in_prop = fuse && c->me_valid && c->opt_measure_prop && fuse->y == c->d_meas && c->opt_early && c->me_M == M && c->me_gen == c->lm_gen &&
+                         c->me_star == fuse->star && same_cam(c->me_cam, fuse->cam);
+    c->me_valid = false;
+    const int zb = !zb_ok ? 0 : (!fuse ? 1 : (in_prop ? 3 : ((fuse->y == c->d_meas && c->opt_early && blocks(m, 32) <= 8) ? 2 : 0)));
+    if (zb == 3)
+        ++c->me_used;
     c->tail_zb = zb != 0;
     c->tail_var = meas_var;
     if (!zb) {
@@ -2469,6 +2505,7 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         return EQF_E_BAD_ARG;
     ++c->spec_calls;
     *updated = 0;
+    c->pred_cam = make_cam(cam), c->pred_star = useEqv ? 1 : 0, c->pred_valid = true; // what the next propagation call evaluates the output blocks with (EQF_OPT_MEASURE_IN_PROPAGATE)
     const int N = c->N;
     if (N == 0 || M > N) {
         *updated = -1; // not applicable (a landmark has to be added first)
@@ -2770,6 +2807,14 @@ int eqf_debug_lookahead_stamps(eqf_ctx* c, unsigned long long* out768) {
     return 0;
 }
 
+int eqf_measure_in_propagate_stats(eqf_ctx* c, long* used, int reset) {
+    if (!c || !used)
+        return EQF_E_BAD_ARG;
+    *used = c->me_used;
+    if (reset)
+        c->me_used = 0;
+    return 0;
+}
 int eqf_speculation_stats(eqf_ctx* c, long* calls, long* queued, long* cancelled, int reset) {
     if (!c || !calls || !queued || !cancelled)
         return EQF_E_BAD_ARG;

@@ -281,13 +281,8 @@ struct ObsSteps {
 // re-normalisation of the unit quaternion uses 1/sqrt(x) = 1.5 - 0.5 x (exact to O((x-1)^2), |x - 1| < 1e-9 here); 1/a is carried
 // along instead of divided out each step. Algebraically this is SO3::SO3FromVectors(p1.normalized(), q_hat.normalized()) and
 // |q_hat| / |p1| of VIOGroup.cpp:254-262; the antiparallel special case keeps the general routine.
-__device__ __forceinline__ void observer_landmark(const ObsStep* __restrict__ steps, int Ncap, int k, int i, const double* __restrict__ q0, const double* __restrict__ QqIn,
-                                                  const double* __restrict__ QaIn, double* __restrict__ Qq, double* __restrict__ Qa) {
-    // QqIn / QaIn == Qq / Qa: in place; otherwise the result goes to the other landmark buffer (fused assembly: the tiles of the
-    // same launch still read the old Q)
-    const V3 p0 = ld3(q0, Ncap, i);
-    Qt q = ldq(QqIn, Ncap, i);
-    double a = QaIn[i];
+// the chain itself, on values: (q, a) <- (q, a) * Lambda_1 * ... * Lambda_k for the landmark with origin point p0
+__device__ __forceinline__ void observer_chain(const ObsStep* __restrict__ steps, int k, const V3 p0, Qt& q, double& a) {
     double inva = 1.0 / a;
     ObsStep nxt = steps[0];
     for (int s = 0; s < k; ++s) {
@@ -333,6 +328,15 @@ __device__ __forceinline__ void observer_landmark(const ObsStep* __restrict__ st
         a = a * La;
         inva = inva * invLa;
     }
+}
+__device__ __forceinline__ void observer_landmark(const ObsStep* __restrict__ steps, int Ncap, int k, int i, const double* __restrict__ q0, const double* __restrict__ QqIn,
+                                                  const double* __restrict__ QaIn, double* __restrict__ Qq, double* __restrict__ Qa) {
+    // QqIn / QaIn == Qq / Qa: in place; otherwise the result goes to the other landmark buffer (fused assembly: the tiles of the
+    // same launch still read the old Q)
+    const V3 p0 = ld3(q0, Ncap, i);
+    Qt q = ldq(QqIn, Ncap, i);
+    double a = QaIn[i];
+    observer_chain(steps, k, p0, q, a);
     Qq[i] = q.w;
     Qq[Ncap + i] = q.x;
     Qq[2 * Ncap + i] = q.y;
@@ -363,6 +367,16 @@ struct FuseArgs {
     double *Qqo, *Qao; // the OTHER dynamic landmark buffer: target of the observer blocks
     CommonK ck;
 };
+// EQF_OPT_MEASURE_IN_PROPAGATE: the observer blocks of the propagation kernel have a landmark's new group element in registers when their chain ends - they evaluate its
+// output block C*_i and residual right there (measure_one: the same function and inputs as everywhere, the same bits) and leave C / yTilde / the index map in
+// memory, so that the update's first kernel (the look-ahead kernel building Z itself, ZB = 3) has no evaluation in front of its first tile (~2.5 us)
+struct MeasEval {
+    int on, star, Mcap;
+    Cam cam;
+    const double* ylm; // the measurement by landmark, pinned host packet of eqf_stage_measurement: planes u, v, measurement index or -1
+    double *C, *ytil;
+    int* lmidx_dev;
+};
 struct StageArgs {
     int M; // 0: nothing to stage
     const double *y_h, *ylm_h; // pinned host packet
@@ -370,303 +384,6 @@ struct StageArgs {
     double *y_d, *ylm_d;       // HBM copies
     int* idx_d;
 };
-// TS = storage type of Sigma (double, or float for EQF_OPT_SIGMA_FP32 = 2): loads convert to double, stores round.
-template <typename TS, bool FUSED, bool SYM = false> // FUSED: fused assembly; SYM: lower tiles only, mirrored (an instantiation of its own: as a run-time
-                                                      // branch it cost the N = 200 frame 0.6 us)
-__global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
-                                                        const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
-                                                        const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
-                                                        const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
-                                                        trace_t* tr, const FuseArgs fa) {
-    trace_start(tr);
-    const double dt = ra.dt;
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    // SYM (large N, chosen by the host): only the lower triangle of landmark tiles is computed, the upper one written as its mirror image - half the
-    // tile workgroups (N = 500: 1024 -> 528, one per CU at a time: 45 -> 32 us). Up to 16 tiles per side all tiles fit the chip in one round and the full
-    // form is 1 us faster (the block row's 21 strip columns spread over more workgroups, no strided mirror stores).
-    constexpr bool sym = SYM;
-    nStrip = 0;
-    const int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
-    if (b > nTiles + nStrip + nObs) {
-        // Staging block (eqf_stage_measurement): the coming frame's measurement moves from the pinned host packet to HBM while Sigma
-        // is being propagated, so that the update's first kernel finds it next to the state instead of across PCIe.
-        for (int t = tid; t < 2 * sg.M; t += PROP_T)
-            sg.y_d[t] = sg.y_h[t];
-        for (int t = tid; t < sg.M; t += PROP_T)
-            sg.idx_d[t] = sg.idx_h[t];
-        for (int t = tid; t < 3 * N; t += PROP_T) {
-            const int pl = t / N, i = t - pl * N;
-            sg.ylm_d[pl * Ncap + i] = sg.ylm_h[pl * Ncap + i];
-        }
-        return;
-    }
-    if (b > nTiles + nStrip) {
-        // Observer blocks (eqf_propagate_fast): the landmark part of the frame's observer steps rides along with the Sigma
-        // propagation. This kernel touches Sigma / Al / Bl only, the assembly kernel before it has already read Q and the
-        // statistics kernel after it wants the new Q: in-stream order gives all three, no second stream, no events.
-        // With fused assembly the tiles of THIS launch read Q, so the observer blocks write the other (Qq, Qa) buffer (the host
-        // flips to it after the launch; q0 and its chart constants live in a buffer of their own and stay where they are).
-        const int i = (b - (nTiles + nStrip + 1)) * PROP_T + tid;
-        if (i < N) {
-            if (FUSED) {
-                observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, fa.Qqo, fa.Qao);
-            } else {
-                observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, Qq, Qa);
-            }
-        }
-        return;
-    }
-    __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
-    __shared__ double sSens[21 * 33]; // per strip column of this workgroup: row c of A_ss (21) | row c of B_s (12)
-    __shared__ double s_cm[66];
-    if (FUSED) {
-        for (int t = tid; t < 66; t += PROP_T)
-            s_cm[t] = fa.ck.lm[t];
-        __syncthreads();
-    }
-    if (b < nTiles) {
-        // tile (bi, bj), bi >= bj, of the lower triangle in row-major order: b = bi (bi + 1) / 2 + bj
-        int bi = b % nT, bj = b / nT;
-        if (sym) {
-            bi = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
-            while (bi * (bi + 1) / 2 > b)
-                --bi;
-            while ((bi + 1) * (bi + 2) / 2 <= b)
-                ++bi;
-            bj = b - bi * (bi + 1) / 2;
-        }
-        const int nb = sym ? bi + 1 : nT; // workgroups of this block row: they share its 21 strip columns
-        // per-i arrays: G (63), Fls (36), D (9), Bl (9) ; per-j arrays: Ssj (63), Fls (36), D (9), Bl (9). layout [e][PT]
-        double* sGi = sm;
-        double* sFi = sGi + 63 * PT;
-        double* sDi = sFi + 36 * PT;
-        double* sBi = sDi + 9 * PT;
-        double* sSj = sBi + 9 * PT;
-        double* sFj = sSj + 63 * PT;
-        double* sDj = sFj + 36 * PT;
-        double* sBj = sDj + 9 * PT;
-        double* sSi = sBj + 9 * PT;   // Sigma[k][l_i + c'] at [(k*3 + c') * PT + x]
-        double* sSs = sSi + 63 * PT;  // Sigma_ss[al_col(e)][k] at [e * 21 + k], e < 12
-        for (int t = tid; t < 63 * PT; t += PROP_T) {
-            const int e = t / PT, x = t % PT;
-            const int i = bi * PT + x, j = bj * PT + x;
-            // Sigma[k][l + c'] with e = k*3 + c'
-            const int kk = e / 3, cc = e % 3;
-            sSi[t] = i < N ? Sig[kk + (size_t)(21 + 3 * i + cc) * ld] : 0.0;
-            sSj[t] = j < N ? Sig[kk + (size_t)(21 + 3 * j + cc) * ld] : 0.0;
-        }
-        if (tid < 12 * 21)
-            sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
-        // the strip columns this workgroup writes (below): c = bj, bj + nb, ... ; their rows of the sensor blocks go to LDS
-        const int ncol = bj < 21 ? (21 - bj + nb - 1) / nb : 0;
-        for (int t = PROP_T - 1 - tid; t < ncol * 33; t += PROP_T) { // taken from the top of the workgroup: the first lanes assemble
-            const int m_ = t / 33, e = t % 33;
-            const int c = bj + nb * m_;
-            sSens[t] = e < 21 ? (FUSED ? sensor_Ass_entry(fa.ck, c * 21 + e) : cm->Ass[c * 21 + e]) : (FUSED ? sensor_Bs_entry(fa.ck, c * 12 + (e - 21)) : cm->Bs[c * 12 + (e - 21)]);
-        }
-        if (FUSED) {
-            // Three wavefronts assemble: lanes 0..2PT-1 of waves 0, 1, 2 take part 0, 1, 2 (assemble_landmark) of the PT i-landmarks and
-            // the PT j-landmarks; the other threads are loading Sigma meanwhile.
-            const int part = tid >> 6, lane_ = tid & 63;
-            if (part < 3 && lane_ < 2 * PT) {
-                const bool isj = lane_ >= PT;
-                const int x = lane_ % PT;
-                const int l = (isj ? bj : bi) * PT + x;
-                double* dF = isj ? sFj : sFi;
-                double* dD = isj ? sDj : sDi;
-                double* dB = isj ? sBj : sBi;
-                double al[45], bl[9];
-#pragma unroll
-                for (int e = 0; e < 45; ++e)
-                    al[e] = 0.0;
-#pragma unroll
-                for (int e = 0; e < 9; ++e)
-                    bl[e] = 0.0;
-                const bool in = l < N;
-                const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
-                const int lc = in ? l : 0;
-                const V3 p0_ = ld3(q0, Ncap, lc);
-                const Qt q_ = ldq(Qq, Ncap, lc);
-                const double a_ = Qa[lc];
-                const M3 e2i = ind ? ld_cc(q0, Ncap, lc, CC_E2I) : M3{};
-                if (part == 0) {
-                    if (in)
-                        assemble_landmark<0>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                        for (int c = 0; c < 6; ++c)
-                            dF[(r * 12 + c) * PT + x] = in ? dt * al[r * 15 + c] : 0.0;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            dB[(r * 3 + c) * PT + x] = bl[r * 3 + c];
-                    }
-                } else if (part == 1) {
-                    if (in)
-                        assemble_landmark<1>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 6; c < 12; ++c)
-                            dF[(r * 12 + c) * PT + x] = in ? dt * al[r * 15 + c] : 0.0;
-                } else {
-                    if (in)
-                        assemble_landmark<2>(s_cm, fa.chart, p0_, q_, a_, e2i, ind ? ld_cc(q0, Ncap, lc, CC_I2E) : M3{}, al, bl);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            dD[(r * 3 + c) * PT + x] = in ? dt * al[r * 15 + 12 + c] + ((r == c) ? 1.0 : 0.0) : 0.0;
-                }
-            }
-        } else {
-            for (int t = tid; t < 36 * PT; t += PROP_T) {
-                const int e = t / PT, x = t % PT;
-                const int r = e / 12, c = e % 12;
-                const int i = bi * PT + x, j = bj * PT + x;
-                sFi[t] = i < N ? dt * Al[(r * 15 + c) * Ncap + i] : 0.0;
-                sFj[t] = j < N ? dt * Al[(r * 15 + c) * Ncap + j] : 0.0;
-            }
-            for (int t = tid; t < 9 * PT; t += PROP_T) {
-                const int e = t / PT, x = t % PT;
-                const int r = e / 3, c = e % 3;
-                const int i = bi * PT + x, j = bj * PT + x;
-                const double eye = (r == c) ? 1.0 : 0.0;
-                sDi[t] = i < N ? dt * Al[(r * 15 + 12 + c) * Ncap + i] + eye : 0.0;
-                sDj[t] = j < N ? dt * Al[(r * 15 + 12 + c) * Ncap + j] + eye : 0.0;
-                sBi[t] = i < N ? Bl[e * Ncap + i] : 0.0;
-                sBj[t] = j < N ? Bl[e * Ncap + j] : 0.0;
-            }
-        }
-        __syncthreads();
-        // G_i[r][k] = sum_e (dt A_ls_i)[r][e] Sigma_ss[al_col(e)][k] + sum_c' (I + dt A_qi)[r][c'] Sigma[l_i + c'][k]
-        for (int t = tid; t < 63 * PT; t += PROP_T) {
-            const int e = t / PT, x = t % PT;
-            const int r = e / 21, k = e % 21;
-            double g = 0.0;
-#pragma unroll
-            for (int q = 0; q < 12; ++q)
-                g += sFi[(r * 12 + q) * PT + x] * sSs[q * 21 + k];
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc)
-                g += sDi[(r * 3 + cc) * PT + x] * sSi[(k * 3 + cc) * PT + x];
-            sGi[t] = g;
-        }
-        __syncthreads();
-        {
-            // Landmark-sensor strips of the PT i-landmarks: Sigma'[l_i + r][c] = sum_k G_i[r][k] Fss[c][k] + dt sum_q Bl_i[r][q] Qd[q] Bs[c][q].
-            // G_i is in LDS here anyway; the nT workgroups of this block row share the 21 columns (c = bj, bj + nT, ...), at most a few
-            // outputs per workgroup. Same sums, in the same order, as a separate strip pass would evaluate.
-            for (int t = tid; t < PT * 3 * ncol; t += PROP_T) {
-                const int x = t % PT, rc = t / PT;
-                const int r = rc % 3, m_ = rc / 3, c = bj + nb * m_;
-                const int i = bi * PT + x;
-                if (i < N) {
-                    double sacc = 0;
-                    for (int k = 0; k < 21; ++k) {
-                        const double f = dt * sSens[m_ * 33 + k] + (k == c ? 1.0 : 0.0);
-                        sacc += sGi[(r * 21 + k) * PT + x] * f;
-                    }
-                    double bq = 0;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        bq += sBi[(r * 3 + q) * PT + x] * ra.Qd[q] * sSens[m_ * 33 + 21 + q];
-                    sacc += dt * bq;
-                    const int li = 21 + 3 * i;
-                    Sout[li + r + (size_t)c * ld] = sacc;
-                    Sout[c + (size_t)(li + r) * ld] = sacc;
-                }
-            }
-        }
-        // lane = (output row r, landmark pair (ti, tj)): three lanes share a 3x3 block, each produces one row of it. The
-        // per-element sums run in the same order as a one-lane-per-block version would (results are bit-identical to it).
-        const int r = tid / (PT * PT), tp = tid % (PT * PT);
-        const int ti = tp % PT, tj = tp / PT;
-        const int i = bi * PT + ti, j = bj * PT + tj;
-        if (i >= N || j >= N || (sym && bi == bj && i < j)) // (a diagonal tile: the pairs above the diagonal are mirrors too)
-            return;
-        const int li = 21 + 3 * i, lj = 21 + 3 * j;
-        // Sigma_ij
-        double Sij[3][3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                Sij[k][c] = Sig[li + k + (size_t)(lj + c) * ld];
-        // E[r][:] = (Fls_i Sigma_sj + D_i Sigma_ij)[r][:]
-        double E[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double s = 0;
-#pragma unroll
-            for (int e = 0; e < 12; ++e)
-                s += sFi[(r * 12 + e) * PT + ti] * sSj[(al_col(e) * 3 + c) * PT + tj];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                s += sDi[(r * 3 + k) * PT + ti] * Sij[k][c];
-            E[c] = s;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double s = 0;
-#pragma unroll
-            for (int e = 0; e < 12; ++e)
-                s += sGi[(r * 21 + al_col(e)) * PT + ti] * sFj[(c * 12 + e) * PT + tj];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                s += E[k] * sDj[(c * 3 + k) * PT + tj];
-            double bq = 0;
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                bq += sBi[(r * 3 + q) * PT + ti] * ra.Qd[q] * sBj[(c * 3 + q) * PT + tj];
-            s += dt * bq;
-            if (i == j && r == c)
-                s += dt * ra.Pd[7];
-            Sout[li + r + (size_t)(lj + c) * ld] = s;
-            if (sym && i != j)
-                Sout[lj + c + (size_t)(li + r) * ld] = s; // Sigma'_ji = Sigma'_ij^T: exactly symmetric between landmark blocks, half the tiles
-        }
-        return;
-    }
-    // sensor-sensor block
-    {
-        double* sF = sm;        // 441
-        double* sS = sm + 441;  // 441
-        double* sT = sm + 882;  // 441  (F Sigma_ss)
-        double* sBs = sm + 1323; // 252 (fused assembly: B_s expanded from the compact terms)
-        for (int t = tid; t < 441; t += PROP_T) {
-            const int r = t / 21, c = t % 21;
-            sF[t] = dt * (FUSED ? sensor_Ass_entry(fa.ck, t) : cm->Ass[t]) + (r == c ? 1.0 : 0.0);
-            sS[t] = Sig[r + (size_t)c * ld];
-        }
-        for (int t = tid; t < 252; t += PROP_T)
-            sBs[t] = FUSED ? sensor_Bs_entry(fa.ck, t) : cm->Bs[t];
-        __syncthreads();
-        for (int t = tid; t < 441; t += PROP_T) {
-            const int r = t / 21, c = t % 21;
-            double s = 0;
-            for (int k = 0; k < 21; ++k)
-                s += sF[r * 21 + k] * sS[k * 21 + c];
-            sT[t] = s;
-        }
-        __syncthreads();
-        for (int t = tid; t < 441; t += PROP_T) {
-            const int r = t / 21, c = t % 21;
-            double s = 0;
-            for (int k = 0; k < 21; ++k)
-                s += sT[r * 21 + k] * sF[c * 21 + k];
-            double bq = 0;
-            for (int q = 0; q < 12; ++q)
-                bq += sBs[r * 12 + q] * ra.Qd[q] * sBs[c * 12 + q];
-            s += dt * bq;
-            if (r == c)
-                s += dt * ra.Pd[r / 3];
-            Sout[r + (size_t)c * ld] = s;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Host doorbell. The two kernels whose results the host waits for (outlier statistics, innovation lift) write them into
 // the pinned result packet; the LAST workgroup to finish then stores a sequence number next to them. The host polls that
@@ -1681,6 +1398,330 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
     }
     __syncthreads();
     ldl_inverse_tile(sPJ, CH_LDP, w2, LinvOut, flags, swork);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2 / K2b, the propagation kernel (described above; it stands behind the measurement helpers because with EQF_OPT_Z_IN_PROPAGATE its tiles build Z themselves)
+// TS = storage type of Sigma (double, or float for EQF_OPT_SIGMA_FP32 = 2): loads convert to double, stores round.
+template <typename TS, bool FUSED, bool SYM = false> // FUSED: fused assembly; SYM: lower tiles only, mirrored (an instantiation of its own: as a run-time
+                                                      // branch it cost the N = 200 frame 0.6 us)
+__global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
+                                                        const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
+                                                        const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
+                                                        const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
+                                                        trace_t* tr, const FuseArgs fa, const MeasEval me) {
+    trace_start(tr);
+    const double dt = ra.dt;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    // SYM (large N, chosen by the host): only the lower triangle of landmark tiles is computed, the upper one written as its mirror image - half the
+    // tile workgroups (N = 500: 1024 -> 528, one per CU at a time: 45 -> 32 us). Up to 16 tiles per side all tiles fit the chip in one round and the full
+    // form is 1 us faster (the block row's 21 strip columns spread over more workgroups, no strided mirror stores).
+    constexpr bool sym = SYM;
+    nStrip = 0;
+    const int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
+    if (b > nTiles + nStrip + nObs) {
+        // Staging block (eqf_stage_measurement): the coming frame's measurement moves from the pinned host packet to HBM while Sigma
+        // is being propagated, so that the update's first kernel finds it next to the state instead of across PCIe.
+        for (int t = tid; t < 2 * sg.M; t += PROP_T)
+            sg.y_d[t] = sg.y_h[t];
+        for (int t = tid; t < sg.M; t += PROP_T)
+            sg.idx_d[t] = sg.idx_h[t];
+        for (int t = tid; t < 3 * N; t += PROP_T) {
+            const int pl = t / N, i = t - pl * N;
+            sg.ylm_d[pl * Ncap + i] = sg.ylm_h[pl * Ncap + i];
+        }
+        return;
+    }
+    if (b > nTiles + nStrip) {
+        // Observer blocks (eqf_propagate_fast): the landmark part of the frame's observer steps rides along with the Sigma
+        // propagation. This kernel touches Sigma / Al / Bl only, the assembly kernel before it has already read Q and the
+        // statistics kernel after it wants the new Q: in-stream order gives all three, no second stream, no events.
+        // With fused assembly the tiles of THIS launch read Q, so the observer blocks write the other (Qq, Qa) buffer (the host
+        // flips to it after the launch; q0 and its chart constants live in a buffer of their own and stay where they are).
+        const int i = (b - (nTiles + nStrip + 1)) * PROP_T + tid;
+        if (i < N) {
+            if (FUSED) {
+                const V3 p0 = ld3(q0, Ncap, i);
+                Qt q = ldq(Qq, Ncap, i);
+                double a_ = Qa[i];
+                double yu = 0.0, yv = 0.0;
+                int jm = -1;
+                if (me.on) { // requested before the chain: a zero-copy read across PCIe
+                    yu = me.ylm[i], yv = me.ylm[Ncap + i];
+                    jm = (int)me.ylm[2 * Ncap + i];
+                }
+                observer_chain(obs.s, obs_k, p0, q, a_);
+                fa.Qqo[i] = q.w;
+                fa.Qqo[Ncap + i] = q.x;
+                fa.Qqo[2 * Ncap + i] = q.y;
+                fa.Qqo[3 * Ncap + i] = q.z;
+                fa.Qao[i] = a_;
+                if (me.on && jm >= 0) {
+                    // (the chain's last products must not be contracted into the evaluation's first sums: the same bits as an evaluation from the stored element)
+                    asm volatile("" : "+v"(q.w), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(a_));
+                    const MeasOut o = measure_one(fa.chart, me.cam, p0, q, a_, yu, yv, me.star != 0, fa.chart == EQVIO_COORD_INVDEPTH ? ld_cc(q0, Ncap, i, CC_R0) : M3{});
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        me.C[e * me.Mcap + jm] = o.c[e];
+                    me.ytil[2 * jm] = o.yt[0];
+                    me.ytil[2 * jm + 1] = o.yt[1];
+                    me.lmidx_dev[jm] = i;
+                }
+            } else {
+                observer_landmark(obs.s, Ncap, obs_k, i, q0, Qq, Qa, Qq, Qa);
+            }
+        }
+        return;
+    }
+    __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
+    __shared__ double sSens[21 * 33]; // per strip column of this workgroup: row c of A_ss (21) | row c of B_s (12)
+    __shared__ double s_cm[66];
+    if (FUSED) {
+        for (int t = tid; t < 66; t += PROP_T)
+            s_cm[t] = fa.ck.lm[t];
+        __syncthreads();
+    }
+    if (b < nTiles) {
+        // tile (bi, bj), bi >= bj, of the lower triangle in row-major order: b = bi (bi + 1) / 2 + bj
+        int bi = b % nT, bj = b / nT;
+        if (sym) {
+            bi = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+            while (bi * (bi + 1) / 2 > b)
+                --bi;
+            while ((bi + 1) * (bi + 2) / 2 <= b)
+                ++bi;
+            bj = b - bi * (bi + 1) / 2;
+        }
+        const int nb = sym ? bi + 1 : nT; // workgroups of this block row: they share its 21 strip columns
+        // per-i arrays: G (63), Fls (36), D (9), Bl (9) ; per-j arrays: Ssj (63), Fls (36), D (9), Bl (9). layout [e][PT]
+        double* sGi = sm;
+        double* sFi = sGi + 63 * PT;
+        double* sDi = sFi + 36 * PT;
+        double* sBi = sDi + 9 * PT;
+        double* sSj = sBi + 9 * PT;
+        double* sFj = sSj + 63 * PT;
+        double* sDj = sFj + 36 * PT;
+        double* sBj = sDj + 9 * PT;
+        double* sSi = sBj + 9 * PT;   // Sigma[k][l_i + c'] at [(k*3 + c') * PT + x]
+        double* sSs = sSi + 63 * PT;  // Sigma_ss[al_col(e)][k] at [e * 21 + k], e < 12
+        for (int t = tid; t < 63 * PT; t += PROP_T) {
+            const int e = t / PT, x = t % PT;
+            const int i = bi * PT + x, j = bj * PT + x;
+            // Sigma[k][l + c'] with e = k*3 + c'
+            const int kk = e / 3, cc = e % 3;
+            sSi[t] = i < N ? Sig[kk + (size_t)(21 + 3 * i + cc) * ld] : 0.0;
+            sSj[t] = j < N ? Sig[kk + (size_t)(21 + 3 * j + cc) * ld] : 0.0;
+        }
+        if (tid < 12 * 21)
+            sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
+        // the strip columns this workgroup writes (below): c = bj, bj + nb, ... ; their rows of the sensor blocks go to LDS
+        const int ncol = bj < 21 ? (21 - bj + nb - 1) / nb : 0;
+        for (int t = PROP_T - 1 - tid; t < ncol * 33; t += PROP_T) { // taken from the top of the workgroup: the first lanes assemble
+            const int m_ = t / 33, e = t % 33;
+            const int c = bj + nb * m_;
+            sSens[t] = e < 21 ? (FUSED ? sensor_Ass_entry(fa.ck, c * 21 + e) : cm->Ass[c * 21 + e]) : (FUSED ? sensor_Bs_entry(fa.ck, c * 12 + (e - 21)) : cm->Bs[c * 12 + (e - 21)]);
+        }
+        if (FUSED) {
+            // Three wavefronts assemble: lanes 0..2PT-1 of waves 0, 1, 2 take part 0, 1, 2 (assemble_landmark) of the PT i-landmarks and
+            // the PT j-landmarks; the other threads are loading Sigma meanwhile.
+            const int part = tid >> 6, lane_ = tid & 63;
+            if (part < 3 && lane_ < 2 * PT) {
+                const bool isj = lane_ >= PT;
+                const int x = lane_ % PT;
+                const int l = (isj ? bj : bi) * PT + x;
+                double* dF = isj ? sFj : sFi;
+                double* dD = isj ? sDj : sDi;
+                double* dB = isj ? sBj : sBi;
+                double al[45], bl[9];
+#pragma unroll
+                for (int e = 0; e < 45; ++e)
+                    al[e] = 0.0;
+#pragma unroll
+                for (int e = 0; e < 9; ++e)
+                    bl[e] = 0.0;
+                const bool in = l < N;
+                const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
+                const int lc = in ? l : 0;
+                const V3 p0_ = ld3(q0, Ncap, lc);
+                const Qt q_ = ldq(Qq, Ncap, lc);
+                const double a_ = Qa[lc];
+                const M3 e2i = ind ? ld_cc(q0, Ncap, lc, CC_E2I) : M3{};
+                if (part == 0) {
+                    if (in)
+                        assemble_landmark<0>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c)
+                            dF[(r * 12 + c) * PT + x] = in ? dt * al[r * 15 + c] : 0.0;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            dB[(r * 3 + c) * PT + x] = bl[r * 3 + c];
+                    }
+                } else if (part == 1) {
+                    if (in)
+                        assemble_landmark<1>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 6; c < 12; ++c)
+                            dF[(r * 12 + c) * PT + x] = in ? dt * al[r * 15 + c] : 0.0;
+                } else {
+                    if (in)
+                        assemble_landmark<2>(s_cm, fa.chart, p0_, q_, a_, e2i, ind ? ld_cc(q0, Ncap, lc, CC_I2E) : M3{}, al, bl);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            dD[(r * 3 + c) * PT + x] = in ? dt * al[r * 15 + 12 + c] + ((r == c) ? 1.0 : 0.0) : 0.0;
+                }
+            }
+        } else {
+            for (int t = tid; t < 36 * PT; t += PROP_T) {
+                const int e = t / PT, x = t % PT;
+                const int r = e / 12, c = e % 12;
+                const int i = bi * PT + x, j = bj * PT + x;
+                sFi[t] = i < N ? dt * Al[(r * 15 + c) * Ncap + i] : 0.0;
+                sFj[t] = j < N ? dt * Al[(r * 15 + c) * Ncap + j] : 0.0;
+            }
+            for (int t = tid; t < 9 * PT; t += PROP_T) {
+                const int e = t / PT, x = t % PT;
+                const int r = e / 3, c = e % 3;
+                const int i = bi * PT + x, j = bj * PT + x;
+                const double eye = (r == c) ? 1.0 : 0.0;
+                sDi[t] = i < N ? dt * Al[(r * 15 + 12 + c) * Ncap + i] + eye : 0.0;
+                sDj[t] = j < N ? dt * Al[(r * 15 + 12 + c) * Ncap + j] + eye : 0.0;
+                sBi[t] = i < N ? Bl[e * Ncap + i] : 0.0;
+                sBj[t] = j < N ? Bl[e * Ncap + j] : 0.0;
+            }
+        }
+        __syncthreads();
+        // G_i[r][k] = sum_e (dt A_ls_i)[r][e] Sigma_ss[al_col(e)][k] + sum_c' (I + dt A_qi)[r][c'] Sigma[l_i + c'][k]
+        for (int t = tid; t < 63 * PT; t += PROP_T) {
+            const int e = t / PT, x = t % PT;
+            const int r = e / 21, k = e % 21;
+            double g = 0.0;
+#pragma unroll
+            for (int q = 0; q < 12; ++q)
+                g += sFi[(r * 12 + q) * PT + x] * sSs[q * 21 + k];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+                g += sDi[(r * 3 + cc) * PT + x] * sSi[(k * 3 + cc) * PT + x];
+            sGi[t] = g;
+        }
+        __syncthreads();
+        {
+            // Landmark-sensor strips of the PT i-landmarks: Sigma'[l_i + r][c] = sum_k G_i[r][k] Fss[c][k] + dt sum_q Bl_i[r][q] Qd[q] Bs[c][q].
+            // G_i is in LDS here anyway; the nT workgroups of this block row share the 21 columns (c = bj, bj + nT, ...), at most a few
+            // outputs per workgroup. Same sums, in the same order, as a separate strip pass would evaluate.
+            for (int t = tid; t < PT * 3 * ncol; t += PROP_T) {
+                const int x = t % PT, rc = t / PT;
+                const int r = rc % 3, m_ = rc / 3, c = bj + nb * m_;
+                const int i = bi * PT + x;
+                if (i < N) {
+                    double sacc = 0;
+                    for (int k = 0; k < 21; ++k) {
+                        const double f = dt * sSens[m_ * 33 + k] + (k == c ? 1.0 : 0.0);
+                        sacc += sGi[(r * 21 + k) * PT + x] * f;
+                    }
+                    double bq = 0;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        bq += sBi[(r * 3 + q) * PT + x] * ra.Qd[q] * sSens[m_ * 33 + 21 + q];
+                    sacc += dt * bq;
+                    const int li = 21 + 3 * i;
+                    Sout[li + r + (size_t)c * ld] = sacc;
+                    Sout[c + (size_t)(li + r) * ld] = sacc;
+                }
+            }
+        }
+        // lane = (output row r, landmark pair (ti, tj)): three lanes share a 3x3 block, each produces one row of it. The
+        // per-element sums run in the same order as a one-lane-per-block version would (results are bit-identical to it).
+        const int r = tid / (PT * PT), tp = tid % (PT * PT);
+        const int ti = tp % PT, tj = tp / PT;
+        const int i = bi * PT + ti, j = bj * PT + tj;
+        if (i >= N || j >= N || (sym && bi == bj && i < j)) // (a diagonal tile: the pairs above the diagonal are mirrors too)
+            return;
+        const int li = 21 + 3 * i, lj = 21 + 3 * j;
+        // Sigma_ij
+        double Sij[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Sij[k][c] = Sig[li + k + (size_t)(lj + c) * ld];
+        // E[r][:] = (Fls_i Sigma_sj + D_i Sigma_ij)[r][:]
+        double E[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
+#pragma unroll
+            for (int e = 0; e < 12; ++e)
+                s += sFi[(r * 12 + e) * PT + ti] * sSj[(al_col(e) * 3 + c) * PT + tj];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                s += sDi[(r * 3 + k) * PT + ti] * Sij[k][c];
+            E[c] = s;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
+#pragma unroll
+            for (int e = 0; e < 12; ++e)
+                s += sGi[(r * 21 + al_col(e)) * PT + ti] * sFj[(c * 12 + e) * PT + tj];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                s += E[k] * sDj[(c * 3 + k) * PT + tj];
+            double bq = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                bq += sBi[(r * 3 + q) * PT + ti] * ra.Qd[q] * sBj[(c * 3 + q) * PT + tj];
+            s += dt * bq;
+            if (i == j && r == c)
+                s += dt * ra.Pd[7];
+            Sout[li + r + (size_t)(lj + c) * ld] = s;
+            if (sym && i != j)
+                Sout[lj + c + (size_t)(li + r) * ld] = s; // Sigma'_ji = Sigma'_ij^T: exactly symmetric between landmark blocks, half the tiles
+        }
+        return;
+    }
+    // sensor-sensor block
+    {
+        double* sF = sm;        // 441
+        double* sS = sm + 441;  // 441
+        double* sT = sm + 882;  // 441  (F Sigma_ss)
+        double* sBs = sm + 1323; // 252 (fused assembly: B_s expanded from the compact terms)
+        for (int t = tid; t < 441; t += PROP_T) {
+            const int r = t / 21, c = t % 21;
+            sF[t] = dt * (FUSED ? sensor_Ass_entry(fa.ck, t) : cm->Ass[t]) + (r == c ? 1.0 : 0.0);
+            sS[t] = Sig[r + (size_t)c * ld];
+        }
+        for (int t = tid; t < 252; t += PROP_T)
+            sBs[t] = FUSED ? sensor_Bs_entry(fa.ck, t) : cm->Bs[t];
+        __syncthreads();
+        for (int t = tid; t < 441; t += PROP_T) {
+            const int r = t / 21, c = t % 21;
+            double s = 0;
+            for (int k = 0; k < 21; ++k)
+                s += sF[r * 21 + k] * sS[k * 21 + c];
+            sT[t] = s;
+        }
+        __syncthreads();
+        for (int t = tid; t < 441; t += PROP_T) {
+            const int r = t / 21, c = t % 21;
+            double s = 0;
+            for (int k = 0; k < 21; ++k)
+                s += sT[r * 21 + k] * sF[c * 21 + k];
+            double bq = 0;
+            for (int q = 0; q < 12; ++q)
+                bq += sBs[r * 12 + q] * ra.Qd[q] * sBs[c * 12 + q];
+            s += dt * bq;
+            if (r == c)
+                s += dt * ra.Pd[r / 3];
+            Sout[r + (size_t)c * ld] = s;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

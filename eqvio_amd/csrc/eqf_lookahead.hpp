@@ -69,6 +69,8 @@ struct LaArgs {
     // ZB = 2 (the speculative frame tail, eqf_stats_then_update): no measurement kernel either - every workgroup evaluates the output blocks C_j it needs
     // (measure_j, one lane per measurement, into LDS), workgroup NI computes the outlier statistics, decides about the tail (speculation word) and
     // leaves C / yTilde / the index map in memory for a retry; zb_C / zb_ytil / zb_lmidx are not read
+    // ZB = 3 (round 4): like 2, but the output blocks were evaluated by the observer blocks of the propagation kernel in front (EQF_OPT_MEASURE_IN_PROPAGATE): the
+    // half-rows and the owner read zb_C / zb_ytil / zb_lmidx like ZB = 1, workgroup NI computes the statistics like ZB = 2
     MeasFuse zb_mf;
     trace_t* tr_zb; // EQF_OPT_TRACE: k_build_Z's slot - this kernel's start stands for it (the span to step 0 is the prologue that replaces k_build_Z)
 };
@@ -211,11 +213,13 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         const int i = tid & 15, jj = (tid >> 4) & 15;
         const int M = a.zb_M;
         double* sC16 = sX; // ZB = 2: the C blocks of the first 16 measurements
-        if (ZB == 2) {
+        if (ZB >= 2) { // (no measurement kernel in front that would have done it)
             if (tid == 0) { // this launch's status words start clean (write-through: no dirty line of them may outlive a later write-through set)
                 __hip_atomic_store(a.flags + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(a.flags + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (flags[3], the stall word, is sequence valued: never cleared)
             }
+        }
+        if (ZB == 2) {
             if (tid < 16 && tid < M) {
                 int lidx;
                 const MeasOut o = measure_j(a.zb_mf, tid, lidx);
@@ -1429,6 +1433,7 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
 // absErr / probErr / depth^2 per landmark to the pinned packet, the speculation word if a measured landmark is an outlier candidate (the lift and the
 // covariance update behind this kernel then return at once; what this kernel computes is scratch), and C / yTilde / the index map in memory (a retry on the
 // launch chain, or the next call with the same measurement, read them).
+template <int ZB> // ZB = 3: the C blocks are in memory already (evaluated by the propagation kernel's observer blocks)
 __device__ __forceinline__ void la_stats(const LaArgs& a) {
     const MeasFuse& mf = a.zb_mf;
     for (int i = threadIdx.x; i < mf.N; i += LA_T) {
@@ -1437,6 +1442,8 @@ __device__ __forceinline__ void la_stats(const LaArgs& a) {
         if (mf.spec_w && abs_err >= 0.0 && (abs_err > mf.thrAbs || prob_err > mf.thrProb)) // the comparisons of VIOFilter.cpp:316-330 (NaN: false)
             *mf.spec_w = mf.spec_seq;
     }
+    if (ZB == 3)
+        return;
     for (int j = threadIdx.x; j < a.zb_M; j += LA_T) {
         int lidx;
         const MeasOut o = measure_j(mf, j, lidx);
@@ -1464,9 +1471,9 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     // block 0: the owner; blocks 1 .. 2 NJ - 2: the S half-rows h = 2 .. 2 NJ - 1 (block row 0 is the first diagonal tile, eliminated by k_build_Z);
     // then the T half-rows, numbered on from 2 NJ
     const int hidx = (int)blockIdx.x + 1;
-    if constexpr (ZB == 2) {
+    if constexpr (ZB >= 2) {
         if ((int)blockIdx.x >= a.NI) { // the statistics workgroup
-            la_stats(a);
+            la_stats<ZB>(a);
             return;
         }
     }

@@ -78,6 +78,14 @@ enum {
                                   MFMA-issue bound per compute unit and those rows handed their tiles to the owner late), if the device has the compute units for the
                                   larger launch (N = 500: 191 instead of 159 workgroups). Same products in the same order per tile: bit-identical. 0: one workgroup
                                   per half-row */
+    EQF_OPT_MEASURE_IN_PROPAGATE = 19, /* 1 (default): when a measurement has been staged (eqf_stage_measurement) the observer blocks of eqf_propagate_fast's kernel - which have a
+                                  landmark's propagated group element in registers when their chain of steps ends - evaluate its output block C_i / C*_i and residual
+                                  there and leave them in memory, with the camera and output choice of the LAST eqf_stats_then_update call. If the next such call asks for
+                                  the same (and the staged measurement and landmark set still stand) there is no k_build_Z launch up to 16 panels: the look-ahead kernel
+                                  builds Z from those blocks and one more workgroup of it computes the outlier statistics; otherwise the call takes its ordinary route.
+                                  Same function and inputs as the update's own evaluation, compiled in another kernel: the compiler contracts the expressions into
+                                  fused multiply-adds differently there, so the results agree to rounding (1e-14 on Sigma), not bit for bit (the other routes do
+                                  among themselves; with -ffp-contract=off all agree bitwise). 0: never. eqf_measure_in_propagate_stats counts */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.
@@ -199,6 +207,8 @@ int eqf_stats_then_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids,
  * statistics kernel (every measured id already a landmark); of those, tails the device cancelled because a landmark exceeded an outlier
  * threshold (the caller then takes the two-round-trip path: removeOutliers / addNewLandmarks / eqf_vision_update). */
 int eqf_speculation_stats(eqf_ctx* ctx, long* calls, long* queued, long* cancelled, int reset);
+/* EQF_OPT_MEASURE_IN_PROPAGATE: update calls whose output blocks had been evaluated by the propagation kernel in front (no k_build_Z launch). */
+int eqf_measure_in_propagate_stats(eqf_ctx* ctx, long* used, int reset);
 /* eqf_stats_then_update with VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) made on the device where that saves the frame a host round trip:
  * while the speculative tail keeps getting cancelled (outlier candidates frame after frame, as with the shipped thresholds) the call queues the statistics,
  * the decision (candidates ranked absolute outliers first by absErr, then probabilistic ones by probErr, the first max_outliers = (size_t)((1 - featureRetention)

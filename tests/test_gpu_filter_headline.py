@@ -181,6 +181,10 @@ def test_measurement_edited_in_place_after_it_was_built():
         edited[f][3] = y.reshape(-1)
     fresh = bench.make_filter(world, settings, N, None, frames, mk)
     inplace = bench.make_filter(world, settings, N, None, frames, mk)
+    from eqvio_amd.capi import OPT_MEASURE_IN_PROPAGATE
+
+    for f in (fresh, inplace): # bit for bit: both filters on routes that evaluate the output blocks in the update's own kernels (see test_output_blocks_from_the_propagation_kernel)
+        assert load_eqf_lib().eqf_set_option(f.core_handle(), OPT_MEASURE_IN_PROPAGATE, 0) == 0
     pf_fresh = PreparedFrames(world.cam, *bench.flatten_frames([tuple(f) for f in edited[:5]]))
     pf_edit = PreparedFrames(world.cam, *bench.flatten_frames(frames[:5]))  # built (flat copies cached) with the OLD pixels ...
     for f, k, u, v in changes:
@@ -205,10 +209,14 @@ def test_measurement_and_z_inside_the_lookahead_kernel_change_nothing(N):
     world, frames = bench.build_workload(seed=21, n_frames=7, N=N)
     settings = bench.eurocish_settings()
     mk = lambda s, sensor, ids, p, t: VIOFilter(s, max_landmarks=N, sensor=sensor, ids=ids, p=p, time=t)  # noqa: E731
+    from eqvio_amd.capi import OPT_MEASURE_IN_PROPAGATE
+
     flts = []
     for val in (0, 2):
         f = bench.make_filter(world, settings, N, None, frames, mk)
         assert lib.eqf_set_option(f.core_handle(), OPT_Z_IN_LOOKAHEAD, val) == 0
+        # (the third route, output blocks evaluated by the propagation kernel, is compiled in another context and agrees to rounding only: its own test below)
+        assert lib.eqf_set_option(f.core_handle(), OPT_MEASURE_IN_PROPAGATE, 0) == 0
         flts.append(f)
     pf = PreparedFrames(world.cam, *bench.flatten_frames(frames[:6]))
     for k in range(6):
@@ -221,3 +229,32 @@ def test_measurement_and_z_inside_the_lookahead_kernel_change_nothing(N):
     assert ca["queued"] == cb["queued"] == 6 and ca["cancelled"] == cb["cancelled"] == 0 and cb["la_launches"] == 6 and cb["la_fallbacks"] == 0
     for f in flts:
         f.close()
+
+
+@pytest.mark.parametrize("N", [200, 60])
+def test_output_blocks_from_the_propagation_kernel(N):
+    """EQF_OPT_MEASURE_IN_PROPAGATE (round 4, default): the observer blocks of the propagation kernel evaluate the output blocks of the staged measurement, the look-ahead kernel
+    builds Z from them (no k_build_Z launch up to 16 panels). Same function and inputs as the update's own evaluation, but compiled in another kernel: the compiler contracts
+    the expressions into fused multiply-adds differently there (with -ffp-contract=off the routes agree bit for bit), so state and Sigma agree to rounding, not bitwise.
+    Every frame must take the route (counter), and a measurement that was edited after it was staged must fall back and give what a freshly built one gives."""
+    from eqvio_amd.capi import OPT_MEASURE_IN_PROPAGATE
+
+    lib = load_eqf_lib()
+    world, frames = bench.build_workload(seed=21, n_frames=9, N=N)
+    settings = bench.eurocish_settings()
+    mk = lambda s, sensor, ids, p, t: VIOFilter(s, max_landmarks=N, sensor=sensor, ids=ids, p=p, time=t)  # noqa: E731
+    on, off = bench.make_filter(world, settings, N, None, frames, mk), bench.make_filter(world, settings, N, None, frames, mk)
+    assert lib.eqf_set_option(off.core_handle(), OPT_MEASURE_IN_PROPAGATE, 0) == 0
+    pf = PreparedFrames(world.cam, *bench.flatten_frames(frames[:8]))
+    for k in range(8):
+        assert on.run_prepared(pf, k, 1) == 1 and off.run_prepared(pf, k, 1) == 1
+        (sa, ia, pa), (sb, ib, pb) = on.state_estimate(), off.state_estimate()
+        assert np.array_equal(ia, ib)
+        assert np.allclose(sa, sb, rtol=1e-12, atol=1e-13) and np.allclose(pa, pb, rtol=1e-12, atol=1e-13), k
+        Sa, Sb = on.get_sigma(), off.get_sigma()
+        assert np.max(np.abs(Sa - Sb)) <= 1e-12 * np.max(np.abs(Sb)), k
+    used = C.c_long()
+    assert lib.eqf_measure_in_propagate_stats(on.core_handle(), C.byref(used), 0) == 0 and used.value == 7  # every frame but the first (no update call had named a camera yet)
+    assert lib.eqf_measure_in_propagate_stats(off.core_handle(), C.byref(used), 0) == 0 and used.value == 0
+    on.close()
+    off.close()
