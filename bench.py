@@ -730,6 +730,12 @@ def measure_roofline(flt, lib, core, cam, frames, args, n, m):
         "launches_per_frame": dom_launches,
         "avg_launch_us": dom_us / max(dom_launches, 1.0),
         "algorithmic_flops_per_launch": fam[dom][1] / max(dom_launches, 1.0),
+        # round 4: with the output blocks evaluated by the propagation kernel there is no k_build_Z launch, the look-ahead kernel builds Z = [S; T; y^T] in front of its
+        # first panel (~6 us of its span). `achieved` / `frac` keep counting the factorisation's flops only (conservative, comparable with earlier rounds); counting the
+        # dense-formulation flops of T = Sigma C^T, S = C T + R (2 n^2 m + 2 n m^2, of which the kernel executes a fraction: C is 2 x 3 block sparse) as well would give:
+        "dominant_kernel_also_builds_Z": bool(launches.get("k_build_Z", 0.0) == 0.0 and launches.get("k_chol_lookahead", 0.0) > 0.0),
+        "frac_if_Z_building_counted": ((fam[dom][1] + 2.0 * n * n * m + 2.0 * n * m * m) / (dom_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS)
+        if (launches.get("k_build_Z", 0.0) == 0.0 and launches.get("k_chol_lookahead", 0.0) > 0.0) else None,
         "measured_mfma_f64_issue_ceiling_tflops": tpeak.value,
         "sclk_ghz_during_mfma_ceiling": round(sclk.value, 3),
         "mfma_ceiling_note": "k_mfma_peak (8 waves per SIMD, 4 independent accumulators each, no memory traffic) while reading the device's own cycle counter against its 100 MHz "
