@@ -176,6 +176,7 @@ struct eqf_ctx {
     int pred_star = 0, me_star = 0, me_M = 0;
     unsigned long me_gen = 0;
     long me_used = 0;
+    bool obs_one_chunk = false;              // the propagation launch in progress carries ALL observer steps of the call (more than kMaxSteps: further k_observer launches follow)
     bool tail_zb = false;                    // the update tail in flight has no Z in memory (built inside the look-ahead kernel): a retry on the chain builds it first
     double tail_var = 0.0;                   // ... and needs the measurement variance again
     long zb_launches = 0;
@@ -1519,7 +1520,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
         // EQF_OPT_MEASURE_IN_PROPAGATE: the observer blocks evaluate the output blocks of the staged measurement with the camera / output choice of the last update call
         MeasEval me{};
         c->me_valid = false;
-        if (c->opt_measure_prop && fused && nObs && sg.M > 0 && c->pred_valid && !c->sig32 && !c->opt_f32 && c->opt_zb && !c->opt_check) {
+        if (c->opt_measure_prop && fused && nObs && c->obs_one_chunk && sg.M > 0 && c->pred_valid && !c->sig32 && !c->opt_f32 && c->opt_zb && !c->opt_check) {
             me.on = 1, me.star = c->pred_star, me.Mcap = c->Ncap, me.cam = c->pred_cam;
             me.ylm = c->h_ylm, me.C = c->d_C, me.ytil = c->d_ytil, me.lmidx_dev = c->d_lmidx;
             c->me_valid = true, c->me_cam = c->pred_cam, c->me_star = c->pred_star, c->me_M = sg.M, c->me_gen = c->staged_gen;
@@ -1900,6 +1901,7 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     //    not touch Q; the assembly before it has read Q, the statistics after it want the new Q): two launches on ONE stream.
     //    Further chunks (k > 24) and the dense mode use the observer kernel, in stream order.
     const bool ride = !c->opt_dense && !chunks.empty() && c->N > 0;
+    c->obs_one_chunk = chunks.size() == 1; // (the group elements are final when the propagation kernel's observer blocks are done)
     rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0, fuse);
     if (rc)
         return rc;

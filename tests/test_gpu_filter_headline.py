@@ -258,3 +258,32 @@ def test_output_blocks_from_the_propagation_kernel(N):
     assert lib.eqf_measure_in_propagate_stats(off.core_handle(), C.byref(used), 0) == 0 and used.value == 0
     on.close()
     off.close()
+
+
+def test_output_blocks_wait_for_the_last_observer_step():
+    """More IMU samples between two frames than one propagation launch carries (kMaxSteps = 24; 600 Hz IMU at 20 Hz camera = 30): the landmarks' group elements are final only
+    after a further k_observer launch, so the propagation kernel must NOT evaluate the output blocks (they would belong to an intermediate state). Teacher forced against the oracle."""
+    from run_configs import parity
+
+    N = 60
+    world = SimWorld(seed=5, num_points=N, max_features=N, trajectory="hover", imu_freq=600.0, image_freq=20.0, noise_px=0.5)
+    frames = list(world.frames(6))
+    assert max(len(f[0]) for f in frames) > 24
+    settings = bench.eurocish_settings()
+    ids0 = frames[0][2]
+    sensor, ids, p = world.true_state(0.0, ids0)
+    p = p * (1.0 + 0.05 * np.random.default_rng(7).normal(size=(len(ids), 1)))
+    flt = VIOFilter(settings, max_landmarks=N, sensor=sensor, ids=ids, p=p, time=0.0)
+    orc = OracleFilter(settings, sensor, ids, p, 0.0)
+    prepared = PreparedFrames(world.cam, *bench.flatten_frames(frames))
+    for f, (imus, stamp, mid, y) in enumerate(frames):
+        assert flt.run_prepared(prepared, f, 1) == 1
+        for k_ in range(len(imus)):
+            orc.process_imu(imus[k_])
+        orc.process_vision(stamp, world.cam, mid, y)
+        es, eS = parity(flt, orc)
+        assert es <= TOL and eS <= TOL, (f, es, eS)
+        teacher_force(flt, orc)
+    used = C.c_long()
+    assert load_eqf_lib().eqf_measure_in_propagate_stats(flt.core_handle(), C.byref(used), 0) == 0 and used.value == 0
+    flt.close()
