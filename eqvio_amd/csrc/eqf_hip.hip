@@ -1869,7 +1869,11 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     ++c->trace_frame; // EQF_OPT_TRACE: a frame starts here
     host_stamp(c, TH_PROP_ENTRY);
     // 1. A / B terms at the CURRENT X (before the observer steps move it): integrateRiccatiStateFast uses X as it is
-    int rc = upload_common(c, imu13_mean);
+    int rc;
+    {
+        HP_SCOPE("pf.upload_common");
+        rc = upload_common(c, imu13_mean);
+    }
     if (rc)
         return rc;
     // 2. the assembly kernel goes out first (its terms, c->ck, are fixed now): the host part of the observer steps below then
@@ -1880,12 +1884,16 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     if (rc)
         return rc;
     host_stamp(c, TH_ASSEMBLE_OUT);
-    rc = stage_prepare(c);
+    {
+        HP_SCOPE("pf.stage_prepare");
+        rc = stage_prepare(c);
+    }
     if (rc)
         return rc;
     // 3. all observer steps on the host (X advances); chunks of kMaxSteps keep the kernel-argument packet small
     std::vector<ObsSteps> chunks;
     std::vector<int> counts;
+    HP_SCOPE("pf.observer_steps_and_launch");
     for (int done = 0; done < k;) {
         const int chunk = std::min(k - done, eqf_ctx::kMaxSteps);
         chunks.emplace_back();
@@ -1902,7 +1910,10 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     //    Further chunks (k > 24) and the dense mode use the observer kernel, in stream order.
     const bool ride = !c->opt_dense && !chunks.empty() && c->N > 0;
     c->obs_one_chunk = chunks.size() == 1; // (the group elements are final when the propagation kernel's observer blocks are done)
-    rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0, fuse);
+    {
+        HP_SCOPE("pf.launch");
+        rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0, fuse);
+    }
     if (rc)
         return rc;
     host_stamp(c, TH_PROP_OUT);
