@@ -150,21 +150,25 @@ __device__ __forceinline__ void la_operand(const double* __restrict__ tile, int 
 
 // ---- the owner --------------------------------------------------------------------------------------------------------------------
 // Round 3: a dataflow of eight specialised waves, synchronised by monotone LDS counters instead of workgroup barriers, so that no wave ever waits
-// for something it does not need - in particular not for the ~1 us acknowledgement of somebody's write-through stores.
-//   wave 0      pivot: waits for D_(k+1) (cD), eliminates it (LDS + write-through tile of L_(k+1)^-1), announces it (cL), then waits for its own stores
-//               and raises the flag of L_(k+1)^-1 while the post-work runs.
-//   waves 4..7  post-work of step k, one 16 x 16 quadrant each, on the critical path: c = P^(k)_(k+1) = R1 L_k^-T -> sX (cC), D_(k+1) = D' - c c^T -> sD (cD).
+// for something it does not need - in particular not for the ~1 us acknowledgement of somebody's write-through stores. Roles as of round 4:
+//   wave 0      pivot: forms the block (0, 0) of D_(k+1) itself (c rows 0 .. 15 = R1[0:16, :] L_k^-T and D'_00 - c c^T on register-operand MFMAs, with the blocks of
+//               L_k^-1 it holds from its last elimination), eliminates it, takes the blocks (1, 0) / (1, 1) from sD when it needs them, finishes the 32 x 32 tile
+//               (register-resident LDL^T, eqf_kernels.hpp: ldl_inverse_tile_regs), writes L_(k+1)^-1 to sLk and announces it (LC_L). Only the LAST tile is
+//               published from here.
+//   waves 5, 7  post-work of step k: rows 16 .. 31 of c = P^(k)_(k+1) -> sX (LC_C), the blocks (1, 0) / (1, 1) of D_(k+1) = D' - c c^T -> sD (LC_D); then tail.
 //   waves 2,5,6,7  tail of step k (under the elimination of D_(k+1)): for block row I2 = k + 2 fetch U2 = Z(I2, k), U1 = Z(I2, k+1), U0 = Z(I2, I2) (panels
-//               <= k - 1 applied by the block row itself, except one product, below) and form b = P^(k)_I2 = U2 L_k^-T (round 2: b came from block row I2,
-//               two dependent hand-offs behind L_k^-1, and was the last input to arrive), R1 = U1 - P^(k-1)_I2 b_prev^T - b c^T, D' = U0 - b b^T (cT).
+//               <= k - 1 applied by the block row itself, except two products, below) and form b = P^(k)_I2 = U2 L_k^-T (waves 2 and 7; round 2: b came from
+//               block row I2, two dependent hand-offs behind L_k^-1), R1 = U1 - P^(k-1)_I2 b_prev^T - b c^T, D' = U0 - b b^T (LC_T).
 //               Quadrant 0 runs on wave 2, not on wave 4: waves sit on SIMD (wave % 4), and fp64 MFMAs of a SIMD-mate slow the pivot wave's fp64 VALU chain
-//               (measured: elimination 3.3 -> 4.0 us with 48 tail MFMAs on wave 4); SIMD 0 is left to the pivot wave while it eliminates.
+//               (measured: elimination 3.3 -> 4.0 us with 48 tail MFMAs on wave 4); SIMD 0 is left to the pivot wave. Wave 4 has no work since round 4 (a poller
+//               there, even asleep between its looks, cost the pivot wave 1 us per factorisation).
 //   wave 1      publishes c (sX -> write-through tile, waits for the acknowledgement, raises the two half-row flags of P^(k)_(k+1)), then b the same way
 //               (from the LDS copy the tail keeps for the next tail).
 //   wave 3      polls the U flags of the block rows, one after the other, so that a tail finds them checked (a flag poll is ~0.9 us of memory latency
-//               even when the flag has been up for long).
+//               even when the flag has been up for long), and in between publishes L_k^-1 out of sLk (the pivot wave keeps its issue slots).
 // The product Z(I, I-1) -= P^(I-3)_I (P^(I-3)_(I-1))^T is left to the owner (r3 below): its second factor is the owner's own b of the step before, and
-// a block row waiting for it closed a cycle b -> block row -> U -> next b of 5.3 us per step (measured).
+// a block row waiting for it closed a cycle b -> block row -> U -> next b of 5.3 us per step (measured). So is (round 4) the block (1, 0) of the diagonal tile's
+// product of the same panel, P^(I-3)_bottom (P^(I-3)_top)^T: the bottom half-row would wait for the top one's factor rows.
 // Same products in the same order as round 2 and as the launch chain: W and Sigma+ are bit-identical.
 // relaxed = true: a wait that is not on the critical path sleeps between its looks, so that five spinning waves do not compete with the pivot wave's
 // own LDS traffic (ds_bpermute, operand reads)
