@@ -169,6 +169,8 @@ struct eqf_ctx {
     int opt_zb = 1;                          // EQF_OPT_Z_IN_LOOKAHEAD
     int opt_la_split = 1;                    // EQF_OPT_LA_SPLIT_ROWS
     int opt_measure_prop = 1;                // EQF_OPT_MEASURE_IN_PROPAGATE
+    int opt_lift_syrk = 1;                   // EQF_OPT_LIFT_WITH_SYRK
+    long lift_syrk_launches = 0;
     // ... its state: what the propagation kernel's observer blocks evaluated the output blocks with (camera and C / C* of the LAST update call stand in for the
     // coming one's; the update call checks), for which staged measurement
     bool pred_valid = false, me_valid = false;
@@ -921,6 +923,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_Z_IN_LOOKAHEAD: *value = c->opt_zb; return 0;
     case EQF_OPT_LA_SPLIT_ROWS: *value = c->opt_la_split; return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE: *value = c->opt_measure_prop; return 0;
+    case EQF_OPT_LIFT_WITH_SYRK: *value = c->opt_lift_syrk; return 0;
     case EQF_OPT_LOOKAHEAD: *value = c->opt_lookahead; return 0;
     case EQF_OPT_LA_TIMEOUT_US: *value = (int)(c->la_timeout_ticks / 100); return 0;
     case EQF_OPT_TRACE: *value = c->d_trace ? 1 : 0; return 0;
@@ -962,6 +965,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case EQF_OPT_MEASURE_IN_PROPAGATE:
         c->opt_measure_prop = value ? 1 : 0;
         c->me_valid = false;
+        return 0;
+    case EQF_OPT_LIFT_WITH_SYRK:
+        c->opt_lift_syrk = value ? 1 : 0;
         return 0;
     case EQF_OPT_LOOKAHEAD:
         c->opt_lookahead = value;
@@ -1205,7 +1211,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -2163,11 +2169,13 @@ static int stage_measurement(eqf_ctx* c, const int* ids, const double* y, int M)
 
 // The device part of the vision update behind the measurement stage: Z, factorisation chain, Sigma update, lift. With
 // spec != nullptr every kernel first compares *spec with spec_seq and returns at once if they match (cancelled tail).
+static LiftArgs lift_args(eqf_ctx* c, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, const double* gpart, int stall_seq) {
+    return LiftArgs{c->N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(), c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags,
+                    c->h_resflags, use_door ? c->d_door + 1 : nullptr, c->h_door + 1, door_seq, spec, spec_seq, gpart, c->ld, trace_slot(c, TR_LIFT), stall_seq};
+}
 static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, const double* gpart, int stall_seq) {
     KTimer t(c, KN_LIFT);
-    hipLaunchKernelGGL(k_lift, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, c->N, c->Ncap, c->chart, discreteCorr, c->d_gamma, c->q0(), c->Qq(), c->Qa(),
-                       c->h_res + 3 * (size_t)c->Ncap, c->h_res + 7 * (size_t)c->Ncap, c->d_flags, c->h_resflags, use_door ? c->d_door + 1 : nullptr, c->h_door + 1, door_seq,
-                       spec, spec_seq, gpart, c->ld, trace_slot(c, TR_LIFT), stall_seq);
+    hipLaunchKernelGGL(k_lift, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, lift_args(c, discreteCorr, spec, spec_seq, use_door, door_seq, gpart, stall_seq));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2303,6 +2311,23 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
     if (rc)
         return rc;
     const int stall_seq = la ? c->la_seq : -1; // the stall word the kernels behind the factorisation compare (sequence valued: eqf_lookahead.hpp)
+    // EQF_OPT_LIFT_WITH_SYRK: lift and covariance update wait for the same kernel and touch different data - one launch, the lift's workgroups in front
+    // (not with per-kernel timing, which wants the two spans apart, and not with fp32 storage, whose rounding pass follows the covariance update)
+    if (c->opt_early && c->opt_lift_syrk && !c->sig32 && !c->opt_timing && c->N > 0) {
+        const int nt = blocks(n, 32), nlift = blocks(c->N, 64);
+        KTimer t(c, KN_SYRK);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_lift<double>), dim3(nlift + nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(),
+                           c->d_gamma, c->d_flags, trace_slot(c, TR_SYRK), c->d_syrk_order + c->syrk_off[nt], lift_args(c, discreteCorr, spec, spec_seq, use_door, door_seq, la ? nullptr : c->d_gpart, stall_seq),
+                           nlift);
+        HIPCHK(hipGetLastError());
+        ++c->lift_syrk_launches;
+        { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }
+        if (c->opt_check) {
+            LAUNCH_TS(c, k_check_finite, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->ld, (const TS*)c->sigma(), c->d_flags);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
     if (c->opt_early) { // Gamma, landmark lift, result packet and doorbell BEFORE the covariance update: the host round trip overlaps with it
         rc = launch_lift(c, discreteCorr, spec, spec_seq, use_door, door_seq, la ? nullptr : c->d_gpart, stall_seq);
         if (rc)

@@ -390,12 +390,12 @@ struct StageArgs {
 // word instead of the stream's completion signal and sees the results about 6 us earlier (scripts/ubench/doorbell.hip).
 // Ordering: every workgroup fences its result stores at system scope before its atomic increment; the workgroup that
 // observes all increments fences again and only then writes the sequence number.
-__device__ __forceinline__ void ring_doorbell(int* __restrict__ count, int* __restrict__ host_flag, int seq) {
+__device__ __forceinline__ void ring_doorbell(int* __restrict__ count, int* __restrict__ host_flag, int seq, int nblocks = (int)gridDim.x) {
     if (!count)
         return;
     __threadfence_system();
     if (threadIdx.x == 0) {
-        if (atomicAdd(count, 1) == (int)gridDim.x - 1) {
+        if (atomicAdd(count, 1) == nblocks - 1) {
             atomicExch(count, 0);
             __threadfence_system();
             *reinterpret_cast<volatile int*>(host_flag) = seq;
@@ -1857,17 +1857,17 @@ template <typename TS, bool WITH_GAMMA>
 // XCD has its own L2: with the tiles handed out in plain column order each XCD touched every 32-row panel of W (131 MB fetched for 12 MB of W at N = 500).
 // The table (built on the host, eqf_hip.hip: build_syrk_order) gives XCD x a compact square of the tile triangle and walks it column by column, so that an
 // XCD fetches ~2 sqrt(tiles / 8) row panels of W instead of all of them.
-__global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
-                                                  double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma, const int* __restrict__ flags,
-                                                  trace_t* tr, const int* __restrict__ tile_of_block, int stall_seq) {
-    trace_start(tr);
+__device__ __forceinline__ void syrk_sub_tile(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec,
+                                              int spec_seq, const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, int stall_seq, int blk) {
+    if (tr && blk == 0 && threadIdx.x == 0)
+        *tr = wall_clock64();
     const int failed = flags[0] | (flags[3] == stall_seq ? 1 : 0); // requested together with the cancellation word: one round trip
     if (spec && *spec == spec_seq)
         return; // cancelled speculative tail
     if (failed)
         return; // the factorisation failed (see k_lift): Sigma stays as it was
     __shared__ double sred[1024 * 4];
-    const int code = tile_of_block[blockIdx.x];
+    const int code = tile_of_block[blk];
     const int bi = code & 0xffff, bj = code >> 16;
     const int i0 = bi * 32, j0 = bj * 32;
     const double* W = Wb + m;
@@ -1894,6 +1894,12 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld,
         }
     }
     trace_end(tr);
+}
+template <typename TS, bool WITH_GAMMA>
+__global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_sub(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, int nt,
+                                                  double* __restrict__ gamma, const int* __restrict__ spec, int spec_seq, int with_gamma, const int* __restrict__ flags,
+                                                  trace_t* tr, const int* __restrict__ tile_of_block, int stall_seq) {
+    syrk_sub_tile<TS, WITH_GAMMA>(n, m, ld, ldz, Wb, Sig, gamma, spec, spec_seq, flags, tr, tile_of_block, stall_seq, (int)blockIdx.x);
 }
 
 
@@ -1956,15 +1962,37 @@ __device__ __forceinline__ double gamma_row(const double* __restrict__ gamma, co
         return gamma[row];
     return ((gpart[row] + gpart[(size_t)ldg + row]) + (gpart[2 * (size_t)ldg + row] + gpart[3 * (size_t)ldg + row])) + gpart[4 * (size_t)ldg + row];
 }
-__global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int discrete, double* __restrict__ gamma, const double* __restrict__ q0,
-                                             double* __restrict__ Qq, double* __restrict__ Qa, double* __restrict__ est, double* __restrict__ gamma_host,
-                                             const int* __restrict__ flags, int* __restrict__ flags_host, int* __restrict__ door_count, int* __restrict__ door_host,
-                                             int door_seq, const int* __restrict__ spec, int spec_seq, const double* __restrict__ gpart, int ldg, trace_t* tr, int stall_seq) {
-    trace_start(tr);
+struct LiftArgs {
+    int N, Ncap, chart, discrete;
+    double* gamma;
+    const double* q0;
+    double *Qq, *Qa, *est, *gamma_host;
+    const int* flags;
+    int *flags_host, *door_count, *door_host;
+    int door_seq;
+    const int* spec;
+    int spec_seq;
+    const double* gpart;
+    int ldg;
+    trace_t* tr;
+    int stall_seq;
+};
+// one block of 64 landmarks (blk of nblk; threads 0 .. 63 of the workgroup)
+__device__ __forceinline__ void lift_block(const LiftArgs& la, const int blk, const int nblk) {
+    const int N = la.N, Ncap = la.Ncap, chart = la.chart, discrete = la.discrete, ldg = la.ldg, spec_seq = la.spec_seq, stall_seq = la.stall_seq;
+    double* __restrict__ gamma = la.gamma;
+    const double* __restrict__ q0 = la.q0;
+    double *__restrict__ Qq = la.Qq, *__restrict__ Qa = la.Qa, *__restrict__ est = la.est, *__restrict__ gamma_host = la.gamma_host;
+    const int *__restrict__ flags = la.flags, *__restrict__ spec = la.spec;
+    int* __restrict__ flags_host = la.flags_host;
+    const double* __restrict__ gpart = la.gpart;
+    trace_t* tr = la.tr;
+    if (tr && blk == 0 && threadIdx.x == 0)
+        *tr = wall_clock64();
     // est / gamma_host / flags_host point into the pinned host packet: the results reach the host without copy kernels.
     // Every load this kernel needs is requested before the first result is used (Gamma partials, landmark state, chart constant, status
     // words, cancellation word): one memory round trip instead of three on the path to the doorbell.
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blk * 64 + threadIdx.x;
     const bool lm = i < N;
     const int ic = lm ? i : 0;
     const double gs = gamma_row(gamma, gpart, ldg, i < 21 ? i : 0);
@@ -1977,7 +2005,7 @@ __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int dis
     // the filter as it was: no landmark is lifted here, k_syrk_sub does not touch Sigma, the host does not apply the sensor lift. The
     // status words are cleared by the first kernel of the next update.
     const bool failed = f0 != 0 || f3 != 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (i == 0) {
         flags_host[2] = aborted ? 1 : 0;
         flags_host[3] = f3; // look-ahead factorisation: a bounded wait ran out
     }
@@ -2000,8 +2028,22 @@ __global__ void __launch_bounds__(64) k_lift(int N, int Ncap, int chart, int dis
             lift_landmark(i, V3{g0, g1, g2}, in, N, Ncap, chart, discrete, Qq, Qa, est);
         }
     }
-    ring_doorbell(door_count, door_host, door_seq);
+    ring_doorbell(la.door_count, la.door_host, la.door_seq, nblk);
     trace_end(tr);
+}
+__global__ void __launch_bounds__(64) k_lift(const LiftArgs la) { lift_block(la, (int)blockIdx.x, (int)gridDim.x); }
+// EQF_OPT_LIFT_WITH_SYRK: k_lift and k_syrk_sub as ONE launch. Both only wait for the factorisation, neither reads what the other writes (landmark elements and the result
+// packet here, Sigma there): the first nlift workgroups lift 64 landmarks each with their first wave and ring the doorbell, the others take a tile of Sigma each. The
+// doorbell rings when it did with two launches; Sigma - which the NEXT frame's first kernel waits for - is complete one lift and one kernel boundary earlier.
+template <typename TS>
+__global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_lift(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, double* __restrict__ gamma,
+                                                            const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, const LiftArgs la, int nlift) {
+    if ((int)blockIdx.x < nlift) {
+        if (threadIdx.x < 64)
+            lift_block(la, (int)blockIdx.x, nlift);
+        return;
+    }
+    syrk_sub_tile<TS, false>(n, m, ld, ldz, Wb, Sig, gamma, la.spec, la.spec_seq, flags, tr, tile_of_block, la.stall_seq, (int)blockIdx.x - nlift);
 }
 // q_hat_i = Q_i^-1 q0_i for all landmarks (stateGroupAction, VIOGroup.cpp:44-52)
 __global__ void __launch_bounds__(64) k_estimate(int N, int Ncap, const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,

@@ -86,6 +86,10 @@ enum {
                                   Same function and inputs as the update's own evaluation, compiled in another kernel: the compiler contracts the expressions into
                                   fused multiply-adds differently there, so the results agree to rounding (1e-14 on Sigma), not bit for bit (the other routes do
                                   among themselves; with -ffp-contract=off all agree bitwise). 0: never. eqf_measure_in_propagate_stats counts */
+    EQF_OPT_LIFT_WITH_SYRK = 20, /* 1 (default): the landmark lift (result packet, doorbell) and Sigma <- Sigma - W W^T, which both only wait for the factorisation and touch
+                                  different data, are ONE launch (the lift's workgroups in front) instead of two in a row: the doorbell rings when it did, Sigma - which the
+                                  next frame's first kernel waits for - is complete a lift and a kernel boundary earlier. Same arithmetic per thread: bit-identical.
+                                  Not with EQF_OPT_SIGMA_FP32 storage or per-kernel timing. 0: two launches */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.

@@ -260,6 +260,34 @@ def test_output_blocks_from_the_propagation_kernel(N):
     off.close()
 
 
+@pytest.mark.parametrize("N,lookahead", [(200, 1), (60, 1), (60, 0), (5, 1)])
+def test_lift_and_covariance_update_in_one_launch_change_nothing(N, lookahead):
+    """EQF_OPT_LIFT_WITH_SYRK (round 4, default): the landmark lift / result packet / doorbell and Sigma <- Sigma - W W^T (VIO_eqf.cpp:130-131) are one launch instead of two in
+    a row - behind the look-ahead kernel, behind the launch chain (whose lift sums Gamma's partial vectors) and at a size without a factorisation kernel of its own.
+    Same arithmetic per thread: state, Sigma and estimates identical bit for bit, frame after frame."""
+    from eqvio_amd.capi import OPT_LIFT_WITH_SYRK, OPT_LOOKAHEAD
+
+    lib = load_eqf_lib()
+    world, frames = bench.build_workload(seed=23, n_frames=7, N=N)
+    settings = bench.eurocish_settings()
+    mk = lambda s, sensor, ids, p, t: VIOFilter(s, max_landmarks=N, sensor=sensor, ids=ids, p=p, time=t)  # noqa: E731
+    flts = []
+    for val in (0, 1):
+        f = bench.make_filter(world, settings, N, None, frames, mk)
+        assert lib.eqf_set_option(f.core_handle(), OPT_LIFT_WITH_SYRK, val) == 0
+        assert lib.eqf_set_option(f.core_handle(), OPT_LOOKAHEAD, lookahead) == 0
+        flts.append(f)
+    pf = PreparedFrames(world.cam, *bench.flatten_frames(frames[:6]))
+    for k in range(6):
+        for f in flts:
+            assert f.run_prepared(pf, k, 1) == 1
+        (sa, ia, pa), (sb, ib, pb) = flts[0].state_estimate(), flts[1].state_estimate()
+        assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(pa, pb), k
+        assert np.array_equal(flts[0].get_sigma(), flts[1].get_sigma()), k
+    for f in flts:
+        f.close()
+
+
 def test_output_blocks_wait_for_the_last_observer_step():
     """More IMU samples between two frames than one propagation launch carries (kMaxSteps = 24; 600 Hz IMU at 20 Hz camera = 30): the landmarks' group elements are final only
     after a further k_observer launch, so the propagation kernel must NOT evaluate the output blocks (they would belong to an intermediate state). Teacher forced against the oracle."""
