@@ -235,6 +235,7 @@ struct eqf_ctx {
     unsigned map_gen = ~0u;
     int map_N = -1;
     bool map_all = false;
+    bool map_ident = false; // ... and measurement j is landmark j for every j
     std::vector<std::pair<int, int>> lookup; // sorted (id, index), valid for lookup_gen == lm_gen
     unsigned lookup_gen = ~0u;
     // host-side wait statistics (eqf_host_wait_stats): doorbell waits and the time spent spinning in them
@@ -2012,6 +2013,8 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     if (zb) { // EQF_OPT_Z_IN_LOOKAHEAD: the half-rows build their rows of Z themselves
         a.zb_sig = (const double*)c->sigma(), a.zb_ld = c->ld, a.zb_M = m / 2, a.zb_Mcap = c->Ncap, a.zb_var = c->tail_var;
         a.zb_C = c->d_C, a.zb_ytil = c->d_ytil, a.zb_lmidx = c->d_lmidx, a.zb_linv0 = c->d_Linv;
+        // (the pinned packet's mapping is the one this update was mapped with - map_measurement ran in this call or, for a staged measurement, in stage_prepare)
+        a.zb_ident = (zb != 2 && c->map_gen == c->lm_gen && c->map_N == c->N && (int)c->map_ids.size() == m / 2 && c->map_ident) ? 1 : 0;
         a.tr_zb = trace_slot(c, TR_BUILD_Z);
         ++c->zb_launches;
         if (zb == 2) { // ... and evaluate the C blocks themselves; one more workgroup for the statistics and the speculation word (the kernel itself does not look at it)
@@ -2058,12 +2061,13 @@ static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, 
     c->map_gen = c->lm_gen - 1; // invalid until this call succeeds
     for (int i = 0; i < c->N; ++i)
         measof[i] = -1;
-    bool all = true;
+    bool all = true, ident = true;
     for (int j = 0; j < M; ++j) {
         if (j > 0 && ids[j] <= ids[j - 1])
             return EQF_E_BAD_ARG; // must be strictly ascending (std::map order)
         const int i = index_of(c, ids[j]);
         lmidx[j] = i;
+        ident = ident && i == j;
         if (i >= 0)
             measof[i] = j;
         else if (require_all)
@@ -2076,6 +2080,7 @@ static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, 
         c->map_gen = c->lm_gen;
         c->map_N = c->N;
         c->map_all = all;
+        c->map_ident = ident;
     }
     return 0;
 }

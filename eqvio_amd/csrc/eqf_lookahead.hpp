@@ -65,7 +65,9 @@ struct LaArgs {
     const double* zb_C;   // C blocks, plane e at [e zb_Mcap + j]
     const double* zb_ytil;
     const int* zb_lmidx;  // measurement -> state landmark index
-    double* zb_linv0;     // out: L_0^-1 (32 x 32 column-major), for the owner itself
+    double* zb_linv0;     // (unused by the kernel since round 4: L_0^-1 goes straight to the owner's LDS and its published tile)
+    int zb_ident;         // measurement j belongs to landmark j for every j (the regular frame: the landmarks without a measurement were removed before the update and both
+                          // are in ascending id order) - nobody loads the index map, which would be a memory round trip IN FRONT of every Sigma load of the prologue
     // ZB = 2 (the speculative frame tail, eqf_stats_then_update): no measurement kernel either - every workgroup evaluates the output blocks C_j it needs
     // (measure_j, one lane per measurement, into LDS), workgroup NI computes the outlier statistics, decides about the tail (speculation word) and
     // leaves C / yTilde / the index map in memory for a retry; zb_C / zb_ytil / zb_lmidx are not read
@@ -234,7 +236,8 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         }
         double sv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (tid < 256 && i < M && jj < M) { // Sigma's blocks requested before the barrier: in flight while the C blocks are evaluated
-            const int li = 21 + 3 * (ZB == 2 ? a.zb_mf.lmidx[i] : a.zb_lmidx[i]), lj2 = 21 + 3 * (ZB == 2 ? a.zb_mf.lmidx[jj] : a.zb_lmidx[jj]);
+            const int* lmg = ZB == 2 ? a.zb_mf.lmidx : a.zb_lmidx;
+            const int li = 21 + 3 * (a.zb_ident ? i : lmg[i]), lj2 = 21 + 3 * (a.zb_ident ? jj : lmg[jj]);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -261,14 +264,24 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                     sD[2 * i + aa + (2 * jj + bb) * 33] = blk[aa][bb];
         }
         __syncthreads();
-        ldl_inverse_tile(sD, 33, min(32, a.m), a.zb_linv0, a.flags, swork); // wave 0; the others wait at the barrier below
-        __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
-    }
-    {
+        // Wave 0 eliminates; L_0^-1 goes straight to sLk and, write-through, to its published tile. No barrier behind it: the other waves take up their roles
+        // now (the tail waves fetch block row 1's tiles while the first tile is being eliminated - 1.7 us of the first step otherwise), everything they read of
+        // this wave's is behind an LDS counter. The flag of L_0^-1 goes up from the pivot wave's first step, when the stores have been acknowledged (*).
+        if (wave == 0) {
+            double* l0 = la_tile(a, la_i_linv(a, 0));
+            ldl_inverse_tile_put(
+                sD, 33, min(32, a.m),
+                [sLk, l0](int r, int c, double v) {
+                    sLk[r + c * CH_LDP] = v;
+                    la_st(l0 + r + 32 * c, v);
+                },
+                a.flags, swork);
+            la_lds_set(cnt + LC_L, 1);
+        }
+    } else {
         double* l0 = la_tile(a, la_i_linv(a, 0));
         for (int e = tid; e < 1024; e += LA_T) {
-            const double v = ZB ? a.zb_linv0[e] : a.Linv0[e];
+            const double v = a.Linv0[e];
             sLk[(e & 31) + (e >> 5) * CH_LDP] = v;
             la_st(l0 + e, v);
         }
@@ -327,6 +340,11 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 sX[lr + (16 + lk + 4 * q) * CH_LDP] = c12[q];
             }
             la_lds_add(cnt + LC_C, 2);
+            if (ZB && k == 0) { // (*) L_0^-1's stores were issued ~0.6 us ago
+                la_stores_done();
+                if (lane == 0)
+                    la_raise_f(a, la_f_linv(a, 0));
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 cc = __builtin_amdgcn_mfma_f64_16x16x4f64(c11[q], c11[q], cc, 0, 0, 0);
@@ -715,6 +733,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         // index map only, and are in flight while the C blocks are evaluated (ZB = 2: ~2.5 us)
         constexpr int KT = 8, KS = 4; // M <= 256
         const int* lmg = ZB == 2 ? a.zb_mf.lmidx : a.zb_lmidx;
+        const bool ident = a.zb_ident != 0;
         const int jmax = min(M, (ncols + 1) / 2); // measurements whose columns this half-row reads
         double preT[KT][3];
         const int r16 = tid & 15, tt = (row0 - m) + r16; // T: row of Sigma / of T; tt == nS: the yTilde row
@@ -724,7 +743,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
             for (int k = 0; k < KT; ++k) {
                 const int jj = (tid >> 4) + 32 * k;
                 if (tt < nS && jj < jmax) {
-                    const int lj = 21 + 3 * lmg[jj];
+                    const int lj = 21 + 3 * (ident ? jj : lmg[jj]);
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
                         preT[k][c] = a.zb_sig[tt + (size_t)(lj + c) * ldS];
@@ -765,7 +784,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
                         const int jj = (tid >> 3) + 64 * k;
                         if (jj >= jbeg && jj < jend) {
                             double cj[6], blk[2][2], sv[9];
-                            const int li = 21 + 3 * lmg[iS], lj = 21 + 3 * lmg[jj];
+                            const int li = 21 + 3 * (ident ? iS : lmg[iS]), lj = 21 + 3 * (ident ? jj : lmg[jj]);
 #pragma unroll
                             for (int c = 0; c < 3; ++c)
 #pragma unroll

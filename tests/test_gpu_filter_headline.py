@@ -315,3 +315,49 @@ def test_output_blocks_wait_for_the_last_observer_step():
     used = C.c_long()
     assert load_eqf_lib().eqf_measure_in_propagate_stats(flt.core_handle(), C.byref(used), 0) == 0 and used.value == 0
     flt.close()
+
+
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_index_map_of_the_z_building_prologue(shuffled):
+    """The look-ahead kernel's prologue builds Z from Sigma's landmark blocks; since round 4 it does not load the measurement -> landmark index map when the host
+    has seen that measurement j belongs to landmark j for every j (the regular frame). Both forms - landmarks in ascending id order (identity) and in shuffled order (the map
+    is loaded) - against the k_build_Z route, through eqf_vision_update (output blocks from the measurement kernel) and through the staged eqf_stats_then_update (output blocks
+    from the propagation kernel, compared at rounding level: test_output_blocks_from_the_propagation_kernel says why)."""
+    from eqvio_amd.capi import COORD_INVDEPTH, OPT_MEASURE_IN_PROPAGATE, OPT_Z_IN_LOOKAHEAD, EqfCore
+    from util import default_camera, random_imu, random_spd, reasonable_state, settings_for, synth_measurement
+
+    N = 72
+    rng = np.random.default_rng(7)
+    s = settings_for(COORD_INVDEPTH, fastRiccati=1)
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N, shuffle_ids=shuffled)
+    assert shuffled == bool(np.any(np.diff(ids) < 0))
+    S0 = random_spd(rng, 21 + 3 * N)
+    cam = default_camera()
+    Qd, Pd = s.input_gain_diag12(), s.state_gain_diag8()
+    imus = np.stack([random_imu(rng, stamp=0.005 * i) for i in range(4)])
+    mean = random_imu(rng)
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=0.5)
+    outs = {}
+    for route in ("update", "staged"):
+        for zb in (0, 1):
+            core = EqfCore(N, COORD_INVDEPTH)
+            core.set_option(OPT_Z_IN_LOOKAHEAD, zb)
+            core.set_state(xi0, Xs, ids, q0, Q)
+            core.set_sigma(S0)
+            if route == "update":
+                core.vision_update(cam, mid, y, 4.0, True, True)
+            else:
+                for rep in range(2):  # the second frame finds the camera of the first: output blocks from the propagation kernel
+                    core.stage_measurement(mid, y)
+                    core.propagate_fast(mean, 0.02, Qd, Pd, imus, np.full(4, 0.005), True)
+                    upd, *_ = core.stats_then_update(cam, mid, y, 1e9, 1e9, 4.0, True, True)
+                    assert upd == 1
+                used = C.c_long()
+                assert core.lib.eqf_measure_in_propagate_stats(core.h, C.byref(used), 0) == 0
+                assert used.value == (1 if zb else 0)
+            outs[route, zb] = (core.get_state(), core.get_sigma())
+            core.close()
+    (sa, Sa), (sb, Sb) = outs["update", 0], outs["update", 1]
+    assert all(np.array_equal(x, z) for x, z in zip(sa, sb)) and np.array_equal(Sa, Sb)
+    (sa, Sa), (sb, Sb) = outs["staged", 0], outs["staged", 1]
+    assert all(np.allclose(x, z, rtol=1e-11, atol=1e-13) for x, z in zip(sa, sb)) and np.allclose(Sa, Sb, rtol=1e-10, atol=1e-12 * np.abs(Sa).max())
