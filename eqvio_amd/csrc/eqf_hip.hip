@@ -170,7 +170,6 @@ struct eqf_ctx {
     int opt_la_split = 1;                    // EQF_OPT_LA_SPLIT_ROWS
     int opt_measure_prop = 1;                // EQF_OPT_MEASURE_IN_PROPAGATE
     int opt_lift_syrk = 1;                   // EQF_OPT_LIFT_WITH_SYRK
-    long lift_syrk_launches = 0;
     // ... its state: what the propagation kernel's observer blocks evaluated the output blocks with (camera and C / C* of the LAST update call stand in for the
     // coming one's; the update call checks), for which staged measurement
     bool pred_valid = false, me_valid = false;
@@ -2325,7 +2324,6 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
                            c->d_gamma, c->d_flags, trace_slot(c, TR_SYRK), c->d_syrk_order + c->syrk_off[nt], lift_args(c, discreteCorr, spec, spec_seq, use_door, door_seq, la ? nullptr : c->d_gpart, stall_seq),
                            nlift);
         HIPCHK(hipGetLastError());
-        ++c->lift_syrk_launches;
         { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }
         if (c->opt_check) {
             LAUNCH_TS(c, k_check_finite, dim3(blocks(n, 256), n), dim3(256), c->stream, n, c->ld, (const TS*)c->sigma(), c->d_flags);
