@@ -887,6 +887,21 @@ __device__ __forceinline__ void ldl_inverse_tile_regs(double (&a)[4], Rest rest,
     for (int k = 0; k < 4; ++k)
         sLi11[lr + (lk + 4 * k) * 16] = o1[k];
     rest(d21, d22);
+    if (w <= 16) {
+        // The tile's rows / columns 16 .. 31 are identity padding (the LAST panel of m = 32 p + w columns, w <= 16: N = 200 has m = 400 = 12 x 32 + 16): D21 = 0, D22 = I, so
+        // L^-1 = diag(L11^-1, I) without the second elimination and the three products around it (~1.5 us of the frame's pivot chain, which ends with this tile)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lk + 4 * k;
+            o2[k] = (lr == c) ? 1.0 : 0.0;
+            xl[k] = 0.0;
+            put(lr, c, o1[k]);
+            put(lr, c + 16, 0.0);
+            put(16 + lr, c, 0.0);
+            put(16 + lr, 16 + c, o2[k]);
+        }
+        return;
+    }
     // B. L21 = D21 L11inv^T ; S22 = D22 - L21 L21^T
     d4 acc = {0, 0, 0, 0};
 #pragma unroll
