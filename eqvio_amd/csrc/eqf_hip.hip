@@ -2281,7 +2281,10 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
             hipLaunchKernelGGL(kern, dim3(blocks(n + M + 1, 256), blocks(M, BZ_JB) + 1 + (mf.enabled ? 1 : 0)), dim3(256), 0, c->stream, n, M, c->Ncap, c->ld, c->ldz, meas_var, c->d_lmidx, sig,
                                c->d_C, c->d_ytil, c->d_Z, c->d_Linv, c->d_flags, mf.enabled ? (const int*)nullptr : spec, spec_seq, mf, trace_slot(c, TR_BUILD_Z));
         };
-        if (c->sig32) {
+        if (mf.enabled && in_prop && !c->sig32) { // the propagation kernel has evaluated this measurement's output blocks: nobody evaluates them again
+            ++c->me_used;
+            launch(k_build_Z<double, true, true>, (const double*)c->sigma());
+        } else if (c->sig32) {
             if (mf.enabled)
                 launch(k_build_Z<float, true>, (const float*)c->sigma());
             else

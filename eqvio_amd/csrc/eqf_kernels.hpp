@@ -1049,7 +1049,9 @@ __device__ __forceinline__ MeasOut measure_j(const MeasFuse& mf, int j, int& i_o
     return measure_one(mf.chart, mf.cam, ld3(mf.q0, mf.Ncap, i), ldq(mf.Qq, mf.Ncap, i), mf.Qa[i], mf.y[2 * j], mf.y[2 * j + 1], mf.star != 0,
                        mf.chart == EQVIO_COORD_INVDEPTH ? ld_cc(mf.q0, mf.Ncap, i, CC_R0) : M3{});
 }
-template <typename TS, bool FUSE> // FUSE: measurement fusion (FUSE); a template so that neither variant carries the other's code
+// CMEM (with FUSE, round 4): the output blocks, residuals and the index map of THIS measurement are in memory already - evaluated by the propagation kernel's observer blocks
+// (EQF_OPT_MEASURE_IN_PROPAGATE) at a size where the look-ahead kernel does not build Z itself: the statistics row stays, nobody evaluates a block again (N = 500: 25.0 -> 15 us)
+template <typename TS, bool FUSE, bool CMEM = false> // FUSE: measurement fusion (FUSE); a template so that neither variant carries the other's code
 __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld, int ldz, double meas_var, const int* __restrict__ lmidx,
                                                  const TS* __restrict__ Sig, const double* __restrict__ C, const double* __restrict__ ytil,
                                                  double* __restrict__ Z, double* __restrict__ LinvOut, int* __restrict__ flags, const int* __restrict__ spec,
@@ -1060,6 +1062,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
     const int m = 2 * M;
     // grid rows: 0 = first tile, 1 = statistics (with fusion), then one per measurement. The two special rows have the longest
     // dependent chains (evaluation + 32 x 32 elimination; evaluation + stores to the host), so they are dispatched first.
+    constexpr bool EVAL = FUSE && !CMEM; // the C blocks are evaluated in this kernel
     const int row0 = FUSE ? 2 : 1;
     if (FUSE && (int)blockIdx.y == 1) {
         // outlier statistics, one lane per landmark
@@ -1080,7 +1083,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
         const int i = threadIdx.x & 15, jj = threadIdx.x >> 4; // pair (i, jj) of measurements, both < 16
         double sv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // Sigma[l_i.., l_jj..], requested before the C blocks are evaluated
         if (i < M && jj < M) {
-            const int li = 21 + 3 * (FUSE ? mf.lmidx[i] : lmidx[i]), lj2 = 21 + 3 * (FUSE ? mf.lmidx[jj] : lmidx[jj]);
+            const int li = 21 + 3 * (EVAL ? mf.lmidx[i] : lmidx[i]), lj2 = 21 + 3 * (EVAL ? mf.lmidx[jj] : lmidx[jj]);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -1093,22 +1096,23 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
                 flags[1] = 0;
                 flags[3] = 0;
             }
-            if (jj == 0 && i < M) {
+            if (EVAL && jj == 0 && i < M) {
                 int lidx;
                 const MeasOut o = measure_j(mf, i, lidx);
 #pragma unroll
                 for (int e = 0; e < 6; ++e)
                     sC16[i * 6 + e] = o.c[e];
             }
-            __syncthreads();
+            if (EVAL)
+                __syncthreads();
         }
         double blk[2][2] = {{(i == jj) ? 1.0 : 0.0, 0.0}, {0.0, (i == jj) ? 1.0 : 0.0}};
         if (i < M && jj < M) {
             double ci[6], cj2[6];
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
-                ci[e] = FUSE ? sC16[i * 6 + e] : C[e * Mcap + i];
-                cj2[e] = FUSE ? sC16[jj * 6 + e] : C[e * Mcap + jj];
+                ci[e] = EVAL ? sC16[i * 6 + e] : C[e * Mcap + i];
+                cj2[e] = EVAL ? sC16[jj * 6 + e] : C[e * Mcap + jj];
             }
             bz_S_block(ci, cj2, sv, i == jj, meas_var, blk); // identical expression to the S entries written to Z below
         }
@@ -1133,7 +1137,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
 #pragma unroll
     for (int q = 0; q < BZ_JB; ++q) {
         const int jc = min(j0 + q, M - 1);
-        lj[q] = 21 + 3 * (FUSE ? mf.lmidx[jc] : lmidx[jc]);
+        lj[q] = 21 + 3 * (EVAL ? mf.lmidx[jc] : lmidx[jc]);
     }
     int li = 0;
     double sv[BZ_JB][9];
@@ -1144,7 +1148,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
             for (int c = 0; c < 3; ++c)
                 sv[q][c] = Sig[t + (size_t)(lj[q] + c) * ld];
     } else if (srow) {
-        li = 21 + 3 * (FUSE ? mf.lmidx[t - n] : lmidx[t - n]);
+        li = 21 + 3 * (EVAL ? mf.lmidx[t - n] : lmidx[t - n]);
 #pragma unroll
         for (int q = 0; q < BZ_JB; ++q)
 #pragma unroll
@@ -1153,7 +1157,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
                 for (int r = 0; r < 3; ++r)
                     sv[q][3 * c + r] = Sig[li + r + (size_t)(lj[q] + c) * ld];
     }
-    if (FUSE) {
+    if (EVAL) {
         if (threadIdx.x < BZ_JB && j0 + (int)threadIdx.x < M) {
             const int j = j0 + threadIdx.x;
             int lidx;
@@ -1183,7 +1187,7 @@ __global__ void __launch_bounds__(256) k_build_Z(int n, int M, int Mcap, int ld,
     // a block row of S needs its own C_i as well: evaluated by the thread that uses it (before the barrier: the evaluations overlap)
     double ci[6] = {0, 0, 0, 0, 0, 0};
     if (srow) {
-        if (FUSE) {
+        if (EVAL) {
             int lidx;
             const MeasOut o = measure_j(mf, t - n, lidx);
 #pragma unroll

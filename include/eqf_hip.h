@@ -82,7 +82,8 @@ enum {
                                   landmark's propagated group element in registers when their chain of steps ends - evaluate its output block C_i / C*_i and residual
                                   there and leave them in memory, with the camera and output choice of the LAST eqf_stats_then_update call. If the next such call asks for
                                   the same (and the staged measurement and landmark set still stand) there is no k_build_Z launch up to 16 panels: the look-ahead kernel
-                                  builds Z from those blocks and one more workgroup of it computes the outlier statistics; otherwise the call takes its ordinary route.
+                                  builds Z from those blocks and one more workgroup of it computes the outlier statistics (above 16 panels, or on the launch chain, k_build_Z runs
+                                  but reads the blocks instead of evaluating them again: 25 -> 15 us at N = 500); otherwise the call takes its ordinary route.
                                   Same function and inputs as the update's own evaluation, compiled in another kernel: the compiler contracts the expressions into
                                   fused multiply-adds differently there, so the results agree to rounding (1e-14 on Sigma), not bit for bit (the other routes do
                                   among themselves; with -ffp-contract=off all agree bitwise). 0: never. eqf_measure_in_propagate_stats counts */
@@ -211,7 +212,7 @@ int eqf_stats_then_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids,
  * statistics kernel (every measured id already a landmark); of those, tails the device cancelled because a landmark exceeded an outlier
  * threshold (the caller then takes the two-round-trip path: removeOutliers / addNewLandmarks / eqf_vision_update). */
 int eqf_speculation_stats(eqf_ctx* ctx, long* calls, long* queued, long* cancelled, int reset);
-/* EQF_OPT_MEASURE_IN_PROPAGATE: update calls whose output blocks had been evaluated by the propagation kernel in front (no k_build_Z launch). */
+/* EQF_OPT_MEASURE_IN_PROPAGATE: update calls that used the output blocks evaluated by the propagation kernel in front (up to 16 panels: no k_build_Z launch). */
 int eqf_measure_in_propagate_stats(eqf_ctx* ctx, long* used, int reset);
 /* eqf_stats_then_update with VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) made on the device where that saves the frame a host round trip:
  * while the speculative tail keeps getting cancelled (outlier candidates frame after frame, as with the shipped thresholds) the call queues the statistics,
