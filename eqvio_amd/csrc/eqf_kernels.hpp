@@ -1439,6 +1439,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
     constexpr bool sym = SYM;
     nStrip = 0;
     const int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
+    __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
     if (b > nTiles + nStrip + nObs) {
         // Staging block (eqf_stage_measurement): the coming frame's measurement moves from the pinned host packet to HBM while Sigma
         // is being propagated, so that the update's first kernel finds it next to the state instead of across PCIe.
@@ -1459,6 +1460,15 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         // With fused assembly the tiles of THIS launch read Q, so the observer blocks write the other (Qq, Qa) buffer (the host
         // flips to it after the launch; q0 and its chart constants live in a buffer of their own and stay where they are).
         const int i = (b - (nTiles + nStrip + 1)) * PROP_T + tid;
+        // The steps' terms go from the argument segment to LDS once: read from the argument segment step by step, every step of the chain - the longest dependent path
+        // of this kernel - waited for a scalar load of its own (round 4)
+        static_assert(sizeof(ObsStep) % 8 == 0 && kObsChunk * sizeof(ObsStep) <= sizeof(sm), "the steps are copied as doubles into the tile buffer");
+        if (FUSED) {
+            for (int t = tid; t < obs_k * (int)(sizeof(ObsStep) / 8); t += PROP_T)
+                sm[t] = reinterpret_cast<const double*>(obs.s)[t];
+            __syncthreads();
+        }
+        const ObsStep* steps_lds = reinterpret_cast<const ObsStep*>(sm);
         if (i < N) {
             if (FUSED) {
                 const V3 p0 = ld3(q0, Ncap, i);
@@ -1470,7 +1480,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                     yu = me.ylm[i], yv = me.ylm[Ncap + i];
                     jm = (int)me.ylm[2 * Ncap + i];
                 }
-                observer_chain(obs.s, obs_k, p0, q, a_);
+                observer_chain(steps_lds, obs_k, p0, q, a_);
                 fa.Qqo[i] = q.w;
                 fa.Qqo[Ncap + i] = q.x;
                 fa.Qqo[2 * Ncap + i] = q.y;
@@ -1493,7 +1503,6 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         }
         return;
     }
-    __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
     __shared__ double sSens[21 * 33]; // per strip column of this workgroup: row c of A_ss (21) | row c of B_s (12)
     __shared__ double s_cm[66];
     if (FUSED) {
