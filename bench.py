@@ -66,7 +66,7 @@ def eurocish_settings():
 
 
 def build_workload(seed, n_frames, N):
-    from simworld import SimWorld
+    from eqvio_amd.simworld import SimWorld
 
     world = SimWorld(seed=seed, num_points=N, max_features=N, trajectory="hover", noise_px=0.5)
     frames = list(world.frames(n_frames))
@@ -557,7 +557,7 @@ def frame_mix(N, device, lib, n_frames=1200, n_warm=200):
     import time
 
     from eqvio_amd.capi import PreparedFrames, VIOFilter
-    from simworld import SimWorld
+    from eqvio_amd.simworld import SimWorld
 
     out = []
     for name, thr_abs, thr_prob, pvar in (("wave world, landmark turnover, outlier thresholds off", 1e8, 1e8, 1.0),

@@ -182,6 +182,7 @@ struct eqf_ctx {
     double tail_var = 0.0;                   // ... and needs the measurement variance again
     long zb_launches = 0;
     int cu_count = 256;                      // compute units of the device: the look-ahead kernel needs all its workgroups resident at once
+    long la_book_timeouts = 0;               // updates that took the launch chain because the compute units did not come free within la_book's bound
     int la_cus_held = 0;                     // compute units this context has booked for a look-ahead launch in flight (la_book / la_release)
     int la_selftest = 0;                     // look-ahead self-test at creation: 0 not run (never eligible at this capacity), 1 passed, -1 failed (launch chain only)
     long long la_timeout_ticks = LA_TIMEOUT_TICKS; // EQF_OPT_LA_TIMEOUT_US: bound of every device-side wait of the look-ahead kernel (100 MHz ticks)
@@ -235,6 +236,7 @@ struct eqf_ctx {
     int map_N = -1;
     bool map_all = false;
     bool map_ident = false; // ... and measurement j is landmark j for every j
+    bool tail_ident = false; // ... checked against the ids of the update being launched (launch_update_tail)
     std::vector<std::pair<int, int>> lookup; // sorted (id, index), valid for lookup_gen == lm_gen
     unsigned lookup_gen = ~0u;
     // host-side wait statistics (eqf_host_wait_stats): doorbell waits and the time spent spinning in them
@@ -375,14 +377,28 @@ static void la_release(eqf_ctx* c) {
     c->la_cus_held = 0;
     la_gate_cv.notify_all();
 }
-static void la_book(eqf_ctx* c, int workgroups) {
+// Returns false when the compute units did not come free within the bound (a context that failed without releasing, or long launches of the others): the caller
+// then factorises on the launch chain, which needs no co-residency. The wait is bounded so that no context can block another one's thread for good.
+static bool la_book(eqf_ctx* c, int workgroups) {
     la_release(c);
     std::unique_lock<std::mutex> g(la_gate_mutex);
     int& booked = la_cus_booked[c->device & 63];
-    la_gate_cv.wait(g, [&] { return booked == 0 || booked + workgroups <= c->cu_count; });
+    const auto bound = std::chrono::microseconds(std::max<long>(2000, 2 * (long)(c->la_timeout_ticks / 100)));
+    if (!la_gate_cv.wait_for(g, bound, [&] { return booked == 0 || booked + workgroups <= c->cu_count; }))
+        return false;
     booked += workgroups;
     c->la_cus_held = workgroups;
+    return true;
 }
+// releases the booking on every exit of a scope that did not hand it over to a doorbell wait
+struct LaBookingGuard {
+    eqf_ctx* c;
+    bool keep = false;
+    ~LaBookingGuard() {
+        if (!keep)
+            la_release(c);
+    }
+};
 int sync_ctx(eqf_ctx* c) {
     {
         int r = spin_stream(c->stream);
@@ -426,10 +442,12 @@ int door_wait(eqf_ctx* c, int which, int seq) {
             if (e == hipSuccess) {
                 if (++spins_after_done > 1000000) {
                     std::fprintf(stderr, "[eqf_hip] doorbell %d never rang (expected %d, have %d)\n", which, seq, (int)*bell);
+                    la_release(c); // the stream is empty: whatever was booked for a look-ahead launch has left the compute units
                     return (int)hipErrorUnknown;
                 }
             } else if (e != hipErrorNotReady) {
                 std::fprintf(stderr, "[eqf_hip] stream error: %s\n", hipGetErrorString(e));
+                la_release(c);
                 return (int)e;
             }
         }
@@ -1227,8 +1245,8 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     t->last_gamma = c->last_gamma, t->n_at_update = c->n_at_update;
     t->spec_calls = c->spec_calls, t->spec_queued = c->spec_queued, t->spec_cancelled = c->spec_cancelled, t->spec_backoff = c->spec_backoff, t->spec_backoff_len = c->spec_backoff_len;
     t->nees_lu_fallbacks = c->nees_lu_fallbacks, t->wait_calls = c->wait_calls, t->launch_calls = c->launch_calls, t->wait_seconds = c->wait_seconds, t->launch_seconds = c->launch_seconds;
-    t->la_launches = c->la_launches, t->la_fallbacks = c->la_fallbacks, t->zb_launches = c->zb_launches, t->la_consecutive_stalls = c->la_consecutive_stalls;
-    t->la_selftest = c->la_selftest;
+    t->la_launches = c->la_launches, t->la_fallbacks = c->la_fallbacks, t->la_book_timeouts = c->la_book_timeouts, t->zb_launches = c->zb_launches, t->la_consecutive_stalls = c->la_consecutive_stalls;
+    t->la_selftest = c->la_selftest < 0 ? -1 : (t->la_selftest != 0 ? t->la_selftest : c->la_selftest); // a failure is never forgotten; otherwise the test that ran on the NEW buffers counts
     t->me_used = c->me_used, t->pred_valid = c->pred_valid, t->pred_cam = c->pred_cam, t->pred_star = c->pred_star;
     t->lm_gen = c->lm_gen + 1;
     std::swap(*c, *t);
@@ -1481,6 +1499,7 @@ static int normal_congruence(eqf_ctx* c, int dir, double dt, const double* Pdiag
 }
 static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs, int obs_k, bool fused) {
     int rc = 0;
+    c->me_valid = false; // whatever propagates Sigma (any mode) leaves output blocks of an earlier propagation behind
     static const ObsSteps kNoSteps{};
     const bool normal = c->chart == EQVIO_COORD_NORMAL;
     static const double kZero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1525,7 +1544,6 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
         }
         // EQF_OPT_MEASURE_IN_PROPAGATE: the observer blocks evaluate the output blocks of the staged measurement with the camera / output choice of the last update call
         MeasEval me{};
-        c->me_valid = false;
         if (c->opt_measure_prop && fused && nObs && c->obs_one_chunk && sg.M > 0 && c->pred_valid && !c->sig32 && !c->opt_f32 && c->opt_zb && !c->opt_check) {
             me.on = 1, me.star = c->pred_star, me.Mcap = c->Ncap, me.cam = c->pred_cam;
             me.ylm = c->h_ylm, me.C = c->d_C, me.ytil = c->d_ytil, me.lmidx_dev = c->d_lmidx;
@@ -1851,6 +1869,7 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
     { int _e = enter(c); if (_e) return _e; }
     c->est_valid = false;
     c->meas_valid = false;
+    c->me_valid = false; // output blocks the propagation kernel evaluated belong to the Q_i from before these steps
     int done = 0;
     while (done < k) {
         const int chunk = std::min(k - done, eqf_ctx::kMaxSteps);
@@ -2013,7 +2032,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
         a.zb_sig = (const double*)c->sigma(), a.zb_ld = c->ld, a.zb_M = m / 2, a.zb_Mcap = c->Ncap, a.zb_var = c->tail_var;
         a.zb_C = c->d_C, a.zb_ytil = c->d_ytil, a.zb_lmidx = c->d_lmidx, a.zb_linv0 = c->d_Linv;
         // (the pinned packet's mapping is the one this update was mapped with - map_measurement ran in this call or, for a staged measurement, in stage_prepare)
-        a.zb_ident = (zb != 2 && c->map_gen == c->lm_gen && c->map_N == c->N && (int)c->map_ids.size() == m / 2 && c->map_ident) ? 1 : 0;
+        a.zb_ident = (zb != 2 && c->tail_ident) ? 1 : 0;
         a.tr_zb = trace_slot(c, TR_BUILD_Z);
         ++c->zb_launches;
         if (zb == 2) { // ... and evaluate the C blocks themselves; one more workgroup for the statistics and the speculation word (the kernel itself does not look at it)
@@ -2216,6 +2235,7 @@ static int lookahead_selftest(eqf_ctx* c) {
             else {
                 hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, 32, c->ldz, c->d_Z, c->d_Linv, c->d_flags);
                 HIPCHK(hipGetLastError());
+                la_book(c, (2 * 3 - 1) + blocks(rows - m, 16) + 1); // (a timeout books nothing: the launch is bounded and a stall repeats the attempt)
                 rc = launch_lookahead(c, rows, m, c->ldz, nullptr, 0);
             }
             if (rc)
@@ -2245,16 +2265,28 @@ static int lookahead_selftest(eqf_ctx* c) {
 }
 static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, int zb = 0,
                               const MeasFuse* zb_mf = nullptr);
-static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq,
+static int launch_update_tail(eqf_ctx* c, const int* ids, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq,
                               const MeasFuse* fuse = nullptr) {
     HP_SCOPE("abi.launch_update_tail");
     const int n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
     int rc = 0;
     c->tail_la = false, c->tail_zb = false, c->tail_M = M; // retry state of finish_update: reset before anything of this tail is queued
+    // "measurement j is landmark j" lets the Z-building prologue skip the index map: true only if the mapping in the pinned packet is the one of THESE ids
+    c->tail_ident = c->map_ident && c->map_gen == c->lm_gen && c->map_N == c->N && (int)c->map_ids.size() == M && std::equal(ids, ids + M, c->map_ids.begin());
+    // The look-ahead kernel's workgroups are booked against the device's compute units BEFORE anything of the tail depends on that kernel (who builds Z); if they
+    // do not come free within the bound (la_book), this update takes k_build_Z + the launch chain
+    bool chain_only = false;
+    LaBookingGuard booking{c}; // an error exit below gives the compute units back
+    if (lookahead_eligible(c, m)) {
+        const int base = (2 * blocks(m, 32) - 1) + blocks(rows - m, 16);
+        chain_only = !la_book(c, base + 1 + la_split_extra(c, blocks(m, 32), base));
+        if (chain_only)
+            ++c->la_book_timeouts;
+    }
     // EQF_OPT_Z_IN_LOOKAHEAD: with the C blocks in memory (k_measure / k_outlier_stats ran), fp64 Sigma and 3 .. 16 panels, the look-ahead kernel builds Z itself
     // (with measurement fusion - the speculative frame tail - it evaluates the C blocks as well, if the measurement has been staged to HBM: ZB = 2)
-    const bool zb_ok = c->opt_zb && !c->sig32 && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
+    const bool zb_ok = c->opt_zb && !c->sig32 && !chain_only && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
     // ZB = 2 up to 8 panels (N <= 128) only: measured +2.8 % at N = 50, +1.8 % at N = 100 and neutral at N = 200, where the tail's first launch then reaches
     // the GPU late
     // ZB = 3 (round 4, up to 16 panels): the propagation kernel's observer blocks have evaluated the output blocks of THIS measurement (staged, same landmark set) with
@@ -2299,7 +2331,9 @@ static int launch_update_tail(eqf_ctx* c, int M, double meas_var, int discreteCo
     }
     host_stamp(c, TH_BUILD_Z_OUT);
     c->tail_M = M; // what a retry of the factorisation on the launch chain needs to know (finish_update)
-    return launch_factor_tail(c, M, discreteCorr, spec, spec_seq, use_door, door_seq, false, zb, fuse);
+    rc = launch_factor_tail(c, M, discreteCorr, spec, spec_seq, use_door, door_seq, chain_only, zb, fuse);
+    booking.keep = rc == 0 && c->tail_la; // released by the doorbell wait (door_wait), sync_ctx or eqf_destroy
+    return rc;
 }
 // Everything behind k_build_Z: factorisation of Z (look-ahead kernel or launch chain), lift, covariance update. force_chain: the retry after a stalled
 // look-ahead kernel (Z and L_0^-1 are inputs of that kernel only, so the chain can start from them again).
@@ -2309,14 +2343,13 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
     int rc = 0;
     const bool la = !force_chain && lookahead_eligible(c, m); // one persistent kernel instead of one launch per panel; Gamma complete in d_gamma
     c->tail_la = la; // the retry state of finish_update always describes the tail in flight (with tail_zb / tail_M / tail_var, set by launch_update_tail)
-    if (la) {
+    LaBookingGuard booking{c}; // (booked by launch_update_tail, before it decided who builds Z; handed over to the doorbell wait when everything is queued)
+    if (la)
         ++c->la_launches;
-        const int base = (2 * blocks(m, 32) - 1) + blocks(rows - m, 16);
-        la_book(c, base + 1 + la_split_extra(c, blocks(m, 32), base));
-    }
     rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, zb, zb_mf) : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
     if (rc)
         return rc;
+    booking.keep = la;
     const int stall_seq = la ? c->la_seq : -1; // the stall word the kernels behind the factorisation compare (sequence valued: eqf_lookahead.hpp)
     // EQF_OPT_LIFT_WITH_SYRK: lift and covariance update wait for the same kernel and touch different data - one launch, the lift's workgroups in front
     // (not with per-kernel timing, which wants the two spans apart, and not with fp32 storage, whose rounding pass follows the covariance update)
@@ -2486,7 +2519,7 @@ int eqf_vision_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids, const
     }
     const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending; // a later kernel (finite check) or the observer stream need the full wait
     const int door_seq = (int)(++c->door_seq);
-    rc = launch_update_tail(c, M, meas_var, discreteCorr, nullptr, 0, use_door, door_seq);
+    rc = launch_update_tail(c, ids, M, meas_var, discreteCorr, nullptr, 0, use_door, door_seq);
     if (rc)
         return rc;
     rc = use_door ? door_wait(c, 1, door_seq) : sync_ctx(c);
@@ -2617,7 +2650,7 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
             HIPCHK(hipGetLastError());
         }
         c->meas_valid = false;
-        rc = launch_update_tail(c, M, meas_var, discreteCorr, nullptr, 0, use_door, seq, nullptr);
+        rc = launch_update_tail(c, ids, M, meas_var, discreteCorr, nullptr, 0, use_door, seq, nullptr);
         if (rc)
             return rc;
         host_stamp(c, TH_TAIL_OUT);
@@ -2679,7 +2712,7 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
     mf.thrAbs = thrAbs, mf.thrProb = thrProb;
     mf.spec_w = c->d_spec, mf.spec_seq = seq;
     c->meas_valid = false; // consumed by the tail below (restored if the tail is cancelled)
-    rc = launch_update_tail(c, M, meas_var, discreteCorr, c->d_spec, seq, use_door, seq, &mf);
+    rc = launch_update_tail(c, ids, M, meas_var, discreteCorr, c->d_spec, seq, use_door, seq, &mf);
     if (rc)
         return rc;
     host_stamp(c, TH_TAIL_OUT);

@@ -6,7 +6,21 @@ pinhole intrinsics, camera looking along body x, lowest-id feature selection, IM
 uses analytic derivatives and numpy's PRNG (the reference uses rand(), not reproducible across libcs)."""
 import numpy as np
 
-from util import euroc_camera, quat_mul
+from eqvio_amd.capi import Camera
+
+
+def euroc_camera():
+    """generatePinholeCameraSquare (src/dataserver/SimulationDataServer.cpp:162-176)."""
+    return Camera.pinhole(458.654, 457.296, 367.215, 248.375, 752, 480)
+
+
+def quat_mul(a, b):
+    return np.array([
+        a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+        a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+        a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3],
+        a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1],
+    ])
 
 GRAVITY = 9.80665
 

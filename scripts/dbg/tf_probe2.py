@@ -7,7 +7,7 @@ from eqvio_amd.capi import VIOFilter, PreparedFrames, Settings, COORD_NORMAL, CO
 from oracle_binding import OracleFilter
 from run_configs import parity
 from util import teacher_force
-from simworld import SimWorld
+from eqvio_amd.simworld import SimWorld
 from test_gpu_filter import sim_settings
 import test_gpu_filter_headline as H
 

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import bench
 from eqvio_amd.capi import OPT_TIMING, PreparedFrames, VIOFilter, load_eqf_lib
-from simworld import SimWorld
+from eqvio_amd.simworld import SimWorld
 mode = sys.argv[1] if len(sys.argv) > 1 else "shipped"
 opts = [tuple(int(v) for v in a.split("=")) for a in sys.argv[2:]]  # extra arguments "option=value" are set on the core (A/B of eqf_set_option switches)
 lib = load_eqf_lib()

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from eqvio_amd.capi import COORD_INVDEPTH, VIOFilter, load_eqf_lib
 from oracle_binding import OracleFilter
-from simworld import SimWorld
+from eqvio_amd.simworld import SimWorld
 from test_gpu_filter import compare, sim_settings
 nfr = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 nfe = int(sys.argv[2]) if len(sys.argv) > 2 else 60

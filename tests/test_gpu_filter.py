@@ -6,7 +6,7 @@ import pytest
 
 from eqvio_amd.capi import COORD_EUCLIDEAN, COORD_INVDEPTH, Settings, VIOFilter
 from oracle_binding import OracleFilter, se3_log_dist
-from simworld import SimWorld
+from eqvio_amd.simworld import SimWorld
 from util import rel_fro, teacher_force
 
 pytestmark = pytest.mark.gpu

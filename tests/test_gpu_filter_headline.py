@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from eqvio_amd.capi import PreparedFrames, SimSettings, SimulationDataServer, VIOFilter, load_eqf_lib  # noqa: E402
 from oracle_binding import OracleFilter  # noqa: E402
-from simworld import SimWorld  # noqa: E402
+from eqvio_amd.simworld import SimWorld  # noqa: E402
 from test_gpu_filter import compare  # noqa: E402
 from util import teacher_force  # noqa: E402
 

@@ -9,7 +9,7 @@ import pytest
 
 from eqvio_amd.capi import COORD_NORMAL, EqfCore, Settings, VIOFilter
 from oracle_binding import OracleFilter, se3_log_dist
-from simworld import SimWorld
+from eqvio_amd.simworld import SimWorld
 from util import CAMERAS, random_imu, random_spd, reasonable_state, rel_fro, settings_for, synth_measurement
 
 from util import teacher_force  # noqa: E402

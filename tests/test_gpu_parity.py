@@ -483,6 +483,52 @@ def test_staged_measurement_is_bit_identical_and_falls_back_when_stale(chart):
     core.stage_measurement(np.array([999999], np.int32), np.array([1.0, 2.0]))
 
 
+@pytest.mark.parametrize("chart", list(CHARTS))
+@pytest.mark.parametrize("between", ["observer", "dense_riccati"])
+def test_output_blocks_of_the_propagation_kernel_are_dropped_when_the_state_moves_on(chart, between):
+    """EQF_OPT_MEASURE_IN_PROPAGATE leaves C / yTilde evaluated at the Q_i the propagation kernel ended with. Anything that moves the state between that kernel and
+    the update - further observer steps (eqf_integrate_observer), another propagation in any Riccati mode - must drop them: the update then evaluates the output blocks
+    itself (eqf_measure_in_propagate_stats stays 0 for that frame) and follows the oracle (a stale cache gave a silently wrong update)."""
+    import ctypes as C
+
+    N = 40
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=17, useDiscreteInnovationLift=0)
+    cam = default_camera()
+    var = settings.measurementNoise**2
+    Qd, Pd = settings.input_gain_diag12(), settings.state_gain_diag8()
+    k = 5
+    used = C.c_long()
+    for frame in range(3):
+        imus = np.stack([random_imu(rng, stamp=0.005 * i) for i in range(k)])
+        dts = rng.uniform(0.002, 0.006, k)
+        mean = imus.mean(axis=0)
+        extra = np.stack([random_imu(rng, stamp=0.1 + 0.005 * i) for i in range(3)])
+        edts = rng.uniform(0.002, 0.006, 3)
+        st = core.get_state()
+        mid, y = synth_measurement(rng, cam, ids, st[3], st[4], noise_px=0.5)
+        core.stage_measurement(mid, y)
+        core.propagate_fast(mean, float(dts.sum()), Qd, Pd, imus, dts, True)
+        orc.integrate_riccati_fast(mean, float(dts.sum()))
+        for s_ in range(k):
+            orc.integrate_observer(imus[s_], dts[s_], True)
+        if frame > 0:  # frame 0 names the camera; from frame 1 on the propagation kernel evaluates the output blocks - and what follows must invalidate them
+            if between == "observer":
+                core.integrate_observer(extra, edts, True)
+                for s_ in range(3):
+                    orc.integrate_observer(extra[s_], edts[s_], True)
+            else:
+                core.set_option(OPT_RICCATI_DENSE, 1)
+                core.integrate_riccati_fast(extra[0], float(edts[0]), Qd, Pd)
+                core.set_option(OPT_RICCATI_DENSE, 0)
+                orc.integrate_riccati_fast(extra[0], float(edts[0]))
+        upd, *_ = core.stats_then_update(cam, mid, y, 1e9, 1e9, var, True, False)
+        assert upd == 1
+        orc.vision_update(cam, mid, y)
+        check_sigma(core, orc)
+        check_state(core, orc)
+        assert core.lib.eqf_measure_in_propagate_stats(core.h, C.byref(used), 0) == 0 and used.value == 0, frame
+
+
 def test_nees_returns_a_number_when_sigma_is_not_numerically_spd():
     """The reference inverts Sigma by partial-pivot LU and returns a number whatever Sigma is (VIO_eqf.cpp:166-168); the device's
     Cholesky-type chain meets a non-positive pivot when Sigma is positive definite only up to rounding and must then fall back to

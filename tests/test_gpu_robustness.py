@@ -7,7 +7,7 @@ import pytest
 
 from eqvio_amd.capi import COORD_EUCLIDEAN, COORD_INVDEPTH, EqfCore, VIOFilter
 from oracle_binding import OracleFilter
-from simworld import SimWorld
+from eqvio_amd.simworld import SimWorld
 from test_gpu_filter import compare, sim_settings
 from util import CHARTS, random_spd, reasonable_state
 

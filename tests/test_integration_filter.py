@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from integration_scenario import EXE, build_driver, plan_from_oracle, read_records, run_driver, write_scenario  # noqa: E402
 from oracle_binding import OracleFilter, se3_log_dist  # noqa: E402
-from simworld import SimWorld  # noqa: E402
+from eqvio_amd.simworld import SimWorld  # noqa: E402
 from util import rel_fro  # noqa: E402
 
 

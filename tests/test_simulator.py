@@ -276,10 +276,9 @@ def test_eqvio_sim_csv_values(tmp_path):
     (1) the files against each other: points.csv holds WORLD-frame points, so mapped back through IMUState.csv x camera.csv they must
         reproduce landmarkError.csv against trueState.csv; the error columns of bias / pose / cameraConsistency.csv against trueState.csv and the
         state files; nees.csv's PoseNEES / AttitudeNEES against the errors and variances of poseConsistency.csv;
-    (2) against a second run of the same scenario through the Python binding (same simulator settings and seed, device filter): state files,
-        points, variances and NEES of every frame, to the 6 significant digits the writer prints."""
-    from eqvio_amd.capi import VIOFilter
-
+    (2) against the ORACLE's filter on the same simulator stream (same settings and seed; CPU restatement of the reference, nothing of the device on that
+        side): state files, points, variances and NEES of every frame to the 6 significant digits the writer prints, and the printed forms themselves
+        (src/VIOWriter.cpp:40, include/eqvio/csv/CSVLine.h:108-113, 204-248) as literal lines built from the oracle's state."""
     exe = os.path.join(ROOT, "eqvio_amd", "lib", "eqvio_sim")
     run = tmp_path / "run"
     out = subprocess.run([exe, "--duration", "3", "--maxFeatures", "25", "--numWalls", "4", "--seed", "3", "--coordinateChoice", "InvDepth", "--fastRiccati", "1",
@@ -324,19 +323,30 @@ def test_eqvio_sim_csv_values(tmp_path):
         pose_nees, att_nees = nees[f][3], nees[f][4]
         assert pose_nees >= np.max(e6**2 / v6) * (1 - 1e-4) and att_nees >= np.max(e6[:3]**2 / v6[:3]) * (1 - 1e-4) and pose_nees >= att_nees * (1 - 1e-4)
 
-    # (2) the same scenario through the Python binding
+    # (2) the same scenario through the ORACLE's filter (CPU restatement of the reference; no device on this side): the same C++ simulator settings and seed give the
+    #     same IMU / feature stream, the oracle filter is driven main_sim-style, and every number the executable printed is compared with the oracle's state, Sigma
+    #     diagonal and NEES at the writer's print precision
     fs = Settings.defaults()
     fs.coordinateChoice, fs.fastRiccati, fs.measurementNoise, fs.initialPointVariance = COORD_INVDEPTH, 1, 0.5, 0.01
     srv, fs = make_server(fs, duration=3.0, maxFeatures=25, numWalls=4, randomSeed=3, outputNoise=1, inputNoise=1)
     s0, ids0, p0 = srv.true_state(0.0, True)
-    flt = VIOFilter(fs, max_landmarks=len(ids0) + 25, sensor=s0, ids=ids0, p=p0, time=0.0)
+    orc = OracleFilter(fs, s0, ids0, p0, 0.0)
+    text = {name: (run / name).read_text().strip().splitlines()[1:] for name in ("IMUState.csv", "camera.csv", "bias.csv", "points.csv")}
     frame = [0]
+
+    def same_print(tok, value, is_int=False):
+        """tok is what a default stream (6 significant digits, %g) prints for `value` - or for a double within 1e-9 relative of it (one unit of the last printed digit)"""
+        if is_int:
+            return tok == str(int(value))
+        if tok == "%g" % value:
+            return True
+        return abs(float(tok) - value) <= 1.01e-6 * max(abs(value), 1e-300) + 1e-300 and tok == "%g" % float(tok)
 
     def on_frame(stamp):
         f = frame[0]
         frame[0] += 1
-        s, ids, p = flt.state_estimate()
-        assert abs(imu_state[f][0] - flt.get_time()) < 1e-12
+        s, ids, p = orc.state_estimate()
+        assert abs(imu_state[f][0] - orc.get_time()) < 1e-12
         np.testing.assert_allclose(imu_state[f][1:], np.concatenate([s[10:13], s[6:10], s[13:16]]), rtol=PRINT, atol=PRINT)
         np.testing.assert_allclose(camera[f][1:], np.concatenate([s[20:23], s[16:20]]), rtol=PRINT, atol=PRINT)
         np.testing.assert_allclose(bias[f][1:], s[0:6], rtol=PRINT, atol=PRINT)
@@ -345,15 +355,38 @@ def test_eqvio_sim_csv_values(tmp_path):
         assert [int(pts[4 * i]) for i in range(len(pts) // 4)] == ids.tolist()
         world = np.array([qrot(PC_q, q) + PC_x for q in p])
         np.testing.assert_allclose(np.array(pts).reshape(-1, 4)[:, 1:], world, rtol=PRINT, atol=PRINT)
-        S = flt.get_sigma()
+        # the printed forms (src/VIOWriter.cpp:40: stamp at setprecision(20), then setprecision(6); include/eqvio/csv/CSVLine.h:108-113: every value through a
+        # fresh default stringstream = %g; :217-219 quaternions as w, x, y, z; :247 SE(3) as position then attitude; points: id, then PC * q.p): the literal line
+        # built from the ORACLE's state by those rules, token by token
+        st = "%.20g" % orc.get_time()
+        expect = {"IMUState.csv": [s[10], s[11], s[12], s[6], s[7], s[8], s[9], s[13], s[14], s[15]],
+                  "camera.csv": [s[20], s[21], s[22], s[16], s[17], s[18], s[19]],
+                  "bias.csv": list(s[0:6])}
+        for name, vals in expect.items():
+            toks = text[name][f].split(", ")
+            assert toks[0] == st and float(toks[0]) == orc.get_time(), (name, f, toks[0], st)  # 20 significant digits: the double round-trips
+            assert len(toks) == 1 + len(vals) and all(same_print(t, v) for t, v in zip(toks[1:], vals)), (name, f, toks, vals)
+        toks = text["points.csv"][f].split(", ")
+        assert toks[0] == st and len(toks) == 1 + 4 * len(ids)
+        for i, lid in enumerate(ids.tolist()):
+            assert same_print(toks[1 + 4 * i], lid, True) and all(same_print(toks[2 + 4 * i + k], world[i][k]) for k in range(3)), (f, lid)
+        S = orc.get_sigma()
         d = np.diag(S)
         np.testing.assert_allclose(pose_c[f][7:13], d[6:12], rtol=PRINT)
         np.testing.assert_allclose(cam_c[f][7:13], d[15:21], rtol=PRINT)
         np.testing.assert_allclose(bias_c[f][7:13], d[0:6], rtol=PRINT)
         e6 = np.array(pose_c[f][1:7])
         assert abs(nees[f][3] - e6 @ np.linalg.solve(S[6:12, 6:12], e6)) <= 1e-3 * max(nees[f][3], 1e-12)  # e6 itself is rounded to 6 digits
-        ts, tids, tp = srv.true_state(flt.get_time())
-        assert abs(nees[f][1] - flt.compute_nees(ts, tids, tp)) <= PRINT * nees[f][1] and nees[f][2] == S.shape[0]
+        ts, tids, tp = srv.true_state(orc.get_time())
+        assert abs(nees[f][1] - orc.compute_nees(ts, tids, tp)) <= PRINT * nees[f][1] and nees[f][2] == S.shape[0]
 
-    drive(srv, [flt], F, on_frame)
+    drive(srv, [orc], F, on_frame)
     assert frame[0] == F
+    # every value token of every file the writer produced is in the default-stream form (6 significant digits), every stamp at 20
+    for name in ("IMUState.csv", "camera.csv", "bias.csv", "points.csv", "features.csv", "landmarkError.csv", "nees.csv", "poseConsistency.csv", "cameraConsistency.csv",
+                 "biasConsistency.csv", "trueState.csv"):
+        for line in (run / name).read_text().strip().splitlines()[1:]:
+            toks = line.split(", ")
+            assert toks[0] == "%.20g" % float(toks[0]), (name, toks[0])
+            for t in toks[1:]:
+                assert t in ("nan", "-nan") or t == "%g" % float(t) or t == str(int(float(t))), (name, t)
