@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 using namespace eqf;
 
@@ -162,6 +163,11 @@ struct eqf_ctx {
     double *d_Zn = nullptr, *d_Wn = nullptr; // NEES factorisation buffers (lazily allocated)
     double* d_pub = nullptr;                 // look-ahead factorisation: published tiles (la_pub_tiles(NJcap) x 8 KB), their flags, the yTilde rows
     int* d_pubf = nullptr;
+    int* d_pubfl = nullptr;                  // EQF_OPT_LA_HOME: flags of the hand-offs that stay inside the home XCD's L2
+    int la_home = 0;                         // the XCD block 0 of this context's grids runs on (an offset of the stream's hardware queue: learnt from a refused launch)
+    long la_home_refused = 0;                // launches that found their blocks elsewhere (the offset is learnt again, the update is redone on the launch chain)
+    int opt_la_home = 1;                     // EQF_OPT_LA_HOME
+    long la_home_launches = 0;
     char* d_puby = nullptr;
     int la_njcap = 0, la_seq = 0;
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
@@ -747,12 +753,14 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipMalloc(&c->d_pubf, sizeof(int) * la_pub_flags(c->la_njcap)));
     HIPCHK(hipMalloc(&c->d_puby, 512 * (size_t)c->la_njcap));
     HIPCHK(hipMemsetAsync(c->d_pubf, 0, sizeof(int) * la_pub_flags(c->la_njcap), c->stream)); // sequence 0 is never used by a launch
+    HIPCHK(hipMalloc(&c->d_pubfl, sizeof(int) * la_pub_flags(c->la_njcap)));
+    HIPCHK(hipMemsetAsync(c->d_pubfl, 0, sizeof(int) * la_pub_flags(c->la_njcap), c->stream));
     HIPCHK(hipMemsetAsync(c->d_puby, 0, 512 * (size_t)c->la_njcap, c->stream));
     HIPCHK(hipMalloc(&c->d_est, sizeof(double) * 4 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_stats, sizeof(double) * 3 * (size_t)c->Ncap));
     HIPCHK(hipMalloc(&c->d_scratch, sizeof(double) * 8 * (size_t)c->Ncap));
-    HIPCHK(hipMalloc(&c->d_flags, sizeof(int) * 4));
-    HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(int) * 4, c->stream));
+    HIPCHK(hipMalloc(&c->d_flags, sizeof(int) * 8)); // [0] pivot not positive, [1] non-finite, [3] look-ahead stalled (sequence valued), [4] HOME placement refused (sequence valued)
+    HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(int) * 8, c->stream));
     {
         const int ntcap = blocks(c->ncap, 32);
         c->syrk_off.assign(ntcap + 2, 0);
@@ -827,6 +835,7 @@ void eqf_destroy(eqf_ctx* c) {
     hipFree(c->d_gpart);
     hipFree(c->d_pub);
     hipFree(c->d_pubf);
+    hipFree(c->d_pubfl);
     hipFree(c->d_puby);
     if (c->d_ladbg)
         hipFree(c->d_ladbg);
@@ -940,6 +949,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_FUSED_ASSEMBLY: *value = c->opt_fuse_asm; return 0;
     case EQF_OPT_Z_IN_LOOKAHEAD: *value = c->opt_zb; return 0;
     case EQF_OPT_LA_SPLIT_ROWS: *value = c->opt_la_split; return 0;
+    case EQF_OPT_LA_HOME: *value = c->opt_la_home; return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE: *value = c->opt_measure_prop; return 0;
     case EQF_OPT_LIFT_WITH_SYRK: *value = c->opt_lift_syrk; return 0;
     case EQF_OPT_LOOKAHEAD: *value = c->opt_lookahead; return 0;
@@ -979,6 +989,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_LA_SPLIT_ROWS:
         c->opt_la_split = value ? 1 : 0;
+        return 0;
+    case EQF_OPT_LA_HOME:
+        c->opt_la_home = value ? 1 : 0;
         return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE:
         c->opt_measure_prop = value ? 1 : 0;
@@ -1229,7 +1242,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1245,7 +1258,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     t->last_gamma = c->last_gamma, t->n_at_update = c->n_at_update;
     t->spec_calls = c->spec_calls, t->spec_queued = c->spec_queued, t->spec_cancelled = c->spec_cancelled, t->spec_backoff = c->spec_backoff, t->spec_backoff_len = c->spec_backoff_len;
     t->nees_lu_fallbacks = c->nees_lu_fallbacks, t->wait_calls = c->wait_calls, t->launch_calls = c->launch_calls, t->wait_seconds = c->wait_seconds, t->launch_seconds = c->launch_seconds;
-    t->la_launches = c->la_launches, t->la_fallbacks = c->la_fallbacks, t->la_book_timeouts = c->la_book_timeouts, t->zb_launches = c->zb_launches, t->la_consecutive_stalls = c->la_consecutive_stalls;
+    t->la_launches = c->la_launches, t->la_fallbacks = c->la_fallbacks, t->la_home_launches = c->la_home_launches, t->la_home_refused = c->la_home_refused, t->la_book_timeouts = c->la_book_timeouts, t->zb_launches = c->zb_launches, t->la_consecutive_stalls = c->la_consecutive_stalls;
     t->la_selftest = c->la_selftest < 0 ? -1 : (t->la_selftest != 0 ? t->la_selftest : c->la_selftest); // a failure is never forgotten; otherwise the test that ran on the NEW buffers counts
     t->me_used = c->me_used, t->pred_valid = c->pred_valid, t->pred_cam = c->pred_cam, t->pred_star = c->pred_star;
     t->lm_gen = c->lm_gen + 1;
@@ -2010,6 +2023,15 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.NI = (2 * a.NJ - 1) + blocks(rows - m, 16); // the owner + the S half-rows 2 .. 2 NJ - 1 + the T half-rows (16 rows each)
     const int extra = zb ? 0 : la_split_extra(c, a.NJ, a.NI);
     a.split_from = extra ? LA_SPLIT_FROM : a.NJ;
+    // EQF_OPT_LA_HOME (up to 16 panels, a device of 8 XCDs x 32 compute units): the owner and the 2 NJ - 2 S half-rows are the blocks of ONE XCD (b & 7 == home), the T
+    // half-rows (+ the statistics workgroup) are dealt to the other seven; the rest of the 8 x slots grid returns at once (eqf_lookahead.hpp: la_st_l)
+    const int nT = a.NI - (2 * a.NJ - 1);
+    const bool home = c->opt_la_home && a.NJ <= 16 && c->cu_count == 256 && c->d_pubfl;
+    a.home = home ? c->la_home : -1;
+    a.pubfl = c->d_pubfl;
+    const int home_grid = 8 * std::max(2 * a.NJ - 1, blocks(nT + (zb >= 2 ? 1 : 0), 7));
+    if (home)
+        ++c->la_home_launches;
     if (++c->la_seq <= 0) // positive: -1 is "no look-ahead launch in front" for k_lift / k_syrk_sub, 0 the initial state of every flag word
         c->la_seq = 1;
     a.seq = c->la_seq;
@@ -2038,16 +2060,27 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
         if (zb == 2) { // ... and evaluate the C blocks themselves; one more workgroup for the statistics and the speculation word (the kernel itself does not look at it)
             a.zb_mf = *zb_mf;
             a.spec = nullptr;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 2>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
+            if (home)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 2, true>), dim3(home_grid), dim3(LA_T), 0, c->stream, a);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 2>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
         } else if (zb == 3) { // C, yTilde, index map from the propagation kernel's observer blocks; the statistics workgroup as above
             a.zb_mf = *zb_mf;
             a.spec = nullptr;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 3>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
-        } else // C, yTilde, index map from the measurement kernel
+            if (home)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 3, true>), dim3(home_grid), dim3(LA_T), 0, c->stream, a);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 3>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
+        } else if (home) // C, yTilde, index map from the measurement kernel
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 1, true>), dim3(home_grid), dim3(LA_T), 0, c->stream, a);
+        else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 1>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
-    } else if (a.NJ <= 16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
-    else
+    } else if (a.NJ <= 16) {
+        if (home)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 0, true>), dim3(home_grid), dim3(LA_T), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
+    } else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8>), dim3(a.NI + extra), dim3(LA_T), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2202,65 +2235,130 @@ static int launch_lift(eqf_ctx* c, int discreteCorr, const int* spec, int spec_s
     HIPCHK(hipGetLastError());
     return 0;
 }
-// Self-test at context creation (ADVICE r2 / VERDICT r3): the look-ahead kernel's hand-offs rest on relaxed agent-scope flags, write-through stores and
-// s_waitcnt ordering (eqf_lookahead.hpp) - measured behaviour of gfx950 under ROCm 7.2, not a guarantee of the HIP memory model. Before a context is
-// used, the same fixed 96-column problem ([S ; T ; y^T], 3 panels, 16 T rows) is factorised on the launch chain and on the look-ahead kernel: the W rows
-// must agree bit for bit and no wait may run out. On a mismatch the context keeps to the launch chain (eqf_lookahead_stats reports it: launches stay 0).
-static int lookahead_selftest(eqf_ctx* c) {
-    constexpr int m = 96, nT = 16, rows = m + nT + 1;
-    c->la_selftest = 0;
-    if (!c->opt_lookahead || c->mcap < m || c->la_njcap < 3 || c->cu_count < 8)
-        return 0; // the look-ahead kernel is never eligible at this capacity / on this device
-    const size_t cnt = (size_t)c->ldz * m;
-    std::vector<double> hz(cnt, 0.0), w[2];
-    for (int j = 0; j < m; ++j) {
-        for (int i = 0; i < m; ++i) // symmetric positive definite S
-            hz[i + (size_t)j * c->ldz] = (i == j ? 4.0 : 0.0) + 1.0 / (1 + std::abs(i - j)) + 1e-3 * ((i + j) % 7);
-        for (int t = 0; t < nT; ++t)
-            hz[m + t + (size_t)j * c->ldz] = ((t * 31 + j * 17) % 23) / 23.0 - 0.5;
-        hz[m + nT + (size_t)j * c->ldz] = ((j * 5) % 13) / 13.0;
-    }
-    // A launch that STALLS (its workgroups were not all resident within the bound: other contexts are being created on the same device, or share it) says nothing about
-    // the kernel: it is repeated a few times, and if the device stays busy the test counts as not run - the look-ahead kernel stays enabled, every launch of it is
-    // bounded and redone on the chain when it stalls (finish_update)
-    int fl[4] = {0, 0, 0, 0};
-    bool stalled = false;
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        for (int pass = (attempt == 0 ? 0 : 1); pass < 2; ++pass) {
-            HIPCHK(hipMemcpyAsync(c->d_Z, hz.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemsetAsync(c->d_W, 0, sizeof(double) * cnt, c->stream));
-            int rc;
-            if (pass == 0)
-                rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W);
-            else {
-                hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, 32, c->ldz, c->d_Z, c->d_Linv, c->d_flags);
-                HIPCHK(hipGetLastError());
-                la_book(c, (2 * 3 - 1) + blocks(rows - m, 16) + 1); // (a timeout books nothing: the launch is bounded and a stall repeats the attempt)
-                rc = launch_lookahead(c, rows, m, c->ldz, nullptr, 0);
-            }
-            if (rc)
-                return rc;
-            w[pass].resize(cnt);
-            HIPCHK(hipMemcpyAsync(w[pass].data(), c->d_W, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            la_release(c);
+// Self-test at context creation (ADVICE r2 / VERDICT r3, r4): the look-ahead kernel's hand-offs rest on relaxed agent-scope flags, write-through stores,
+// s_waitcnt ordering and - EQF_OPT_LA_HOME - on plain stores being visible to the other compute units of one XCD (eqf_lookahead.hpp): measured behaviour of gfx950
+// under ROCm 7.2, not a guarantee of the HIP memory model. Before a context is used, fixed problems [S ; T ; y^T] of up to three shapes - 3 panels, the largest shape up to
+// 13 panels this capacity allows (ragged last panel: la_row and, when the device qualifies, the HOME placement at the size it was built for) and 17 panels (la_row2, split
+// late block rows) - are factorised on the launch chain once and on the look-ahead kernel EIGHT times each (the protocol slip of round 3 showed in ~8 % of the launches): the
+// W rows must agree bit for bit every time and no wait may run out. A refused or failing HOME placement is retried in the classic placement (and stays off); a mismatch
+// there leaves the context on the launch chain (eqf_lookahead_stats reports it: launches stay 0).
+static int lookahead_selftest_pass(eqf_ctx* c, bool& placement_refused) {
+    constexpr int nT = 16, REPS = 8;
+    placement_refused = false;
+    int shapes[3] = {96, std::min(416, c->mcap & ~1), 544};
+    if (shapes[1] <= 128)
+        shapes[1] = 0;
+    int verdict = 0; // 0: nothing ran, 1: every launch agreed, -1: a mismatch
+    double* d_z0 = nullptr;
+    for (int si = 0; si < 3; ++si) {
+        const int m = shapes[si], rows = m + nT + 1;
+        if (m == 0 || m > c->mcap || blocks(m, 32) > c->la_njcap || !lookahead_eligible(c, m))
+            continue;
+        const size_t cnt = (size_t)c->ldz * m;
+        std::vector<double> hz(cnt, 0.0), wref(cnt), w(cnt);
+        for (int j = 0; j < m; ++j) {
+            for (int i = 0; i < m; ++i) // symmetric positive definite S
+                hz[i + (size_t)j * c->ldz] = (i == j ? 4.0 + 0.01 * (j % 5) : 0.0) + 1.0 / (1 + std::abs(i - j)) + 1e-3 * ((i + j) % 7);
+            for (int t = 0; t < nT; ++t)
+                hz[m + t + (size_t)j * c->ldz] = ((t * 31 + j * 17) % 23) / 23.0 - 0.5;
+            hz[m + nT + (size_t)j * c->ldz] = ((j * 5) % 13) / 13.0;
         }
-        HIPCHK(hipMemcpy(fl, c->d_flags, sizeof(fl), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemset(c->d_flags, 0, sizeof(int) * 4));
-        stalled = fl[3] == c->la_seq;
-        if (!stalled)
-            break;
+        if (!d_z0)
+            HIPCHK(hipMalloc(&d_z0, sizeof(double) * (size_t)c->ldz * std::min(c->mcap, 544)));
+        auto fail = [&](int rc) {
+            hipFree(d_z0);
+            return rc;
+        };
+        if (hipMemcpy(d_z0, hz.data(), sizeof(double) * cnt, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(EQF_E_NO_DEVICE);
+        for (int rep = -1; rep < REPS; ++rep) { // rep -1: the launch chain
+            int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            bool stalled = false;
+            // A launch that STALLS (its workgroups were not all resident within the bound: other contexts are being created on the same device, or share it) says nothing
+            // about the kernel: it is repeated a few times, and if the device stays busy the test counts as not run - the look-ahead kernel stays enabled, every launch of
+            // it is bounded and redone on the chain when it stalls (finish_update)
+            int learnt = 0;
+            for (int attempt = 0; attempt < 4; ++attempt) {
+                if (hipMemcpyAsync(c->d_Z, d_z0, sizeof(double) * cnt, hipMemcpyDeviceToDevice, c->stream) != hipSuccess || hipMemsetAsync(c->d_W, 0, sizeof(double) * cnt, c->stream) != hipSuccess)
+                    return fail(EQF_E_NO_DEVICE);
+                int rc;
+                if (rep < 0)
+                    rc = launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W);
+                else {
+                    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, c->stream, 32, c->ldz, c->d_Z, c->d_Linv, c->d_flags);
+                    if (hipGetLastError() != hipSuccess)
+                        return fail(EQF_E_NO_DEVICE);
+                    const int base = (2 * blocks(m, 32) - 1) + blocks(rows - m, 16);
+                    la_book(c, base + 1 + la_split_extra(c, blocks(m, 32), base)); // (a timeout books nothing: the launch is bounded and a stall repeats the attempt)
+                    rc = launch_lookahead(c, rows, m, c->ldz, nullptr, 0);
+                }
+                if (rc)
+                    return fail(rc);
+                if (hipMemcpyAsync((rep < 0 ? wref : w).data(), c->d_W, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+                    return fail(EQF_E_NO_DEVICE);
+                la_release(c);
+                if (hipMemcpy(fl, c->d_flags, sizeof(fl), hipMemcpyDeviceToHost) != hipSuccess || hipMemset(c->d_flags, 0, sizeof(int) * 8) != hipSuccess)
+                    return fail(EQF_E_NO_DEVICE);
+                stalled = rep >= 0 && fl[3] == c->la_seq;
+                if (rep >= 0 && fl[4] == c->la_seq) { // the blocks of the grid do not sit on the XCDs the HOME placement assumed: block 0 ran on XCD fl[5]
+                    if (++learnt > 2 || fl[5] < 0 || fl[5] > 7) { // (learnt once per stream in practice: the offset belongs to its hardware queue)
+                        placement_refused = true;
+                        return fail(0);
+                    }
+                    c->la_home = fl[5];
+                    --attempt;
+                    continue;
+                }
+                if (!stalled)
+                    break;
+            }
+            if (stalled) {
+                std::fprintf(stderr, "[eqf_hip] look-ahead self-test could not run on device %d (the launch stalled four times: the device is busy); not counted as a failure\n", c->device);
+                return fail(0);
+            }
+            if (rep < 0) {
+                if (fl[0]) { // (cannot happen: the problem is positive definite)
+                    c->la_selftest = -1;
+                    return fail(0);
+                }
+                continue;
+            }
+            bool same = !fl[0];
+            for (int j = 0; j < m && same; ++j)
+                same = std::memcmp(&wref[m + (size_t)j * c->ldz], &w[m + (size_t)j * c->ldz], sizeof(double) * (nT + 1)) == 0;
+            if (!same) {
+                std::fprintf(stderr, "[eqf_hip] look-ahead self-test: %d columns, launch %d of %d differs from the launch chain on device %d (pivot flag %d)\n", m, rep + 1, REPS, c->device, fl[0]);
+                c->la_selftest = -1;
+                return fail(0);
+            }
+            verdict = 1;
+        }
     }
-    if (stalled) {
-        std::fprintf(stderr, "[eqf_hip] look-ahead self-test could not run on device %d (the launch stalled four times: the device is busy); not counted as a failure\n", c->device);
-        return 0; // la_selftest stays 0
+    hipFree(d_z0);
+    if (verdict > 0)
+        c->la_selftest = 1;
+    return 0;
+}
+static int lookahead_selftest(eqf_ctx* c) {
+    c->la_selftest = 0;
+    if (!c->opt_lookahead || c->mcap < 96 || c->la_njcap < 3 || c->cu_count < 8)
+        return 0; // the look-ahead kernel is never eligible at this capacity / on this device
+    bool refused = false;
+    int rc = lookahead_selftest_pass(c, refused);
+    if (rc)
+        return rc;
+    const bool home_on = c->opt_la_home != 0;
+    if (home_on && (refused || c->la_selftest < 0)) {
+        std::fprintf(stderr, "[eqf_hip] device %d: the look-ahead kernel's HOME placement %s; this context uses the classic placement\n", c->device,
+                     refused ? "was refused (blocks are not dealt to the XCDs round robin)" : "failed its self-test");
+        c->opt_la_home = 0;
+        c->la_selftest = 0;
+        rc = lookahead_selftest_pass(c, refused);
+        if (rc)
+            return rc;
     }
-    bool same = !fl[0];
-    for (int j = 0; j < m && same; ++j)
-        same = std::memcmp(&w[0][m + (size_t)j * c->ldz], &w[1][m + (size_t)j * c->ldz], sizeof(double) * (nT + 1)) == 0;
-    c->la_selftest = same ? 1 : -1;
-    if (!same)
-        std::fprintf(stderr, "[eqf_hip] look-ahead self-test failed on device %d (pivot flag %d): this context factorises on the launch chain\n", c->device, fl[0]);
+    if (c->la_selftest < 0)
+        std::fprintf(stderr, "[eqf_hip] look-ahead self-test failed on device %d: this context factorises on the launch chain\n", c->device);
     return 0;
 }
 static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, int zb = 0,
@@ -2412,6 +2510,16 @@ static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
         // on the launch chain (which needs no co-residency), then lift and update Sigma as usual. Three stalls in a row switch the look-ahead
         // kernel off for this context. EQF_E_STALLED reaches the caller only if the chain fails as well (it cannot stall).
         ++c->la_fallbacks;
+        if (c->opt_la_home) { // a HOME launch that found its blocks on other XCDs than assumed (the stream moved to another hardware queue) ended at once: learn the offset again
+            int fl[8];
+            HIPCHK(hipMemcpy(fl, c->d_flags, sizeof(fl), hipMemcpyDeviceToHost));
+            if (fl[4] == c->la_seq && fl[5] >= 0 && fl[5] <= 7) {
+                c->la_home = fl[5];
+                --c->la_consecutive_stalls; // not a stall of the kernel
+                if (++c->la_home_refused > 16)
+                    c->opt_la_home = 0; // a device that does not keep its offsets: classic placement from here on
+            }
+        }
         if (++c->la_consecutive_stalls >= 3)
             c->opt_lookahead = 0;
         HIPCHK(hipMemsetAsync(c->d_flags + 3, 0, sizeof(int), c->stream));
@@ -2923,6 +3031,15 @@ int eqf_lookahead_stats(eqf_ctx* c, long* launches, long* fallbacks, int reset) 
 }
 
 int eqf_lookahead_selftest(const eqf_ctx* c) { return c ? c->la_selftest : EQF_E_BAD_ARG; }
+int eqf_lookahead_home(const eqf_ctx* c, int* home_xcd, long* home_launches) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    if (home_xcd)
+        *home_xcd = (c->opt_la_home && c->cu_count == 256) ? c->la_home : -1;
+    if (home_launches)
+        *home_launches = c->la_home_launches;
+    return 0;
+}
 
 int eqf_nees_lu_fallbacks(eqf_ctx* c, long* count) {
     if (!c || !count)

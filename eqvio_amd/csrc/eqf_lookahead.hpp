@@ -44,6 +44,8 @@ constexpr long long LA_TIMEOUT_TICKS = 2000000; // 20 ms at 100 MHz
 struct LaArgs {
     int rows, m, ldz, NJ, NI, seq;
     int split_from;          // S block rows I >= split_from are held by TWO workgroups per half-row (la_row2: Jlo, partA); >= NJ: none
+    int home;                // HOME instantiations (round 5): the XCD block 0 of this stream's grids runs on (block b runs on XCD (home + b) & 7); -1 otherwise
+    int* pubfl;              // HOME: the flags of the hand-offs that stay inside the home XCD's L2 (same indices as pubf)
     long long timeout_ticks; // bound of every device-side wait (100 MHz ticks; default LA_TIMEOUT_TICKS)
     const double* Z;     // [S ; T ; y^T] from k_build_Z (plain memory; complete when this kernel starts)
     double* W;           // out, plain: rows >= m receive W = T L^-T and the z row
@@ -93,6 +95,19 @@ __device__ __forceinline__ double* la_tile(const LaArgs& a, int idx) { return a.
 __device__ __forceinline__ void la_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } // global_store_dwordx2 sc1
 __device__ __forceinline__ void la_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void la_raise_f(const LaArgs& a, int fidx) { __hip_atomic_store(a.pubf + fidx, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Round 5, the HOME placement: the owner and every S half-row run on ONE XCD - the blocks b with b & 7 == 0. The hardware deals the blocks of a grid round robin to the
+// eight XCDs, block b to XCD (o + b) & 7 with an offset o that belongs to the hardware queue (measured: scripts/ubench/xcd_map.hip, profiles/r05_xcd_map.txt - also with
+// two grids in flight at once); the host passes the o it has learnt (LaArgs::home) and EVERY block compares HW_REG_XCC_ID with the XCD that gives it before it does
+// anything: a launch whose blocks sit elsewhere ends at once, reports the XCD of block 0 (flags[4], flags[5]) and is redone on the launch chain. What the home
+// workgroups hand to EACH OTHER then never has to leave that XCD's L2:
+// plain stores (acknowledged by the L2: 0.26 us instead of 0.55 for a write-through store), a flag in a second array (pubfl) written the same way and polled with sc1
+// loads (the L2 answers), plain tile loads that hit the L2 (0.24 instead of 0.42 us) - 1.10 us per hop instead of 2.00 between two XCDs (scripts/ubench/xcd_hop2.hip,
+// profiles/r05_xcd_hop.txt). What the T half-rows (other XCDs) read as well - L_p^-1, the factor rows P^(p)_J - is stored a SECOND time, written through, behind the
+// local flag, with the flag in pubf as before. A plain store is invisible to another XCD (the ubench reads stale tiles there), so no consumer outside the home XCD
+// ever looks at pubfl.
+__device__ __forceinline__ void la_st_l(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); } // global_store_dwordx2, no cache bits
+__device__ __forceinline__ void la_raise_fl(const LaArgs& a, int fidx) { __hip_atomic_store(a.pubfl + fidx, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ int la_xcc_id() { return __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 0xf; } // HW_REG_XCC_ID, bits 3:0
 struct LaPoll {
     long long deadline;
     int seq;
@@ -196,7 +211,7 @@ __device__ __forceinline__ void la_lds_add(int* c, int by = 1) {
 }
 enum { LC_L = 0, LC_T, LC_C, LC_D, LC_B, LC_CCOPIED, LC_BCOPIED, LC_U, LC_LCOPIED, LC_COUNT };
 
-template <int ZB>
+template <int ZB, bool HOME>
 __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_abort_words, int* cnt, const LaPoll& pl) {
     int* const s_abort = s_abort_words + 1; // the owner has no barriers: its waves act on the request word
     // `wave` as a scalar: the role branches become real (scalar) branches. With a vector condition the compiler predicates short blocks instead of
@@ -273,7 +288,9 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 sD, 33, min(32, a.m),
                 [sLk, l0](int r, int c, double v) {
                     sLk[r + c * CH_LDP] = v;
-                    la_st(l0 + r + 32 * c, v);
+                    if (HOME)
+                        la_st_l(l0 + r + 32 * c, v); // for the S half-rows (home XCD) ...
+                    la_st(l0 + r + 32 * c, v);       // ... and, written through, for the T half-rows
                 },
                 a.flags, swork);
             la_lds_set(cnt + LC_L, 1);
@@ -283,11 +300,15 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         for (int e = tid; e < 1024; e += LA_T) {
             const double v = a.Linv0[e];
             sLk[(e & 31) + (e >> 5) * CH_LDP] = v;
+            if (HOME)
+                la_st_l(l0 + e, v);
             la_st(l0 + e, v);
         }
         la_stores_done();
         __syncthreads(); // the only workgroup barrier of the owner
         if (tid == 0) {
+            if (HOME)
+                la_raise_fl(a, la_f_linv(a, 0));
             la_raise_f(a, la_f_linv(a, 0));
             __hip_atomic_store(cnt + LC_L, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -342,8 +363,11 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             la_lds_add(cnt + LC_C, 2);
             if (ZB && k == 0) { // (*) L_0^-1's stores were issued ~0.6 us ago
                 la_stores_done();
-                if (lane == 0)
+                if (lane == 0) {
+                    if (HOME)
+                        la_raise_fl(a, la_f_linv(a, 0));
                     la_raise_f(a, la_f_linv(a, 0));
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -363,7 +387,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             bool gone = false;
             auto rest = [&](double (&d21)[4], double (&d22)[4]) {
                 // waves 5 / 7 have written the blocks (1, 0) / (1, 1) of D_(k+1) to sD; they, wave 2 and wave 3 have read L_k^-1 out of sLk (rewritten below)
-                if (!la_lds_wait(cnt + LC_D, 3 * (k + 1), s_abort) || (k >= 1 && !la_lds_wait(cnt + LC_LCOPIED, k, s_abort)))
+                if (!la_lds_wait(cnt + LC_D, 4 * (k + 1), s_abort) || (k >= 1 && !la_lds_wait(cnt + LC_LCOPIED, k, s_abort)))
                     gone = true;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -408,6 +432,14 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     if (wave == 1) {
         auto publish = [&](const double (&v)[16], int I_, int k_) { // 32 x 32 tile of P^(k_)_I_: write through, wait for the acknowledgement, raise both half-row flags
             double* t = la_tile(a, la_i_p(a, I_, k_));
+            if (HOME) { // first for the S half-rows next door (L2 of the home XCD), then written through for the T half-rows
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    la_st_l(t + lane + 64 * i, v[i]);
+                la_stores_done();
+                if (lane < 2)
+                    la_raise_fl(a, la_f_p(a, k_, 2 * I_ + lane));
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 la_st(t + lane + 64 * i, v[i]);
@@ -446,50 +478,83 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     // ... and, round 4, publishes L_1^-1 .. L_(NJ-2)^-1 out of sLk (the pivot wave keeps its issue slots for the elimination). The two jobs alternate in the order
     // the data appears: L_k^-1 is complete ~2 us before block row k + 2 hands its tiles over (which needs L_(k-1)^-1 and earlier ones only: no cycle), and the next
     // L^-1 another ~2.5 us later. The flag of L_k^-1 is the first link of the chain L -> block row -> U -> tail, so it goes up as soon as its stores are acknowledged.
-    if (wave == 3) {
-        auto wait_u = [&](int I) { // both halves of block row I have handed their tiles over: tell the tail waves (bounded like every poll)
-            la_wait(a.pubf + la_f_u(a, I, 0), 2, pl);
-            if (*(volatile int*)s_abort)
-                return false;
-            la_lds_set(cnt + LC_U, I);
-            return true;
-        };
-        if (!wait_u(1) || (NJ > 2 && !wait_u(2)))
-            return;
-        for (int k = 1; k + 1 < NJ; ++k) {
-            if (k + 2 <= NJ - 1 || k <= NJ - 2) {
-                if (k <= NJ - 2) {
-                    if (!la_lds_wait<true>(cnt + LC_L, k + 1, s_abort)) // relaxed: a tight LDS poll for ~2 us would compete with the pivot wave's own LDS traffic
-                        return;
-                    double v[16];
+    if (wave == 6) {
+        // Round 5: ONE loop over both jobs instead of taking them in turns (and on wave 6: wave 3, SIMD 3, is a tail wave now - see the quadrants below). In turns, a hand-off whose flag went up while L_k^-1 was being published (stores, acknowledgement,
+        // flag - twice in the HOME placement) was seen 1.8 us late (profiles/r05_h4_lookahead_trace.txt), and L_k^-1 waited for the hand-off in front of it. Every pass:
+        // if the next L^-1 is complete in sLk, copy it out (HOME: plain stores + acknowledgement + local flag first; then the written-through copy, whose flag goes up with the
+        // next pass' wait); then look at the next block row's flags once. A poller on wave 4 instead costs the pivot wave, its SIMD-mate, 0.8 us per step (measured).
+        int next_u = 1, next_l = 1, remote_k = -1;
+        const int* const uf = HOME ? a.pubfl : a.pubf;
+        while (next_u < NJ || next_l <= NJ - 2 || remote_k >= 0) {
+            if (next_l <= NJ - 2 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt + LC_L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= next_l + 1) {
+                asm volatile("" ::: "memory");
+                const int k = next_l++;
+                double v[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int e = lane + 64 * i;
-                        v[i] = sLk[(e & 31) + (e >> 5) * CH_LDP];
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    la_lds_set(cnt + LC_LCOPIED, k); // the pivot wave may overwrite sLk
-                    double* t = la_tile(a, la_i_linv(a, k));
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        la_st(t + lane + 64 * i, v[i]);
+                for (int i = 0; i < 16; ++i) {
+                    const int e = lane + 64 * i;
+                    v[i] = sLk[(e & 31) + (e >> 5) * CH_LDP];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                la_lds_set(cnt + LC_LCOPIED, k); // the pivot wave may overwrite sLk
+                double* t = la_tile(a, la_i_linv(a, k));
+                if (remote_k >= 0) { // (the written-through copy in front of this one: acknowledged long ago)
                     la_stores_done();
                     if (lane == 0)
-                        la_raise_f(a, la_f_linv(a, k));
+                        la_raise_f(a, la_f_linv(a, remote_k));
                 }
-                if (k + 2 < NJ && !wait_u(k + 2))
-                    return;
+                if (HOME) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        la_st_l(t + lane + 64 * i, v[i]);
+                    la_stores_done();
+                    if (lane == 0)
+                        la_raise_fl(a, la_f_linv(a, k));
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    la_st(t + lane + 64 * i, v[i]);
+                remote_k = k;
             }
+            int fv = pl.seq;
+            if (next_u < NJ && lane < 2)
+                fv = __hip_atomic_load(uf + la_f_u(a, next_u, 0) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // global_load_dword sc1
+            la_stores_done(); // the flags are in - and so is the acknowledgement of every store in front of them
+            if (remote_k >= 0) {
+                if (lane == 0)
+                    la_raise_f(a, la_f_linv(a, remote_k));
+                remote_k = -1;
+            }
+            if (next_u < NJ) {
+                if (__builtin_amdgcn_readfirstlane(__builtin_popcountll(__ballot(fv == pl.seq))) == 64) { // both halves of block row next_u have handed their tiles over
+                    la_lds_set(cnt + LC_U, next_u);
+                    if (a.dbg && lane == 0 && next_u >= 2)
+                        a.dbg[8 * (next_u - 2) + 7] = wall_clock64(); // the hand-off the tail of step next_u - 2 needs
+                    ++next_u;
+                } else if ((long long)wall_clock64() > pl.deadline) {
+                    pl.s_abort[1] = 1;
+                    return;
+                }
+            } else if (next_l <= NJ - 2)
+                __builtin_amdgcn_s_sleep(2);
+            if (*(volatile int*)s_abort)
+                return;
         }
         return;
     }
     // ------------------------------------------------------------------------------------------------------------------ waves 2, 4..7: post-work and tail
     const bool post = wave == 5 || wave == 7; // rows 16 .. 31 of c and the blocks (1, 0) / (1, 1) of D_(k+1); rows 0 .. 15 and the block (0, 0) are the pivot wave's
     const int pw = wave & 3;
-    const bool tailw = wave == 2 || wave >= 5;
-    if (wave == 4) // round 3's fourth post-work wave: nothing left to do (kept in the launch: 512 threads = the half-rows' workgroup size)
+    const bool tailw = wave == 2 || wave == 3 || wave == 5 || wave == 7;
+    if (wave == 4) // no work (round 3: a fourth post-work wave; a poller here, even asleep between its looks, slows the pivot wave, its SIMD-mate)
         return;
-    const int tq = wave == 2 ? 0 : pw, ihT = tq & 1, jhT = tq >> 1;
+    // Quadrants of the tail: wave 2 (0, 0), wave 5 (1, 0), wave 3 (1, 1), wave 7 (0, 1). Round 5: b = P^(k)_I2 is formed by the two waves WITHOUT post-work (2: rows 0 .. 15,
+    // 3: rows 16 .. 31; round 4: 2 and 7): they request the block row's tiles when its hand-off is seen and have b ready when c^(k) is, while the post-work waves' requests
+    // would have to fly across their post-work (measured: the post-work then takes 2.3 instead of 1.1 us) or go out behind it. The two sit on different SIMDs (2 and 3), and
+    // the fp64 MFMAs of a step are spread 48 / 36 / 68 over the SIMDs 1 / 2 / 3 (round 4: 48 / 72 / 44 with both tail-only waves on SIMD 2, whose 1.5 us of tail products
+    // were what the pivot wave waited for); the poller / publisher of L^-1 has moved to wave 6.
+    const int tq = wave == 2 ? 0 : (wave == 5 ? 1 : (wave == 3 ? 3 : 2)), ihT = tq & 1, jhT = tq >> 1;
+    double* sDq2 = swork + 800;          // 16 x 16: the block (1, 1) of D' on its way from the tail wave 3 to the post-work wave 7 (free like sDq)
     double dacc[4] = {0, 0, 0, 0};
     auto put_prepared = [&](const double (&r1)[4], const double (&dp)[4]) { // a tail wave's quadrant of R1 and D' to where the post-work finds them
 #pragma unroll
@@ -497,8 +562,10 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             sY[16 * ihT + lr + (16 * jhT + lk + 4 * q) * CH_LDP] = r1[q];
             if (wave == 2)
                 sDq[lr + 16 * (lk + 4 * q)] = dp[q];
+            else if (wave == 3)
+                sDq2[lr + 16 * (lk + 4 * q)] = dp[q];
             else
-                dacc[q] = dp[q];
+                dacc[q] = dp[q]; // (wave 5: its own post-work's block (1, 0); wave 7: the block (0, 1), never read)
         }
     };
     if (tailw) { // block row 1: no panel to apply
@@ -515,12 +582,34 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
         put_prepared(u1r, u0r);
         la_lds_add(cnt + LC_T);
     }
+    // Round 5: a tail's tiles are REQUESTED as soon as wave 3 has seen the block row's hand-off - the tail-only waves 2 and 6 wait for it in front of their wait for
+    // c^(k), the waves 5 and 7 look once before their post-work - and land while c^(k) is being formed. Before, the requests went out when c^(k) was complete and the tail
+    // waited 1.0 - 1.9 us for them with the pivot wave waiting behind it (the loop post-work -> tail -> post-work of DESIGN.md section 3.1).
+    double u2i[8], u1r[4], u0r[4], p3[8], p3t[8];
+    int have = -1; // block row whose tiles are in (or on their way into) the registers above
+    auto fetch_tiles = [&](int I2) {
+        if (tq == 0 || tq == 3) // first: b is formed from it, and everybody waits for b (loads return in the order they were requested)
+            la_operand(la_tile(a, la_i_u(a, I2, 2)), ihT, u2i);
+        if (I2 >= 3) { // complete before the block row raised its U flags (published at its last panel)
+            la_operand(la_tile(a, la_i_p(a, I2, I2 - 3)), ihT, p3);
+            if (tq == 1)
+                la_operand(la_tile(a, la_i_p(a, I2, I2 - 3)), 0, p3t);
+        }
+        const double* t1 = la_tile(a, la_i_u(a, I2, 0)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
+        const double* t0 = la_tile(a, la_i_u(a, I2, 1)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u1r[q] = t1[128 * q];
+            u0r[q] = t0[128 * q];
+        }
+        have = I2;
+    };
     for (int k = 0; k + 1 < NJ; ++k) { // step k produces D_(k+1)
         const int I = k + 1;
         // L_k^-1 as B operand, both column halves, for the two waves that form b in the tail (wave 2: rows 0 .. 15, wave 7: rows 16 .. 31): read from sLk
         // now, before the elimination of D_(k+1) rewrites it - the pivot wave writes L_(k+1)^-1 only when wave 2 has counted itself into LC_D as well
         double lkop[2][8];
-        if (wave == 2) {
+        if (wave == 2 || wave == 3) {
             if (!la_lds_wait(cnt + LC_L, k + 1, s_abort))
                 return;
 #pragma unroll
@@ -531,17 +620,21 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             la_lds_add(cnt + LC_D);
         }
+        if (tailw && !post && k + 2 < NJ) { // waves 2, 3: nothing else to do until c^(k) is complete
+            if (!la_lds_wait<true>(cnt + LC_U, k + 2, s_abort)) // wave 6 saw both U flags of block row k + 2
+                return;
+            fetch_tiles(k + 2);
+        }
         if (post) {
             if (!la_lds_wait(cnt + LC_L, k + 1, s_abort) || !la_lds_wait(cnt + LC_T, 4 * (k + 1), s_abort))
                 return;
             if (k >= 1 && !la_lds_wait(cnt + LC_CCOPIED, k, s_abort)) // wave 1 has read the previous c out of sX (it did, 3 us ago)
                 return;
-            if (wave == 7) {
+            if (wave == 7) { // the block (1, 1) of D', from wave 3's tail: read before this wave counts itself into LC_C (wave 3's next tail starts behind LC_C and rewrites it)
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                    for (int st = 0; st < 8; ++st)
-                        lkop[ch][st] = sLk[16 * ch + lr + (4 * st + lk) * CH_LDP];
+                for (int q = 0; q < 4; ++q)
+                    dacc[q] = sDq2[lr + 16 * (lk + 4 * q)];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             const int ch = pw >> 1; // c = P^(k)_I = R1 L_k^-T : sub-tile (1, ch)
             d4 acc = {0, 0, 0, 0};
@@ -579,27 +672,13 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                 return;
             if (a.dbg && wave == 5 && lane == 0)
                 a.dbg[8 * k + 0] = wall_clock64();
-            if (!la_lds_wait<true>(cnt + LC_U, I2, s_abort)) // wave 3 saw both U flags of block row I2
-                return;
-            double u2i[8], u1r[4], u0r[4], p3[8], p3t[8];
-            {
-                const double* t1 = la_tile(a, la_i_u(a, I2, 0)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
-                const double* t0 = la_tile(a, la_i_u(a, I2, 1)) + (16 * ihT + lr) + 32 * (16 * jhT + lk);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    u1r[q] = t1[128 * q];
-                    u0r[q] = t0[128 * q];
-                }
-                if (tq == 0 || tq == 3)
-                    la_operand(la_tile(a, la_i_u(a, I2, 2)), ihT, u2i);
-                if (I2 >= 3) { // complete before the block row raised its U flags (published at its last panel)
-                    la_operand(la_tile(a, la_i_p(a, I2, I2 - 3)), ihT, p3);
-                    if (tq == 1)
-                        la_operand(la_tile(a, la_i_p(a, I2, I2 - 3)), 0, p3t);
-                }
+            if (have != I2) {
+                if (!la_lds_wait<true>(cnt + LC_U, I2, s_abort)) // wave 3 saw both U flags of block row I2
+                    return;
+                fetch_tiles(I2);
             }
-            // b = P^(k)_I2 = U2 L_k^-T. Wave 2 forms its rows 0 .. 15, wave 7 its rows 16 .. 31 (the two column halves' accumulators ARE the operand layout:
-            // column 16 ch + lk + 4 q); the triangular L_k^-1 has no columns >= 16 in its rows < 16. The rows are kept in LDS for waves 5 and 6, for the
+            // b = P^(k)_I2 = U2 L_k^-T. Wave 2 forms its rows 0 .. 15, wave 3 its rows 16 .. 31 (the two column halves' accumulators ARE the operand layout:
+            // column 16 ch + lk + 4 q); the triangular L_k^-1 has no columns >= 16 in its rows < 16. The rows are kept in LDS for waves 5 and 7, for the
             // next tail and for wave 1, which publishes them.
             double bi[8], bj[8];
             if (tq == 0 || tq == 3) {
@@ -626,6 +705,8 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
                     keep[lr + (16 + lk + 4 * q) * CH_LDP] = b1[q];
                 }
                 la_lds_add(cnt + LC_B);
+                if (a.dbg && wave == 3 && lane == 0 && k < 32)
+                    a.dbg[8 * (32 + k) + 6] = wall_clock64(); // b complete in LDS
             } else {
                 if (!la_lds_wait<true>(cnt + LC_B, 2 * (k + 1), s_abort)) // both halves of this step's b are in LDS
                     return;
@@ -674,6 +755,8 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
             la_lds_add(cnt + LC_T);
             if (a.dbg && wave == 5 && lane == 0)
                 a.dbg[8 * k + 2] = wall_clock64();
+            if (a.dbg && wave != 5 && lane == 0 && k < 32)
+                a.dbg[8 * (32 + k) + (wave == 2 ? 3 : (wave == 3 ? 4 : 5))] = wall_clock64(); // the other three tail waves (the first T half-row uses columns 0 .. 2 of these rows)
         }
     }
 }
@@ -688,7 +771,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
 //   wave w: jh = w & 1 is the 16-column half of a tile, jr = w >> 1 the tile column modulo 4; acc[t] = Z(h, J = 4 t + jr)[:, 16 jh .. 16 jh + 15].
 //   A wave's B operand is rows 16 jh .. 16 jh + 15 of P_J, i.e. what ONE half-row (2 J + jh) published: flags are per (panel, half-row).
 //   P^(p)_h = Z(h, p) L_p^-T is formed by waves 0 / 1 (column halves; the zero block of the triangular L_p^-1 skipped).
-template <int MAXT, int ZB> // ZB: the rows of Z are built here
+template <int MAXT, int ZB, bool HOME> // ZB: the rows of Z are built here; HOME: the S half-rows share an XCD with the owner (la_st_l)
 __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* smem, int* s_abort, int* row_cnt, const LaPoll& pl) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     double* sLinv = smem;                   // L_p^-1, operand layout [r + c CH_LDP]
@@ -698,6 +781,8 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
     double* sZp = sYv + 32;                 // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
     const int NJ = a.NJ, m = a.m, rows = a.rows, ldz = a.ldz, seq = a.seq;
     const bool srow = hidx < 2 * NJ;
+    const bool loc = HOME && srow;                 // this half-row and everybody it exchanges tiles with sit on the home XCD
+    const int* const fl = loc ? a.pubfl : a.pubf;  // the flags it polls
     const int I = hidx >> 1, s = hidx & 1;
     const int row0 = srow ? 16 * hidx : m + 16 * (hidx - 2 * NJ);
     const int ilim = srow ? min(m, row0 + 16) : min(rows, row0 + 16);
@@ -851,14 +936,24 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
             if (J >= 0 && J >= I - 2 && J <= I) {
                 double* u = la_tile(a, la_i_u(a, I, J == I ? 1 : (J == I - 1 ? 0 : 2)));
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    la_st(u + (16 * s + lr) + 32 * (16 * jh + lk + 4 * q), acc[t][q]);
+                for (int q = 0; q < 4; ++q) {
+                    if (loc)
+                        la_st_l(u + (16 * s + lr) + 32 * (16 * jh + lk + 4 * q), acc[t][q]);
+                    else
+                        la_st(u + (16 * s + lr) + 32 * (16 * jh + lk + 4 * q), acc[t][q]);
+                }
             }
         }
         la_stores_done();
         __syncthreads();
-        if (tid == 0)
-            la_raise_f(a, la_f_u(a, I, s));
+        if (tid == 0) {
+            if (loc)
+                la_raise_fl(a, la_f_u(a, I, s));
+            else
+                la_raise_f(a, la_f_u(a, I, s));
+            if (a.dbg && s == 0 && I < 32)
+                a.dbg[8 * (64 + I) + 4] = wall_clock64();
+        }
     };
     for (int p = 0; p < np; ++p) {
         // laundered once per panel: otherwise the body's address / mask expressions are loop invariant, get hoisted and spilled
@@ -866,7 +961,9 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         asm volatile("" : "+v"(lrv), "+v"(lkv));
         const int w = min(32, m - 32 * p);
         // (a) L_p^-1 -> LDS; this half-row's part of the panel tile Z(h, p) -> LDS in operand layout (masked like the chain's operand loads); yTilde row
-        la_wait(a.pubf + la_f_linv(a, p), 1, pl);
+        if (a.dbg && tid == 0 && srow && s == 0 && p == np - 1 && I < 32)
+            a.dbg[8 * (64 + I) + 5] = wall_clock64();
+        la_wait(fl + la_f_linv(a, p), 1, pl);
         {
             const double* lt = la_tile(a, la_i_linv(a, p));
             const double v0 = lt[tid], v1 = lt[tid + LA_T];
@@ -891,8 +988,9 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         __syncthreads();
         if (*s_abort)
             return;
-        const bool dbg_row = a.dbg && tid == 0 && (hidx == 2 * NJ || hidx == 2 * (NJ - 2)) && p < 32;
-        unsigned long long* dbr = a.dbg + 8 * ((hidx == 2 * NJ ? 32 : 64) + p);
+        // EQF_OPT_TRACE: the first T half-row, every panel ([32 + p]); the top half of every S block row at its LAST panel, the one in front of its hand-off ([64 + I])
+        const bool dbg_row = a.dbg && tid == 0 && ((hidx == 2 * NJ && p < 32) || (srow && s == 0 && p == np - 1 && I < 32));
+        unsigned long long* dbr = a.dbg + 8 * (hidx == 2 * NJ ? 32 + p : 64 + I);
         if (dbg_row)
             dbr[0] = wall_clock64();
         // (b) P_h = Z(h, p) L_p^-T on waves 0, 1 (column half ch = wave; L_p^-1 is lower triangular: its columns >= 16 are zero in the rows < 16);
@@ -910,8 +1008,12 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
             if (srow) { // the factor rows leave for the other half-rows straight from the accumulators
                 double* pt = la_tile(a, la_i_p(a, I, p));
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    la_st(pt + (16 * s + lr) + 32 * (16 * ch + lk + 4 * q), pacc[q]);
+                for (int q = 0; q < 4; ++q) {
+                    if (loc)
+                        la_st_l(pt + (16 * s + lr) + 32 * (16 * ch + lk + 4 * q), pacc[q]);
+                    else
+                        la_st(pt + (16 * s + lr) + 32 * (16 * ch + lk + 4 * q), pacc[q]);
+                }
                 la_stores_done();
             }
         } else if (!srow && wave >= 4) {
@@ -926,8 +1028,12 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
         __syncthreads();
         // (c) P_h: flag for the consumers of an S half-row; final W rows (+ Gamma) for a T half-row
         if (srow) {
-            if (tid == 0)
-                la_raise_f(a, la_f_p(a, p, hidx));
+            if (tid == 0) {
+                if (loc)
+                    la_raise_fl(a, la_f_p(a, p, hidx));
+                else
+                    la_raise_f(a, la_f_p(a, p, hidx));
+            }
         } else {
             const int r = tid & 15, c = tid >> 4;
             const double pv = sPI[r + c * CH_LDP];
@@ -942,12 +1048,18 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
 #pragma unroll
         for (int st = 0; st < 8; ++st)
             aI[st] = sPI[lr + (4 * st + lk) * CH_LDP];
+        if (loc && wave == 0) { // HOME: the T half-rows' copy of these factor rows, written through; its flag goes up at the end of this panel's trailing update (below)
+            double* pt = la_tile(a, la_i_p(a, I, p));
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+                la_st(pt + (16 * s + lr) + 32 * (4 * st + lk), aI[st]);
+        }
         // this wave's operands: rows 16 jh .. of P^(p)_J = what half-row 2 J + jh published; lane t watches the flag of tile t. An S half-row's own
         // P_h (J = I, jh = s) is in LDS; its block above the diagonal (J = I, jh > s) is never used.
         {
             const int J = 4 * lane + jr;
             if (lane < MAXT && J > p && J <= Jmax && !(srow && J == I && jh >= s) && !(srow && p == I - 3 && J >= I - 1)) {
-                const int* f = a.pubf + la_f_p(a, p, 2 * J + jh);
+                const int* f = fl + la_f_p(a, p, 2 * J + jh);
                 for (;;) {
                     const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (v == pl.seq || !la_retry(pl))
@@ -992,6 +1104,11 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
                     }
                 }
             }
+        }
+        if (loc && wave == 0) { // the written-through copy of P_h(p) has been on its way for the whole trailing update
+            la_stores_done();
+            if (lane == 0)
+                la_raise_f(a, la_f_p(a, p, hidx));
         }
         if (dbg_row)
             dbr[2] = wall_clock64();
@@ -1479,7 +1596,7 @@ __device__ __forceinline__ void la_stats(const LaArgs& a) {
     }
 }
 
-template <int MAXT, int ZB = 0>
+template <int MAXT, int ZB = 0, bool HOME = false>
 __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     if (a.spec && *a.spec == a.spec_seq) // cancelled speculative tail
         return;
@@ -1493,15 +1610,47 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     const LaPoll pl{(long long)wall_clock64() + a.timeout_ticks, a.seq, s_abort};
     // block 0: the owner; blocks 1 .. 2 NJ - 2: the S half-rows h = 2 .. 2 NJ - 1 (block row 0 is the first diagonal tile, eliminated by k_build_Z);
     // then the T half-rows, numbered on from 2 NJ
-    const int hidx = (int)blockIdx.x + 1;
-    if constexpr (ZB >= 2) {
+    int hidx = (int)blockIdx.x + 1;
+    bool owner = blockIdx.x == 0;
+    if constexpr (HOME) {
+        // HOME placement (up to 16 panels): block b runs on XCD (a.home + b) & 7. The blocks b & 7 == 0 are, in this order, the owner and the S half-rows 2 .. 2 NJ - 1; the
+        // blocks of the other seven XCDs are the T half-rows (and the statistics workgroup behind them); what is left of the grid returns at once.
+        const int x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        const int nT = a.NI - (2 * a.NJ - 1);
+        const int xcc = la_xcc_id();
+        if (xcc != ((a.home + x) & 7)) { // not where the placement assumes: nothing may be exchanged through an L2. Every block of the grid finds the same and leaves.
+            if (threadIdx.x == 0) {
+                if (blockIdx.x == 0) // (the host learns the offset of this stream's queue from it)
+                    __hip_atomic_store(a.flags + 5, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.flags + 4, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.flags + 3, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        if (x == 0) {
+            if (slot > 2 * a.NJ - 2)
+                return;
+            owner = slot == 0;
+            hidx = slot + 1;
+        } else {
+            const int r = 7 * slot + (x - 1);
+            owner = false;
+            if (r < nT)
+                hidx = 2 * a.NJ + r;
+            else if (ZB >= 2 && r == nT) {
+                la_stats<ZB>(a);
+                return;
+            } else
+                return;
+        }
+    } else if constexpr (ZB >= 2) {
         if ((int)blockIdx.x >= a.NI) { // the statistics workgroup
             la_stats<ZB>(a);
             return;
         }
     }
-    if (blockIdx.x == 0)
-        la_owner<ZB>(a, smem, s_abort, s_cnt, pl);
+    if (owner)
+        la_owner<ZB, HOME>(a, smem, s_abort, s_cnt, pl);
     else if (MAXT > 4) { // 17 .. 32 panels: the half-rows with a look-ahead of their own
         const int nbase = a.NI; // owner + S half-rows + T half-rows; behind them the parts A of the split half-rows (block rows >= split_from, two halves each)
         if ((int)blockIdx.x >= nbase) {
@@ -1513,7 +1662,7 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
         } else
             la_row2<MAXT, false>(a, hidx, smem, s_abort, s_cnt, pl);
     } else
-        la_row<MAXT, ZB>(a, hidx, smem, s_abort, s_cnt, pl);
+        la_row<MAXT, ZB, HOME>(a, hidx, smem, s_abort, s_cnt, pl);
     // any wave that saw a timeout reports it (the owner's waves return at different times). The stall word carries the launch's sequence number: nobody has to
     // clear it, so no clear can race with a workgroup that reports early, and a stale word of an earlier launch never matches
     if ((threadIdx.x & 63) == 0 && (s_abort[0] | s_abort[1]))

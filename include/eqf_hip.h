@@ -91,6 +91,11 @@ enum {
                                   different data, are ONE launch (the lift's workgroups in front) instead of two in a row: the doorbell rings when it did, Sigma - which the
                                   next frame's first kernel waits for - is complete a lift and a kernel boundary earlier. Same arithmetic per thread: bit-identical.
                                   Not with EQF_OPT_SIGMA_FP32 storage or per-kernel timing. 0: two launches */
+    EQF_OPT_LA_HOME = 21,      /* 1 (default): up to 16 panels (N <= 256) on a device of 8 XCDs x 32 compute units the look-ahead kernel keeps its owner and all S half-rows on ONE
+                                  XCD (the context's "home", claimed at eqf_create) and their hand-offs inside that XCD's L2 (plain stores, a second flag array): 1.1 instead of
+                                  2.0 us per hop. What the T half-rows on the other XCDs read is written through a second time. Same arithmetic: bit-identical to 0 and to the
+                                  launch chain. Checked at eqf_create (self-test; every home workgroup compares HW_REG_XCC_ID with the XCD it expects) and switched off for the
+                                  context if the device deals its blocks differently. eqf_lookahead_home reports the home and the launches that used it. 0: classic placement */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.
@@ -226,11 +231,14 @@ int eqf_stats_select_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* id
 /* look-ahead factorisation since the last reset: launches of the persistent kernel; of those, launches whose bounded wait ran out and whose
  * factorisation was redone on the launch chain (same Z: W and Sigma+ bit-identical, Gamma up to rounding; three in a row switch EQF_OPT_LOOKAHEAD off for the context). */
 int eqf_lookahead_stats(eqf_ctx* ctx, long* launches, long* fallbacks, int reset);
-/* Result of the look-ahead kernel's self-test at eqf_create (the persistent kernel against the launch chain on a fixed 96-column problem, W compared bit
+/* Result of the look-ahead kernel's self-test at eqf_create (the persistent kernel against the launch chain on fixed problems of 3, up to 13 and 17 panels, eight launches each, W compared bit
  * for bit): 1 passed, 0 not run (the kernel is never eligible at this capacity / on this device, or its launch stalled four times because the device was busy -
  * e.g. eight processes creating contexts on one device at once: a stall says nothing about the kernel, and every later launch is bounded and redone on the chain
  * if it stalls), -1 failed (W differed): the context factorises on the launch chain. */
 int eqf_lookahead_selftest(const eqf_ctx* ctx);
+/* EQF_OPT_LA_HOME: the XCD this context's look-ahead launches keep their owner and S half-rows on (-1: none was free at creation, or the placement was refused /
+ * switched off), and the look-ahead launches that used it. */
+int eqf_lookahead_home(const eqf_ctx* ctx, int* home_xcd, long* home_launches);
 /* frames that took the device-side decision, landmarks it discarded */
 int eqf_selection_stats(eqf_ctx* ctx, long* frames, long* discarded, int reset);
 
