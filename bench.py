@@ -306,7 +306,7 @@ def batch8_sequence(q, duration=60.0):
     return fs, srv.cam, s0, frames
 
 
-def batch8(args, rank, world_size, dist, backend, stand_in, one_device):
+def batch8(args, rank, world_size, dist, backend, stand_in, one_device, placement=None):
     """`bench.py --gpus N --config batch8`: the 8 sequences are shared out over the N ranks (rank r takes q = r, r + N, ...), one filter per sequence (main_opt-like: it starts
     without landmarks and adds / drops them itself), the input containers built before the timed region. value = vision updates of the whole batch / the slowest rank's time:
     total work is fixed, so this line is "scaling": "strong". Parity of two of the sequences against the oracle: tests/test_gpu_batch8.py."""
@@ -333,10 +333,10 @@ def batch8(args, rank, world_size, dist, backend, stand_in, one_device):
         assert done == nfr, (q, done, nfr)
         per_seq[q] = {"frames": nfr, "seconds": time.perf_counter() - t1, "final_landmarks": (flt.sigma_dim() - 21) // 3}
     mine = time.perf_counter() - t0
-    gathered = [(mine, per_seq)]
+    gathered = [(mine, per_seq, placement)]
     if dist is not None:
         gathered = [None] * world_size
-        dist.all_gather_object(gathered, (mine, per_seq))
+        dist.all_gather_object(gathered, (mine, per_seq, placement))
         dist.barrier()
     if rank == 0:
         slowest = max(g[0] for g in gathered)
@@ -350,6 +350,7 @@ def batch8(args, rank, world_size, dist, backend, stand_in, one_device):
                                    "EuRoC-structured settings, one filter per sequence, sequences shared out over the ranks" + (" (every rank on GPU 0: EQVIO_BENCH_ONE_DEVICE)" if one_device else ""),
                        "parallelism": f"replicas x{world_size}"},
             "per_rank_seconds": {"min": min(g[0] for g in gathered), "max": slowest},
+            "placement": [g[2] for g in gathered],
             "per_sequence_updates_per_s": {"min": min(rates), "max": max(rates)},
             "sequences": {str(q): dict(BATCH8[q], **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in seqs[q].items()}) for q in sorted(seqs)},
         }))
@@ -420,6 +421,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = args.gpus
     one_device = bool(os.environ.get("EQVIO_BENCH_ONE_DEVICE"))  # test hook: every rank on GPU 0 (rehearsal of the N > 1 launch on a 1-GPU box)
+    # Every rank's host threads go onto physical cores of its GPU's NUMA node BEFORE the HIP context (and with it the pinned doorbell / result packets) exists:
+    # the frame boundary runs through the host (eqvio_amd/placement.py). Restored before the CPU legs of the single-rank run, which want every core.
+    all_cpus = os.sched_getaffinity(0)
+    placement = None
+    if not os.environ.get("EQVIO_BENCH_BACKEND") and not os.environ.get("EQVIO_BENCH_NO_PIN"):
+        from eqvio_amd.placement import pin_rank
+
+        placement = pin_rank(local_rank, world_size, devices=[0] * world_size if one_device else None)
     if one_device:
         local_rank = 0
     backend, stand_in = load_backend(local_rank)
@@ -428,17 +437,18 @@ def main():
         assert have >= world_size, "bench.py --gpus %d: only %d device(s) visible" % (world_size, have)
     dist = init_control_group(world_size)
     if args.config == "batch8":
-        return batch8(args, rank, world_size, dist, backend, stand_in, one_device)
+        return batch8(args, rank, world_size, dist, backend, stand_in, one_device, placement)
     N = args.landmarks
 
     def Filter(settings, sensor, ids, p, t):
         return backend.make_filter(settings, N, sensor, ids, p, t)
 
     value, elapsed, flt, world, frames, settings, mine = rank_pass(args, rank, world_size, dist, backend)
-    per_rank = [mine]
+    per_rank, placements = [mine], [placement]
     if dist is not None:  # every rank's own wall time of the timed region, for the min / max next to the aggregate
-        per_rank = [None] * world_size
+        per_rank, placements = [None] * world_size, [None] * world_size
         dist.all_gather_object(per_rank, mine)
+        dist.all_gather_object(placements, placement)
     n, m = 21 + 3 * N, 2 * N
     ms_per_step = 1e3 * elapsed / args.steps
     frame_flops = flops_propagate(n) + flops_update(n, m)
@@ -461,6 +471,8 @@ def main():
             roofline = measure_roofline(flt, lib, core, cam, frames, args, n, m)
             if not args.no_pmc and world_size == 1 and not stand_in:
                 roofline.update(live_pmc(N, roofline, args.steps / elapsed))
+        if placement is not None and placement.get("pinned"):
+            os.sched_setaffinity(0, all_cpus)  # the legs below start threads / processes of their own on every core
         if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(world, frames, settings, N)
         if rank == 0 and world_size == 1 and not args.no_multi_filter:
@@ -492,6 +504,7 @@ def main():
                 "parallelism": f"replicas x{world_size}",
             },
             "per_rank_updates_per_s": {"min": args.steps / max(per_rank), "max": args.steps / min(per_rank)},
+            "placement": placements,  # per rank: PCI bus id of its GPU, that GPU's NUMA node, the cores the rank was pinned to (eqvio_amd/placement.py)
             "launcher": "self" if os.environ.get("EQVIO_BENCH_SELF_LAUNCHED") else ("external" if "WORLD_SIZE" in os.environ else "single process"),
             "frame_dense_flops": frame_flops,
             "dense_equiv_tflops": frame_flops * value / world_size / 1e12,
