@@ -467,6 +467,10 @@ def main():
         la_l, la_f = C.c_long(), C.c_long()
         assert lib.eqf_lookahead_stats(core, C.byref(la_l), C.byref(la_f), 0) == 0
         factorisation = {"lookahead_launches": la_l.value, "stalled_and_redone_on_the_chain": la_f.value, "frames": args.warmup + args.steps}
+        if hasattr(lib, "eqf_lookahead_home"):  # EQF_OPT_LA_HOME: launches that kept the owner and the S half-rows on one XCD (a filter that has the device to itself)
+            hx, hl = C.c_int(), C.c_long()
+            assert lib.eqf_lookahead_home(core, C.byref(hx), C.byref(hl)) == 0
+            factorisation.update({"home_placement_launches": hl.value, "home_xcd": hx.value})
         if rank == 0 and not args.no_roofline:
             roofline = measure_roofline(flt, lib, core, cam, frames, args, n, m)
             if not args.no_pmc and world_size == 1 and not stand_in:

@@ -14,6 +14,10 @@
 #include <string>
 #include <vector>
 #include <unistd.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <cerrno>
 
 using namespace eqf;
 
@@ -168,6 +172,9 @@ struct eqf_ctx {
     long la_home_refused = 0;                // launches that found their blocks elsewhere (the offset is learnt again, the update is redone on the launch chain)
     int opt_la_home = 1;                     // EQF_OPT_LA_HOME
     long la_home_launches = 0;
+    bool la_home_force = false;              // the self-test exercises the HOME placement whoever else is on the device
+    int reg_slot = -1;                       // this context's slot in the device's registry of contexts (shared memory: device_to_itself)
+    unsigned reg_checks = 0;
     char* d_puby = nullptr;
     int la_njcap = 0, la_seq = 0;
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
@@ -373,6 +380,82 @@ std::mutex la_gate_mutex;
 std::condition_variable la_gate_cv;
 int la_cus_booked[64] = {0}; // per device
 } // namespace
+// EQF_OPT_LA_HOME needs the device for itself. The HOME placement puts 2 NJ - 1 workgroups (25 at N = 200) of every look-ahead launch on ONE XCD of 32 compute units -
+// and which XCD is a property of the stream's hardware queue: the FIRST queue of every process gives the same one (measured: four processes, one filter each, 26.3 k
+// updates/s with HOME against 31.3 k without - their launches took turns on that XCD). Filters that share a GPU therefore keep the classic placement, which spreads
+// every launch evenly over the XCDs, and HOME is for the filter that has the device to itself - BASELINE's configuration, one filter per GPU. "To itself" is counted
+// across processes: every context registers its pid in a small table in shared memory (one per user and device), slots of dead processes are reclaimed.
+namespace {
+constexpr int REG_SLOTS = 64;
+struct DeviceRegistry {
+    std::atomic<int> pid[REG_SLOTS];
+};
+DeviceRegistry* registry_of(int device) {
+    static std::mutex mu;
+    static DeviceRegistry* maps[64] = {};
+    std::lock_guard<std::mutex> g(mu);
+    DeviceRegistry*& r = maps[device & 63];
+    if (r)
+        return r;
+    char name[96];
+    std::snprintf(name, sizeof(name), "/eqf_hip_contexts_u%u_d%d", (unsigned)getuid(), device);
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0)
+        return nullptr;
+    if (ftruncate(fd, sizeof(DeviceRegistry)) != 0) {
+        close(fd);
+        return nullptr;
+    }
+    void* p = mmap(nullptr, sizeof(DeviceRegistry), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED)
+        return nullptr;
+    r = static_cast<DeviceRegistry*>(p); // (a fresh object is all zeros: no slot taken)
+    return r;
+}
+bool pid_alive(int pid) { return pid > 0 && (kill(pid, 0) == 0 || errno == EPERM); }
+} // namespace
+static void registry_enter(eqf_ctx* c) {
+    DeviceRegistry* r = registry_of(c->device);
+    c->reg_slot = -1;
+    if (!r)
+        return;
+    const int me = (int)getpid();
+    for (int pass = 0; pass < 2 && c->reg_slot < 0; ++pass)
+        for (int i = 0; i < REG_SLOTS && c->reg_slot < 0; ++i) {
+            int cur = r->pid[i].load(std::memory_order_relaxed);
+            if (cur != 0 && (pass == 0 || pid_alive(cur)))
+                continue; // pass 0: free slots only; pass 1: slots of processes that are gone as well
+            if (r->pid[i].compare_exchange_strong(cur, me))
+                c->reg_slot = i;
+        }
+}
+static void registry_leave(eqf_ctx* c) {
+    DeviceRegistry* r = c->reg_slot >= 0 ? registry_of(c->device) : nullptr;
+    if (r)
+        r->pid[c->reg_slot].store(0, std::memory_order_relaxed);
+    c->reg_slot = -1;
+}
+// true when no other context - of this or of any other process of this user - is registered on the device
+static bool device_to_itself(eqf_ctx* c) {
+    DeviceRegistry* r = c->reg_slot >= 0 ? registry_of(c->device) : nullptr;
+    if (!r)
+        return false; // (no shared memory: nothing is known about the neighbours)
+    int others = 0;
+    for (int i = 0; i < REG_SLOTS; ++i)
+        others += (i != c->reg_slot && r->pid[i].load(std::memory_order_relaxed) != 0) ? 1 : 0;
+    if (others == 0)
+        return true;
+    // somebody else is registered: alive? (a crashed process leaves its slots behind; looked at once per 4096 launches)
+    if ((++c->reg_checks & 0xfff) == 1) {
+        for (int i = 0; i < REG_SLOTS; ++i) {
+            int cur = r->pid[i].load(std::memory_order_relaxed);
+            if (i != c->reg_slot && cur != 0 && cur != (int)getpid() && !pid_alive(cur))
+                r->pid[i].compare_exchange_strong(cur, 0);
+        }
+    }
+    return false;
+}
 static void la_release(eqf_ctx* c) {
     if (!c->la_cus_held)
         return;
@@ -647,6 +730,7 @@ int eqf_create(eqf_ctx** out, int device, int max_landmarks, int coordinate_choi
     c->device = device;
     c->chart = coordinate_choice;
     c->cu_count = prop.multiProcessorCount;
+    registry_enter(c);
     const int rc = create_buffers(c, max_landmarks);
     if (rc) { // a failed allocation half way (e.g. the pinned Sigma staging at a large capacity): release what exists
         eqf_destroy(c);
@@ -803,8 +887,10 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
 }
 
 void eqf_destroy(eqf_ctx* c) {
-    if (c)
+    if (c) {
         la_release(c);
+        registry_leave(c);
+    }
     if (c && std::getenv("EQF_DEBUG_STATS"))
         std::fprintf(stderr, "[eqf_hip] look-ahead launches %ld (stalled %ld), of them with Z built inside %ld\n", c->la_launches, c->la_fallbacks, c->zb_launches);
     if (!c)
@@ -991,7 +1077,7 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         c->opt_la_split = value ? 1 : 0;
         return 0;
     case EQF_OPT_LA_HOME:
-        c->opt_la_home = value ? 1 : 0;
+        c->opt_la_home = value < 0 ? 0 : std::min(value, 2); // 2: also when the device is shared (tests)
         return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE:
         c->opt_measure_prop = value ? 1 : 0;
@@ -2026,7 +2112,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     // EQF_OPT_LA_HOME (up to 16 panels, a device of 8 XCDs x 32 compute units): the owner and the 2 NJ - 2 S half-rows are the blocks of ONE XCD (b & 7 == home), the T
     // half-rows (+ the statistics workgroup) are dealt to the other seven; the rest of the 8 x slots grid returns at once (eqf_lookahead.hpp: la_st_l)
     const int nT = a.NI - (2 * a.NJ - 1);
-    const bool home = c->opt_la_home && a.NJ <= 16 && c->cu_count == 256 && c->d_pubfl;
+    const bool home = c->opt_la_home && a.NJ <= 16 && c->cu_count == 256 && c->d_pubfl && (c->opt_la_home == 2 || c->la_home_force || device_to_itself(c));
     a.home = home ? c->la_home : -1;
     a.pubfl = c->d_pubfl;
     const int home_grid = 8 * std::max(2 * a.NJ - 1, blocks(nT + (zb >= 2 ? 1 : 0), 7));
@@ -2344,7 +2430,9 @@ static int lookahead_selftest(eqf_ctx* c) {
     if (!c->opt_lookahead || c->mcap < 96 || c->la_njcap < 3 || c->cu_count < 8)
         return 0; // the look-ahead kernel is never eligible at this capacity / on this device
     bool refused = false;
+    c->la_home_force = true;
     int rc = lookahead_selftest_pass(c, refused);
+    c->la_home_force = false;
     if (rc)
         return rc;
     const bool home_on = c->opt_la_home != 0;

@@ -596,7 +596,7 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
     instantiation), M < N with a ragged last panel, the 16-panel instantiation, and the two large ones (17 .. 24 and 25 .. 32 panels: N = 300 .. 512,
     the stress configuration N = 500 among them). A second update on the same context
     meets the first one's tiles and flags in the hand-off buffers (the sequence number in the flags tells them apart)."""
-    from eqvio_amd.capi import OPT_LOOKAHEAD
+    from eqvio_amd.capi import OPT_LA_HOME, OPT_LOOKAHEAD
 
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=N + M, useDiscreteInnovationLift=0)
     cam = default_camera()
@@ -604,11 +604,14 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
     rows, m = 2 * M + 21 + 3 * N + 1, 2 * M
     outs = []
     cores = []
-    for la in (0, 1, 1):
+    # the look-ahead kernel in its classic placement and (round 5, up to 16 panels) in the HOME placement - owner and S half-rows on one XCD, their hand-offs through its
+    # L2 (2 = also while other contexts share the device, as they do in this test)
+    for la, home in ((0, 0), (1, 0), (1, 2)):
         c = EqfCore(N, CHARTS["invdepth"])
         c.set_state(xi0, Xs, ids, q0, Q)
         c.set_sigma(S)
         c.set_option(OPT_LOOKAHEAD, la)
+        c.set_option(OPT_LA_HOME, home)
         c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
         outs.append((c.get_sigma(), c.get_state(), c.last_gamma(), c.debug_get_W(rows, m)[m:]))
         cores.append(c)
@@ -636,7 +639,7 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
 def test_lookahead_factorisation_soak():
     """The hand-offs of the persistent kernel under repetition: fresh contexts (zeroed buffers, sequence 1) and one context reused
     (every word of the previous launch still in place), every result compared bit by bit with the launch chain's."""
-    from eqvio_amd.capi import OPT_LOOKAHEAD
+    from eqvio_amd.capi import OPT_LA_HOME, OPT_LOOKAHEAD
 
     # (300, 270) and (500, 500): the 17 .. 32-panel instantiation, whose half-rows run a look-ahead of their own (la_row2: LDS double buffers by panel parity,
     # pair counters, flags raised under a later round trip) - fewer repetitions, they are 10 x the work
@@ -651,6 +654,7 @@ def test_lookahead_factorisation_soak():
             c.set_state(xi0, Xs, ids, q0, Q)
             c.set_sigma(S)
             c.set_option(OPT_LOOKAHEAD, 0 if it == 0 else 1)
+            c.set_option(OPT_LA_HOME, 2 if it % 2 else 0)  # HOME placement (up to 16 panels) and classic placement in turns
             c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
             Sg = c.get_sigma()
             if it == 0:
