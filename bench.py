@@ -557,6 +557,10 @@ def reference_side_binding(N, n_frames=400):
                     write_scenario(scen + ".short", settings, world.cam, sensor, ids, p, 0.0, frames[:nfr], plan_without_decisions(frames[:nfr], 0.0))
                 info = run_driver(scen if nfr == n_frames else scen + ".short", os.path.join(tmp, "out.bin"), fused, warm=20)
                 out[key] = {"value": info["updates_per_s"], "unit": "updates/s", "frames": info["frames"]}
+                if info.get("gain_matrix_seconds"):  # what the unmodified caller spends building its dense n x n / m x m gain matrices per frame (src/VIOFilter.cpp:155-158, :232): not the binding's
+                    g = info["gain_matrix_seconds"]
+                    out[key]["caller_side_gain_matrix_us_per_frame"] = 1e6 * g / info["frames"]
+                    out[key]["value_without_the_callers_gain_matrices"] = info["frames"] / (info["seconds"] - g)
         out["note"] = ("reference-side VIO_eqf binding (tests/integration/VIO_eqf_mi355x.cpp): the member sequence of VIOFilter::processVisionData replayed + stateEstimate per frame, "
                        "N = %d hover world; the mirror's own rate is the headline value" % N)
         return out

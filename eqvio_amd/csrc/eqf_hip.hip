@@ -230,6 +230,10 @@ struct eqf_ctx {
     Common* h_common = nullptr;
     ObsStep* h_steps = nullptr;
     double* h_buf = nullptr; // general staging, size hbuf_doubles
+    bool ocov_valid = false; // h_ocov holds the output covariances of ALL landmarks at the current state for the camera ocov_cam (computed along with a state estimate)
+    Cam ocov_cam{};
+    bool ocov_hint_valid = false; // a caller has asked for output covariances before (eqf_output_cov_all): the next state estimate computes them along, for that camera
+    Cam ocov_hint{};
     size_t hbuf_doubles = 0;
     int* h_ibuf = nullptr;
     int* h_flags = nullptr;
@@ -709,6 +713,7 @@ static int round_sigma(eqf_ctx* c, const int* spec = nullptr, int spec_seq = 0);
 // first statement of every entry point that uses the device state: select the device, apply the recorded landmark bookkeeping
 static int enter(eqf_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
+    c->ocov_valid = false; // (every call that can change the state or Sigma passes through here)
     return flush_reshape(c);
 }
 static int lookahead_selftest(eqf_ctx* c);
@@ -1272,10 +1277,22 @@ static int fetch_estimates(eqf_ctx* c) { // d_est -> h_buf (4 planes of stride N
     }
     { int _e = enter(c); if (_e) return _e; }
     { int _r = join_observer(c); if (_r) return _r; }
-    hipLaunchKernelGGL(k_estimate, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->d_est);
+    // straight into the pinned staging buffer (no copy command behind the kernel: a blit and its boundary cost more than the 6 KB written across the bus)
+    hipLaunchKernelGGL(k_estimate, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->h_buf);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_buf, c->d_est, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, c->stream));
+    // A caller that reads the state estimate between propagation and update is the reference's removeOutliers (src/VIOFilter.cpp:304-334), which asks for the output
+    // covariance of every measured landmark next: computed here as well, for the camera of the last such request, behind the same wait (eqf_output_cov_all returns it)
+    const bool with_ocov = c->ocov_hint_valid && !c->sig32;
+    if (with_ocov) {
+        if (!c->h_ocov)
+            HIPCHK(hipHostMalloc(&c->h_ocov, sizeof(double) * 4 * (size_t)c->Ncap));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_output_cov<double>), dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, c->chart, c->ocov_hint, c->q0(), c->Qq(), c->Qa(),
+                           (const double*)c->sigma(), c->h_ocov);
+        HIPCHK(hipGetLastError());
+    }
     { int _r = sync_ctx(c); if (_r) return _r; }
+    if (with_ocov)
+        c->ocov_valid = true, c->ocov_cam = c->ocov_hint;
     return 0;
 }
 
@@ -2228,6 +2245,15 @@ int eqf_output_cov_all(eqf_ctx* c, const eqvio_camera* cam, double* out4N) {
     const int N = c->N;
     if (N == 0)
         return 0;
+    {
+        const Cam k = make_cam(cam);
+        if (c->ocov_valid && k.fx == c->ocov_cam.fx && k.fy == c->ocov_cam.fy && k.cx == c->ocov_cam.cx && k.cy == c->ocov_cam.cy && k.model == c->ocov_cam.model &&
+            std::equal(k.d, k.d + 5, c->ocov_cam.d)) { // computed with the state estimate that was read just before (fetch_estimates); nothing has touched the state since
+            std::memcpy(out4N, c->h_ocov, sizeof(double) * 4 * N);
+            return 0;
+        }
+    }
+    c->ocov_hint = make_cam(cam), c->ocov_hint_valid = true;
     { int _e = enter(c); if (_e) return _e; }
     { int _r = join_observer(c); if (_r) return _r; }
     if (!c->h_ocov)

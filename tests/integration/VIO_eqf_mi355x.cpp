@@ -147,9 +147,20 @@ void download(eqf_ctx* ctx, VIO_eqf& f) { // device -> host members
     check(eqf_get_sigma(ctx, f.Sigma.data(), n), "eqf_get_sigma");
 }
 
-// make the device current for `f`; `extra` landmarks are about to be appended
-eqf_ctx* ensure(const VIO_eqf& f, int extra = 0) {
+// the recorded integrateRiccatiStateFast + k x integrateObserverState of one integrateUpToTime as ONE device call (DeviceTwin: "Deferred propagation")
+void flushPending(eqvio_mi355x::DeviceTwin& t) {
+    if (!t.pendingRiccati)
+        return;
+    t.pendingRiccati = false;
+    const int k = (int)t.pendingDts.size();
+    check(eqf_propagate_fast(t.ctx, t.pendingMean, t.pendingDt, t.pendingQd, t.pendingPd8, t.pendingImu.data(), t.pendingDts.data(), k, t.pendingDiscrete ? 1 : 0), "deferred propagation");
+    t.pendingImu.clear(), t.pendingDts.clear();
+}
+// make the device current for `f`; `extra` landmarks are about to be appended. `keepPending`: the caller is an observer step that joins the deferred propagation
+eqf_ctx* ensure(const VIO_eqf& f, int extra = 0, bool keepPending = false) {
     eqvio_mi355x::DeviceTwin& t = f.twin;
+    if (!keepPending && t.ctx)
+        flushPending(t); // (before anything else looks at the device, or rebuilds / re-uploads it)
     const int chart = chartOf(f.coordinateSuite);
     const int need = (int)f.X.id.size() + extra;
     if (t.ctx && (t.chart != chart || t.capacity < need)) { // another chart or more landmarks than the context holds: rebuild it
@@ -178,6 +189,8 @@ eqf_ctx* ensure(const VIO_eqf& f, int extra = 0) {
 // ---------------------------------------------------------------- the device twin
 namespace eqvio_mi355x {
 DeviceTwin::DeviceTwin(const DeviceTwin& o) : chart(o.chart), capacity(o.capacity), deviceNewer(o.deviceNewer), hostEdited(o.hostEdited) {
+    if (o.ctx)
+        flushPending(const_cast<DeviceTwin&>(o)); // a recorded propagation belongs to the state that is being copied
     if (o.ctx && o.deviceNewer && !o.hostEdited) { // the source's host members are behind its device: clone device -> device (through the host)
         VIO_eqf scratch;
         download(o.ctx, scratch);
@@ -195,12 +208,24 @@ DeviceTwin& DeviceTwin::operator=(const DeviceTwin& o) {
     }
     return *this;
 }
-DeviceTwin::DeviceTwin(DeviceTwin&& o) noexcept : ctx(o.ctx), chart(o.chart), capacity(o.capacity), deviceNewer(o.deviceNewer), hostEdited(o.hostEdited) { o.ctx = nullptr; }
+static void movePending(DeviceTwin& to, DeviceTwin& from) {
+    to.pendingRiccati = from.pendingRiccati, to.pendingDiscrete = from.pendingDiscrete, to.pendingDt = from.pendingDt;
+    std::copy(from.pendingMean, from.pendingMean + 13, to.pendingMean);
+    std::copy(from.pendingQd, from.pendingQd + 12, to.pendingQd);
+    std::copy(from.pendingPd8, from.pendingPd8 + 8, to.pendingPd8);
+    to.pendingImu.swap(from.pendingImu), to.pendingDts.swap(from.pendingDts);
+    from.pendingRiccati = false;
+}
+DeviceTwin::DeviceTwin(DeviceTwin&& o) noexcept : ctx(o.ctx), chart(o.chart), capacity(o.capacity), deviceNewer(o.deviceNewer), hostEdited(o.hostEdited) {
+    movePending(*this, o);
+    o.ctx = nullptr;
+}
 DeviceTwin& DeviceTwin::operator=(DeviceTwin&& o) noexcept {
     if (this != &o) {
         if (ctx)
             eqf_destroy(ctx);
         ctx = o.ctx, chart = o.chart, capacity = o.capacity, deviceNewer = o.deviceNewer, hostEdited = o.hostEdited;
+        movePending(*this, o);
         o.ctx = nullptr;
     }
     return *this;
@@ -212,6 +237,8 @@ DeviceTwin::~DeviceTwin() {
 } // namespace eqvio_mi355x
 
 void VIO_eqf::pull() const {
+    if (twin.ctx)
+        flushPending(twin);
     if (twin.ctx && twin.deviceNewer && !twin.hostEdited) {
         download(twin.ctx, const_cast<VIO_eqf&>(*this)); // the host members are a cache of the device state
         twin.deviceNewer = false;
@@ -220,19 +247,29 @@ void VIO_eqf::pull() const {
 
 // ---------------------------------------------------------------- propagation (VIO_eqf.cpp:47-103)
 void VIO_eqf::integrateObserverState(const IMUVelocity& imuVelocity, const double& dt, const bool& discreteLift) {
-    eqf_ctx* ctx = ensure(*this);
     double imu[13];
     packImu(imuVelocity, imu);
+    if (twin.ctx && twin.pendingRiccati && (twin.pendingDts.empty() || twin.pendingDiscrete == discreteLift)) { // joins the propagation recorded in front of it
+        ensure(*this, 0, true);
+        twin.pendingDiscrete = discreteLift;
+        twin.pendingImu.insert(twin.pendingImu.end(), imu, imu + 13);
+        twin.pendingDts.push_back(dt);
+        twin.touch();
+        return;
+    }
+    eqf_ctx* ctx = ensure(*this);
     check(eqf_integrate_observer(ctx, imu, &dt, 1, discreteLift ? 1 : 0), "integrateObserverState");
     twin.touch();
 }
 void VIO_eqf::integrateRiccatiStateFast(const IMUVelocity& imuVelocity, const double& dt, const Eigen::Matrix<double, 12, 12>& inputGainMatrix,
                                         const Eigen::MatrixXd& stateGainMatrix) {
-    eqf_ctx* ctx = ensure(*this);
-    double imu[13], Qd[12], Pd8[8];
-    packImu(imuVelocity, imu);
-    packGains(inputGainMatrix, stateGainMatrix, Qd, Pd8);
-    check(eqf_integrate_riccati_fast(ctx, imu, dt, Qd, Pd8), "integrateRiccatiStateFast");
+    ensure(*this); // (flushes whatever was recorded before)
+    // recorded, not issued: the observer steps that VIOFilter::integrateUpToTime makes next join it, and the first other member call issues everything as one launch
+    packImu(imuVelocity, twin.pendingMean);
+    packGains(inputGainMatrix, stateGainMatrix, twin.pendingQd, twin.pendingPd8);
+    twin.pendingDt = dt;
+    twin.pendingRiccati = true;
+    twin.pendingImu.clear(), twin.pendingDts.clear();
     twin.touch();
 }
 void VIO_eqf::integrateRiccatiStateAccurate(const IMUVelocity& imuVelocity, const double& dt, const Eigen::Matrix<double, 12, 12>& inputGainMatrix,
@@ -321,19 +358,25 @@ Eigen::Matrix2d VIO_eqf::getOutputCovById(const int& id, const Eigen::Vector2d&,
     // 200 landmarks. The first call after the state changed now fetches the covariances of ALL landmarks (eqf_output_cov_all: one kernel, one wait);
     // the following calls of the frame read the cache. (eqf_outlier_stats is the fused form this repo's own VIOFilter mirror uses instead.)
     eqf_ctx* ctx = ensure(*this);
-    const auto it = std::find(X.id.begin(), X.id.end(), id);
-    if (it == X.id.end())
-        throw std::out_of_range("getOutputCovById: unknown id");
+    eqvio_mi355x::DeviceTwin& t = twin;
+    // removeOutliers walks the landmarks in state order (VIOFilter.cpp:316-334): the id asked for is usually the one behind the last one
+    size_t idx = t.outCovLast + 1;
+    if (idx >= X.id.size() || X.id[idx] != id) {
+        const auto it = std::find(X.id.begin(), X.id.end(), id);
+        if (it == X.id.end())
+            throw std::out_of_range("getOutputCovById: unknown id");
+        idx = (size_t)(it - X.id.begin());
+    }
+    t.outCovLast = idx;
     const eqvio_camera cam = toEqvioCamera(*camPtr);
     const double key[10] = {(double)cam.model, cam.fx, cam.fy, cam.cx, cam.cy, cam.dist[0], cam.dist[1], cam.dist[2], cam.dist[3], cam.dist[4]};
-    eqvio_mi355x::DeviceTwin& t = twin;
     if (!t.outCovValid || t.outCov.size() != 4 * X.id.size() || !std::equal(key, key + 10, t.outCovCam)) {
         t.outCov.assign(4 * X.id.size(), 0.0);
         check(eqf_output_cov_all(ctx, &cam, t.outCov.data()), "getOutputCovById");
         std::copy(key, key + 10, t.outCovCam);
         t.outCovValid = true;
     }
-    const double* v = &t.outCov[4 * (size_t)(it - X.id.begin())];
+    const double* v = &t.outCov[4 * idx];
     Eigen::Matrix2d out;
     out(0, 0) = v[0], out(0, 1) = v[1], out(1, 0) = v[2], out(1, 1) = v[3];
     return out;

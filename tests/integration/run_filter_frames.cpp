@@ -146,6 +146,16 @@ int main(int argc, char** argv) {
             lm.p = Eigen::Vector3d(p[0], p[1], p[2]);
         }
     }
+    double seconds = 0.0, gainSeconds = 0.0; // gainSeconds: inside the reference's own dense gain-matrix constructors (VIOFilterSettings.h:176-206), caller side
+    int visionDataCounter = 0;
+    bool timedFrame = false;
+    const auto timed = [&](auto&& make) { // evaluates make() and books its time under gainSeconds
+        const auto g0 = std::chrono::steady_clock::now();
+        auto m = make();
+        if (timedFrame)
+            gainSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
+        return m;
+    };
     const auto add_fresh = [&](const Frame& fr) { // VIO_eqf::addNewLandmarks as src/VIOFilter.cpp:273-277 calls it
         if (fr.fresh.empty())
             return;
@@ -162,13 +172,12 @@ int main(int argc, char** argv) {
         if (!fresh_already_added)
             add_fresh(fr);
         if (!matched.camCoordinates.empty())
-            filterState.performVisionUpdate(matched, s.constructOutputGainMatrix(matched.camCoordinates.size()), s.useEquivariantOutput, s.useDiscreteInnovationLift);
+            filterState.performVisionUpdate(matched, timed([&] { return s.constructOutputGainMatrix(matched.camCoordinates.size()); }), s.useEquivariantOutput, s.useDiscreteInnovationLift);
         filterState.removeInvalidLandmarks();
     };
-    double seconds = 0.0;
-    int visionDataCounter = 0;
     for (int f = 0; f < nFrames; ++f) {
         const Frame& fr = plan[f];
+        timedFrame = f >= warm;
         const auto t0 = std::chrono::steady_clock::now();
         double totalTime = 0.0;
         IMUVelocity meanVelocity = IMUVelocity::Zero();
@@ -181,7 +190,7 @@ int main(int argc, char** argv) {
             filterState.stageMeasurement(fr.vision); // the measurement travels to HBM inside the propagation kernel
             eqvio_mi355x::fusedPropagation(filterState, s, meanVelocity, totalTime, fr.samples, fr.dt);
         } else {
-            filterState.integrateRiccatiStateFast(meanVelocity, totalTime, s.constructInputGainMatrix(), s.constructStateGainMatrix(filterState.xi0.cameraLandmarks.size()));
+            filterState.integrateRiccatiStateFast(meanVelocity, totalTime, s.constructInputGainMatrix(), timed([&] { return s.constructStateGainMatrix(filterState.xi0.cameraLandmarks.size()); }));
             for (size_t i = 0; i < fr.samples.size(); ++i)
                 filterState.integrateObserverState(fr.samples[i], fr.dt[i], s.useDiscreteVelocityLift);
         }
@@ -246,6 +255,6 @@ int main(int argc, char** argv) {
         }
     }
     std::fclose(fout);
-    std::printf("frames %d seconds %.9f updates_per_s %.3f\n", visionDataCounter, seconds, visionDataCounter / seconds);
+    std::printf("frames %d seconds %.9f updates_per_s %.3f gain_matrix_seconds %.9f\n", visionDataCounter, seconds, visionDataCounter / seconds, gainSeconds);
     return 0;
 }

@@ -106,8 +106,15 @@ struct DeviceTwin {
     // the 2 x 2 output covariances of ALL landmarks in one device call (eqf_output_cov_all), the others are served from here. Not copied with the twin.
     std::vector<double> outCov;
     bool outCovValid = false;
+    size_t outCovLast = (size_t)-1; // index of the landmark the last getOutputCovById asked for
     double outCovCam[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // the camera the cache was computed for
     void touch() { deviceNewer = true, outCovValid = false; } // every mutating member
+    // Deferred propagation: VIOFilter::integrateUpToTime (src/VIOFilter.cpp:140-178) calls integrateRiccatiStateFast once and then integrateObserverState once per
+    // buffered IMU sample, and reads nothing of the filter in between. The binding records those calls and issues them as ONE eqf_propagate_fast (one launch instead
+    // of 2 + k) at the first member call that is not an observer step - same arithmetic (eqf_propagate_fast IS that sequence), same results bit for bit.
+    bool pendingRiccati = false, pendingDiscrete = false;
+    double pendingMean[13] = {0}, pendingDt = 0.0, pendingQd[12] = {0}, pendingPd8[8] = {0};
+    std::vector<double> pendingImu, pendingDts; // 13 doubles per deferred observer step
     DeviceTwin() = default;
     DeviceTwin(const DeviceTwin& o);
     DeviceTwin& operator=(const DeviceTwin& o);

@@ -102,7 +102,10 @@ def write_scenario(path, settings, cam, sensor, ids, p, t0, frames, plan):
 def run_driver(scenario, out, fused, state_every=0, sigma_every=0, warm=0, timeout=1200):
     res = subprocess.run([EXE, scenario, out, str(int(fused)), str(state_every), str(sigma_every), str(warm)], check=True, capture_output=True, text=True, timeout=timeout)
     tok = res.stdout.split()
-    return {"frames": int(tok[1]), "seconds": float(tok[3]), "updates_per_s": float(tok[5])}
+    out = {"frames": int(tok[1]), "seconds": float(tok[3]), "updates_per_s": float(tok[5])}
+    if len(tok) >= 8:  # time inside the reference's own dense gain-matrix constructors (caller side of the member-for-member sequence)
+        out["gain_matrix_seconds"] = float(tok[7])
+    return out
 
 
 def read_records(path):
