@@ -1020,10 +1020,10 @@ static int set_sigma_storage(eqf_ctx* c, bool f32) {
 }
 
 static int round_sigma(eqf_ctx* c, const int* spec, int spec_seq) {
-    if (c->opt_f32 != 1 || c->n() == 0) // 2 = real float storage: every store already rounds
+    if ((c->opt_f32 != 1 && c->opt_f32 != 3) || c->n() == 0) // 2 = real float storage: every store already rounds
         return 0;
     const int n = c->n();
-    hipLaunchKernelGGL(k_round_f32, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), spec, spec_seq);
+    hipLaunchKernelGGL(k_round_f32, dim3(blocks(n, 256), n), dim3(256), 0, c->stream, n, c->ld, c->sigma(), spec, spec_seq, c->opt_f32 == 3 ? 1 : 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1117,7 +1117,7 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     }
     case EQF_OPT_SIGMA_FP32: {
-        if (value < 0 || value > 2)
+        if (value < 0 || value > 3)
             return EQF_E_BAD_ARG;
         if (value == 2 && c->opt_dense)
             return EQF_E_UNSUPPORTED; // the float store exists for the structured fast path only

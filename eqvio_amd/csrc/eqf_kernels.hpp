@@ -2377,13 +2377,19 @@ __global__ void __launch_bounds__(256) k_set_diag(int n, int ld, const double* _
 }
 // count non-finite entries of Sigma (the reference's assert(!Sigma.hasNaN()))
 // EQF_OPT_SIGMA_FP32: numerical model of an fp32 Sigma store - every element rounded to the nearest float
-__global__ void __launch_bounds__(256) k_round_f32(int n, int ld, double* __restrict__ Sig, const int* __restrict__ spec, int spec_seq) {
+// mixed = 1 (EQF_OPT_SIGMA_FP32 = 3): only the landmark-landmark OFF-DIAGONAL 3 x 3 blocks are rounded; the 21 x 21 sensor block, the sensor-landmark
+// strips and the 3 x 3 landmark diagonal blocks (21 (n + 3 N) - 441 + 9 N entries: 4.6 % of Sigma at N = 200) keep their doubles - the numerical model of a store that
+// holds those separately in fp64
+__global__ void __launch_bounds__(256) k_round_f32(int n, int ld, double* __restrict__ Sig, const int* __restrict__ spec, int spec_seq, int mixed) {
     if (spec && *spec == spec_seq)
         return;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
-    if (r < n)
-        Sig[r + (size_t)c * ld] = (double)(float)Sig[r + (size_t)c * ld];
+    if (r >= n)
+        return;
+    if (mixed && (r < 21 || c < 21 || (r - 21) / 3 == (c - 21) / 3))
+        return;
+    Sig[r + (size_t)c * ld] = (double)(float)Sig[r + (size_t)c * ld];
 }
 // storage conversion between the two Sigma buffers (same leading dimension in elements)
 template <typename TI, typename TO>

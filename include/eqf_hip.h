@@ -101,6 +101,11 @@ enum {
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.
                                   1: numerical model of the same thing on the fp64 store: Sigma rounded to the nearest float after
                                      every store - bit-identical results to mode 2 (tests/test_gpu_fp32_sigma.py), any mode.
+                                  3: numerical model of a MIXED store (round 5): the 21 x 21 sensor block, the sensor-landmark strips and the 3 x 3 landmark
+                                     diagonal blocks keep their doubles (4.6 % of Sigma at 200 landmarks), only the landmark-landmark off-diagonal blocks are
+                                     rounded to float after every store. Against the fp64 oracle at <= 200 features: Sigma 1.2e-7, pose 1.0e-8, worst landmark
+                                     2.6e-6 (all-float store: 1.3e-5 / 2.4e-6 / 2.0e-4) - SURVEY's 1e-5 landmark bound holds. A model on the fp64 store only: the
+                                     HBM layout that goes with it (a float matrix + fp64 side arrays for the kept parts) is not built.
                                   0: fp64 (default). Switching converts the live Sigma. */
 };
 
