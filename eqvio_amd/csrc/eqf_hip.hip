@@ -2618,7 +2618,9 @@ static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
     c->h_flags[1] = c->h_resflags[1];
     // A failed factorisation is reported BEFORE anything of the filter changes: the device kept Sigma and the landmarks (k_lift,
     // k_syrk_sub), the sensor lift below is not applied.
-    if (c->h_resflags[3] && !c->h_flags[0] && c->tail_la && !retried) {
+    // (round 5, found by the concurrent time-out soak: a launch that gives up half way may ALSO have raised the pivot flag - its pivot wave goes on eliminating
+    // whatever is in its LDS until it notices - so the pivot flag of a stalled launch says nothing; the chain decides, from a cleared flag)
+    if (c->h_resflags[3] && c->tail_la && !retried) {
         // A bounded wait of the look-ahead kernel ran out: its workgroups were not all resident within the bound (another process or a long kernel
         // of this process holds the CUs). Nothing of the filter was modified, and Z / L_0^-1 are inputs of that kernel only: redo the factorisation
         // on the launch chain (which needs no co-residency), then lift and update Sigma as usual. Three stalls in a row switch the look-ahead
@@ -2637,6 +2639,7 @@ static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
         if (++c->la_consecutive_stalls >= 3)
             c->opt_lookahead = 0;
         HIPCHK(hipMemsetAsync(c->d_flags + 3, 0, sizeof(int), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
         const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
         const int door_seq = (int)(++c->door_seq);
         if (c->tail_zb) { // the stalled kernel had built Z in its registers: the chain needs it (and L_0^-1) in memory
@@ -2655,6 +2658,9 @@ static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
         return finish_update(c, discreteCorr, true);
     }
     if (c->h_resflags[3] || c->h_flags[0]) {
+        if (std::getenv("EQF_DEBUG_STATS"))
+            std::fprintf(stderr, "[eqf_hip] update failed: retried %d tail_la %d tail_zb %d resflags %d %d %d %d la_seq %d\n", (int)retried, (int)c->tail_la, (int)c->tail_zb, c->h_resflags[0],
+                         c->h_resflags[1], c->h_resflags[2], c->h_resflags[3], c->la_seq);
         c->est_valid = false;
         c->meas_valid = false;
         return c->h_resflags[3] ? EQF_E_STALLED : EQF_E_NOT_SPD;

@@ -322,3 +322,65 @@ def test_concurrent_persistent_kernels_stay_on_their_oracles(N, n_filters):
     assert all(la - fb >= 1 for la, fb in stats) or N == 500, stats  # and, where the grids fit the chip together, it also completed
     for j in jobs:
         j[2].close()
+
+
+def test_lookahead_timeouts_under_four_concurrent_contexts_soak():
+    """VERDICT r4 item 9: the hand-off protocol under its own failure handling, concurrently. Four contexts on four host threads update the same problem 36 times each;
+    before every update a context's EQF_OPT_LA_TIMEOUT_US is set to 0 (the launch gives up at its first wait), to a bound of the order of one panel step (8 us: gives up
+    somewhere in the middle, depending on what the other three contexts' kernels leave of the device) or to the default, the look-ahead kernel re-armed every time, the
+    HOME placement in turns. Whatever happens - completed, stalled at once, stalled half way and redone on the launch chain - Sigma+ of EVERY update must equal, bit for bit,
+    what the launch chain alone computes from the same state."""
+    import ctypes as C
+    import threading
+
+    from eqvio_amd.capi import OPT_LA_HOME, OPT_LA_TIMEOUT_US, OPT_LOOKAHEAD, EqfCore
+    from util import CHARTS, default_camera, random_spd, reasonable_state, settings_for, synth_measurement
+
+    rng = np.random.default_rng(321)
+    N, reps = 200, 36
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N)
+    S = random_spd(rng, 21 + 3 * N)
+    settings = settings_for(CHARTS["invdepth"])
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0)
+    var = settings.measurementNoise**2
+    ref = EqfCore(N, CHARTS["invdepth"])
+    ref.set_option(OPT_LOOKAHEAD, 0)
+    ref.set_state(xi0, Xs, ids, q0, Q)
+    ref.set_sigma(S)
+    ref.vision_update(cam, mid, y, var, True, False)
+    S_ref = ref.get_sigma()
+    ref.close()
+    cores = [EqfCore(N, CHARTS["invdepth"]) for _ in range(4)]
+    errs, stalls = [], [0, 0, 0, 0]
+    barrier = threading.Barrier(4)
+
+    def work(t):
+        c = cores[t]
+        try:
+            barrier.wait()
+            for it in range(reps):
+                c.set_state(xi0, Xs, ids, q0, Q)
+                c.set_sigma(S)
+                c.set_option(OPT_LOOKAHEAD, 1)  # (three stalls in a row switch it off: re-armed)
+                c.set_option(OPT_LA_TIMEOUT_US, (0, 8, 20000)[(it + t) % 3])
+                c.set_option(OPT_LA_HOME, 2 if (it // 3 + t) % 2 else 0)
+                c.vision_update(cam, mid, y, var, True, False)
+                if not np.array_equal(c.get_sigma(), S_ref):
+                    errs.append((t, it, float(np.abs(c.get_sigma() - S_ref).max())))
+            a, b = C.c_long(), C.c_long()
+            assert c.lib.eqf_lookahead_stats(c.h, C.byref(a), C.byref(b), 0) == 0
+            stalls[t] = (a.value, b.value)
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for c in cores:
+        c.close()
+    assert not errs, errs[:4]
+    for launches, stalled in stalls:
+        assert launches == reps and stalled >= reps // 3, stalls  # every timeout-0 launch stalled; the 8 us ones may or may not
