@@ -596,6 +596,17 @@ bool VIOFilter::integrateUpToTime(const double& newTime) { // :134-192
 void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :194-241
     HP_SCOPE("processVisionData");
     loopTimer.startTiming("propagation");
+    // Round 5: the landmarks that are not in this measurement leave the state BEFORE the propagation instead of behind it (reference: :210-212 behind :196). The
+    // propagation is block triangular - a landmark's rows and columns depend on the sensor block and on themselves only - so marginalising a landmark out before or
+    // after it gives the other entries bit for bit, and the order matters to the clock: the removal is recorded on the host (7.6 us at 200 landmarks) and applied by the
+    // pass in front of the propagation kernel, which used to run while the GPU sat idle behind that kernel; now the host's share (this, and the new landmarks below)
+    // overlaps with kernels. Only when the propagation will really take place (integrateUpToTime's own precondition, :135): a frame it skips must not lose landmarks.
+    const bool willIntegrate = !(measurement.stamp <= filterState.currentTime || filterState.currentTime < 0 || velocityBuffer.empty());
+    const bool removedEarly = initialisedFlag && willIntegrate && settings->removeLostLandmarks;
+    if (removedEarly) {
+        HP_SCOPE("pv.removeOldLandmarks");
+        removeOldLandmarks(measurement.getIds());
+    }
     // The measurement is in hand before the propagation (VIOFilter.cpp:194-196): hand it to the device now, so that it travels to
     // HBM inside the propagation kernel instead of across PCIe in the update's first kernel (a hint: ignored if an id is unknown).
     if (initialisedFlag && settings->fastRiccati) {
@@ -612,7 +623,7 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     loopTimer.endTiming("propagation");
 
     loopTimer.startTiming("preprocessing");
-    if (settings->removeLostLandmarks) {
+    if (settings->removeLostLandmarks && !removedEarly) {
         HP_SCOPE("pv.removeOldLandmarks");
         removeOldLandmarks(measurement.getIds());
     }

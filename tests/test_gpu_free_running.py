@@ -100,3 +100,29 @@ def test_config2_euroc_structured_sine_50_landmarks_free_running():
     assert worst_state <= max(TOL, 2.0 * floor_state) and worst_sigma <= max(TOL, 2.0 * floor_sigma), (worst_state, floor_state, worst_sigma, floor_sigma)
     assert worst_state <= 1e-8 and worst_sigma <= 1e-9
     assert counters(flt)["la_launches"] >= 90
+
+
+@pytest.mark.parametrize("chart", [0, 1])  # Euclidean, InvDepth (the Normal chart's own free-running run: tests/test_gpu_normal_chart.py)
+def test_discrete_state_matrix_free_running(chart):
+    """useDiscreteStateMatrix (integrateRiccatiStateDiscrete, VIO_eqf.cpp:93-103) with device and oracle each on their OWN state for 20 frames - the
+    teacher-forced form (tests/test_gpu_filter.py::test_discrete_state_matrix_filter_run) bounds one frame's error and cannot see drift. The bound is not 1e-9: A_d is a
+    central difference with h = 6e-6 on both sides, whose rounding noise (eps / h = 4e-11 per entry, amplified by A_d Sigma A_d^T over ~10 IMU steps per frame) is the
+    reference's own; measured 6e-9 per frame teacher forced. Free running it may accumulate - it must not grow faster than linearly in the frames: 2e-7 after 20."""
+    from eqvio_amd.capi import VIOFilter
+    from eqvio_amd.simworld import SimWorld
+    from test_gpu_filter import compare, sim_settings
+
+    world = SimWorld(seed=13, num_points=500, max_features=14, trajectory="wave", noise_px=0.3)
+    settings = sim_settings(chart, fastRiccati=0, useDiscreteStateMatrix=1)
+    ids0, _ = world.vision(0.0)
+    sensor, ids, p = world.true_state(0.0, ids0)
+    orc = OracleFilter(settings, sensor, ids, p, 0.0)
+    flt = VIOFilter(settings, max_landmarks=48, sensor=sensor, ids=ids, p=p, time=0.0)
+    for k, (imus, stamp, mid, y) in enumerate(world.frames(20)):
+        for s in range(len(imus)):
+            orc.process_imu(imus[s])
+            flt.process_imu(imus[s])
+        orc.process_vision(stamp, world.cam, mid, y)
+        flt.process_vision(stamp, world.cam, mid, y)
+        compare(flt, orc, 1e-8 * (k + 1))
+    flt.close()
