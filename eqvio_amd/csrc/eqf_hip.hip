@@ -2129,7 +2129,9 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     // EQF_OPT_LA_HOME (up to 16 panels, a device of 8 XCDs x 32 compute units): the owner and the 2 NJ - 2 S half-rows are the blocks of ONE XCD (b & 7 == home), the T
     // half-rows (+ the statistics workgroup) are dealt to the other seven; the rest of the 8 x slots grid returns at once (eqf_lookahead.hpp: la_st_l)
     const int nT = a.NI - (2 * a.NJ - 1);
-    const bool home = c->opt_la_home && a.NJ <= 16 && c->cu_count == 256 && c->d_pubfl && (c->opt_la_home == 2 || c->la_home_force || device_to_itself(c));
+    // (from 6 panels on, unless forced: the 8 x slots grid costs a small kernel more than the shorter hops give it - N = 50: -2 %, N = 100: +3 %, N = 200: +2.3 %)
+    const bool home = c->opt_la_home && a.NJ <= 16 && c->cu_count == 256 && c->d_pubfl &&
+                      (c->opt_la_home == 2 || c->la_home_force || (a.NJ >= 6 && device_to_itself(c)));
     a.home = home ? c->la_home : -1;
     a.pubfl = c->d_pubfl;
     const int home_grid = 8 * std::max(2 * a.NJ - 1, blocks(nT + (zb >= 2 ? 1 : 0), 7));
