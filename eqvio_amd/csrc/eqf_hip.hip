@@ -2218,10 +2218,23 @@ static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, 
     for (int i = 0; i < c->N; ++i)
         measof[i] = -1;
     bool all = true, ident = true;
+    // The landmark ids of the state are usually ascending as well (a tracker numbers its features as they appear, removals keep the order, new landmarks are appended
+    // with larger ids): then one merge pass maps the measurement - no sorted lookup table to rebuild (3-4 us at 200 landmarks, on every frame that gains or loses a
+    // landmark) and no binary searches
+    bool state_ascending = true;
+    for (int i = 1; i < c->N && state_ascending; ++i)
+        state_ascending = c->ids[i] > c->ids[i - 1];
+    int h = 0;
     for (int j = 0; j < M; ++j) {
         if (j > 0 && ids[j] <= ids[j - 1])
             return EQF_E_BAD_ARG; // must be strictly ascending (std::map order)
-        const int i = index_of(c, ids[j]);
+        int i;
+        if (state_ascending) {
+            while (h < c->N && c->ids[h] < ids[j])
+                ++h;
+            i = (h < c->N && c->ids[h] == ids[j]) ? h : -1;
+        } else
+            i = index_of(c, ids[j]);
         lmidx[j] = i;
         ident = ident && i == j;
         if (i >= 0)

@@ -43,6 +43,8 @@ void VisionMeasurement::refreshFlat() const {
     // noticing. The cache is therefore trusted only after ONE walk over the map that compares every id and both pixel values (O(M), no allocation;
     // about as long as the two allocations a rebuild would cost); the first difference rebuilds it.
     const size_t n = camCoordinates.size();
+    if (flatTrusted_ && flatN_ == n && flatIds_.size() == n)
+        return; // validated at the start of the call that holds this measurement (Validated)
     if (flatN_ == n && flatIds_.size() == n) {
         size_t j = 0;
         for (auto it = camCoordinates.begin(); it != camCoordinates.end(); ++it, ++j)
@@ -595,6 +597,7 @@ bool VIOFilter::integrateUpToTime(const double& newTime) { // :134-192
 }
 void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :194-241
     HP_SCOPE("processVisionData");
+    const VisionMeasurement::Validated oneWalk(measurement); // the flat arrays of the measurement, validated once for this call
     loopTimer.startTiming("propagation");
     // Round 5: the landmarks that are not in this measurement leave the state BEFORE the propagation instead of behind it (reference: :210-212 behind :196). The
     // propagation is block triangular - a landmark's rows and columns depend on the sensor block and on themselves only - so marginalising a landmark out before or
@@ -605,7 +608,7 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     const bool removedEarly = initialisedFlag && willIntegrate && settings->removeLostLandmarks;
     if (removedEarly) {
         HP_SCOPE("pv.removeOldLandmarks");
-        removeOldLandmarks(measurement.getIds());
+        removeOldLandmarks(measurement.flatIds());
     }
     // The measurement is in hand before the propagation (VIOFilter.cpp:194-196): hand it to the device now, so that it travels to
     // HBM inside the propagation kernel instead of across PCIe in the update's first kernel (a hint: ignored if an id is unknown).
@@ -625,7 +628,7 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     loopTimer.startTiming("preprocessing");
     if (settings->removeLostLandmarks && !removedEarly) {
         HP_SCOPE("pv.removeOldLandmarks");
-        removeOldLandmarks(measurement.getIds());
+        removeOldLandmarks(measurement.flatIds());
     }
     // With a fixed initial depth (both shipped dataset configurations) a new landmark depends on its pixel only, and the outlier test
     // never looks at it (it is not in the state yet in the reference's order; here its residual is zero by construction): appending the
