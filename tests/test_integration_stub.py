@@ -37,9 +37,10 @@ def test_binding_compiles_and_links(tmp_path):
     exe = build(tmp_path)
     syms = subprocess.run(["nm", "-C", "--undefined-only", exe], check=True, capture_output=True, text=True).stdout
     used = {ln.split()[-1] for ln in syms.splitlines() if " eqf_" in ln}
-    # every member the reference declares forwards to the ABI: these are the entry points the binding pulls from libeqf_hip.so
+    # every member the reference declares forwards to the ABI: these are the entry points the binding pulls from libeqf_hip.so (integrateRiccatiStateFast
+    # through eqf_propagate_fast since round 5: it is issued together with the observer steps that follow it)
     assert {"eqf_create", "eqf_destroy", "eqf_set_state", "eqf_get_state", "eqf_set_sigma", "eqf_get_sigma", "eqf_get_sigma_block", "eqf_integrate_observer",
-            "eqf_integrate_riccati_fast", "eqf_integrate_riccati_accurate", "eqf_integrate_riccati_discrete", "eqf_vision_update", "eqf_state_estimate",
+            "eqf_propagate_fast", "eqf_integrate_riccati_accurate", "eqf_integrate_riccati_discrete", "eqf_vision_update", "eqf_state_estimate",
             "eqf_compute_nees", "eqf_add_landmarks", "eqf_remove_landmarks", "eqf_remove_invalid_landmarks", "eqf_get_ids", "eqf_output_cov_all"} <= used, used
 
 
