@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.environ.get("EQVIO_AMD_LIB_DIR") or os.path.join(_HERE, "lib")  # the override: same-box A/B of two builds (scripts/ab_builds.sh)
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_LA_TIMEOUT_US, OPT_Z_IN_LOOKAHEAD, OPT_LA_SPLIT_ROWS, OPT_MEASURE_IN_PROPAGATE, OPT_LIFT_WITH_SYRK, OPT_LA_HOME, OPT_TIMING = 1, 2, 3, 6, 7, 8, 9, 11, 12, 15, 17, 18, 19, 20, 21, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_LA_TIMEOUT_US, OPT_Z_IN_LOOKAHEAD, OPT_LA_SPLIT_ROWS, OPT_MEASURE_IN_PROPAGATE, OPT_LIFT_WITH_SYRK, OPT_LA_HOME, OPT_TILES_PER_WORKGROUP, OPT_TIMING = 1, 2, 3, 6, 7, 8, 9, 11, 12, 15, 17, 18, 19, 20, 21, 22, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)

@@ -181,6 +181,7 @@ struct eqf_ctx {
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int opt_zb = 1;                          // EQF_OPT_Z_IN_LOOKAHEAD
     int opt_la_split = 1;                    // EQF_OPT_LA_SPLIT_ROWS
+    int opt_prop_tpw = 1;                    // EQF_OPT_TILES_PER_WORKGROUP
     int opt_measure_prop = 1;                // EQF_OPT_MEASURE_IN_PROPAGATE
     int opt_lift_syrk = 1;                   // EQF_OPT_LIFT_WITH_SYRK
     // ... its state: what the propagation kernel's observer blocks evaluated the output blocks with (camera and C / C* of the LAST update call stand in for the
@@ -1040,6 +1041,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_FUSED_ASSEMBLY: *value = c->opt_fuse_asm; return 0;
     case EQF_OPT_Z_IN_LOOKAHEAD: *value = c->opt_zb; return 0;
     case EQF_OPT_LA_SPLIT_ROWS: *value = c->opt_la_split; return 0;
+    case EQF_OPT_TILES_PER_WORKGROUP: *value = c->opt_prop_tpw; return 0;
     case EQF_OPT_LA_HOME: *value = c->opt_la_home; return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE: *value = c->opt_measure_prop; return 0;
     case EQF_OPT_LIFT_WITH_SYRK: *value = c->opt_lift_syrk; return 0;
@@ -1083,6 +1085,11 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_LA_HOME:
         c->opt_la_home = value < 0 ? 0 : std::min(value, 2); // 2: also when the device is shared (tests)
+        return 0;
+    case EQF_OPT_TILES_PER_WORKGROUP:
+        if (value < 0 || value > 8)
+            return EQF_E_BAD_ARG;
+        c->opt_prop_tpw = value;
         return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE:
         c->opt_measure_prop = value ? 1 : 0;
@@ -1345,7 +1352,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1636,9 +1643,23 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
     if (!c->opt_dense) {
         const int nT = blocks(N, PT);
         const bool sym = nT > 16;           // more tiles than fit the chip in one round: lower triangle only, mirrored (k_propagate_main)
-        const int nStrip = 0;               // (no strip workgroups: the landmark-sensor strips are written by the tile workgroups)
-        const int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
         const int nObs = (obs && obs_k > 0) ? blocks(N, PROP_T) : 0;
+        // Lower triangle: tpw consecutive tiles of a block row per workgroup, the smallest tpw with which every workgroup of the launch is resident at once (one of
+        // these workgroups per compute unit: a second ROUND costs a whole tile chain, a second tile of the same block row about a third of one; k_propagate_main)
+        int tpw = 1, nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
+        if (sym && c->opt_prop_tpw) {
+            auto wgs = [&](int t) {
+                int w = 0;
+                for (int r = 0; r < nT; ++r)
+                    w += (r + t) / t;
+                return w;
+            };
+            while (tpw < 8 && wgs(tpw) + 2 + nObs > c->cu_count)
+                ++tpw;
+            if (c->opt_prop_tpw > 1)
+                tpw = c->opt_prop_tpw; // forced (A/B)
+            nTiles = wgs(tpw);
+        }
         StageArgs sg{};
         if (c->stage_pending) { // one more block copies the staged measurement from the pinned packet to HBM
             sg.M = c->staged_M;
@@ -1667,7 +1688,7 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
         }
         KTimer t(c, KN_PROP_MAIN);
         auto launch = [&](auto kern, auto* sin, auto* sout) {
-            hipLaunchKernelGGL(kern, dim3(nTiles + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, sin, sout, c->d_Al, c->d_Bl, nT, nStrip,
+            hipLaunchKernelGGL(kern, dim3(nTiles + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, sin, sout, c->d_Al, c->d_Bl, nT, tpw,
                                nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa, me);
         };
 #define PROP_LAUNCH(TS_, F_) \
@@ -3152,7 +3173,6 @@ int eqf_debug_syrk_order(int nt, int* tile_of_block) {
     build_syrk_order(nt, tile_of_block);
     return 0;
 }
-
 int eqf_lookahead_stats(eqf_ctx* c, long* launches, long* fallbacks, int reset) {
     if (!c)
         return EQF_E_BAD_ARG;

@@ -1426,7 +1426,7 @@ template <typename TS, bool FUSED, bool SYM = false> // FUSED: fused assembly; S
                                                       // branch it cost the N = 200 frame 0.6 us)
 __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
-                                                        const double* __restrict__ Bl, int nT, int nStrip, const ObsSteps obs, int obs_k,
+                                                        const double* __restrict__ Bl, int nT, int tpw, const ObsSteps obs, int obs_k,
                                                         const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
                                                         trace_t* tr, const FuseArgs fa, const MeasEval me) {
     trace_start(tr);
@@ -1437,9 +1437,18 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
     // tile workgroups (N = 500: 1024 -> 528, one per CU at a time: 45 -> 32 us). Up to 16 tiles per side all tiles fit the chip in one round and the full
     // form is 1 us faster (the block row's 21 strip columns spread over more workgroups, no strided mirror stores).
     constexpr bool sym = SYM;
-    nStrip = 0;
-    const int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
+    constexpr int nStrip = 0;
+    // Round 5, SYM only: tpw > 1 consecutive tiles of ONE block row per workgroup. A tile is a dependent chain of ~10 us (loads -> assembly -> G_i -> blocks -> stores) and this
+    // kernel's 168 VGPRs allow one workgroup of 12 waves per CU: 528 tiles (N = 500) ran as three rounds of that chain. The host picks the smallest tpw with which all tile
+    // workgroups are resident at once; the i side (Sigma strips, assembly, G_i) is then formed once per workgroup. Same sums per entry: bit-identical for every tpw.
+    int nTiles = sym ? nT * (nT + 1) / 2 : nT * nT;
+    if (sym && tpw > 1) {
+        nTiles = 0;
+        for (int r_ = 0; r_ < nT; ++r_)
+            nTiles += (r_ + tpw) / tpw;
+    }
     __shared__ double sm[2 * PT * (63 + 36 + 9 + 9) + 63 * PT + 12 * 21 + 8];
+    __shared__ double sJ1[PT * (63 + 36 + 9 + 9)]; // the j side of a workgroup's odd tiles (several tiles per workgroup: tile it + 1 is staged while tile it computes)
     if (b > nTiles + nStrip + nObs) {
         // Staging block (eqf_stage_measurement): the coming frame's measurement moves from the pinned host packet to HBM while Sigma
         // is being propagated, so that the update's first kernel finds it next to the state instead of across PCIe.
@@ -1504,6 +1513,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         return;
     }
     __shared__ double sSens[21 * 33]; // per strip column of this workgroup: row c of A_ss (21) | row c of B_s (12)
+    __shared__ double sSens1[21 * 33]; // ... of an odd tile
     __shared__ double s_cm[66];
     if (FUSED) {
         for (int t = tid; t < 66; t += PROP_T)
@@ -1512,205 +1522,248 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
     }
     if (b < nTiles) {
         // tile (bi, bj), bi >= bj, of the lower triangle in row-major order: b = bi (bi + 1) / 2 + bj
-        int bi = b % nT, bj = b / nT;
-        if (sym) {
+        int bi = b % nT, bj0 = b / nT, ntile = 1;
+        if (sym && tpw > 1) {
+            int base = 0;
+            bi = 0;
+            for (;;) {
+                const int w_ = (bi + tpw) / tpw; // workgroups of block row bi
+                if (b < base + w_)
+                    break;
+                base += w_;
+                ++bi;
+            }
+            bj0 = (b - base) * tpw;
+            ntile = min(tpw, bi + 1 - bj0);
+        } else if (sym) {
             bi = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
             while (bi * (bi + 1) / 2 > b)
                 --bi;
             while ((bi + 1) * (bi + 2) / 2 <= b)
                 ++bi;
-            bj = b - bi * (bi + 1) / 2;
+            bj0 = b - bi * (bi + 1) / 2;
         }
-        const int nb = sym ? bi + 1 : nT; // workgroups of this block row: they share its 21 strip columns
+        const int nb = sym ? bi + 1 : nT; // tiles of this block row: they share its 21 strip columns
         // per-i arrays: G (63), Fls (36), D (9), Bl (9) ; per-j arrays: Ssj (63), Fls (36), D (9), Bl (9). layout [e][PT]
+        // The j side exists twice (parity of the tile inside the workgroup): with several tiles per workgroup the loads and the assembly of tile it + 1 are issued
+        // in front of the arithmetic of tile it and are in flight during it - one barrier per tile.
         double* sGi = sm;
         double* sFi = sGi + 63 * PT;
         double* sDi = sFi + 36 * PT;
         double* sBi = sDi + 9 * PT;
-        double* sSj = sBi + 9 * PT;
-        double* sFj = sSj + 63 * PT;
-        double* sDj = sFj + 36 * PT;
-        double* sBj = sDj + 9 * PT;
-        double* sSi = sBj + 9 * PT;   // Sigma[k][l_i + c'] at [(k*3 + c') * PT + x]
-        double* sSs = sSi + 63 * PT;  // Sigma_ss[al_col(e)][k] at [e * 21 + k], e < 12
-        for (int t = tid; t < 63 * PT; t += PROP_T) {
-            const int e = t / PT, x = t % PT;
-            const int i = bi * PT + x, j = bj * PT + x;
-            // Sigma[k][l + c'] with e = k*3 + c'
-            const int kk = e / 3, cc = e % 3;
-            sSi[t] = i < N ? Sig[kk + (size_t)(21 + 3 * i + cc) * ld] : 0.0;
-            sSj[t] = j < N ? Sig[kk + (size_t)(21 + 3 * j + cc) * ld] : 0.0;
-        }
-        if (tid < 12 * 21)
-            sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
-        // the strip columns this workgroup writes (below): c = bj, bj + nb, ... ; their rows of the sensor blocks go to LDS
-        const int ncol = bj < 21 ? (21 - bj + nb - 1) / nb : 0;
-        for (int t = PROP_T - 1 - tid; t < ncol * 33; t += PROP_T) { // taken from the top of the workgroup: the first lanes assemble
-            const int m_ = t / 33, e = t % 33;
-            const int c = bj + nb * m_;
-            sSens[t] = e < 21 ? (FUSED ? sensor_Ass_entry(fa.ck, c * 21 + e) : cm->Ass[c * 21 + e]) : (FUSED ? sensor_Bs_entry(fa.ck, c * 12 + (e - 21)) : cm->Bs[c * 12 + (e - 21)]);
-        }
-        if (FUSED) {
-            // Three wavefronts assemble: lanes 0..2PT-1 of waves 0, 1, 2 take part 0, 1, 2 (assemble_landmark) of the PT i-landmarks and
-            // the PT j-landmarks; the other threads are loading Sigma meanwhile.
-            const int part = tid >> 6, lane_ = tid & 63;
-            if (part < 3 && lane_ < 2 * PT) {
-                const bool isj = lane_ >= PT;
-                const int x = lane_ % PT;
-                const int l = (isj ? bj : bi) * PT + x;
-                double* dF = isj ? sFj : sFi;
-                double* dD = isj ? sDj : sDi;
-                double* dB = isj ? sBj : sBi;
-                double al[45], bl[9];
+        double* sJ0 = sBi + 9 * PT;            // j side, parity 0: Ssj (63) | Fls (36) | D (9) | Bl (9)
+        double* sSi = sJ0 + 117 * PT;          // Sigma[k][l_i + c'] at [(k*3 + c') * PT + x]
+        double* sSs = sSi + 63 * PT;           // Sigma_ss[al_col(e)][k] at [e * 21 + k], e < 12
+        const int r = tid / (PT * PT), tp = tid % (PT * PT); // main part: lane = (output row r, landmark pair (ti, tj))
+        const int ti = tp % PT, tj = tp / PT;
+        // stage A of tile `it`: everything its arithmetic reads from LDS (the i side with the workgroup's first tile)
+        auto stage = [&](const int it) {
+            const bool first = it == 0;
+            const int bj = bj0 + it;
+            double* sSj = (it & 1) ? sJ1 : sJ0;
+            double* sFj = sSj + 63 * PT;
+            double* sDj = sFj + 36 * PT;
+            double* sBj = sDj + 9 * PT;
+            double* sSn = (it & 1) ? sSens1 : sSens;
+            for (int t = tid; t < 63 * PT; t += PROP_T) {
+                const int e = t / PT, x = t % PT;
+                const int i = bi * PT + x, j = bj * PT + x;
+                // Sigma[k][l + c'] with e = k*3 + c'
+                const int kk = e / 3, cc = e % 3;
+                if (first)
+                    sSi[t] = i < N ? Sig[kk + (size_t)(21 + 3 * i + cc) * ld] : 0.0;
+                sSj[t] = j < N ? Sig[kk + (size_t)(21 + 3 * j + cc) * ld] : 0.0;
+            }
+            if (first && tid < 12 * 21)
+                sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
+            // the strip columns this tile writes: c = bj, bj + nb, ... ; their rows of the sensor blocks go to LDS
+            const int ncol = bj < 21 ? (21 - bj + nb - 1) / nb : 0;
+            for (int t = PROP_T - 1 - tid; t < ncol * 33; t += PROP_T) { // taken from the top of the workgroup: the first lanes assemble
+                const int m_ = t / 33, e = t % 33;
+                const int c = bj + nb * m_;
+                sSn[t] = e < 21 ? (FUSED ? sensor_Ass_entry(fa.ck, c * 21 + e) : cm->Ass[c * 21 + e]) : (FUSED ? sensor_Bs_entry(fa.ck, c * 12 + (e - 21)) : cm->Bs[c * 12 + (e - 21)]);
+            }
+            if (FUSED) {
+                // Three wavefronts assemble: lanes 0..2PT-1 of waves 0, 1, 2 take part 0, 1, 2 (assemble_landmark) of the PT i-landmarks and
+                // the PT j-landmarks; the other threads are loading Sigma meanwhile.
+                const int part = tid >> 6, lane_ = tid & 63;
+                if (part < 3 && lane_ < 2 * PT && (first || lane_ >= PT)) {
+                    const bool isj = lane_ >= PT;
+                    const int x = lane_ % PT;
+                    const int l = (isj ? bj : bi) * PT + x;
+                    double* dF = isj ? sFj : sFi;
+                    double* dD = isj ? sDj : sDi;
+                    double* dB = isj ? sBj : sBi;
+                    double al[45], bl[9];
 #pragma unroll
-                for (int e = 0; e < 45; ++e)
-                    al[e] = 0.0;
+                    for (int e = 0; e < 45; ++e)
+                        al[e] = 0.0;
 #pragma unroll
-                for (int e = 0; e < 9; ++e)
-                    bl[e] = 0.0;
-                const bool in = l < N;
-                const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
-                const int lc = in ? l : 0;
-                const V3 p0_ = ld3(q0, Ncap, lc);
-                const Qt q_ = ldq(Qq, Ncap, lc);
-                const double a_ = Qa[lc];
-                const M3 e2i = ind ? ld_cc(q0, Ncap, lc, CC_E2I) : M3{};
-                if (part == 0) {
-                    if (in)
-                        assemble_landmark<0>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
+                    for (int e = 0; e < 9; ++e)
+                        bl[e] = 0.0;
+                    const bool in = l < N;
+                    const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
+                    const int lc = in ? l : 0;
+                    const V3 p0_ = ld3(q0, Ncap, lc);
+                    const Qt q_ = ldq(Qq, Ncap, lc);
+                    const double a_ = Qa[lc];
+                    const M3 e2i = ind ? ld_cc(q0, Ncap, lc, CC_E2I) : M3{};
+                    if (part == 0) {
+                        if (in)
+                            assemble_landmark<0>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
+                        for (int rr = 0; rr < 3; ++rr) {
 #pragma unroll
-                        for (int c = 0; c < 6; ++c)
-                            dF[(r * 12 + c) * PT + x] = in ? dt * al[r * 15 + c] : 0.0;
+                            for (int c = 0; c < 6; ++c)
+                                dF[(rr * 12 + c) * PT + x] = in ? dt * al[rr * 15 + c] : 0.0;
 #pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            dB[(r * 3 + c) * PT + x] = bl[r * 3 + c];
+                            for (int c = 0; c < 3; ++c)
+                                dB[(rr * 3 + c) * PT + x] = bl[rr * 3 + c];
+                        }
+                    } else if (part == 1) {
+                        if (in)
+                            assemble_landmark<1>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
+#pragma unroll
+                        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                            for (int c = 6; c < 12; ++c)
+                                dF[(rr * 12 + c) * PT + x] = in ? dt * al[rr * 15 + c] : 0.0;
+                    } else {
+                        if (in)
+                            assemble_landmark<2>(s_cm, fa.chart, p0_, q_, a_, e2i, ind ? ld_cc(q0, Ncap, lc, CC_I2E) : M3{}, al, bl);
+#pragma unroll
+                        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                dD[(rr * 3 + c) * PT + x] = in ? dt * al[rr * 15 + 12 + c] + ((rr == c) ? 1.0 : 0.0) : 0.0;
                     }
-                } else if (part == 1) {
-                    if (in)
-                        assemble_landmark<1>(s_cm, fa.chart, p0_, q_, a_, e2i, M3{}, al, bl);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 6; c < 12; ++c)
-                            dF[(r * 12 + c) * PT + x] = in ? dt * al[r * 15 + c] : 0.0;
-                } else {
-                    if (in)
-                        assemble_landmark<2>(s_cm, fa.chart, p0_, q_, a_, e2i, ind ? ld_cc(q0, Ncap, lc, CC_I2E) : M3{}, al, bl);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            dD[(r * 3 + c) * PT + x] = in ? dt * al[r * 15 + 12 + c] + ((r == c) ? 1.0 : 0.0) : 0.0;
+                }
+            } else {
+                for (int t = tid; t < 36 * PT; t += PROP_T) {
+                    const int e = t / PT, x = t % PT;
+                    const int rr = e / 12, c = e % 12;
+                    const int i = bi * PT + x, j = bj * PT + x;
+                    if (first)
+                        sFi[t] = i < N ? dt * Al[(rr * 15 + c) * Ncap + i] : 0.0;
+                    sFj[t] = j < N ? dt * Al[(rr * 15 + c) * Ncap + j] : 0.0;
+                }
+                for (int t = tid; t < 9 * PT; t += PROP_T) {
+                    const int e = t / PT, x = t % PT;
+                    const int rr = e / 3, c = e % 3;
+                    const int i = bi * PT + x, j = bj * PT + x;
+                    const double eye = (rr == c) ? 1.0 : 0.0;
+                    if (first) {
+                        sDi[t] = i < N ? dt * Al[(rr * 15 + 12 + c) * Ncap + i] + eye : 0.0;
+                        sBi[t] = i < N ? Bl[e * Ncap + i] : 0.0;
+                    }
+                    sDj[t] = j < N ? dt * Al[(rr * 15 + 12 + c) * Ncap + j] + eye : 0.0;
+                    sBj[t] = j < N ? Bl[e * Ncap + j] : 0.0;
                 }
             }
-        } else {
-            for (int t = tid; t < 36 * PT; t += PROP_T) {
-                const int e = t / PT, x = t % PT;
-                const int r = e / 12, c = e % 12;
-                const int i = bi * PT + x, j = bj * PT + x;
-                sFi[t] = i < N ? dt * Al[(r * 15 + c) * Ncap + i] : 0.0;
-                sFj[t] = j < N ? dt * Al[(r * 15 + c) * Ncap + j] : 0.0;
-            }
-            for (int t = tid; t < 9 * PT; t += PROP_T) {
-                const int e = t / PT, x = t % PT;
-                const int r = e / 3, c = e % 3;
-                const int i = bi * PT + x, j = bj * PT + x;
-                const double eye = (r == c) ? 1.0 : 0.0;
-                sDi[t] = i < N ? dt * Al[(r * 15 + 12 + c) * Ncap + i] + eye : 0.0;
-                sDj[t] = j < N ? dt * Al[(r * 15 + 12 + c) * Ncap + j] + eye : 0.0;
-                sBi[t] = i < N ? Bl[e * Ncap + i] : 0.0;
-                sBj[t] = j < N ? Bl[e * Ncap + j] : 0.0;
-            }
-        }
+        };
+        stage(0);
         __syncthreads();
         // G_i[r][k] = sum_e (dt A_ls_i)[r][e] Sigma_ss[al_col(e)][k] + sum_c' (I + dt A_qi)[r][c'] Sigma[l_i + c'][k]
         for (int t = tid; t < 63 * PT; t += PROP_T) {
             const int e = t / PT, x = t % PT;
-            const int r = e / 21, k = e % 21;
+            const int rr = e / 21, k = e % 21;
             double g = 0.0;
 #pragma unroll
             for (int q = 0; q < 12; ++q)
-                g += sFi[(r * 12 + q) * PT + x] * sSs[q * 21 + k];
+                g += sFi[(rr * 12 + q) * PT + x] * sSs[q * 21 + k];
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc)
-                g += sDi[(r * 3 + cc) * PT + x] * sSi[(k * 3 + cc) * PT + x];
+                g += sDi[(rr * 3 + cc) * PT + x] * sSi[(k * 3 + cc) * PT + x];
             sGi[t] = g;
         }
         __syncthreads();
-        {
-            // Landmark-sensor strips of the PT i-landmarks: Sigma'[l_i + r][c] = sum_k G_i[r][k] Fss[c][k] + dt sum_q Bl_i[r][q] Qd[q] Bs[c][q].
-            // G_i is in LDS here anyway; the nT workgroups of this block row share the 21 columns (c = bj, bj + nT, ...), at most a few
-            // outputs per workgroup. Same sums, in the same order, as a separate strip pass would evaluate.
-            for (int t = tid; t < PT * 3 * ncol; t += PROP_T) {
-                const int x = t % PT, rc = t / PT;
-                const int r = rc % 3, m_ = rc / 3, c = bj + nb * m_;
-                const int i = bi * PT + x;
-                if (i < N) {
-                    double sacc = 0;
-                    for (int k = 0; k < 21; ++k) {
-                        const double f = dt * sSens[m_ * 33 + k] + (k == c ? 1.0 : 0.0);
-                        sacc += sGi[(r * 21 + k) * PT + x] * f;
+        for (int it = 0; it < ntile; ++it) {
+            const int bj = bj0 + it;
+            const double* sSj = (it & 1) ? sJ1 : sJ0;
+            const double* sFj = sSj + 63 * PT;
+            const double* sDj = sFj + 36 * PT;
+            const double* sBj = sDj + 9 * PT;
+            const double* sSn = (it & 1) ? sSens1 : sSens;
+            const int ncol = bj < 21 ? (21 - bj + nb - 1) / nb : 0;
+            const int i = bi * PT + ti, j = bj * PT + tj;
+            const bool mine = !(i >= N || j >= N || (sym && bi == bj && i < j)); // (a diagonal tile: the pairs above the diagonal are mirrors too)
+            const int li = 21 + 3 * i, lj = 21 + 3 * j;
+            // Sigma_ij: requested first ...
+            double Sij[3][3];
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        Sij[k][c] = Sig[li + k + (size_t)(lj + c) * ld];
+            }
+            // ... then the next tile's stage (other parity: its last readers passed the barrier at the end of tile it - 1) ...
+            if (it + 1 < ntile)
+                stage(it + 1);
+            {
+                // Landmark-sensor strips of the PT i-landmarks: Sigma'[l_i + r][c] = sum_k G_i[r][k] Fss[c][k] + dt sum_q Bl_i[r][q] Qd[q] Bs[c][q].
+                // G_i is in LDS here anyway; the nT tiles of this block row share the 21 columns (c = bj, bj + nT, ...), at most a few
+                // outputs per tile. Same sums, in the same order, as a separate strip pass would evaluate.
+                for (int t = tid; t < PT * 3 * ncol; t += PROP_T) {
+                    const int x = t % PT, rc = t / PT;
+                    const int rr = rc % 3, m_ = rc / 3, c = bj + nb * m_;
+                    const int ii = bi * PT + x;
+                    if (ii < N) {
+                        double sacc = 0;
+                        for (int k = 0; k < 21; ++k) {
+                            const double f = dt * sSn[m_ * 33 + k] + (k == c ? 1.0 : 0.0);
+                            sacc += sGi[(rr * 21 + k) * PT + x] * f;
+                        }
+                        double bq = 0;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            bq += sBi[(rr * 3 + q) * PT + x] * ra.Qd[q] * sSn[m_ * 33 + 21 + q];
+                        sacc += dt * bq;
+                        const int lii = 21 + 3 * ii;
+                        Sout[lii + rr + (size_t)c * ld] = sacc;
+                        Sout[c + (size_t)(lii + rr) * ld] = sacc;
                     }
+                }
+            }
+            // ... and this tile's blocks: three lanes share a 3x3 block, each produces one row of it. The per-element sums run in the same order as a
+            // one-lane-per-block version would (results are bit-identical to it).
+            if (mine) {
+                // E[r][:] = (Fls_i Sigma_sj + D_i Sigma_ij)[r][:]
+                double E[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double s = 0;
+#pragma unroll
+                    for (int e = 0; e < 12; ++e)
+                        s += sFi[(r * 12 + e) * PT + ti] * sSj[(al_col(e) * 3 + c) * PT + tj];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        s += sDi[(r * 3 + k) * PT + ti] * Sij[k][c];
+                    E[c] = s;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double s = 0;
+#pragma unroll
+                    for (int e = 0; e < 12; ++e)
+                        s += sGi[(r * 21 + al_col(e)) * PT + ti] * sFj[(c * 12 + e) * PT + tj];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        s += E[k] * sDj[(c * 3 + k) * PT + tj];
                     double bq = 0;
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
-                        bq += sBi[(r * 3 + q) * PT + x] * ra.Qd[q] * sSens[m_ * 33 + 21 + q];
-                    sacc += dt * bq;
-                    const int li = 21 + 3 * i;
-                    Sout[li + r + (size_t)c * ld] = sacc;
-                    Sout[c + (size_t)(li + r) * ld] = sacc;
+                        bq += sBi[(r * 3 + q) * PT + ti] * ra.Qd[q] * sBj[(c * 3 + q) * PT + tj];
+                    s += dt * bq;
+                    if (i == j && r == c)
+                        s += dt * ra.Pd[7];
+                    Sout[li + r + (size_t)(lj + c) * ld] = s;
+                    if (sym && i != j)
+                        Sout[lj + c + (size_t)(li + r) * ld] = s; // Sigma'_ji = Sigma'_ij^T: exactly symmetric between landmark blocks, half the tiles
                 }
             }
-        }
-        // lane = (output row r, landmark pair (ti, tj)): three lanes share a 3x3 block, each produces one row of it. The
-        // per-element sums run in the same order as a one-lane-per-block version would (results are bit-identical to it).
-        const int r = tid / (PT * PT), tp = tid % (PT * PT);
-        const int ti = tp % PT, tj = tp / PT;
-        const int i = bi * PT + ti, j = bj * PT + tj;
-        if (i >= N || j >= N || (sym && bi == bj && i < j)) // (a diagonal tile: the pairs above the diagonal are mirrors too)
-            return;
-        const int li = 21 + 3 * i, lj = 21 + 3 * j;
-        // Sigma_ij
-        double Sij[3][3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                Sij[k][c] = Sig[li + k + (size_t)(lj + c) * ld];
-        // E[r][:] = (Fls_i Sigma_sj + D_i Sigma_ij)[r][:]
-        double E[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double s = 0;
-#pragma unroll
-            for (int e = 0; e < 12; ++e)
-                s += sFi[(r * 12 + e) * PT + ti] * sSj[(al_col(e) * 3 + c) * PT + tj];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                s += sDi[(r * 3 + k) * PT + ti] * Sij[k][c];
-            E[c] = s;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double s = 0;
-#pragma unroll
-            for (int e = 0; e < 12; ++e)
-                s += sGi[(r * 21 + al_col(e)) * PT + ti] * sFj[(c * 12 + e) * PT + tj];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                s += E[k] * sDj[(c * 3 + k) * PT + tj];
-            double bq = 0;
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                bq += sBi[(r * 3 + q) * PT + ti] * ra.Qd[q] * sBj[(c * 3 + q) * PT + tj];
-            s += dt * bq;
-            if (i == j && r == c)
-                s += dt * ra.Pd[7];
-            Sout[li + r + (size_t)(lj + c) * ld] = s;
-            if (sym && i != j)
-                Sout[lj + c + (size_t)(li + r) * ld] = s; // Sigma'_ji = Sigma'_ij^T: exactly symmetric between landmark blocks, half the tiles
+            if (it + 1 < ntile)
+                __syncthreads(); // the next tile's stage is complete, this tile's readers are done with their parity
         }
         return;
     }

@@ -96,6 +96,9 @@ enum {
                                   2.0 us per hop. What the T half-rows on the other XCDs read is written through a second time. Same arithmetic: bit-identical to 0 and to the
                                   launch chain. Checked at eqf_create (self-test; every home workgroup compares HW_REG_XCC_ID with the XCD it expects) and switched off for the
                                   context if the device deals its blocks differently. eqf_lookahead_home reports the home and the launches that used it. 0: classic placement */
+    EQF_OPT_TILES_PER_WORKGROUP = 22, /* 1 (default): above 256 landmarks (lower-triangle form of the propagation kernel) a workgroup takes as many consecutive tiles of one block
+                                  row as it needs for ALL tile workgroups of the launch to be resident at once (N = 500: 3, 187 workgroups instead of 528 in three rounds) and forms
+                                  the i side of its tiles once. Same sums per entry: bit-identical. 0: one tile per workgroup; k > 1: k tiles (tests, A/B) */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.

@@ -636,6 +636,42 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
         assert rel_fro(outs[1][0], orc.get_sigma()) <= 1e-9
 
 
+@pytest.mark.parametrize("N,M", [(330, 330), (400, 371), (500, 500), (512, 512)])
+def test_large_state_kernel_forms_are_bit_identical(N, M):
+    """Round 5, above 256 landmarks: the propagation kernel's workgroups take several tiles of a block row each (EQF_OPT_TILES_PER_WORKGROUP; both assembly forms: the
+    stand-alone Riccati step reads the assembled A / B terms, eqf_propagate_fast assembles them in the kernel). Every entry is the same sum in the same order as with one
+    tile per workgroup: Sigma must not change by a bit over two frames, whatever the number of tiles per workgroup."""
+    from eqvio_amd.capi import OPT_TILES_PER_WORKGROUP
+
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=3 * N + M, useDiscreteInnovationLift=0)
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=np.sort(rng.permutation(N)[:M]))
+    imus = [random_imu(rng) for _ in range(4)]
+    dts = [0.005] * 4
+    mean = np.mean(imus, axis=0)
+    y2 = y + rng.normal(size=y.shape) * 0.5
+    outs = []
+    for tpw in (0, 1, 2, 5):
+        c = EqfCore(N, CHARTS["invdepth"])
+        c.set_state(xi0, Xs, ids, q0, Q)
+        c.set_sigma(S)
+        c.set_option(OPT_TILES_PER_WORKGROUP, tpw)
+        trail = []
+        c.integrate_riccati_fast(imus[0], 0.02, settings.input_gain_diag12(), settings.state_gain_diag8())
+        trail.append(c.get_sigma())
+        c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+        trail.append(c.get_sigma())
+        c.propagate_fast(mean, sum(dts), settings.input_gain_diag12(), settings.state_gain_diag8(), imus, dts, True)
+        trail.append(c.get_sigma())
+        c.vision_update(cam, mid, y2, settings.measurementNoise**2, True, False)
+        trail.append(c.get_sigma())
+        outs.append(trail)
+    for trail in outs[1:]:
+        for k, (a, b) in enumerate(zip(trail, outs[0])):
+            assert np.array_equal(a, b), (N, k, np.abs(a - b).max())
+    assert np.all(np.isfinite(outs[0][-1])) and np.array_equal(outs[0][-1], outs[0][-1].T)
+
+
 def test_lookahead_factorisation_soak():
     """The hand-offs of the persistent kernel under repetition: fresh contexts (zeroed buffers, sequence 1) and one context reused
     (every word of the previous launch still in place), every result compared bit by bit with the launch chain's."""
