@@ -2904,7 +2904,12 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         // Outlier candidates frame after frame (speculation has backed off): statistics, the outlier decision (k_select_outliers: the discarded
         // landmarks' measurements are masked out of C) and the whole update queued at once, ONE host wait. The discarded landmarks leave the
         // state after the update (an unmeasured landmark can be marginalised before or after it).
-        {
+        if (N <= SEL_ONE_WG) { // statistics and decision as one launch of one workgroup
+            KTimer t(c, KN_STATS);
+            LAUNCH_TS(c, k_stats_select, dim3(1), dim3(256), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
+                      (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, thrAbs, thrProb, max_outliers, M, c->h_sel);
+            HIPCHK(hipGetLastError());
+        } else {
             KTimer t(c, KN_STATS);
             LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(),
                       c->Qa(), (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, (int*)nullptr, c->h_door, seq, thrAbs, thrProb,

@@ -668,6 +668,67 @@ __global__ void __launch_bounds__(256) k_select_outliers(int N, int Ncap, int M,
     }
 }
 
+// k_outlier_stats and k_select_outliers as ONE launch of one workgroup (round 5; up to SEL_ONE_WG landmarks): in a frame whose outlier decision is taken on the device the
+// host queues statistics, decision and the whole update back to back, and its launch calls (5 - 6 us each) - not the kernels in front of the factorisation - set the pace
+// of that part of the frame. Same arithmetic per landmark (outlier_stats_body), same ranking: identical results to the two launches.
+constexpr int SEL_ONE_WG = 512;
+template <typename TS>
+__global__ void __launch_bounds__(256) k_stats_select(int N, int Ncap, int ld, int chart, Cam cam, const double* __restrict__ ylm, const double* __restrict__ q0,
+                                                      const double* __restrict__ Qq, const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
+                                                      double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags, double thrAbs,
+                                                      double thrProb, int max_outliers, int M, int* __restrict__ removed_host) {
+    __shared__ double s_val[SEL_ONE_WG];
+    __shared__ signed char s_kind[SEL_ONE_WG]; // 0: no candidate, 1: probabilistic, 2: absolute
+    __shared__ unsigned char s_rm[SEL_ONE_WG];
+    __shared__ int s_cnt[2];
+    const int tid = threadIdx.x;
+    if (tid < 2)
+        s_cnt[tid] = 0;
+    for (int i = tid; i < N; i += 256) {
+        double a = -1.0, p = -1.0; // stay negative for a landmark without a measurement
+        outlier_stats_body<TS>(N, Ncap, ld, chart, cam, ylm, q0, Qq, Qa, Sig, out, star, C, ytil, lmidx_dev, flags, a, p, true, i);
+        const bool measured = a >= 0.0;
+        const bool isabs = measured && a > thrAbs; // the comparisons of VIOFilter.cpp:316, 330 (NaN: false)
+        const bool isprob = measured && !isabs && p > thrProb;
+        s_kind[i] = isabs ? 2 : (isprob ? 1 : 0);
+        s_val[i] = isabs ? a : p;
+    }
+    __threadfence(); // C / yTilde / the index map are in memory before another thread of this workgroup masks or reads them
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        int rank = 0;
+        const int ki = s_kind[i];
+        const double vi = s_val[i];
+        if (ki) {
+            for (int j = 0; j < N; ++j) {
+                const int kj = s_kind[j];
+                rank += (kj > ki) || (kj == ki && (s_val[j] > vi || (s_val[j] == vi && j < i)));
+            }
+            atomicAdd(&s_cnt[0], 1);
+        }
+        const bool rm = ki && rank < max_outliers;
+        s_rm[i] = rm;
+        removed_host[i] = rm ? 1 : 0;
+        if (rm)
+            atomicAdd(&s_cnt[1], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        removed_host[Ncap] = s_cnt[0];
+        removed_host[Ncap + 1] = s_cnt[1];
+    }
+    for (int j = tid; j < M; j += 256) {
+        const int li = __hip_atomic_load(lmidx_dev + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_rm[li]) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                C[e * Ncap + j] = 0.0;
+            ytil[2 * j] = 0.0;
+            ytil[2 * j + 1] = 0.0;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K8b: blocked right-looking factorisation of Z = [S ; T ; y^T], ONE kernel launch per 32-column panel.
 //
