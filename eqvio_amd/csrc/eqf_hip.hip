@@ -182,6 +182,8 @@ struct eqf_ctx {
     int opt_zb = 1;                          // EQF_OPT_Z_IN_LOOKAHEAD
     int opt_la_split = 1;                    // EQF_OPT_LA_SPLIT_ROWS
     int opt_prop_tpw = 1;                    // EQF_OPT_TILES_PER_WORKGROUP
+    int opt_gather = 1;                      // EQF_OPT_GATHER_IN_PROPAGATE
+    long gather_launches = 0;                // propagation launches that applied a removal record themselves
     int opt_measure_prop = 1;                // EQF_OPT_MEASURE_IN_PROPAGATE
     int opt_lift_syrk = 1;                   // EQF_OPT_LIFT_WITH_SYRK
     // ... its state: what the propagation kernel's observer blocks evaluated the output blocks with (camera and C / C* of the LAST update call stand in for the
@@ -1042,6 +1044,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_Z_IN_LOOKAHEAD: *value = c->opt_zb; return 0;
     case EQF_OPT_LA_SPLIT_ROWS: *value = c->opt_la_split; return 0;
     case EQF_OPT_TILES_PER_WORKGROUP: *value = c->opt_prop_tpw; return 0;
+    case EQF_OPT_GATHER_IN_PROPAGATE: *value = c->opt_gather; return 0;
     case EQF_OPT_LA_HOME: *value = c->opt_la_home; return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE: *value = c->opt_measure_prop; return 0;
     case EQF_OPT_LIFT_WITH_SYRK: *value = c->opt_lift_syrk; return 0;
@@ -1090,6 +1093,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         if (value < 0 || value > 8)
             return EQF_E_BAD_ARG;
         c->opt_prop_tpw = value;
+        return 0;
+    case EQF_OPT_GATHER_IN_PROPAGATE:
+        c->opt_gather = value ? 1 : 0;
         return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE:
         c->opt_measure_prop = value ? 1 : 0;
@@ -1352,7 +1358,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1586,7 +1592,8 @@ int eqf_remove_invalid_landmarks(eqf_ctx* c) {
     return rc ? rc : (int)bad.size();
 }
 
-static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs = nullptr, int obs_k = 0, bool fused = false);
+static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs = nullptr, int obs_k = 0, bool fused = false,
+                                  const GatherArgs* gather = nullptr);
 int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
     if (!c || !imu13 || !Qdiag12 || !Pdiag8)
         return EQF_E_BAD_ARG;
@@ -1620,7 +1627,7 @@ static int normal_congruence(eqf_ctx* c, int dir, double dt, const double* Pdiag
     c->cur = 1 - c->cur;
     return 0;
 }
-static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs, int obs_k, bool fused) {
+static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs, int obs_k, bool fused, const GatherArgs* gather) {
     int rc = 0;
     c->me_valid = false; // whatever propagates Sigma (any mode) leaves output blocks of an earlier propagation behind
     static const ObsSteps kNoSteps{};
@@ -1686,10 +1693,18 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
             me.ylm = c->h_ylm, me.C = c->d_C, me.ytil = c->d_ytil, me.lmidx_dev = c->d_lmidx;
             c->me_valid = true, c->me_cam = c->pred_cam, c->me_star = c->pred_star, c->me_M = sg.M, c->me_gen = c->staged_gen;
         }
+        // EQF_OPT_GATHER_IN_PROPAGATE: the landmarks removed since the last kernel leave inside this launch (eqf_propagate_fast decided; fused assembly + observer blocks)
+        GatherArgs ga{};
+        if (gather) {
+            if (!(fused && nObs))
+                return EQF_E_UNSUPPORTED; // (eqf_propagate_fast checks the same conditions before it asks for this)
+            ga = *gather;
+            ga.st_in = c->d_st[c->stcur], ga.st_out = c->d_st[1 - c->stcur];
+        }
         KTimer t(c, KN_PROP_MAIN);
         auto launch = [&](auto kern, auto* sin, auto* sout) {
             hipLaunchKernelGGL(kern, dim3(nTiles + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, sin, sout, c->d_Al, c->d_Bl, nT, tpw,
-                               nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa, me);
+                               nObs ? *obs : kNoSteps, nObs ? obs_k : 0, c->q0(), c->Qq(), c->Qa(), nObs, sg, trace_slot(c, TR_PROPAGATE), fa, me, ga);
         };
 #define PROP_LAUNCH(TS_, F_) \
     do { \
@@ -1713,6 +1728,12 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
         HIPCHK(hipGetLastError());
         if (fused && nObs)
             c->lmcur = 1 - c->lmcur;
+        if (gather) { // what flush_reshape does behind its pass
+            c->stcur = 1 - c->stcur;
+            c->dev_N = N;
+            c->reshape_pending = false;
+            ++c->gather_launches;
+        }
     } else {
         // dense: F materialised, tmp = F Sigma (= (Sigma F^T)^T, Sigma symmetric), Sigma' = tmp F^T + noise
         const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
@@ -2027,7 +2048,34 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     HP_SCOPE("abi.propagate_fast");
     if (!c || !imu13_mean || !Qdiag12 || !Pdiag8 || k < 0 || (k > 0 && (!imu13_k || !dt_k)))
         return EQF_E_BAD_ARG;
-    { int _e = enter(c); if (_e) return _e; }
+    // EQF_OPT_GATHER_IN_PROPAGATE: a pending record of removals only (the frame's lost landmarks, the last frame's discarded outliers) is applied by the propagation kernel
+    // itself instead of a compaction pass in front of it - when this call takes the fused kernel with observer blocks, the record is short and nothing was appended
+    GatherArgs gather{};
+    bool use_gather = false;
+    if (c->reshape_pending && c->opt_gather && c->opt_fuse_asm && !c->opt_dense && !c->sig32 && c->chart != EQVIO_COORD_NORMAL && k > 0 && k <= eqf_ctx::kMaxSteps &&
+        c->pend_var.empty() && c->N > 0 && (int)c->pend_map.size() == c->N && c->dev_N > c->N && c->dev_N <= GATHER_MAXN) {
+        int prev = -1;
+        bool ok = true;
+        for (int i = 0; i < c->N && ok; ++i) {
+            const int o = c->pend_map[i];
+            ok = o > prev && o < c->dev_N; // survivors keep their order
+            if (ok)
+                gather.surv[o >> 6] |= 1ull << (o & 63);
+            prev = o;
+        }
+        if (ok) {
+            gather.n = c->dev_N - c->N;
+            use_gather = true;
+        }
+    }
+    if (use_gather) { // enter() without the flush
+        HIPCHK(hipSetDevice(c->device));
+        c->ocov_valid = false;
+    } else {
+        int _e = enter(c);
+        if (_e)
+            return _e;
+    }
     ++c->trace_frame; // EQF_OPT_TRACE: a frame starts here
     host_stamp(c, TH_PROP_ENTRY);
     // 1. A / B terms at the CURRENT X (before the observer steps move it): integrateRiccatiStateFast uses X as it is
@@ -2074,7 +2122,13 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     c->obs_one_chunk = chunks.size() == 1; // (the group elements are final when the propagation kernel's observer blocks are done)
     {
         HP_SCOPE("pf.launch");
-        rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0, fuse);
+        if (use_gather && !(ride && fuse)) { // (cannot happen: the conditions above are the ones of `ride` and `fuse`) - apply the record the ordinary way
+            rc = flush_reshape(c);
+            if (rc)
+                return rc;
+            use_gather = false;
+        }
+        rc = riccati_after_assemble(c, dt_total, Qdiag12, Pdiag8, ride ? &chunks[0] : nullptr, ride ? counts[0] : 0, fuse, use_gather ? &gather : nullptr);
     }
     if (rc)
         return rc;
@@ -3159,6 +3213,14 @@ int eqf_measure_in_propagate_stats(eqf_ctx* c, long* used, int reset) {
     *used = c->me_used;
     if (reset)
         c->me_used = 0;
+    return 0;
+}
+int eqf_gather_stats(eqf_ctx* c, long* launches, int reset) {
+    if (!c || !launches)
+        return EQF_E_BAD_ARG;
+    *launches = c->gather_launches;
+    if (reset)
+        c->gather_launches = 0;
     return 0;
 }
 int eqf_speculation_stats(eqf_ctx* c, long* calls, long* queued, long* cancelled, int reset) {

@@ -377,6 +377,78 @@ struct MeasEval {
     double *C, *ytil;
     int* lmidx_dev;
 };
+// Round 5: landmarks that left the state since the last kernel (lost features, discarded outliers: a record of removals only) leave INSIDE the propagation kernel - it
+// reads Sigma and the landmark planes at their old positions and writes the other buffers at the new ones anyway - instead of in a compaction pass of its own in front of
+// it (k_reshape_args: one launch and a 3 MB copy per frame of a feature tracker's normal turnover). old(i) = i + #{r : rem[r] - r <= i} for the ascending old indices
+// rem[0 .. n) of the removed landmarks; the observer blocks also move the origin points and chart constants (st planes) to the other buffer. n = 0: nothing to do.
+constexpr int GATHER_WORDS = 8, GATHER_MAXN = 64 * GATHER_WORDS; // up to 512 landmarks in the buffers the launch reads
+struct GatherArgs {
+    int n;                                 // landmarks removed (0: nothing to do)
+    unsigned long long surv[GATHER_WORDS]; // bit o set: the landmark at the old position o survives; landmark i of the new state is the (i + 1)-th set bit
+    const double* st_in;                   // q0 + chart constants, (CC_OFF + CC_PLANES) planes of stride Ncap
+    double* st_out;
+};
+// position of the k-th (0-based) set bit of x (k < popcount(x))
+__device__ __forceinline__ int select64(unsigned long long x, int k) {
+    int pos = 0;
+    unsigned v = (unsigned)x;
+    int c = __popc(v);
+    if (k >= c) {
+        k -= c;
+        pos = 32;
+        v = (unsigned)(x >> 32);
+    }
+    c = __popc(v & 0xffffu);
+    if (k >= c) {
+        k -= c;
+        pos += 16;
+        v >>= 16;
+    }
+    c = __popc(v & 0xffu);
+    if (k >= c) {
+        k -= c;
+        pos += 8;
+        v >>= 8;
+    }
+    c = __popc(v & 0xfu);
+    if (k >= c) {
+        k -= c;
+        pos += 4;
+        v >>= 4;
+    }
+    c = __popc(v & 0x3u);
+    if (k >= c) {
+        k -= c;
+        pos += 2;
+        v >>= 2;
+    }
+    if (k >= (int)(v & 1u))
+        pos += 1;
+    return pos;
+}
+// the old position of landmark i of the new state: a few dozen VALU operations on the survivor mask in the argument segment (a table of removed indices walked entry by
+// entry cost the propagation kernel 2.3 us: one scalar load per entry in front of every Sigma load)
+__device__ __forceinline__ int gather_old(const GatherArgs& ga, int i) {
+    if (!ga.n)
+        return i;
+    int k = i, base = 0;
+    unsigned long long word = ga.surv[0];
+    bool found = false;
+#pragma unroll
+    for (int w = 0; w < GATHER_WORDS; ++w) {
+        const unsigned long long x = ga.surv[w];
+        const int c = __popcll(x);
+        if (!found) {
+            if (k < c) {
+                found = true;
+                word = x;
+                base = 64 * w;
+            } else
+                k -= c;
+        }
+    }
+    return found ? base + select64(word, k) : i;
+}
 struct StageArgs {
     int M; // 0: nothing to stage
     const double *y_h, *ylm_h; // pinned host packet
@@ -1489,7 +1561,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
                                                         const double* __restrict__ Bl, int nT, int tpw, const ObsSteps obs, int obs_k,
                                                         const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
-                                                        trace_t* tr, const FuseArgs fa, const MeasEval me) {
+                                                        trace_t* tr, const FuseArgs fa, const MeasEval me, const GatherArgs ga) {
     trace_start(tr);
     const double dt = ra.dt;
     const int b = blockIdx.x;
@@ -1541,9 +1613,10 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         const ObsStep* steps_lds = reinterpret_cast<const ObsStep*>(sm);
         if (i < N) {
             if (FUSED) {
-                const V3 p0 = ld3(q0, Ncap, i);
-                Qt q = ldq(Qq, Ncap, i);
-                double a_ = Qa[i];
+                const int io = gather_old(ga, i); // where landmark i sits in the buffers this launch reads (its origin point and chart constants are moved by the sensor block's workgroup)
+                const V3 p0 = ld3(q0, Ncap, io);
+                Qt q = ldq(Qq, Ncap, io);
+                double a_ = Qa[io];
                 double yu = 0.0, yv = 0.0;
                 int jm = -1;
                 if (me.on) { // requested before the chain: a zero-copy read across PCIe
@@ -1559,7 +1632,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                 if (me.on && jm >= 0) {
                     // (the chain's last products must not be contracted into the evaluation's first sums: the same bits as an evaluation from the stored element)
                     asm volatile("" : "+v"(q.w), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(a_));
-                    const MeasOut o = measure_one(fa.chart, me.cam, p0, q, a_, yu, yv, me.star != 0, fa.chart == EQVIO_COORD_INVDEPTH ? ld_cc(q0, Ncap, i, CC_R0) : M3{});
+                    const MeasOut o = measure_one(fa.chart, me.cam, p0, q, a_, yu, yv, me.star != 0, fa.chart == EQVIO_COORD_INVDEPTH ? ld_cc(q0, Ncap, io, CC_R0) : M3{});
 #pragma unroll
                     for (int e = 0; e < 6; ++e)
                         me.C[e * me.Mcap + jm] = o.c[e];
@@ -1632,8 +1705,8 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                 // Sigma[k][l + c'] with e = k*3 + c'
                 const int kk = e / 3, cc = e % 3;
                 if (first)
-                    sSi[t] = i < N ? Sig[kk + (size_t)(21 + 3 * i + cc) * ld] : 0.0;
-                sSj[t] = j < N ? Sig[kk + (size_t)(21 + 3 * j + cc) * ld] : 0.0;
+                    sSi[t] = i < N ? Sig[kk + (size_t)(21 + 3 * gather_old(ga, i) + cc) * ld] : 0.0;
+                sSj[t] = j < N ? Sig[kk + (size_t)(21 + 3 * gather_old(ga, j) + cc) * ld] : 0.0;
             }
             if (first && tid < 12 * 21)
                 sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
@@ -1664,7 +1737,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                         bl[e] = 0.0;
                     const bool in = l < N;
                     const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
-                    const int lc = in ? l : 0;
+                    const int lc = in ? gather_old(ga, l) : 0;
                     const V3 p0_ = ld3(q0, Ncap, lc);
                     const Qt q_ = ldq(Qq, Ncap, lc);
                     const double a_ = Qa[lc];
@@ -1752,11 +1825,12 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             // Sigma_ij: requested first ...
             double Sij[3][3];
             if (mine) {
+                const int lio = 21 + 3 * gather_old(ga, i), ljo = 21 + 3 * gather_old(ga, j);
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        Sij[k][c] = Sig[li + k + (size_t)(lj + c) * ld];
+                        Sij[k][c] = Sig[lio + k + (size_t)(ljo + c) * ld];
             }
             // ... then the next tile's stage (other parity: its last readers passed the barrier at the end of tile it - 1) ...
             if (it + 1 < ntile)
@@ -1830,6 +1904,14 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
     }
     // sensor-sensor block
     {
+        if (FUSED && ga.n) {
+            // EQF_OPT_GATHER_IN_PROPAGATE: the origin points and chart constants of the surviving landmarks move to the other buffer (everything else of a landmark is
+            // rewritten by this kernel anyway); this workgroup has the shortest chain of the launch
+            for (int t = tid; t < (CC_OFF + CC_PLANES) * N; t += PROP_T) {
+                const int pl = t / N, i = t - pl * N;
+                ga.st_out[(size_t)pl * Ncap + i] = ga.st_in[(size_t)pl * Ncap + gather_old(ga, i)];
+            }
+        }
         double* sF = sm;        // 441
         double* sS = sm + 441;  // 441
         double* sT = sm + 882;  // 441  (F Sigma_ss)

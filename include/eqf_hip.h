@@ -99,6 +99,11 @@ enum {
     EQF_OPT_TILES_PER_WORKGROUP = 22, /* 1 (default): above 256 landmarks (lower-triangle form of the propagation kernel) a workgroup takes as many consecutive tiles of one block
                                   row as it needs for ALL tile workgroups of the launch to be resident at once (N = 500: 3, 187 workgroups instead of 528 in three rounds) and forms
                                   the i side of its tiles once. Same sums per entry: bit-identical. 0: one tile per workgroup; k > 1: k tiles (tests, A/B) */
+    EQF_OPT_GATHER_IN_PROPAGATE = 23, /* 1 (default): landmarks removed since the last kernel (eqf_remove_landmarks records; up to 512 landmarks in the state before, nothing appended in between)
+                                  leave the device state INSIDE the kernel of eqf_propagate_fast - it reads Sigma and the landmark planes at their old positions and writes the
+                                  other buffers at the new ones anyway - instead of in a compaction pass in front of it: one launch and a copy of Sigma less in every frame of a
+                                  feature tracker's normal turnover. Same values, same arithmetic: bit-identical. Not with the Normal chart, the dense mode or the float store;
+                                  eqf_gather_stats counts. 0: always the pass */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.
@@ -227,6 +232,8 @@ int eqf_stats_then_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids,
 int eqf_speculation_stats(eqf_ctx* ctx, long* calls, long* queued, long* cancelled, int reset);
 /* EQF_OPT_MEASURE_IN_PROPAGATE: update calls that used the output blocks evaluated by the propagation kernel in front (up to 16 panels: no k_build_Z launch). */
 int eqf_measure_in_propagate_stats(eqf_ctx* ctx, long* used, int reset);
+/* EQF_OPT_GATHER_IN_PROPAGATE: propagation launches that applied a record of removed landmarks themselves */
+int eqf_gather_stats(eqf_ctx* ctx, long* launches, int reset);
 /* eqf_stats_then_update with VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) made on the device where that saves the frame a host round trip:
  * while the speculative tail keeps getting cancelled (outlier candidates frame after frame, as with the shipped thresholds) the call queues the statistics,
  * the decision (candidates ranked absolute outliers first by absErr, then probabilistic ones by probErr, the first max_outliers = (size_t)((1 - featureRetention)

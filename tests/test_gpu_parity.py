@@ -636,6 +636,67 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
         assert rel_fro(outs[1][0], orc.get_sigma()) <= 1e-9
 
 
+@pytest.mark.parametrize("chart", ["euclid", "invdepth"])
+@pytest.mark.parametrize("N,drop", [(200, [3, 17, 18, 19, 100, 199]), (60, [0]), (60, [59]), (47, list(range(20, 44))), (300, [0, 1, 2, 63, 64, 65, 127, 128, 150, 299]), (33, list(range(1, 33))), (512, list(range(0, 512, 3)))])
+def test_removed_landmarks_leave_inside_the_propagation_kernel(chart, N, drop):
+    """EQF_OPT_GATHER_IN_PROPAGATE: a record of removals only is applied by eqf_propagate_fast's kernel itself (it reads the old positions, writes the new ones) instead of
+    a compaction pass in front of it. Against the same calls with the option off: Sigma, the landmark elements, the origin points and the next update must agree bit for bit;
+    first / last / a block of 24 / all but one landmark removed; above 256 landmarks (several tiles per workgroup); the record is NOT taken over when something was appended
+    or when no observer steps ride along (then the ordinary pass runs, same result)."""
+    import ctypes as C
+
+    from eqvio_amd.capi import OPT_GATHER_IN_PROPAGATE, load_eqf_lib
+
+    lib = load_eqf_lib()
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=5 * N + len(drop), useDiscreteInnovationLift=0)
+    cam = default_camera()
+    imus = [random_imu(rng) for _ in range(5)]
+    dts = [0.004] * 5
+    mean = np.mean(imus, axis=0)
+    keep = np.array([i for i in range(N) if i not in set(drop)])
+    outs = []
+    for opt in (0, 1):
+        c = EqfCore(N, CHARTS[chart])
+        c.set_state(xi0, Xs, ids, q0, Q)
+        c.set_sigma(S)
+        c.set_option(OPT_GATHER_IN_PROPAGATE, opt)
+        c.remove_landmarks(np.array(drop, np.int32))
+        c.propagate_fast(mean, sum(dts), settings.input_gain_diag12(), settings.state_gain_diag8(), imus, dts, True)
+        used = C.c_long()
+        assert lib.eqf_gather_stats(c.h, C.byref(used), 0) == 0
+        assert used.value == (1 if opt else 0), (opt, used.value)
+        trail = [c.get_sigma(), c.get_state()]
+        outs.append((c, trail))
+    (c0, t0), (c1, t1) = outs
+    assert np.array_equal(t0[0], t1[0])
+    for u, v in zip(t0[1], t1[1]):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+    assert t0[0].shape == (21 + 3 * len(keep),) * 2
+    # the same measurement on both contexts: the update reads the buffers the propagation left current (Sigma, landmark elements, origin points, chart constants)
+    ids_k, q0_k, Q_k = t1[1][2], t1[1][3], t1[1][4]
+    mid, y = synth_measurement(rng, cam, ids_k, q0_k, Q_k, noise_px=1.0)
+    for c in (c0, c1):
+        c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+    assert np.array_equal(c0.get_sigma(), c1.get_sigma())
+    for u, v in zip(c0.get_state(), c1.get_state()):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+    # a record with an appended landmark, and a propagation without observer steps: the ordinary pass, same results on both
+    if len(keep) >= 3:
+        new_id = np.array([int(np.max(ids)) + 7], np.int32)
+        new_p = np.array([[0.1, -0.2, 4.0]])
+        for c in (c0, c1):
+            c.remove_landmarks(np.array([1], np.int32))
+            c.add_landmarks(new_id, new_p, 1.5)
+            c.propagate_fast(mean, sum(dts), settings.input_gain_diag12(), settings.state_gain_diag8(), imus, dts, True)
+            c.remove_landmarks(np.array([0], np.int32))
+            c.integrate_riccati_fast(imus[0], 0.01, settings.input_gain_diag12(), settings.state_gain_diag8())
+        used = C.c_long()
+        assert lib.eqf_gather_stats(c1.h, C.byref(used), 0) == 0 and used.value == 1
+        assert np.array_equal(c0.get_sigma(), c1.get_sigma())
+        for u, v in zip(c0.get_state(), c1.get_state()):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
 @pytest.mark.parametrize("N,M", [(330, 330), (400, 371), (500, 500), (512, 512)])
 def test_large_state_kernel_forms_are_bit_identical(N, M):
     """Round 5, above 256 landmarks: the propagation kernel's workgroups take several tiles of a block row each (EQF_OPT_TILES_PER_WORKGROUP; both assembly forms: the
