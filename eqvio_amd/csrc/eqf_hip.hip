@@ -258,6 +258,7 @@ struct eqf_ctx {
     bool map_ident = false; // ... and measurement j is landmark j for every j
     bool tail_ident = false; // ... checked against the ids of the update being launched (launch_update_tail)
     std::vector<std::pair<int, int>> lookup; // sorted (id, index), valid for lookup_gen == lm_gen
+    std::vector<int> renum_scratch;
     unsigned lookup_gen = ~0u;
     // host-side wait statistics (eqf_host_wait_stats): doorbell waits and the time spent spinning in them
     // EQF_OPT_TRACE: device-side frame timeline (ring of TR_FRAMES frames x TR_SLOTS stamps, 100 MHz device wall clock)
@@ -669,7 +670,9 @@ int read_flags(eqf_ctx* c) {
 }
 // id -> state index. The filter looks up every measured id every frame: a sorted (id, index) table, rebuilt only when the
 // landmark set changes, makes that O(M log N) instead of O(M N).
-int index_of(eqf_ctx* c, int id) {
+// (round 5: eqf_add_landmarks / eqf_remove_landmarks keep the table up to date in O(N) - a feature source whose ids are not ascending in the state, like the synthetic
+// worlds', paid a 200-element sort in every frame with landmark turnover)
+void ensure_lookup(eqf_ctx* c) {
     if (c->lookup_gen != c->lm_gen || (int)c->lookup.size() != c->N) {
         c->lookup.resize(c->N);
         for (int i = 0; i < c->N; ++i)
@@ -677,6 +680,9 @@ int index_of(eqf_ctx* c, int id) {
         std::sort(c->lookup.begin(), c->lookup.end());
         c->lookup_gen = c->lm_gen;
     }
+}
+int index_of(eqf_ctx* c, int id) {
+    ensure_lookup(c);
     const auto it = std::lower_bound(c->lookup.begin(), c->lookup.end(), std::make_pair(id, -1));
     return (it != c->lookup.end() && it->first == id) ? it->second : -1;
 }
@@ -1511,9 +1517,19 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
         }
         c->est_cache.swap(e);
     }
+    const bool keep_lookup = c->lookup_gen == c->lm_gen && (int)c->lookup.size() == c->N;
+    if (keep_lookup) { // the sorted (id, index) table follows: k new pairs sorted and merged in
+        const size_t n0 = c->lookup.size();
+        for (int t = 0; t < k; ++t)
+            c->lookup.push_back({ids[t], c->N + t});
+        std::sort(c->lookup.begin() + n0, c->lookup.end());
+        std::inplace_merge(c->lookup.begin(), c->lookup.begin() + n0, c->lookup.end());
+    }
     c->ids.insert(c->ids.end(), ids, ids + k);
     c->N += k;
     ++c->lm_gen;
+    if (keep_lookup)
+        c->lookup_gen = c->lm_gen;
     c->meas_valid = false;
     return 0;
 }
@@ -1565,11 +1581,65 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
         }
         c->est_cache.swap(e);
     }
+    const bool keep_lookup = c->lookup_gen == c->lm_gen && (int)c->lookup.size() == N;
+    if (keep_lookup) { // the sorted (id, index) table follows: dropped entries out, the others renumbered
+        std::vector<int>& renum = c->renum_scratch;
+        renum.assign(N, -1);
+        for (int i = 0, w = 0; i < N; ++i)
+            if (!drop[i])
+                renum[i] = w++;
+        size_t o = 0;
+        for (const auto& e : c->lookup)
+            if (renum[e.second] >= 0)
+                c->lookup[o++] = {e.first, renum[e.second]};
+        c->lookup.resize(o);
+    }
     c->ids.swap(newids);
     c->N = Nnew;
     ++c->lm_gen;
+    if (keep_lookup)
+        c->lookup_gen = c->lm_gen;
     c->meas_valid = false;
     return 0;
+}
+
+// VIOFilter::removeOldLandmarks (VIOFilter.cpp:280-302) in one call: the landmarks of the state whose id is not among the (strictly ascending) measured ids leave the state
+// (recorded like eqf_remove_landmarks). Their indices, ascending, go to removed_idx (room for the current landmark count). O(N + M): one merge pass against the state's ids
+// when these ascend as well, else against the sorted (id, index) table.
+int eqf_remove_unmeasured_landmarks(eqf_ctx* c, const int* ids, int M, int* removed_idx, int* n_removed) {
+    HP_SCOPE("abi.remove_unmeasured");
+    if (!c || M < 0 || (M > 0 && !ids) || !removed_idx || !n_removed)
+        return EQF_E_BAD_ARG;
+    *n_removed = 0;
+    for (int j = 1; j < M; ++j)
+        if (ids[j] <= ids[j - 1])
+            return EQF_E_BAD_ARG;
+    const int N = c->N;
+    bool state_ascending = true;
+    for (int i = 1; i < N && state_ascending; ++i)
+        state_ascending = c->ids[i] > c->ids[i - 1];
+    int k = 0;
+    if (state_ascending) {
+        int q = 0;
+        for (int i = 0; i < N; ++i) {
+            while (q < M && ids[q] < c->ids[i])
+                ++q;
+            if (q == M || ids[q] != c->ids[i])
+                removed_idx[k++] = i;
+        }
+    } else {
+        ensure_lookup(c);
+        int q = 0;
+        for (const auto& e : c->lookup) { // ascending ids
+            while (q < M && ids[q] < e.first)
+                ++q;
+            if (q == M || ids[q] != e.first)
+                removed_idx[k++] = e.second;
+        }
+        std::sort(removed_idx, removed_idx + k);
+    }
+    *n_removed = k;
+    return k ? eqf_remove_landmarks(c, removed_idx, k) : 0;
 }
 
 int eqf_remove_invalid_landmarks(eqf_ctx* c) {
@@ -2289,6 +2359,7 @@ static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, 
     if (c->map_gen == c->lm_gen && c->map_N == c->N && (int)c->map_ids.size() == M && lmidx == c->h_lmidx && (M == 0 || std::memcmp(ids, c->map_ids.data(), sizeof(int) * M) == 0) &&
         (!require_all || c->map_all))
         return 0;
+    HP_SCOPE("mm.miss");
     c->map_gen = c->lm_gen - 1; // invalid until this call succeeds
     for (int i = 0; i < c->N; ++i)
         measof[i] = -1;
@@ -2300,6 +2371,8 @@ static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, 
     for (int i = 1; i < c->N && state_ascending; ++i)
         state_ascending = c->ids[i] > c->ids[i - 1];
     int h = 0;
+    if (!state_ascending)
+        ensure_lookup(c); // (kept up to date by eqf_add_landmarks / eqf_remove_landmarks: no sort in a frame with landmark turnover)
     for (int j = 0; j < M; ++j) {
         if (j > 0 && ids[j] <= ids[j - 1])
             return EQF_E_BAD_ARG; // must be strictly ascending (std::map order)
@@ -2308,8 +2381,11 @@ static int map_measurement(eqf_ctx* c, const int* ids, int M, bool require_all, 
             while (h < c->N && c->ids[h] < ids[j])
                 ++h;
             i = (h < c->N && c->ids[h] == ids[j]) ? h : -1;
-        } else
-            i = index_of(c, ids[j]);
+        } else { // the same merge against the sorted (id, index) table
+            while (h < c->N && c->lookup[h].first < ids[j])
+                ++h;
+            i = (h < c->N && c->lookup[h].first == ids[j]) ? c->lookup[h].second : -1;
+        }
         lmidx[j] = i;
         ident = ident && i == j;
         if (i >= 0)
@@ -2942,6 +3018,7 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
             }
         std::memcpy(c->h_y, y, sizeof(double) * 2 * M);
     }
+    HP_SCOPE("stu.after_map");
     const int seq = (int)(++c->door_seq);
     auto copy_stats = [&]() {
         if (absErr)

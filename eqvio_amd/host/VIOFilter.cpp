@@ -247,6 +247,28 @@ void VIO_eqf::removeLandmarksByIndex(const std::vector<int>& idx) {
             kept.push_back(ids_[i]);
     ids_ = kept;
 }
+// the landmarks whose id is not in the (ascending) measurement leave the state: one call of the core, which has the ids sorted (eqf_remove_unmeasured_landmarks)
+bool VIO_eqf::removeUnmeasured(const std::vector<int>& measurementIds) {
+    scratchIdx_.resize(ids_.size() + 1);
+    int n = 0;
+    const int rc = eqf_remove_unmeasured_landmarks(ctx, measurementIds.data(), (int)measurementIds.size(), scratchIdx_.data(), &n);
+    if (rc == EQF_E_BAD_ARG)
+        return false; // ids not ascending: the caller takes the general route
+    check(rc, "eqf_remove_unmeasured_landmarks");
+    if (n > 0) { // the indices are ascending: compact ids_ in place
+        size_t w = 0;
+        int t = 0;
+        for (size_t i = 0; i < ids_.size(); ++i) {
+            if (t < n && scratchIdx_[t] == (int)i) {
+                ++t;
+                continue;
+            }
+            ids_[w++] = ids_[i];
+        }
+        ids_.resize(w);
+    }
+    return true;
+}
 void VIO_eqf::removeLandmarkByIndex(const int& idx) { removeLandmarksByIndex({idx}); } // VIO_eqf.cpp:172-178
 void VIO_eqf::removeLandmarkById(const int& id) {                                      // VIO_eqf.cpp:180-186
     const auto it = std::find(ids_.begin(), ids_.end(), id);
@@ -768,17 +790,28 @@ void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std:
     filterState.addNewLandmarks(newLandmarks, settings->initialPointVariance);
 }
 void VIOFilter::removeOldLandmarks(const std::vector<int>& measurementIds) { // :280-302
+    if (filterState.removeUnmeasured(measurementIds)) // (ascending measurement ids, as a VisionMeasurement's are: one merge pass inside the core)
+        return;
     const std::vector<int>& have = filterState.ids();
     std::vector<int> lost;
-    const bool sorted = std::is_sorted(measurementIds.begin(), measurementIds.end()); // ids from a VisionMeasurement are
-    if (sorted && std::is_sorted(have.begin(), have.end())) { // both ascending (the usual case): one merge pass
-        size_t q = 0;
-        for (int i = 0; i < (int)have.size(); ++i) {
-            while (q < measurementIds.size() && measurementIds[q] < have[i])
-                ++q;
-            if (q == measurementIds.size() || measurementIds[q] != have[i])
-                lost.push_back(i);
+    bool bothSorted;
+    {
+        HP_SCOPE("ro.sorted");
+        bothSorted = std::is_sorted(measurementIds.begin(), measurementIds.end()) && std::is_sorted(have.begin(), have.end());
+    }
+    const bool sorted = bothSorted || std::is_sorted(measurementIds.begin(), measurementIds.end()); // ids from a VisionMeasurement are
+    if (bothSorted) { // both ascending (the usual case): one merge pass
+        {
+            HP_SCOPE("ro.merge");
+            size_t q = 0;
+            for (int i = 0; i < (int)have.size(); ++i) {
+                while (q < measurementIds.size() && measurementIds[q] < have[i])
+                    ++q;
+                if (q == measurementIds.size() || measurementIds[q] != have[i])
+                    lost.push_back(i);
+            }
         }
+        HP_SCOPE("ro.removeByIndex");
         filterState.removeLandmarksByIndex(lost);
         return;
     }

@@ -192,6 +192,7 @@ struct VIO_eqf {
     void removeLandmarkById(const int& id);
     void removeLandmarksByIndex(const std::vector<int>& idx); // batched form of the above
     void removeInvalidLandmarks();
+    bool removeUnmeasured(const std::vector<int>& measurementIds); // false: ids not ascending, nothing done
     std::array<double, 9> getLandmarkCovById(const int& id) const;
     void integrateObserverState(const IMUVelocity& imuVelocity, const double& dt, const bool& discreteLift = true);
     void integrateObserverStates(const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift); // batched
@@ -216,6 +217,7 @@ struct VIO_eqf {
 
   private:
     std::vector<int> ids_;
+    std::vector<int> scratchIdx_;
     void check(int rc, const char* what) const;
 };
 

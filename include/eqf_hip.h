@@ -158,6 +158,10 @@ int eqf_state_estimate(eqf_ctx* ctx, double* sensor, int* ids, double* p, int ca
 int eqf_add_landmarks(eqf_ctx* ctx, const int* ids, const double* p, int k, double var);
 /* VIO_eqf::removeLandmarkByIndex (VIO_eqf.cpp:172-178) for k indices at once (one compaction pass of Sigma). */
 int eqf_remove_landmarks(eqf_ctx* ctx, const int* indices, int k);
+/* VIOFilter::removeOldLandmarks (src/VIOFilter.cpp:280-302) in one call: every landmark of the state whose id is not among the M measured ids (strictly ascending, the order of
+ * a VisionMeasurement's std::map; EQF_E_BAD_ARG otherwise) leaves the state like eqf_remove_landmarks. removed_idx (room for the current landmark count) receives their
+ * indices, ascending, *n_removed their number. O(N + M) whatever the order of the ids in the state. */
+int eqf_remove_unmeasured_landmarks(eqf_ctx* ctx, const int* ids, int M, int* removed_idx, int* n_removed);
 /* VIO_eqf::removeInvalidLandmarks (VIO_eqf.cpp:213-223). Returns the number removed (>=0) or <0. */
 int eqf_remove_invalid_landmarks(eqf_ctx* ctx);
 

@@ -636,6 +636,68 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
         assert rel_fro(outs[1][0], orc.get_sigma()) <= 1e-9
 
 
+def test_remove_unmeasured_landmarks_and_the_id_table_under_turnover():
+    """eqf_remove_unmeasured_landmarks (VIOFilter::removeOldLandmarks, VIOFilter.cpp:280-302, in one call) and the sorted (id, index) table behind it, which
+    eqf_add_landmarks / eqf_remove_landmarks keep up to date instead of re-sorting: 60 rounds of random turnover with ids in NO particular order in the state (and a
+    stretch with ascending ids), every round checked against a plain numpy restatement - the indices removed, the ids left, and the id -> landmark mapping of a
+    measurement (through the outlier statistics: a measured landmark has absErr >= 0, an unmeasured one -1)."""
+    import ctypes as C
+
+    from eqvio_amd.capi import load_eqf_lib
+
+    lib = load_eqf_lib()
+    rng = np.random.default_rng(2024)
+    cam = default_camera()
+    for ascending in (False, True):
+        N = 40
+        rng2, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=11, cap=96)
+        ids = (np.sort(ids) if ascending else ids).astype(np.int32)
+        core.set_state(xi0, Xs, ids, q0, Q)
+        core.set_sigma(S)
+        cur = list(ids)
+        next_id = int(max(cur)) + 1
+        for rnd in range(60):
+            # a measurement of a random subset (ascending ids, as a VisionMeasurement's are)
+            keep = sorted(int(v) for v in rng.choice(cur, size=max(1, len(cur) - int(rng.integers(0, 6))), replace=False))
+            meas = np.array(keep, np.int32)
+            removed = np.zeros(len(cur) + 1, np.int32)
+            n = C.c_int()
+            assert lib.eqf_remove_unmeasured_landmarks(core.h, meas.ctypes.data_as(C.POINTER(C.c_int)), len(meas), removed.ctypes.data_as(C.POINTER(C.c_int)), C.byref(n)) == 0
+            expect = [i for i, v in enumerate(cur) if v not in set(keep)]
+            assert list(removed[: n.value]) == expect, (ascending, rnd)
+            cur = [v for v in cur if v in set(keep)]
+            assert list(core.get_state()[2]) == cur
+            # append a few landmarks with ids that do not ascend (or do, in the second pass)
+            k = int(rng.integers(0, 5))
+            if k:
+                new_ids = np.arange(next_id, next_id + k, dtype=np.int32)
+                next_id += k
+                if not ascending:
+                    new_ids = (new_ids * 7919) % 100003 + 1000  # scattered, distinct
+                    new_ids = np.array([v for v in new_ids if v not in set(cur)], np.int32)
+                    k = len(new_ids)
+                if k:
+                    core.add_landmarks(new_ids, rng.uniform(-1, 1, (k, 3)) + np.array([0, 0, 5.0]), 1.0)
+                    cur += [int(v) for v in new_ids]
+            # the mapping of a measurement of every second landmark
+            st = core.get_state()
+            sub = np.sort(np.array(cur)[:: 2]).astype(np.int32)
+            pos = {v: i for i, v in enumerate(cur)}
+            y = np.zeros((len(sub), 2))
+            for j, v in enumerate(sub):
+                p = st[3][pos[int(v)]]
+                y[j] = [cam.fx * p[0] / p[2] + cam.cx, cam.fy * p[1] / p[2] + cam.cy]
+            absErr, probErr, depth2 = core.outlier_stats(cam, sub, y.reshape(-1))
+            measured = set(int(v) for v in sub)
+            for i, v in enumerate(cur):
+                assert (absErr[i] != -1.0) == (v in measured), (ascending, rnd, i)
+    # ids that do not ascend are refused (the caller takes its general route)
+    bad = np.array([5, 3], np.int32)
+    n = C.c_int()
+    removed = np.zeros(200, np.int32)
+    assert lib.eqf_remove_unmeasured_landmarks(core.h, bad.ctypes.data_as(C.POINTER(C.c_int)), 2, removed.ctypes.data_as(C.POINTER(C.c_int)), C.byref(n)) == -3
+
+
 @pytest.mark.parametrize("chart", ["euclid", "invdepth"])
 @pytest.mark.parametrize("N,drop", [(200, [3, 17, 18, 19, 100, 199]), (60, [0]), (60, [59]), (47, list(range(20, 44))), (300, [0, 1, 2, 63, 64, 65, 127, 128, 150, 299]), (33, list(range(1, 33))), (512, list(range(0, 512, 3)))])
 def test_removed_landmarks_leave_inside_the_propagation_kernel(chart, N, drop):
