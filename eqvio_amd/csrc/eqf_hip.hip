@@ -1642,6 +1642,33 @@ int eqf_remove_unmeasured_landmarks(eqf_ctx* c, const int* ids, int M, int* remo
     return k ? eqf_remove_landmarks(c, removed_idx, k) : 0;
 }
 
+// The measured ids (strictly ascending) that have no landmark in the state - VIOFilter::addNewLandmarks' membership test (VIOFilter.cpp:258-278) in one merge pass:
+// unknown_j (room for M) receives their positions j in `ids`, ascending; *n_unknown their number.
+int eqf_find_unknown_ids(eqf_ctx* c, const int* ids, int M, int* unknown_j, int* n_unknown) {
+    HP_SCOPE("abi.find_unknown");
+    if (!c || M < 0 || (M > 0 && !ids) || !unknown_j || !n_unknown)
+        return EQF_E_BAD_ARG;
+    *n_unknown = 0;
+    for (int j = 1; j < M; ++j)
+        if (ids[j] <= ids[j - 1])
+            return EQF_E_BAD_ARG;
+    const int N = c->N;
+    bool state_ascending = true;
+    for (int i = 1; i < N && state_ascending; ++i)
+        state_ascending = c->ids[i] > c->ids[i - 1];
+    if (!state_ascending)
+        ensure_lookup(c);
+    int h = 0, k = 0;
+    for (int j = 0; j < M; ++j) {
+        while (h < N && (state_ascending ? c->ids[h] : c->lookup[h].first) < ids[j])
+            ++h;
+        if (h == N || (state_ascending ? c->ids[h] : c->lookup[h].first) != ids[j])
+            unknown_j[k++] = j;
+    }
+    *n_unknown = k;
+    return 0;
+}
+
 int eqf_remove_invalid_landmarks(eqf_ctx* c) {
     HP_SCOPE("abi.remove_invalid");
     if (!c)

@@ -269,6 +269,14 @@ bool VIO_eqf::removeUnmeasured(const std::vector<int>& measurementIds) {
     }
     return true;
 }
+bool VIO_eqf::findUnknownIds(const std::vector<int>& measurementIds, std::vector<int>& unknownJ, int& n) const {
+    unknownJ.resize(measurementIds.size() + 1);
+    const int rc = eqf_find_unknown_ids(ctx, measurementIds.data(), (int)measurementIds.size(), unknownJ.data(), &n);
+    if (rc == EQF_E_BAD_ARG)
+        return false;
+    check(rc, "eqf_find_unknown_ids");
+    return true;
+}
 void VIO_eqf::removeLandmarkByIndex(const int& idx) { removeLandmarksByIndex({idx}); } // VIO_eqf.cpp:172-178
 void VIO_eqf::removeLandmarkById(const int& id) {                                      // VIO_eqf.cpp:180-186
     const auto it = std::find(ids_.begin(), ids_.end(), id);
@@ -754,6 +762,28 @@ VisionMeasurement VIOFilter::getFeaturePredictions(const GICameraPtr& camPtr, co
 }
 void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2) { // :258-278
     std::vector<Landmark> newLandmarks;
+    {
+        // ascending measurement ids (a VisionMeasurement's): the core, which keeps the state's ids sorted, says which of them are new in one merge pass
+        const auto fv = measurement.flat();
+        const std::vector<int>& mids = *fv.first;
+        const std::vector<double>& my = *fv.second;
+        int n = 0;
+        if (filterState.findUnknownIds(mids, unknownScratch_, n)) {
+            if (n == 0)
+                return;
+            newLandmarks.reserve(n);
+            for (int t = 0; t < n; ++t) {
+                const int j = unknownScratch_[t];
+                const V3 bearing = measurement.cameraPtr->undistortPoint(my[2 * j], my[2 * j + 1]);
+                newLandmarks.emplace_back(Landmark{bearing, mids[j]});
+            }
+            const double initialDepth = settings->useMedianDepth ? getMedianSceneDepth(depth2) : settings->initialSceneDepth;
+            for (Landmark& blm : newLandmarks)
+                blm.p = initialDepth * blm.p;
+            filterState.addNewLandmarks(newLandmarks, settings->initialPointVariance);
+            return;
+        }
+    }
     // O(M log N) membership instead of the reference's O(M N) scan. The state's ids are usually ascending already (a tracker numbers its features
     // as they appear, removals keep the order): no copy and no sort then, and one merge pass against the measurement's ascending ids.
     const std::vector<int>& stateIds = filterState.ids();

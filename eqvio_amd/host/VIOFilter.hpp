@@ -193,6 +193,7 @@ struct VIO_eqf {
     void removeLandmarksByIndex(const std::vector<int>& idx); // batched form of the above
     void removeInvalidLandmarks();
     bool removeUnmeasured(const std::vector<int>& measurementIds); // false: ids not ascending, nothing done
+    bool findUnknownIds(const std::vector<int>& measurementIds, std::vector<int>& unknownJ, int& n) const; // false: ids not ascending
     std::array<double, 9> getLandmarkCovById(const int& id) const;
     void integrateObserverState(const IMUVelocity& imuVelocity, const double& dt, const bool& discreteLift = true);
     void integrateObserverStates(const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift); // batched
@@ -233,6 +234,7 @@ class VIOFilter {
     void removeOutliers(VisionMeasurement& measurement, std::vector<double>& depth2, const std::vector<double>* absErrIn = nullptr,
                         const std::vector<double>* probErrIn = nullptr);
     double getMedianSceneDepth(const std::vector<double>* depth2) const;
+    std::vector<int> unknownScratch_; // addNewLandmarks: positions of the measured ids without a landmark
 
   public:
     struct Settings;

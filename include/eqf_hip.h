@@ -162,6 +162,9 @@ int eqf_remove_landmarks(eqf_ctx* ctx, const int* indices, int k);
  * a VisionMeasurement's std::map; EQF_E_BAD_ARG otherwise) leaves the state like eqf_remove_landmarks. removed_idx (room for the current landmark count) receives their
  * indices, ascending, *n_removed their number. O(N + M) whatever the order of the ids in the state. */
 int eqf_remove_unmeasured_landmarks(eqf_ctx* ctx, const int* ids, int M, int* removed_idx, int* n_removed);
+/* The membership test of VIOFilter::addNewLandmarks (src/VIOFilter.cpp:258-278) in one merge pass: the positions j (ascending) of the measured ids (strictly ascending;
+ * EQF_E_BAD_ARG otherwise) that have no landmark in the state go to unknown_j (room for M), their number to *n_unknown. Host only. */
+int eqf_find_unknown_ids(eqf_ctx* ctx, const int* ids, int M, int* unknown_j, int* n_unknown);
 /* VIO_eqf::removeInvalidLandmarks (VIO_eqf.cpp:213-223). Returns the number removed (>=0) or <0. */
 int eqf_remove_invalid_landmarks(eqf_ctx* ctx);
 
