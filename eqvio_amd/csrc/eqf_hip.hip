@@ -183,6 +183,14 @@ struct eqf_ctx {
     int opt_la_split = 1;                    // EQF_OPT_LA_SPLIT_ROWS
     int opt_prop_tpw = 1;                    // EQF_OPT_TILES_PER_WORKGROUP
     int opt_gather = 1;                      // EQF_OPT_GATHER_IN_PROPAGATE
+    int opt_hold = 1;                        // EQF_OPT_HOLD_NEW_LANDMARKS
+    // eqf_add_landmarks_held: the last n_held landmarks of the state wait for the next eqf_propagate_fast, which passes them through untouched (GatherArgs)
+    int n_held = 0;
+    double held_var = 0.0;
+    bool held_in_memory = false;             // an entry point other than eqf_propagate_fast came in between: they were appended by an ordinary pass (still passed through untouched)
+    double* h_held = nullptr;                // pinned: [0] variance, [1 + 3 t ..] point of held landmark t
+    bool held_busy = false;                  // a propagation that reads h_held may still be queued (cleared by every host wait)
+    long held_launches = 0;                  // propagation launches that created held landmarks themselves
     long gather_launches = 0;                // propagation launches that applied a removal record themselves
     int opt_measure_prop = 1;                // EQF_OPT_MEASURE_IN_PROPAGATE
     int opt_lift_syrk = 1;                   // EQF_OPT_LIFT_WITH_SYRK
@@ -510,6 +518,7 @@ int sync_ctx(eqf_ctx* c) {
     }
     c->busy_common = c->busy_steps = c->busy_meas = false;
     c->ring_inflight = 0;
+    c->held_busy = false;
     la_release(c);
     return 0;
 }
@@ -526,6 +535,7 @@ int door_wait(eqf_ctx* c, int which, int seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
             c->busy_common = c->busy_steps = c->busy_meas = false;
             c->ring_inflight = 0; // the kernel that rang was queued behind every flush of this context
+            c->held_busy = false;
             ++c->wait_calls;
             c->wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (which == 1) {
@@ -720,9 +730,11 @@ static int grow_capacity(eqf_ctx* c, int new_cap);
 static int flush_reshape(eqf_ctx* c);
 static int round_sigma(eqf_ctx* c, const int* spec = nullptr, int spec_seq = 0);
 // first statement of every entry point that uses the device state: select the device, apply the recorded landmark bookkeeping
+static void materialise_held(eqf_ctx* c);
 static int enter(eqf_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     c->ocov_valid = false; // (every call that can change the state or Sigma passes through here)
+    materialise_held(c); // held landmarks (eqf_add_landmarks_held) meet an entry point other than eqf_propagate_fast: an ordinary append, still passed through by that propagation
     return flush_reshape(c);
 }
 static int lookahead_selftest(eqf_ctx* c);
@@ -887,6 +899,7 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     HIPCHK(hipHostMalloc(&c->h_res, sizeof(double) * (7 * (size_t)c->Ncap + 32)));
     HIPCHK(hipHostMalloc(&c->h_resflags, sizeof(int) * 4));
     HIPCHK(hipHostMalloc(&c->h_sel, sizeof(int) * ((size_t)c->Ncap + 2)));
+    HIPCHK(hipHostMalloc(&c->h_held, sizeof(double) * (3 * (size_t)c->Ncap + 1)));
     HIPCHK(hipHostMalloc(&c->h_door, sizeof(int) * 4));
     std::memset(c->h_door, 0, sizeof(int) * 4);
     HIPCHK(hipMalloc(&c->d_door, sizeof(int) * 4));
@@ -981,6 +994,7 @@ void eqf_destroy(eqf_ctx* c) {
     c->h_ocov = nullptr;
     hipHostFree(c->h_resflags);
     hipHostFree(c->h_sel);
+    hipHostFree(c->h_held);
     hipHostFree(c->h_door);
     hipFree(c->d_door);
     hipFree(c->d_spec);
@@ -1051,6 +1065,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_LA_SPLIT_ROWS: *value = c->opt_la_split; return 0;
     case EQF_OPT_TILES_PER_WORKGROUP: *value = c->opt_prop_tpw; return 0;
     case EQF_OPT_GATHER_IN_PROPAGATE: *value = c->opt_gather; return 0;
+    case EQF_OPT_HOLD_NEW_LANDMARKS: *value = c->opt_hold; return 0;
     case EQF_OPT_LA_HOME: *value = c->opt_la_home; return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE: *value = c->opt_measure_prop; return 0;
     case EQF_OPT_LIFT_WITH_SYRK: *value = c->opt_lift_syrk; return 0;
@@ -1102,6 +1117,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_GATHER_IN_PROPAGATE:
         c->opt_gather = value ? 1 : 0;
+        return 0;
+    case EQF_OPT_HOLD_NEW_LANDMARKS:
+        c->opt_hold = value ? 1 : 0;
         return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE:
         c->opt_measure_prop = value ? 1 : 0;
@@ -1181,6 +1199,7 @@ int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, 
     { int _r = sync_ctx(c); if (_r) return _r; }
     c->est_valid = false;
     c->meas_valid = false;
+    c->n_held = 0, c->held_in_memory = false;
     c->xi0 = unpack_sensor(xi0_sensor);
     c->X = unpack_group(X_sensor);
     c->ids.assign(ids, ids + N);
@@ -1364,7 +1383,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_HOLD_NEW_LANDMARKS, c->opt_hold}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1383,6 +1402,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     t->la_launches = c->la_launches, t->la_fallbacks = c->la_fallbacks, t->la_home_launches = c->la_home_launches, t->la_home_refused = c->la_home_refused, t->la_book_timeouts = c->la_book_timeouts, t->zb_launches = c->zb_launches, t->la_consecutive_stalls = c->la_consecutive_stalls;
     t->la_selftest = c->la_selftest < 0 ? -1 : (t->la_selftest != 0 ? t->la_selftest : c->la_selftest); // a failure is never forgotten; otherwise the test that ran on the NEW buffers counts
     t->me_used = c->me_used, t->pred_valid = c->pred_valid, t->pred_cam = c->pred_cam, t->pred_star = c->pred_star;
+    t->n_held = c->n_held, t->held_var = c->held_var, t->held_in_memory = c->n_held > 0; // (eqf_get_state above went through enter(): held landmarks are in memory now)
     t->lm_gen = c->lm_gen + 1;
     std::swap(*c, *t);
     eqf_destroy(t);
@@ -1399,6 +1419,18 @@ static void pend_begin(eqf_ctx* c) {
         c->pend_var.clear();
         c->reshape_pending = true;
     }
+}
+// held landmarks that are not in the device arrays yet become an ordinary pending append (flush_reshape writes them); they stay "held" for the propagation
+static void materialise_held(eqf_ctx* c) {
+    if (c->n_held == 0 || c->held_in_memory)
+        return;
+    pend_begin(c);
+    for (int t = 0; t < c->n_held; ++t) {
+        c->pend_map.push_back(-((int)c->pend_var.size() + 1));
+        c->pend_p.insert(c->pend_p.end(), c->h_held + 1 + 3 * t, c->h_held + 4 + 3 * t);
+        c->pend_var.push_back(c->held_var);
+    }
+    c->held_in_memory = true;
 }
 static int flush_reshape(eqf_ctx* c) {
     if (!c->reshape_pending)
@@ -1495,6 +1527,8 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
         return EQF_E_BAD_ARG;
     if (k == 0)
         return 0;
+    if (c->n_held > 0)
+        return EQF_E_UNSUPPORTED; // held landmarks are the LAST ones of the state until the propagation they wait for
     HIPCHK(hipSetDevice(c->device));
     if (c->N + k > c->Ncap) { // the reference has no cap (VIO_eqf.cpp:225-245 resizes Sigma): grow, at least doubling
         const int rc = grow_capacity(c, std::max(c->N + k, 2 * c->Ncap));
@@ -1534,6 +1568,65 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
     return 0;
 }
 
+// eqf_hip.h: landmarks that belong to the time BEHIND the next eqf_propagate_fast
+int eqf_hold_supported(const eqf_ctx* c) {
+    return (c && c->opt_hold && c->opt_gather && c->opt_fuse_asm && !c->opt_dense && c->chart != EQVIO_COORD_NORMAL && !c->sig32 && !c->opt_check && c->h_held) ? 1 : 0;
+}
+int eqf_add_landmarks_held(eqf_ctx* c, const int* ids, const double* p, int k, double var) {
+    HP_SCOPE("abi.add_landmarks_held");
+    if (!c || k < 0 || (k > 0 && (!ids || !p)))
+        return EQF_E_BAD_ARG;
+    if (k == 0)
+        return 0;
+    // refused (nothing added: the caller appends them behind the propagation, as the reference does) when the options do not allow it, when the capacity would have to
+    // grow, or when landmarks with another variance are already held
+    if (!eqf_hold_supported(c) || c->N + k > c->Ncap || (c->n_held > 0 && (var != c->held_var || c->held_in_memory)))
+        return EQF_E_UNSUPPORTED;
+    if (c->n_held == 0 && c->held_busy) { // a propagation that reads the packet may still be queued (no host wait since): wait for it before the packet is rewritten
+        HIPCHK(hipSetDevice(c->device));
+        const int r = sync_ctx(c);
+        if (r)
+            return r;
+    }
+    c->held_var = var;
+    c->h_held[0] = var;
+    std::memcpy(c->h_held + 1 + 3 * (size_t)c->n_held, p, sizeof(double) * 3 * k);
+    if (c->est_valid) { // the estimate of a fresh landmark is its origin point (Q = identity): the cache follows without asking the device
+        const int N = c->N;
+        std::vector<double> e(4 * (size_t)(N + k));
+        for (int pl = 0; pl < 4; ++pl) {
+            std::copy(c->est_cache.begin() + (size_t)pl * N, c->est_cache.begin() + (size_t)(pl + 1) * N, e.begin() + (size_t)pl * (N + k));
+            for (int t = 0; t < k; ++t)
+                e[(size_t)pl * (N + k) + N + t] = pl < 3 ? p[3 * t + pl] : 0.0;
+        }
+        c->est_cache.swap(e);
+    }
+    const bool keep_lookup = c->lookup_gen == c->lm_gen && (int)c->lookup.size() == c->N;
+    if (keep_lookup) {
+        const size_t n0 = c->lookup.size();
+        for (int t = 0; t < k; ++t)
+            c->lookup.push_back({ids[t], c->N + t});
+        std::sort(c->lookup.begin() + n0, c->lookup.end());
+        std::inplace_merge(c->lookup.begin(), c->lookup.begin() + n0, c->lookup.end());
+    }
+    c->ids.insert(c->ids.end(), ids, ids + k);
+    c->N += k;
+    c->n_held += k;
+    ++c->lm_gen;
+    if (keep_lookup)
+        c->lookup_gen = c->lm_gen;
+    c->meas_valid = false;
+    return 0;
+}
+int eqf_hold_stats(eqf_ctx* c, long* launches, int reset) {
+    if (!c || !launches)
+        return EQF_E_BAD_ARG;
+    *launches = c->held_launches;
+    if (reset)
+        c->held_launches = 0;
+    return 0;
+}
+
 int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
     HP_SCOPE("abi.remove_landmarks");
     if (!c || k < 0 || (k > 0 && !indices))
@@ -1545,6 +1638,13 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
         if (indices[t] < 0 || indices[t] >= c->N)
             return EQF_E_BAD_ARG;
         drop[indices[t]] = 1;
+    }
+    if (c->n_held > 0) { // a removal while landmarks are held: they become an ordinary pending append first; a held landmark that is removed again is not held any more
+        materialise_held(c);
+        for (int i = c->N - c->n_held, held = c->n_held; i < c->N && held > 0; ++i)
+            c->n_held -= drop[i] ? 1 : 0;
+        if (c->n_held == 0)
+            c->held_in_memory = false;
     }
     pend_begin(c);
     const int N = c->N;
@@ -1603,6 +1703,13 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
     return 0;
 }
 
+// These are exactly the ids of the measurement that was mapped last (map_measurement: validated ascending, every one with a landmark), the landmark set has not changed
+// since, and there is one id per landmark: every landmark is measured and every measured id known.
+static bool same_as_mapped(const eqf_ctx* c, const int* ids, int M) {
+    return M > 0 && M == c->N && c->map_gen == c->lm_gen && c->map_N == c->N && c->map_all && (int)c->map_ids.size() == M &&
+           std::memcmp(ids, c->map_ids.data(), sizeof(int) * M) == 0;
+}
+int eqf_same_as_mapped(const eqf_ctx* c, const int* ids, int M) { return (c && ids && same_as_mapped(c, ids, M)) ? 1 : 0; }
 // VIOFilter::removeOldLandmarks (VIOFilter.cpp:280-302) in one call: the landmarks of the state whose id is not among the (strictly ascending) measured ids leave the state
 // (recorded like eqf_remove_landmarks). Their indices, ascending, go to removed_idx (room for the current landmark count). O(N + M): one merge pass against the state's ids
 // when these ascend as well, else against the sorted (id, index) table.
@@ -1611,6 +1718,8 @@ int eqf_remove_unmeasured_landmarks(eqf_ctx* c, const int* ids, int M, int* remo
     if (!c || M < 0 || (M > 0 && !ids) || !removed_idx || !n_removed)
         return EQF_E_BAD_ARG;
     *n_removed = 0;
+    if (same_as_mapped(c, ids, M))
+        return 0; // the ids of the last mapped measurement, one per landmark: nobody is lost (the steady frame: 0.1 instead of 1 us in front of the propagation's launch)
     for (int j = 1; j < M; ++j)
         if (ids[j] <= ids[j - 1])
             return EQF_E_BAD_ARG;
@@ -1649,6 +1758,8 @@ int eqf_find_unknown_ids(eqf_ctx* c, const int* ids, int M, int* unknown_j, int*
     if (!c || M < 0 || (M > 0 && !ids) || !unknown_j || !n_unknown)
         return EQF_E_BAD_ARG;
     *n_unknown = 0;
+    if (same_as_mapped(c, ids, M))
+        return 0; // (see eqf_remove_unmeasured_landmarks)
     for (int j = 1; j < M; ++j)
         if (ids[j] <= ids[j - 1])
             return EQF_E_BAD_ARG;
@@ -1692,6 +1803,8 @@ int eqf_remove_invalid_landmarks(eqf_ctx* c) {
 static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, const double* Pdiag8, const ObsSteps* obs = nullptr, int obs_k = 0, bool fused = false,
                                   const GatherArgs* gather = nullptr);
 int eqf_integrate_riccati_fast(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
+    if (c && c->n_held > 0)
+        return EQF_E_UNSUPPORTED; // landmarks held for eqf_propagate_fast (eqf_add_landmarks_held): only that call knows to leave them alone
     if (!c || !imu13 || !Qdiag12 || !Pdiag8)
         return EQF_E_BAD_ARG;
     { int _e = enter(c); if (_e) return _e; }
@@ -1796,8 +1909,11 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
             if (!(fused && nObs))
                 return EQF_E_UNSUPPORTED; // (eqf_propagate_fast checks the same conditions before it asks for this)
             ga = *gather;
-            ga.st_in = c->d_st[c->stcur], ga.st_out = c->d_st[1 - c->stcur];
+            ga.st_in = c->d_st[c->stcur], ga.st_out = ga.n ? c->d_st[1 - c->stcur] : c->d_st[c->stcur]; // (nothing removed: the planes stay where they are, only held landmarks are written)
         }
+        ga.nprop = N - c->n_held; // (held landmarks that an ordinary pass appended: read from memory, passed through untouched)
+        if (c->n_held > 0 && !(fused && nObs))
+            return EQF_E_UNSUPPORTED;
         KTimer t(c, KN_PROP_MAIN);
         auto launch = [&](auto kern, auto* sin, auto* sout) {
             hipLaunchKernelGGL(kern, dim3(nTiles + 1 + nObs + (sg.M ? 1 : 0)), dim3(PROP_T), 0, c->stream, N, c->Ncap, c->ld, ra, c->d_common, sin, sout, c->d_Al, c->d_Bl, nT, tpw,
@@ -1815,6 +1931,11 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
                 PROP_LAUNCH(float, true);
             else
                 PROP_LAUNCH(float, false);
+        } else if (fused && (ga.n > 0 || ga.nprop < N)) { // landmarks leave / are created / pass through inside this launch: the instantiation that knows how
+            if (sym)
+                launch(k_propagate_main<double, true, true, true>, (const double*)Sin, (double*)Sout);
+            else
+                launch(k_propagate_main<double, true, false, true>, (const double*)Sin, (double*)Sout);
         } else {
             if (fused)
                 PROP_LAUNCH(double, true);
@@ -1826,11 +1947,18 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
         if (fused && nObs)
             c->lmcur = 1 - c->lmcur;
         if (gather) { // what flush_reshape does behind its pass
-            c->stcur = 1 - c->stcur;
+            if (gather->n) {
+                c->stcur = 1 - c->stcur;
+                ++c->gather_launches;
+            }
+            if (gather->held) {
+                ++c->held_launches;
+                c->held_busy = true;
+            }
             c->dev_N = N;
             c->reshape_pending = false;
-            ++c->gather_launches;
         }
+        c->n_held = 0, c->held_in_memory = false; // they are ordinary landmarks from here on
     } else {
         // dense: F materialised, tmp = F Sigma (= (Sigma F^T)^T, Sigma symmetric), Sigma' = tmp F^T + noise
         const size_t bytes = sizeof(double) * (size_t)c->ld * c->ncap;
@@ -1870,6 +1998,8 @@ static int riccati_after_assemble(eqf_ctx* c, double dt, const double* Qdiag12, 
 }
 
 int eqf_integrate_riccati_accurate(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
+    if (c && c->n_held > 0)
+        return EQF_E_UNSUPPORTED; // landmarks held for eqf_propagate_fast (eqf_add_landmarks_held): only that call knows to leave them alone
     if (!c || !imu13 || !Qdiag12 || !Pdiag8 || !(dt > 0.0))
         return EQF_E_BAD_ARG;
     if (c->sig32)
@@ -1956,6 +2086,8 @@ static GroupSensor group_inv(const GroupSensor& X) { // VIOGroup::inverse, senso
     return r;
 }
 int eqf_integrate_riccati_discrete(eqf_ctx* c, const double* imu13, double dt, const double* Qdiag12, const double* Pdiag8) {
+    if (c && c->n_held > 0)
+        return EQF_E_UNSUPPORTED; // landmarks held for eqf_propagate_fast (eqf_add_landmarks_held): only that call knows to leave them alone
     if (!c || !imu13 || !Qdiag12 || !Pdiag8 || !(dt > 0.0))
         return EQF_E_BAD_ARG;
     if (c->sig32)
@@ -2117,6 +2249,8 @@ static int observer_launch(eqf_ctx* c, const ObsSteps& steps_arg, int chunk) {
     return 0;
 }
 int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k, int k, int discreteLift) {
+    if (c && c->n_held > 0)
+        return EQF_E_UNSUPPORTED; // landmarks held for eqf_propagate_fast (eqf_add_landmarks_held): only that call knows to leave them alone
     if (!c || k < 0 || (k > 0 && (!imu13_k || !dt_k)))
         return EQF_E_BAD_ARG;
     if (k == 0)
@@ -2146,23 +2280,34 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     if (!c || !imu13_mean || !Qdiag12 || !Pdiag8 || k < 0 || (k > 0 && (!imu13_k || !dt_k)))
         return EQF_E_BAD_ARG;
     // EQF_OPT_GATHER_IN_PROPAGATE: a pending record of removals only (the frame's lost landmarks, the last frame's discarded outliers) is applied by the propagation kernel
-    // itself instead of a compaction pass in front of it - when this call takes the fused kernel with observer blocks, the record is short and nothing was appended
+    // itself instead of a compaction pass in front of it - when this call takes the fused kernel with observer blocks and nothing was appended.
+    // eqf_add_landmarks_held: the held landmarks (the last n_held of the state) are created by the same kernel (GatherArgs::held) unless an ordinary pass has appended them.
     GatherArgs gather{};
     bool use_gather = false;
-    if (c->reshape_pending && c->opt_gather && c->opt_fuse_asm && !c->opt_dense && !c->sig32 && c->chart != EQVIO_COORD_NORMAL && k > 0 && k <= eqf_ctx::kMaxSteps &&
-        c->pend_var.empty() && c->N > 0 && (int)c->pend_map.size() == c->N && c->dev_N > c->N && c->dev_N <= GATHER_MAXN) {
-        int prev = -1;
+    const bool fused_kernel = c->opt_fuse_asm && !c->opt_dense && !c->sig32 && c->chart != EQVIO_COORD_NORMAL && k > 0 && k <= eqf_ctx::kMaxSteps && c->N > 0;
+    if (c->n_held > 0 && !fused_kernel)
+        return EQF_E_UNSUPPORTED; // (eqf_add_landmarks_held checked the options: one was changed in between, or there are no observer steps to ride along)
+    const int Nprop = c->N - c->n_held;
+    const bool hold_here = c->n_held > 0 && !c->held_in_memory;
+    if (fused_kernel && c->opt_gather && (c->reshape_pending || hold_here) && c->pend_var.empty() && c->dev_N <= GATHER_MAXN &&
+        (!c->reshape_pending || ((int)c->pend_map.size() == Nprop && c->dev_N >= Nprop))) {
         bool ok = true;
-        for (int i = 0; i < c->N && ok; ++i) {
-            const int o = c->pend_map[i];
-            ok = o > prev && o < c->dev_N; // survivors keep their order
-            if (ok)
-                gather.surv[o >> 6] |= 1ull << (o & 63);
-            prev = o;
-        }
-        if (ok) {
-            gather.n = c->dev_N - c->N;
+        if (c->reshape_pending) {
+            int prev = -1;
+            for (int i = 0; i < Nprop && ok; ++i) {
+                const int o = c->pend_map[i];
+                ok = o > prev && o < c->dev_N; // survivors keep their order
+                if (ok)
+                    gather.surv[o >> 6] |= 1ull << (o & 63);
+                prev = o;
+            }
+            gather.n = c->dev_N - Nprop;
+        } else
+            ok = c->dev_N == Nprop;
+        if (ok && (gather.n > 0 || hold_here)) {
             use_gather = true;
+            if (hold_here)
+                gather.held = c->h_held;
         }
     }
     if (use_gather) { // enter() without the flush
@@ -2220,6 +2365,7 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     {
         HP_SCOPE("pf.launch");
         if (use_gather && !(ride && fuse)) { // (cannot happen: the conditions above are the ones of `ride` and `fuse`) - apply the record the ordinary way
+            materialise_held(c);
             rc = flush_reshape(c);
             if (rc)
                 return rc;
@@ -2230,9 +2376,9 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     if (rc)
         return rc;
     host_stamp(c, TH_PROP_OUT);
-    for (size_t q = ride ? 1 : 0; q < chunks.size() && c->N > 0; ++q) {
+    for (size_t q = ride ? 1 : 0; q < chunks.size() && Nprop > 0; ++q) { // (held landmarks are the last ones: the observer kernel does not reach them)
         c->ev_assembled_early = false;
-        hipLaunchKernelGGL(k_observer, dim3(blocks(c->N, 64)), dim3(64), 0, c->stream, chunks[q], c->N, c->Ncap, counts[q], c->q0(), c->Qq(), c->Qa());
+        hipLaunchKernelGGL(k_observer, dim3(blocks(Nprop, 64)), dim3(64), 0, c->stream, chunks[q], Nprop, c->Ncap, counts[q], c->q0(), c->Qq(), c->Qa());
         HIPCHK(hipGetLastError());
     }
     return 0;

@@ -106,6 +106,18 @@ __device__ __forceinline__ M3 ld_cc(const double* __restrict__ q0, int Ncap, int
     const double* b = q0 + (size_t)(CC_OFF + which) * Ncap + i;
     return M3{b[0], b[Ncap], b[2 * (size_t)Ncap], b[3 * (size_t)Ncap], b[4 * (size_t)Ncap], b[5 * (size_t)Ncap], b[6 * (size_t)Ncap], b[7 * (size_t)Ncap], b[8 * (size_t)Ncap]};
 }
+// The chart constants of a new origin point, computed and stored by ONE function body (noinline): they are computed in four kernels (scatter, the two append / reshape
+// passes, the propagation kernel's lanes for held landmarks), and inlined into different surroundings the compiler contracts their multiply-adds differently - the last
+// bit of a constant differed for 5 of 200 landmarks between two of them (round 5), and with it every later propagation of those landmarks. r0: also handed back.
+__device__ __attribute__((noinline)) void store_chart_constants(double* __restrict__ cc, int Ncap, int i, double px, double py, double pz, M3* r0) {
+    const V3 p{px, py, pz};
+    st_plane9(cc, Ncap, i, CC_E2I, conv_euc2ind(p));
+    st_plane9(cc, Ncap, i, CC_I2E, conv_ind2euc(p));
+    const M3 R = ind2euc_r0(p);
+    st_plane9(cc, Ncap, i, CC_R0, R);
+    if (r0)
+        *r0 = R;
+}
 
 // column index in A of packed column e (0..11) of the landmark-sensor block
 __host__ __device__ __forceinline__ int al_col(int e) { return e < 3 ? e : (e < 6 ? 12 + (e - 3) : 15 + (e - 6)); }
@@ -384,10 +396,18 @@ struct MeasEval {
 constexpr int GATHER_WORDS = 8, GATHER_MAXN = 64 * GATHER_WORDS; // up to 512 landmarks in the buffers the launch reads
 struct GatherArgs {
     int n;                                 // landmarks removed (0: nothing to do)
-    unsigned long long surv[GATHER_WORDS]; // bit o set: the landmark at the old position o survives; landmark i of the new state is the (i + 1)-th set bit
+    int nprop;                             // landmarks that are propagated: the first nprop of the N the launch covers. The others are HELD (eqf_add_landmarks_held, below)
+    unsigned long long surv[GATHER_WORDS]; // bit o set: the landmark at the old position o survives; landmark i < nprop of the new state is the (i + 1)-th set bit
     const double* st_in;                   // q0 + chart constants, (CC_OFF + CC_PLANES) planes of stride Ncap
-    double* st_out;
+    double* st_out;                        // where the planes go (the other buffer when landmarks are removed, else the same one: only held landmarks are written then)
+    const double* held;                    // pinned host packet of the held landmarks: [0] their variance, [1 + 3 t ..] the point of held landmark t; nullptr: they are in
+                                           // memory already (appended by an ordinary pass in front of this launch)
 };
+// HELD landmarks (round 5, eqf_add_landmarks_held): the frame's new landmarks, appended IN FRONT of the propagation that the reference runs before it appends them
+// (src/VIOFilter.cpp:217 behind :196). They belong to the time behind this propagation and pass through it untouched - F = I, no input and no process noise for their rows, no
+// observer steps - and their cross-covariances are exact zeros, so every sum that involves them adds 0 * x: the result is bit for bit what appending them afterwards
+// gives. With `held` set nothing of them is in memory yet: the tile workgroups take Sigma's entries for them as (variance on the diagonal, 0 elsewhere) and WRITE their rows and
+// columns of the new Sigma, the observer block's lanes write their planes (origin point, chart constants, Q = identity) and evaluate their output blocks - no append pass.
 // position of the k-th (0-based) set bit of x (k < popcount(x))
 __device__ __forceinline__ int select64(unsigned long long x, int k) {
     int pos = 0;
@@ -1555,13 +1575,20 @@ __global__ void __launch_bounds__(256) k_chol_step(int rows, int m, int kb, int 
 // ---------------------------------------------------------------------------------------------------
 // K2 / K2b, the propagation kernel (described above; it stands behind the measurement helpers because with EQF_OPT_Z_IN_PROPAGATE its tiles build Z themselves)
 // TS = storage type of Sigma (double, or float for EQF_OPT_SIGMA_FP32 = 2): loads convert to double, stores round.
-template <typename TS, bool FUSED, bool SYM = false> // FUSED: fused assembly; SYM: lower tiles only, mirrored (an instantiation of its own: as a run-time
-                                                      // branch it cost the N = 200 frame 0.6 us)
+template <typename TS, bool FUSED, bool SYM = false, bool GH = false> // FUSED: fused assembly; SYM: lower tiles only, mirrored (an instantiation of its own: as a run-time
+                                                      // branch it cost the N = 200 frame 0.6 us); GH: landmarks leave / are created inside this launch (GatherArgs) - an
+                                                      // instantiation of its own as well: carried by every launch, that code cost the steady frame's kernel 0.7 us
 __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int ld, RiccatiArgs ra, const Common* __restrict__ cm,
                                                         const TS* __restrict__ Sig, TS* __restrict__ Sout, const double* __restrict__ Al,
                                                         const double* __restrict__ Bl, int nT, int tpw, const ObsSteps obs, int obs_k,
                                                         const double* __restrict__ q0, double* __restrict__ Qq, double* __restrict__ Qa, int nObs, const StageArgs sg,
-                                                        trace_t* tr, const FuseArgs fa, const MeasEval me, const GatherArgs ga) {
+                                                        trace_t* tr, const FuseArgs fa, const MeasEval me, const GatherArgs ga_in) {
+    GatherArgs ga; // GH = false: constants the compiler folds away (nothing removed, nobody held)
+    if constexpr (GH)
+        ga = ga_in;
+    else {
+        ga.n = 0, ga.nprop = N, ga.held = nullptr, ga.st_in = nullptr, ga.st_out = nullptr;
+    }
     trace_start(tr);
     const double dt = ra.dt;
     const int b = blockIdx.x;
@@ -1613,17 +1640,39 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         const ObsStep* steps_lds = reinterpret_cast<const ObsStep*>(sm);
         if (i < N) {
             if (FUSED) {
-                const int io = gather_old(ga, i); // where landmark i sits in the buffers this launch reads (its origin point and chart constants are moved by the sensor block's workgroup)
-                const V3 p0 = ld3(q0, Ncap, io);
-                Qt q = ldq(Qq, Ncap, io);
-                double a_ = Qa[io];
+                const bool held = i >= ga.nprop;
+                const bool synth = held && ga.held != nullptr; // a held landmark that is not in memory yet: this lane creates it
+                const int io = held ? i : gather_old(ga, i); // where landmark i sits in the buffers this launch reads (its origin point and chart constants are moved by the sensor block's workgroup)
+                V3 p0;
+                Qt q;
+                double a_;
+                if (synth) {
+                    const double* hp = ga.held + 1 + 3 * (i - ga.nprop); // zero-copy across PCIe
+                    p0 = V3{hp[0], hp[1], hp[2]};
+                    q = Qt{1.0, 0.0, 0.0, 0.0};
+                    a_ = 1.0;
+                } else {
+                    p0 = ld3(q0, Ncap, io);
+                    q = ldq(Qq, Ncap, io);
+                    a_ = Qa[io];
+                }
                 double yu = 0.0, yv = 0.0;
                 int jm = -1;
                 if (me.on) { // requested before the chain: a zero-copy read across PCIe
                     yu = me.ylm[i], yv = me.ylm[Ncap + i];
                     jm = (int)me.ylm[2 * Ncap + i];
                 }
-                observer_chain(steps_lds, obs_k, p0, q, a_);
+                M3 r0_new{};
+                if (synth) { // the planes k_append_inplace would have written (the only other place the chart constants are computed)
+                    double* st = ga.st_out;
+                    st[i] = p0.x;
+                    st[Ncap + i] = p0.y;
+                    st[2 * (size_t)Ncap + i] = p0.z;
+                    double* cc = st + (size_t)CC_OFF * Ncap;
+                    store_chart_constants(cc, Ncap, i, p0.x, p0.y, p0.z, &r0_new);
+                }
+                if (!held)
+                    observer_chain(steps_lds, obs_k, p0, q, a_);
                 fa.Qqo[i] = q.w;
                 fa.Qqo[Ncap + i] = q.x;
                 fa.Qqo[2 * Ncap + i] = q.y;
@@ -1632,7 +1681,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                 if (me.on && jm >= 0) {
                     // (the chain's last products must not be contracted into the evaluation's first sums: the same bits as an evaluation from the stored element)
                     asm volatile("" : "+v"(q.w), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(a_));
-                    const MeasOut o = measure_one(fa.chart, me.cam, p0, q, a_, yu, yv, me.star != 0, fa.chart == EQVIO_COORD_INVDEPTH ? ld_cc(q0, Ncap, io, CC_R0) : M3{});
+                    const MeasOut o = measure_one(fa.chart, me.cam, p0, q, a_, yu, yv, me.star != 0, fa.chart == EQVIO_COORD_INVDEPTH ? (synth ? r0_new : ld_cc(q0, Ncap, io, CC_R0)) : M3{});
 #pragma unroll
                     for (int e = 0; e < 6; ++e)
                         me.C[e * me.Mcap + jm] = o.c[e];
@@ -1678,6 +1727,9 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             bj0 = b - bi * (bi + 1) / 2;
         }
         const int nb = sym ? bi + 1 : nT; // tiles of this block row: they share its 21 strip columns
+        const int Nprop = FUSED ? ga.nprop : N;                      // landmarks that are propagated; the others are held (GatherArgs)
+        const int Nmem = (FUSED && ga.held) ? Nprop : N;             // landmarks whose rows of Sigma exist in the buffer this launch reads
+        const double held_var = (FUSED && ga.held && Nprop < N) ? ga.held[0] : 0.0; // (zero-copy across PCIe, consumed at the very end of the tile)
         // per-i arrays: G (63), Fls (36), D (9), Bl (9) ; per-j arrays: Ssj (63), Fls (36), D (9), Bl (9). layout [e][PT]
         // The j side exists twice (parity of the tile inside the workgroup): with several tiles per workgroup the loads and the assembly of tile it + 1 are issued
         // in front of the arithmetic of tile it and are in flight during it - one barrier per tile.
@@ -1704,9 +1756,10 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                 const int i = bi * PT + x, j = bj * PT + x;
                 // Sigma[k][l + c'] with e = k*3 + c'
                 const int kk = e / 3, cc = e % 3;
+                // (a held landmark that is not in memory yet: its cross-covariances with the sensor states are zeros)
                 if (first)
-                    sSi[t] = i < N ? Sig[kk + (size_t)(21 + 3 * gather_old(ga, i) + cc) * ld] : 0.0;
-                sSj[t] = j < N ? Sig[kk + (size_t)(21 + 3 * gather_old(ga, j) + cc) * ld] : 0.0;
+                    sSi[t] = i < Nmem ? Sig[kk + (size_t)(21 + 3 * (i < Nprop ? gather_old(ga, i) : i) + cc) * ld] : 0.0;
+                sSj[t] = j < Nmem ? Sig[kk + (size_t)(21 + 3 * (j < Nprop ? gather_old(ga, j) : j) + cc) * ld] : 0.0;
             }
             if (first && tid < 12 * 21)
                 sSs[tid] = Sig[al_col(tid / 21) + (size_t)(tid % 21) * ld];
@@ -1735,7 +1788,8 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
 #pragma unroll
                     for (int e = 0; e < 9; ++e)
                         bl[e] = 0.0;
-                    const bool in = l < N;
+                    const bool in = l < Nprop; // (a held landmark assembles like the padding of a ragged tile, except for the identity in D below)
+                    const bool heldl = l >= Nprop && l < N;
                     const bool ind = fa.chart == EQVIO_COORD_INVDEPTH;
                     const int lc = in ? gather_old(ga, l) : 0;
                     const V3 p0_ = ld3(q0, Ncap, lc);
@@ -1769,7 +1823,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                         for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
                             for (int c = 0; c < 3; ++c)
-                                dD[(rr * 3 + c) * PT + x] = in ? dt * al[rr * 15 + 12 + c] + ((rr == c) ? 1.0 : 0.0) : 0.0;
+                                dD[(rr * 3 + c) * PT + x] = in ? dt * al[rr * 15 + 12 + c] + ((rr == c) ? 1.0 : 0.0) : ((heldl && rr == c) ? 1.0 : 0.0);
                     }
                 }
             } else {
@@ -1825,12 +1879,20 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
             // Sigma_ij: requested first ...
             double Sij[3][3];
             if (mine) {
-                const int lio = 21 + 3 * gather_old(ga, i), ljo = 21 + 3 * gather_old(ga, j);
+                if (i < Nmem && j < Nmem) {
+                    const int lio = 21 + 3 * (i < Nprop ? gather_old(ga, i) : i), ljo = 21 + 3 * (j < Nprop ? gather_old(ga, j) : j);
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
+                    for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        Sij[k][c] = Sig[lio + k + (size_t)(ljo + c) * ld];
+                        for (int c = 0; c < 3; ++c)
+                            Sij[k][c] = Sig[lio + k + (size_t)(ljo + c) * ld];
+                } else { // a held landmark that is not in memory yet: its own block is (variance) I, everything else of its rows and columns zero
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            Sij[k][c] = (i == j && k == c) ? held_var : 0.0;
+                }
             }
             // ... then the next tile's stage (other parity: its last readers passed the barrier at the end of tile it - 1) ...
             if (it + 1 < ntile)
@@ -1890,7 +1952,7 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
                     for (int q = 0; q < 3; ++q)
                         bq += sBi[(r * 3 + q) * PT + ti] * ra.Qd[q] * sBj[(c * 3 + q) * PT + tj];
                     s += dt * bq;
-                    if (i == j && r == c)
+                    if (i == j && r == c && i < Nprop)
                         s += dt * ra.Pd[7];
                     Sout[li + r + (size_t)(lj + c) * ld] = s;
                     if (sym && i != j)
@@ -1907,8 +1969,9 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
         if (FUSED && ga.n) {
             // EQF_OPT_GATHER_IN_PROPAGATE: the origin points and chart constants of the surviving landmarks move to the other buffer (everything else of a landmark is
             // rewritten by this kernel anyway); this workgroup has the shortest chain of the launch
-            for (int t = tid; t < (CC_OFF + CC_PLANES) * N; t += PROP_T) {
-                const int pl = t / N, i = t - pl * N;
+            const int Np = ga.nprop;
+            for (int t = tid; t < (CC_OFF + CC_PLANES) * Np; t += PROP_T) {
+                const int pl = t / Np, i = t - pl * Np;
                 ga.st_out[(size_t)pl * Ncap + i] = ga.st_in[(size_t)pl * Ncap + gather_old(ga, i)];
             }
         }
@@ -2297,9 +2360,7 @@ __global__ void k_scatter_landmarks(int k, int dst0, int Ncap, const double* __r
     { // chart constants of the new origin point (ld_cc): the only place they are computed
         const V3 p{p_aos[3 * t], p_aos[3 * t + 1], p_aos[3 * t + 2]};
         double* cc = q0 + (size_t)CC_OFF * Ncap;
-        st_plane9(cc, Ncap, i, CC_E2I, conv_euc2ind(p));
-        st_plane9(cc, Ncap, i, CC_I2E, conv_ind2euc(p));
-        st_plane9(cc, Ncap, i, CC_R0, ind2euc_r0(p));
+        store_chart_constants(cc, Ncap, i, p.x, p.y, p.z, nullptr);
     }
     if (Q_aos) {
         for (int c = 0; c < 4; ++c)
@@ -2493,9 +2554,7 @@ __device__ __forceinline__ void reshape_body(int Nnew, int Ncap, int ld, const M
         st_out[Ncap + i] = p.y;
         st_out[2 * Ncap + i] = p.z;
         double* cc = st_out + (size_t)CC_OFF * Ncap;
-        st_plane9(cc, Ncap, i, CC_E2I, conv_euc2ind(p));
-        st_plane9(cc, Ncap, i, CC_I2E, conv_ind2euc(p));
-        st_plane9(cc, Ncap, i, CC_R0, ind2euc_r0(p));
+        store_chart_constants(cc, Ncap, i, p.x, p.y, p.z, nullptr);
         Qqo[i] = 1.0;
         Qqo[Ncap + i] = 0.0;
         Qqo[2 * Ncap + i] = 0.0;
@@ -2554,9 +2613,7 @@ __global__ void __launch_bounds__(256) k_append_inplace(int Nold, int k, int Nca
     st[Ncap + i] = p.y;
     st[2 * Ncap + i] = p.z;
     double* cc = st + (size_t)CC_OFF * Ncap;
-    st_plane9(cc, Ncap, i, CC_E2I, conv_euc2ind(p));
-    st_plane9(cc, Ncap, i, CC_I2E, conv_ind2euc(p));
-    st_plane9(cc, Ncap, i, CC_R0, ind2euc_r0(p));
+    store_chart_constants(cc, Ncap, i, p.x, p.y, p.z, nullptr);
     lm[i] = 1.0;
     lm[Ncap + i] = 0.0;
     lm[2 * Ncap + i] = 0.0;

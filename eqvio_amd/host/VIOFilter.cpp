@@ -2,6 +2,7 @@
 // src/mathematical/VIO_eqf.cpp); every matrix operation goes through the C-ABI of include/eqf_hip.h.
 #include "VIOFilter.hpp"
 #include "../csrc/host_prof.hpp"
+#include <optional>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -219,10 +220,10 @@ MatrixXd VIO_eqf::Sigma() const {
 void VIO_eqf::setSigma(const MatrixXd& S) { check(eqf_set_sigma(ctx, S.d.data(), S.r), "eqf_set_sigma"); }
 void VIO_eqf::setSigmaDiag(const std::vector<double>& diag) { check(eqf_set_sigma_diag(ctx, diag.data(), (int)diag.size()), "eqf_set_sigma_diag"); }
 
-void VIO_eqf::addNewLandmarks(std::vector<Landmark>& newLandmarks, double var) { // VIO_eqf.cpp:225-245
+bool VIO_eqf::addNewLandmarks(std::vector<Landmark>& newLandmarks, double var, bool held) { // VIO_eqf.cpp:225-245
     const int k = (int)newLandmarks.size();
     if (k == 0)
-        return;
+        return true;
     std::vector<int> ids(k);
     std::vector<double> p(3 * k);
     for (int i = 0; i < k; ++i) {
@@ -231,8 +232,15 @@ void VIO_eqf::addNewLandmarks(std::vector<Landmark>& newLandmarks, double var) {
         p[3 * i + 1] = newLandmarks[i].p.y;
         p[3 * i + 2] = newLandmarks[i].p.z;
     }
-    check(eqf_add_landmarks(ctx, ids.data(), p.data(), k, var), "eqf_add_landmarks");
+    if (held) { // eqf_add_landmarks_held: refused (nothing added) when the core cannot hold them - the caller appends them behind the propagation
+        const int rc = eqf_add_landmarks_held(ctx, ids.data(), p.data(), k, var);
+        if (rc == EQF_E_UNSUPPORTED)
+            return false;
+        check(rc, "eqf_add_landmarks_held");
+    } else
+        check(eqf_add_landmarks(ctx, ids.data(), p.data(), k, var), "eqf_add_landmarks");
     ids_.insert(ids_.end(), ids.begin(), ids.end());
+    return true;
 }
 void VIO_eqf::removeLandmarksByIndex(const std::vector<int>& idx) {
     if (idx.empty())
@@ -269,6 +277,7 @@ bool VIO_eqf::removeUnmeasured(const std::vector<int>& measurementIds) {
     }
     return true;
 }
+bool VIO_eqf::sameAsMapped(const std::vector<int>& measurementIds) const { return eqf_same_as_mapped(ctx, measurementIds.data(), (int)measurementIds.size()) == 1; }
 bool VIO_eqf::findUnknownIds(const std::vector<int>& measurementIds, std::vector<int>& unknownJ, int& n) const {
     unknownJ.resize(measurementIds.size() + 1);
     const int rc = eqf_find_unknown_ids(ctx, measurementIds.data(), (int)measurementIds.size(), unknownJ.data(), &n);
@@ -627,7 +636,11 @@ bool VIOFilter::integrateUpToTime(const double& newTime) { // :134-192
 }
 void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :194-241
     HP_SCOPE("processVisionData");
-    const VisionMeasurement::Validated oneWalk(measurement); // the flat arrays of the measurement, validated once for this call
+    // The flat arrays of the measurement are validated against its std::map ONCE per call (Validated) - in front of the propagation when the frame gains or loses
+    // landmarks, behind its launch when it does not: in the steady frame the unvalidated cache (flatHint) holds exactly the ids the last update mapped, one per landmark,
+    // so nothing is removed or added on its word; the walk (1 us at 200 features, GPU idle time in front of the launch) then runs beside the propagation kernel, and if
+    // it finds the map edited the lost / new landmarks are dealt with THERE, behind the propagation - the reference's own order (:210-217 behind :196).
+    std::optional<VisionMeasurement::Validated> oneWalk;
     loopTimer.startTiming("propagation");
     // Round 5: the landmarks that are not in this measurement leave the state BEFORE the propagation instead of behind it (reference: :210-212 behind :196). The
     // propagation is block triangular - a landmark's rows and columns depend on the sensor block and on themselves only - so marginalising a landmark out before or
@@ -635,10 +648,25 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     // pass in front of the propagation kernel, which used to run while the GPU sat idle behind that kernel; now the host's share (this, and the new landmarks below)
     // overlaps with kernels. Only when the propagation will really take place (integrateUpToTime's own precondition, :135): a frame it skips must not lose landmarks.
     const bool willIntegrate = !(measurement.stamp <= filterState.currentTime || filterState.currentTime < 0 || velocityBuffer.empty());
-    const bool removedEarly = initialisedFlag && willIntegrate && settings->removeLostLandmarks;
-    if (removedEarly) {
+    bool quiet = false; // the cache says: the ids of the last mapped measurement, one per landmark - nobody lost, nobody new
+    if (initialisedFlag && willIntegrate && settings->fastRiccati)
+        quiet = filterState.sameAsMapped(*measurement.flatHint().first);
+    if (!quiet)
+        oneWalk.emplace(measurement);
+    bool removedEarly = initialisedFlag && willIntegrate && settings->removeLostLandmarks;
+    if (removedEarly && !quiet) {
         HP_SCOPE("pv.removeOldLandmarks");
         removeOldLandmarks(measurement.flatIds());
+    }
+    // ... and the frame's NEW landmarks enter in front of the propagation too, held (eqf_add_landmarks_held): with a fixed initial depth (both shipped dataset
+    // configurations) a new landmark depends on its pixel only (a point in the camera frame AT the measurement's time: nothing of the propagation enters), and the
+    // propagation passes a held landmark through untouched - the same state as appending it behind the propagation (:217), bit for bit. Every id of the measurement
+    // is then known before the propagation: the measurement is staged, the propagation kernel evaluates its output blocks and creates the new landmarks itself, and a
+    // frame with landmark turnover is three launches like any other. Refused by the core (options, capacity): they are appended behind the propagation as before.
+    bool heldAdd = quiet; // (a quiet frame has no new landmark)
+    if (!quiet && initialisedFlag && willIntegrate && settings->fastRiccati && !settings->useMedianDepth && filterState.holdSupported()) {
+        HP_SCOPE("pv.addNewLandmarks");
+        heldAdd = addNewLandmarks(measurement, nullptr, true);
     }
     // The measurement is in hand before the propagation (VIOFilter.cpp:194-196): hand it to the device now, so that it travels to
     // HBM inside the propagation kernel instead of across PCIe in the update's first kernel (a hint: ignored if an id is unknown).
@@ -650,6 +678,12 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     {
         HP_SCOPE("pv.integrateUpToTime");
         integrationFlag = integrateUpToTime(measurement.stamp);
+    }
+    if (quiet) { // the walk the decisions above stand on, beside the propagation kernel
+        const size_t before = measurement.flatRebuilds();
+        oneWalk.emplace(measurement);
+        if (measurement.flatRebuilds() != before) // the map had been edited behind the cache: lost and new landmarks are looked for now, behind the propagation
+            removedEarly = false, heldAdd = false;
     }
     if (!integrationFlag || !initialisedFlag)
         return;
@@ -666,7 +700,7 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
     // the new rows keep their relative order at the end - and lets a frame with landmark turnover take the one-round-trip path too
     // (statistics + update queued back to back) instead of statistics -> host -> append -> update.
     const bool earlyAdd = !settings->useMedianDepth;
-    if (earlyAdd) {
+    if (earlyAdd && !heldAdd) {
         HP_SCOPE("pv.addNewLandmarks");
         addNewLandmarks(measurement, nullptr);
     }
@@ -760,7 +794,7 @@ VisionMeasurement VIOFilter::getFeaturePredictions(const GICameraPtr& camPtr, co
     }
     return r;
 }
-void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2) { // :258-278
+bool VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2, bool held) { // :258-278
     std::vector<Landmark> newLandmarks;
     {
         // ascending measurement ids (a VisionMeasurement's): the core, which keeps the state's ids sorted, says which of them are new in one merge pass
@@ -770,7 +804,7 @@ void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std:
         int n = 0;
         if (filterState.findUnknownIds(mids, unknownScratch_, n)) {
             if (n == 0)
-                return;
+                return true;
             newLandmarks.reserve(n);
             for (int t = 0; t < n; ++t) {
                 const int j = unknownScratch_[t];
@@ -780,10 +814,11 @@ void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std:
             const double initialDepth = settings->useMedianDepth ? getMedianSceneDepth(depth2) : settings->initialSceneDepth;
             for (Landmark& blm : newLandmarks)
                 blm.p = initialDepth * blm.p;
-            filterState.addNewLandmarks(newLandmarks, settings->initialPointVariance);
-            return;
+            return filterState.addNewLandmarks(newLandmarks, settings->initialPointVariance, held);
         }
     }
+    if (held)
+        return false; // (ids not ascending: the general route below runs behind the propagation)
     // O(M log N) membership instead of the reference's O(M N) scan. The state's ids are usually ascending already (a tracker numbers its features
     // as they appear, removals keep the order): no copy and no sort then, and one merge pass against the measurement's ascending ids.
     const std::vector<int>& stateIds = filterState.ids();
@@ -813,11 +848,11 @@ void VIOFilter::addNewLandmarks(const VisionMeasurement& measurement, const std:
         }
     }
     if (newLandmarks.empty())
-        return;
+        return true;
     const double initialDepth = settings->useMedianDepth ? getMedianSceneDepth(depth2) : settings->initialSceneDepth;
     for (Landmark& blm : newLandmarks)
         blm.p = initialDepth * blm.p;
-    filterState.addNewLandmarks(newLandmarks, settings->initialPointVariance);
+    return filterState.addNewLandmarks(newLandmarks, settings->initialPointVariance);
 }
 void VIOFilter::removeOldLandmarks(const std::vector<int>& measurementIds) { // :280-302
     if (filterState.removeUnmeasured(measurementIds)) // (ascending measurement ids, as a VisionMeasurement's are: one merge pass inside the core)

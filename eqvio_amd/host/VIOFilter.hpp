@@ -121,6 +121,7 @@ struct VisionMeasurement {
     const std::vector<int>& flatIds() const { return refreshFlat(), flatIds_; }
     const std::vector<double>& flatY() const { return refreshFlat(), flatY_; }
     void invalidateFlat() const { flatIds_.clear(), flatY_.clear(), flatN_ = (size_t)-1; }
+    size_t flatRebuilds() const { return flatRebuilds_; } // how often a walk found the cache different from the map
     // The cached arrays WITHOUT the validating walk (built if there are none of the right size): for a consumer that treats them as a hint and checks them
     // against validated data later - eqf_stage_measurement: the staged copy is compared with the measurement of the update call (eqf_stats_then_update) and
     // ignored if it differs. Takes the 1.7 us walk over the std::map off the host path between the doorbell and the propagation's launch.
@@ -149,6 +150,7 @@ struct VisionMeasurement {
     mutable std::vector<int> flatIds_;
     mutable std::vector<double> flatY_;
     mutable size_t flatN_ = (size_t)-1;
+    mutable size_t flatRebuilds_ = 0;
 };
 
 enum class CoordinateChoice { Euclidean = 0, InvDepth = 1, Normal = 2 };
@@ -187,12 +189,14 @@ struct VIO_eqf {
     void setSigmaDiag(const std::vector<double>& diag);
 
     // VIO_eqf members (include/eqvio/mathematical/VIO_eqf.h:44-134)
-    void addNewLandmarks(std::vector<Landmark>& newLandmarks, double newLandmarkVar);
+    bool addNewLandmarks(std::vector<Landmark>& newLandmarks, double newLandmarkVar, bool held = false); // held: eqf_add_landmarks_held; false: refused, nothing added
+    bool holdSupported() const { return eqf_hold_supported(ctx) == 1; }
     void removeLandmarkByIndex(const int& idx);
     void removeLandmarkById(const int& id);
     void removeLandmarksByIndex(const std::vector<int>& idx); // batched form of the above
     void removeInvalidLandmarks();
     bool removeUnmeasured(const std::vector<int>& measurementIds); // false: ids not ascending, nothing done
+    bool sameAsMapped(const std::vector<int>& measurementIds) const; // exactly the ids the last update mapped, one per landmark
     bool findUnknownIds(const std::vector<int>& measurementIds, std::vector<int>& unknownJ, int& n) const; // false: ids not ascending
     std::array<double, 9> getLandmarkCovById(const int& id) const;
     void integrateObserverState(const IMUVelocity& imuVelocity, const double& dt, const bool& discreteLift = true);
@@ -229,7 +233,7 @@ class VIOFilter {
     std::vector<IMUVelocity> velocityBuffer;
 
     bool integrateUpToTime(const double& newTime);
-    void addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2);
+    bool addNewLandmarks(const VisionMeasurement& measurement, const std::vector<double>* depth2, bool held = false);
     void removeOldLandmarks(const std::vector<int>& measurementIds);
     void removeOutliers(VisionMeasurement& measurement, std::vector<double>& depth2, const std::vector<double>* absErrIn = nullptr,
                         const std::vector<double>* probErrIn = nullptr);

@@ -104,6 +104,8 @@ enum {
                                   other buffers at the new ones anyway - instead of in a compaction pass in front of it: one launch and a copy of Sigma less in every frame of a
                                   feature tracker's normal turnover. Same values, same arithmetic: bit-identical. Not with the Normal chart, the dense mode or the float store;
                                   eqf_gather_stats counts. 0: always the pass */
+    EQF_OPT_HOLD_NEW_LANDMARKS = 24, /* 1 (default): eqf_add_landmarks_held is available (with EQF_OPT_GATHER_IN_PROPAGATE, fused assembly, fp64 Sigma, not the Normal chart;
+                                  eqf_hold_supported says). 0: it returns EQF_E_UNSUPPORTED and the caller appends its new landmarks behind the propagation */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.
@@ -156,6 +158,18 @@ int eqf_state_estimate(eqf_ctx* ctx, double* sensor, int* ids, double* p, int ca
 /* VIO_eqf::addNewLandmarks (VIO_eqf.cpp:225-245): appends k landmarks with Q = identity and
  * newLandmarkCov = var * I (the only form the reference's callers use, src/VIOFilter.cpp:129-130, 274-276). */
 int eqf_add_landmarks(eqf_ctx* ctx, const int* ids, const double* p, int k, double var);
+/* Round 5: addNewLandmarks for landmarks that belong to the time BEHIND the next eqf_propagate_fast. The reference propagates (src/VIOFilter.cpp:196) and then
+ * appends the frame's new landmarks (:217); appending them first and letting the propagation pass them through untouched (F = I, no input and no process noise for their
+ * rows, no observer steps; their cross-covariances are exact zeros) gives the same state bit for bit - and every id of the coming measurement is known BEFORE the
+ * propagation: the measurement can be staged (eqf_stage_measurement), the propagation kernel evaluates its output blocks and CREATES the held landmarks itself (their
+ * rows of Sigma, their planes: no append pass), and the update takes its three-launch route in a frame with landmark turnover as well. The held landmarks are the last
+ * ones of the state until that propagation; until then eqf_add_landmarks and the other propagation entry points return EQF_E_UNSUPPORTED; any other entry point turns
+ * them into an ordinary pending append (they still pass through the propagation untouched). Returns EQF_E_UNSUPPORTED - nothing added, the caller appends them behind the
+ * propagation as the reference does - when the options do not allow it (eqf_hold_supported), the capacity would have to grow, or landmarks with another variance are held.
+ * eqf_hold_stats: propagation launches that created held landmarks. */
+int eqf_add_landmarks_held(eqf_ctx* ctx, const int* ids, const double* p, int k, double var);
+int eqf_hold_supported(const eqf_ctx* ctx);
+int eqf_hold_stats(eqf_ctx* ctx, long* launches, int reset);
 /* VIO_eqf::removeLandmarkByIndex (VIO_eqf.cpp:172-178) for k indices at once (one compaction pass of Sigma). */
 int eqf_remove_landmarks(eqf_ctx* ctx, const int* indices, int k);
 /* VIOFilter::removeOldLandmarks (src/VIOFilter.cpp:280-302) in one call: every landmark of the state whose id is not among the M measured ids (strictly ascending, the order of
@@ -165,6 +179,9 @@ int eqf_remove_unmeasured_landmarks(eqf_ctx* ctx, const int* ids, int M, int* re
 /* The membership test of VIOFilter::addNewLandmarks (src/VIOFilter.cpp:258-278) in one merge pass: the positions j (ascending) of the measured ids (strictly ascending;
  * EQF_E_BAD_ARG otherwise) that have no landmark in the state go to unknown_j (room for M), their number to *n_unknown. Host only. */
 int eqf_find_unknown_ids(eqf_ctx* ctx, const int* ids, int M, int* unknown_j, int* n_unknown);
+/* 1 when `ids` are exactly the ids of the measurement the last update mapped, the landmark set has not changed since and there is one id per landmark (no landmark
+ * is lost, no id is new: the steady frame of a tracker), else 0. Host only, O(M). */
+int eqf_same_as_mapped(const eqf_ctx* ctx, const int* ids, int M);
 /* VIO_eqf::removeInvalidLandmarks (VIO_eqf.cpp:213-223). Returns the number removed (>=0) or <0. */
 int eqf_remove_invalid_landmarks(eqf_ctx* ctx);
 

@@ -46,4 +46,6 @@ lib.eqf_host_wait_stats(core, calls, secs, 0)
 gl = C.c_long()
 if hasattr(lib, "eqf_gather_stats") and lib.eqf_gather_stats(core, C.byref(gl), 0) == 0:
     print("propagation launches that applied a removal record themselves:", gl.value)
+if hasattr(lib, "eqf_hold_stats") and lib.eqf_hold_stats(core, C.byref(gl), 0) == 0:
+    print("propagation launches that created the frame's new landmarks themselves:", gl.value)
 print("host: doorbell waits", calls[0], f"{1e6 * secs[0] / max(calls[0], 1):.1f} us each; launches", calls[1], f"{1e6 * secs[1] / max(calls[1], 1):.2f} us each")

@@ -636,6 +636,98 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
         assert rel_fro(outs[1][0], orc.get_sigma()) <= 1e-9
 
 
+@pytest.mark.parametrize("chart", ["euclid", "invdepth"])
+@pytest.mark.parametrize("N,drop,knew", [(200, [3, 17, 100, 199], 5), (60, [], 3), (48, [0, 47], 16), (20, list(range(1, 20)), 30), (300, [0, 150, 299], 9), (16, [], 1)])
+def test_held_landmarks_pass_through_the_propagation(chart, N, drop, knew):
+    """eqf_add_landmarks_held: the frame's new landmarks appended IN FRONT of the propagation (the reference appends them behind it, VIOFilter.cpp:217 behind :196) and
+    passed through it untouched - created by the propagation kernel itself (rows of Sigma, planes, output blocks; no append pass). Against the reference's order
+    (remove, propagate, append) on a second context: Sigma, the state and the following update must agree bit for bit - with and without removals in the same frame, a
+    new landmark that fills a tile exactly, more new landmarks than old ones, above 256 landmarks; with an entry point in between (the held landmarks become an ordinary
+    append and still pass through); and the refusals (another variance, ordinary append while landmarks are held, the other propagation entry points)."""
+    import ctypes as C
+
+    from eqvio_amd.capi import EqfError, load_eqf_lib
+
+    lib = load_eqf_lib()
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=7 * N + knew, cap=N + knew + 8, useDiscreteInnovationLift=0)
+    cam = default_camera()
+    imus = [random_imu(rng) for _ in range(6)]
+    dts = [0.003] * 6
+    mean = np.mean(imus, axis=0)
+    new_ids = (np.arange(knew) * 13 + int(np.max(ids)) + 5).astype(np.int32)
+    new_p = rng.uniform(-1, 1, (knew, 3)) + np.array([0, 0, 5.0])
+    var = 1.7
+    Qg, Pg = settings.input_gain_diag12(), settings.state_gain_diag8()
+
+    def fresh():
+        c = EqfCore(N + knew + 8, CHARTS[chart])
+        c.set_state(xi0, Xs, ids, q0, Q)
+        c.set_sigma(S)
+        return c
+
+    # reference order
+    ref = fresh()
+    if drop:
+        ref.remove_landmarks(np.array(drop, np.int32))
+    ref.propagate_fast(mean, sum(dts), Qg, Pg, imus, dts, True)
+    ref.add_landmarks(new_ids, new_p, var)
+    # held, created by the propagation kernel
+    a = fresh()
+    if drop:
+        a.remove_landmarks(np.array(drop, np.int32))
+    assert a.add_landmarks_held(new_ids, new_p, var)
+    a.propagate_fast(mean, sum(dts), Qg, Pg, imus, dts, True)
+    used = C.c_long()
+    assert lib.eqf_hold_stats(a.h, C.byref(used), 0) == 0 and used.value == 1
+    # held, with an entry point in between (they are appended by an ordinary pass, and still pass through)
+    b = fresh()
+    if drop:
+        b.remove_landmarks(np.array(drop, np.int32))
+    assert b.add_landmarks_held(new_ids[:1], new_p[:1], var)
+    if knew > 1:
+        assert b.add_landmarks_held(new_ids[1:], new_p[1:], var)  # a second call joins the first
+    # refusals while landmarks are held
+    assert not b.add_landmarks_held(np.array([99991], np.int32), np.array([[0.0, 0.0, 4.0]]), var + 1.0)  # another variance
+    with pytest.raises(EqfError):
+        b.add_landmarks(np.array([99992], np.int32), np.array([[0.0, 0.0, 4.0]]), var)
+    with pytest.raises(EqfError):
+        b.integrate_riccati_fast(imus[0], 0.01, Qg, Pg)
+    assert b.get_sigma().shape == (21 + 3 * (N - len(drop) + knew),) * 2  # an entry point: ordinary append
+    b.propagate_fast(mean, sum(dts), Qg, Pg, imus, dts, True)
+    assert lib.eqf_hold_stats(b.h, C.byref(used), 0) == 0 and used.value == 0
+    Sr, str_ = ref.get_sigma(), ref.get_state()
+    for c in (a, b):
+        assert np.array_equal(c.get_sigma(), Sr)
+        for u, v in zip(c.get_state(), str_):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+    # the update that follows reads everything the propagation left (Sigma, elements, origin points, chart constants)
+    mid, y = synth_measurement(rng, cam, str_[2], str_[3], str_[4], noise_px=1.0)
+    for c in (ref, a, b):
+        c.vision_update(cam, mid, y, settings.measurementNoise**2, True, False)
+    for c in (a, b):
+        assert np.array_equal(c.get_sigma(), ref.get_sigma())
+        for u, v in zip(c.get_state(), ref.get_state()):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+    # ... and a second propagation reads what only a propagation reads of a landmark: its chart constants (computed where the landmark was created)
+    for c in (ref, a, b):
+        c.propagate_fast(mean, sum(dts), Qg, Pg, imus, dts, True)
+    for c in (a, b):
+        assert np.array_equal(c.get_sigma(), ref.get_sigma())
+        for u, v in zip(c.get_state(), ref.get_state()):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+    # a held landmark that is removed again is gone; the others still pass through
+    if knew >= 2:
+        d, r2 = fresh(), fresh()
+        assert d.add_landmarks_held(new_ids, new_p, var)
+        d.remove_landmarks(np.array([N], np.int32))  # the first held one
+        d.propagate_fast(mean, sum(dts), Qg, Pg, imus, dts, True)
+        r2.propagate_fast(mean, sum(dts), Qg, Pg, imus, dts, True)
+        r2.add_landmarks(new_ids[1:], new_p[1:], var)
+        assert np.array_equal(d.get_sigma(), r2.get_sigma())
+        for u, v in zip(d.get_state(), r2.get_state()):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
 def test_remove_unmeasured_landmarks_and_the_id_table_under_turnover():
     """eqf_remove_unmeasured_landmarks (VIOFilter::removeOldLandmarks, VIOFilter.cpp:280-302, in one call) and the sorted (id, index) table behind it, which
     eqf_add_landmarks / eqf_remove_landmarks keep up to date instead of re-sorting: 60 rounds of random turnover with ids in NO particular order in the state (and a
