@@ -3169,13 +3169,16 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
     }
     const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
     // staged by eqf_stage_measurement and copied to HBM by the propagation kernel: same measurement, same landmark set?
-    const bool staged = speculate && c->staged_valid && c->staged_gen == c->lm_gen && c->staged_M == M && std::equal(ids, ids + M, c->staged_ids.begin()) &&
-                        std::memcmp(c->staged_y.data(), y, sizeof(double) * 2 * M) == 0;
+    // (the pinned packet holds exactly this measurement, mapped and packed by stage_prepare: nothing to rewrite - and no wait for the propagation kernel's staging block,
+    //  which may still be reading it - whichever route the frame takes)
+    const bool same_as_staged = c->staged_valid && c->staged_gen == c->lm_gen && c->staged_M == M && std::equal(ids, ids + M, c->staged_ids.begin()) &&
+                                std::memcmp(c->staged_y.data(), y, sizeof(double) * 2 * M) == 0;
+    const bool staged = speculate && same_as_staged;
     c->staged_valid = c->stage_pending = c->stage_requested = false;
     int* lmidx = c->h_lmidx;
     int* measof = c->h_lmidx + c->Ncap;
     int rc = 0;
-    if (!staged) {
+    if (!same_as_staged) {
         if (c->busy_meas) {
             int r = sync_ctx(c);
             if (r)
@@ -3210,12 +3213,12 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         // state after the update (an unmeasured landmark can be marginalised before or after it).
         if (N <= SEL_ONE_WG) { // statistics and decision as one launch of one workgroup
             KTimer t(c, KN_STATS);
-            LAUNCH_TS(c, k_stats_select, dim3(1), dim3(256), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
+            LAUNCH_TS(c, k_stats_select, dim3(1), dim3(256), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), same_as_staged ? (const double*)c->h_ylm : pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
                       (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, thrAbs, thrProb, max_outliers, M, c->h_sel);
             HIPCHK(hipGetLastError());
         } else {
             KTimer t(c, KN_STATS);
-            LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(),
+            LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), same_as_staged ? (const double*)c->h_ylm : pack_by_landmark(c, measof, y), c->q0(), c->Qq(),
                       c->Qa(), (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, (int*)nullptr, c->h_door, seq, thrAbs, thrProb,
                       (int*)nullptr, seq, c->d_stats);
             HIPCHK(hipGetLastError());
@@ -3252,7 +3255,7 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
     if (!speculate) { // plain statistics call: the caller decides and calls eqf_vision_update
         {
             KTimer t(c, KN_STATS);
-            LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), pack_by_landmark(c, measof, y), c->q0(), c->Qq(),
+            LAUNCH_TS(c, k_outlier_stats, dim3(blocks(N, 64)), dim3(64), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), same_as_staged ? (const double*)c->h_ylm : pack_by_landmark(c, measof, y), c->q0(), c->Qq(),
                       c->Qa(), (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, use_door ? c->d_door : nullptr, c->h_door, seq, thrAbs,
                       thrProb, (int*)nullptr, seq, (double*)nullptr);
             HIPCHK(hipGetLastError());
