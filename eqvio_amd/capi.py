@@ -667,6 +667,13 @@ class PreparedFrames:
     def __len__(self):
         return self.lib.eqvio_frames_count(self.h)
 
+    def edit_id(self, frame, k, new_id):
+        """eqvio_frames_edit_id: the k-th feature of the frame's public map gets another id (erase + insert)."""
+        self.lib.eqvio_frames_edit_id.restype = C.c_int
+        self.lib.eqvio_frames_edit_id.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        if self.lib.eqvio_frames_edit_id(self.h, frame, k, new_id) != 0:
+            raise IndexError("eqvio_frames_edit_id")
+
     def edit_pixel(self, frame, k, u, v):
         """eqvio_frames_edit_pixel: write a pixel through the measurement's public map, as a caller of the reference's type may."""
         self.lib.eqvio_frames_edit_pixel.restype = C.c_int

@@ -54,6 +54,7 @@ void VisionMeasurement::refreshFlat() const {
         if (j == n)
             return;
     }
+    ++flatRebuilds_;
     flatIds_.resize(n);
     flatY_.resize(2 * n);
     size_t j = 0;

@@ -236,6 +236,20 @@ int eqvio_frames_edit_pixel(eqvio_frames* fr, int frame, int k, double u, double
     it->second = {u, v};
     return 0;
 }
+int eqvio_frames_edit_id(eqvio_frames* fr, int frame, int k, int new_id) {
+    // ... or replace a feature: erase the k-th entry of the public std::map and insert its pixel under another id (the size stays: a cached copy cannot tell by it)
+    if (!fr || frame < 0 || (size_t)frame >= fr->meas.size() || k < 0 || (size_t)k >= fr->meas[frame].camCoordinates.size())
+        return -1;
+    auto& m = fr->meas[frame].camCoordinates;
+    if (m.count(new_id))
+        return -1;
+    auto it = m.begin();
+    std::advance(it, k);
+    const auto px = it->second;
+    m.erase(it);
+    m[new_id] = px;
+    return 0;
+}
 void eqvio_frames_destroy(eqvio_frames* fr) { delete fr; }
 int eqvio_frames_count(const eqvio_frames* fr) { return fr ? (int)fr->meas.size() : -1; }
 int eqvio_filter_run_prepared(eqvio_filter* f, const eqvio_frames* fr, int first, int count) {

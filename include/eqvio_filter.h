@@ -65,6 +65,7 @@ eqvio_frames* eqvio_frames_create(const eqvio_camera* cam, int nframes, const in
  * caches next to the map are validated against the map before every use that matters (tests/test_gpu_filter.py: an edited frame gives the same state as a
  * frame built with the new value). Returns 0, or -1 for a bad index. */
 int eqvio_frames_edit_pixel(eqvio_frames* frames, int frame, int k, double u, double v);
+int eqvio_frames_edit_id(eqvio_frames* frames, int frame, int k, int new_id); /* the k-th feature of the frame's std::map gets another id (erase + insert: same size) */
 void eqvio_frames_destroy(eqvio_frames* frames);
 int eqvio_frames_count(const eqvio_frames* frames);
 int eqvio_filter_run_prepared(eqvio_filter* f, const eqvio_frames* frames, int first, int count);

@@ -41,7 +41,7 @@ def test_filter_lib_exports_every_declared_symbol(built):
     from eqvio_amd.capi import load_filter_lib
 
     assert sorted(load_filter_lib()._declared) == sorted(names)
-    for n in ("eqvio_frames_create", "eqvio_frames_destroy", "eqvio_frames_count", "eqvio_frames_edit_pixel"):  # prepared replay (same header)
+    for n in ("eqvio_frames_create", "eqvio_frames_destroy", "eqvio_frames_count", "eqvio_frames_edit_pixel", "eqvio_frames_edit_id"):  # prepared replay (same header)
         assert n in declared_symbols("eqvio_filter.h") and hasattr(lib, n)
     # the simulator's C view lives in the same library (include/eqvio_sim.h)
     sim_names = [n for n in declared_symbols("eqvio_sim.h") if (n.startswith("eqvio_sim_") and n != "eqvio_sim_settings") or n.startswith("eqvio_camera_")]

@@ -198,6 +198,47 @@ def test_measurement_edited_in_place_after_it_was_built():
     inplace.close()
 
 
+def test_feature_replaced_in_place_in_an_otherwise_quiet_frame():
+    """Round 5: in a frame whose (cached, unvalidated) ids are exactly the ones the last update mapped, VIOFilter::processVisionData decides "nobody lost, nobody new"
+    on the cache's word, launches the propagation and validates the measurement against its std::map BESIDE that kernel. A caller who replaced a feature in the public
+    map of an already built measurement (erase + insert under another id: the size stays, eqvio_frames_edit_id) is then found out behind the launch, and the lost and
+    the new landmark are dealt with there - the reference's own order. Against a filter that is given measurements built with the replaced ids from the start (whose
+    frames take the turnover route: removal inside the propagation kernel, held new landmark): identical state and Sigma to rounding (the two orders are the same
+    arithmetic; the output blocks come from different kernels, see test_output_blocks_from_the_propagation_kernel) - and identical landmark sets, frame by frame."""
+    N = 60
+    world, frames = bench.build_workload(seed=9, n_frames=7, N=N)
+    settings = bench.eurocish_settings()
+    mk = lambda s, sensor, ids, p, t: VIOFilter(s, max_landmarks=N + 8, sensor=sensor, ids=ids, p=p, time=t)  # noqa: E731
+    edited = [list(f) for f in frames]
+    swaps = []
+    next_id = int(max(int(np.max(f[2])) for f in frames)) + 100
+    for f, k in ((3, 7), (5, 0), (6, 59)):
+        ids = np.array(edited[f][2]).copy()
+        y = np.array(edited[f][3], dtype=np.float64).reshape(-1, 2).copy()
+        # erase + insert: the new id is the largest, so the pixel moves to the end of the (ascending) flat arrays
+        px = y[k].copy()
+        ids = np.concatenate([np.delete(ids, k), [next_id]])
+        y = np.vstack([np.delete(y, k, axis=0), px])
+        edited[f][2], edited[f][3] = ids.astype(np.int32), y.reshape(-1)
+        swaps.append((f, k, next_id))
+        next_id += 1
+    fresh = bench.make_filter(world, settings, N, None, frames, mk)
+    inplace = bench.make_filter(world, settings, N, None, frames, mk)
+    pf_fresh = PreparedFrames(world.cam, *bench.flatten_frames([tuple(f) for f in edited[:7]]))
+    pf_edit = PreparedFrames(world.cam, *bench.flatten_frames(frames[:7]))  # built (flat copies cached) with the OLD ids ...
+    for f, k, nid in swaps:  # ... then edited through the map only
+        pf_edit.edit_id(f, k, nid)
+    for f in range(7):
+        assert fresh.run_prepared(pf_fresh, f, 1) == 1 and inplace.run_prepared(pf_edit, f, 1) == 1
+        (sa, ia, pa), (sb, ib, pb) = fresh.state_estimate(), inplace.state_estimate()
+        assert np.array_equal(ia, ib), f
+        assert np.allclose(sa, sb, rtol=0, atol=1e-11) and np.allclose(pa, pb, rtol=0, atol=1e-10), f
+        Sa, Sb = fresh.get_sigma(), inplace.get_sigma()
+        assert np.linalg.norm(Sa - Sb) <= 1e-10 * np.linalg.norm(Sa), f
+    fresh.close()
+    inplace.close()
+
+
 @pytest.mark.parametrize("N", [200, 60])
 def test_measurement_and_z_inside_the_lookahead_kernel_change_nothing(N):
     """EQF_OPT_Z_IN_LOOKAHEAD in the speculative frame tail (bench.py's path): 0 = k_build_Z in front of the look-ahead kernel, 2 = the look-ahead kernel
