@@ -1316,19 +1316,24 @@ static int fetch_estimates(eqf_ctx* c) { // d_est -> h_buf (4 planes of stride N
     { int _e = enter(c); if (_e) return _e; }
     { int _r = join_observer(c); if (_r) return _r; }
     // straight into the pinned staging buffer (no copy command behind the kernel: a blit and its boundary cost more than the 6 KB written across the bus)
-    hipLaunchKernelGGL(k_estimate, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->h_buf);
+    // (round 5) the host waits on a doorbell rung by the last of these kernels instead of the stream's completion signal (~8 us per state estimate read between propagation
+    // and update: the reference's removeOutliers, the reference-side binding's member-for-member sequence)
+    const bool with_ocov = c->ocov_hint_valid && !c->sig32;
+    const bool use_door = c->opt_door && !c->opt_check && !c->obs_pending;
+    const int door_seq = use_door ? (int)(++c->door_seq) : 0;
+    int* const dcount = use_door ? c->d_door + 2 : nullptr;
+    hipLaunchKernelGGL(k_estimate, dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->q0(), c->Qq(), c->Qa(), c->h_buf, with_ocov ? (int*)nullptr : dcount, c->h_door + 2, door_seq);
     HIPCHK(hipGetLastError());
     // A caller that reads the state estimate between propagation and update is the reference's removeOutliers (src/VIOFilter.cpp:304-334), which asks for the output
     // covariance of every measured landmark next: computed here as well, for the camera of the last such request, behind the same wait (eqf_output_cov_all returns it)
-    const bool with_ocov = c->ocov_hint_valid && !c->sig32;
     if (with_ocov) {
         if (!c->h_ocov)
             HIPCHK(hipHostMalloc(&c->h_ocov, sizeof(double) * 4 * (size_t)c->Ncap));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_output_cov<double>), dim3(blocks(N, 64)), dim3(64), 0, c->stream, N, c->Ncap, c->ld, c->chart, c->ocov_hint, c->q0(), c->Qq(), c->Qa(),
-                           (const double*)c->sigma(), c->h_ocov);
+                           (const double*)c->sigma(), c->h_ocov, dcount, c->h_door + 2, door_seq);
         HIPCHK(hipGetLastError());
     }
-    { int _r = sync_ctx(c); if (_r) return _r; }
+    { int _r = use_door ? door_wait(c, 2, door_seq) : sync_ctx(c); if (_r) return _r; }
     if (with_ocov)
         c->ocov_valid = true, c->ocov_cam = c->ocov_hint;
     return 0;

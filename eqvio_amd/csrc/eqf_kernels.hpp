@@ -648,10 +648,13 @@ __device__ __forceinline__ void outlier_stats_body(int N, int Ncap, int ld, int 
 // them one id at a time; a binding that keeps the reference's VIOFilter.cpp unchanged fetches all of them on the first call of a frame.
 template <typename TS>
 __global__ void __launch_bounds__(64) k_output_cov(int N, int Ncap, int ld, int chart, Cam cam, const double* __restrict__ q0, const double* __restrict__ Qq,
-                                                   const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out) {
+                                                   const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int* __restrict__ door_count = nullptr,
+                                                   int* __restrict__ door_host = nullptr, int door_seq = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
+    if (i >= N) {
+        ring_doorbell(door_count, door_host, door_seq); // (round 5: a caller that waits for these numbers polls a doorbell instead of the stream's completion signal)
         return;
+    }
     const V3 p0 = ld3(q0, Ncap, i);
     const Qt q = ldq(Qq, Ncap, i);
     const double a = Qa[i];
@@ -674,6 +677,7 @@ __global__ void __launch_bounds__(64) k_output_cov(int N, int Ncap, int ld, int 
     out[4 * i + 1] = CS[0][0] * o.c[3] + CS[0][1] * o.c[4] + CS[0][2] * o.c[5];
     out[4 * i + 2] = CS[1][0] * o.c[0] + CS[1][1] * o.c[1] + CS[1][2] * o.c[2];
     out[4 * i + 3] = CS[1][0] * o.c[3] + CS[1][1] * o.c[4] + CS[1][2] * o.c[5];
+    ring_doorbell(door_count, door_host, door_seq);
 }
 template <typename TS>
 __global__ void __launch_bounds__(64) k_outlier_stats(int N, int Ncap, int ld, int chart, Cam cam, const double* __restrict__ ylm,
@@ -2334,16 +2338,17 @@ __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_lift(int n, int m, int ld
 }
 // q_hat_i = Q_i^-1 q0_i for all landmarks (stateGroupAction, VIOGroup.cpp:44-52)
 __global__ void __launch_bounds__(64) k_estimate(int N, int Ncap, const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
-                                                 double* __restrict__ est) {
+                                                 double* __restrict__ est, int* __restrict__ door_count = nullptr, int* __restrict__ door_host = nullptr, int door_seq = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
-    const double a = Qa[i];
-    const V3 qh = (1.0 / a) * q_rot(q_inv(ldq(Qq, Ncap, i)), ld3(q0, Ncap, i));
-    est[i] = qh.x;
-    est[N + i] = qh.y;
-    est[2 * N + i] = qh.z;
-    est[3 * N + i] = (a <= 1e-8 || a > 1e8 || !(a == a)) ? 1.0 : 0.0;
+    if (i < N) {
+        const double a = Qa[i];
+        const V3 qh = (1.0 / a) * q_rot(q_inv(ldq(Qq, Ncap, i)), ld3(q0, Ncap, i));
+        est[i] = qh.x;
+        est[N + i] = qh.y;
+        est[2 * N + i] = qh.z;
+        est[3 * N + i] = (a <= 1e-8 || a > 1e8 || !(a == a)) ? 1.0 : 0.0;
+    }
+    ring_doorbell(door_count, door_host, door_seq);
 }
 
 // ---------------------------------------------------------------------------------------------------
