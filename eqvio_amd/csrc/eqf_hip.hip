@@ -2289,7 +2289,7 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
     // eqf_add_landmarks_held: the held landmarks (the last n_held of the state) are created by the same kernel (GatherArgs::held) unless an ordinary pass has appended them.
     GatherArgs gather{};
     bool use_gather = false;
-    const bool fused_kernel = c->opt_fuse_asm && !c->opt_dense && !c->sig32 && c->chart != EQVIO_COORD_NORMAL && k > 0 && k <= eqf_ctx::kMaxSteps && c->N > 0;
+    const bool fused_kernel = c->opt_fuse_asm && !c->opt_dense && !c->sig32 && c->chart != EQVIO_COORD_NORMAL && k > 0 && c->N > 0; // (more steps than one chunk holds: the further chunks are k_observer launches on the new buffers, for the propagated landmarks only)
     if (c->n_held > 0 && !fused_kernel)
         return EQF_E_UNSUPPORTED; // (eqf_add_landmarks_held checked the options: one was changed in between, or there are no observer steps to ride along)
     const int Nprop = c->N - c->n_held;

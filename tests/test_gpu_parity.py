@@ -637,7 +637,7 @@ def test_lookahead_factorisation_is_bit_identical_to_the_launch_chain(N, M):
 
 
 @pytest.mark.parametrize("chart", ["euclid", "invdepth"])
-@pytest.mark.parametrize("N,drop,knew", [(200, [3, 17, 100, 199], 5), (60, [], 3), (48, [0, 47], 16), (20, list(range(1, 20)), 30), (300, [0, 150, 299], 9), (16, [], 1)])
+@pytest.mark.parametrize("N,drop,knew", [(200, [3, 17, 100, 199], 5), (60, [], 3), (48, [0, 47], 16), (20, list(range(1, 20)), 30), (300, [0, 150, 299], 9), (16, [], 1), (61, [5, 60], 4)])
 def test_held_landmarks_pass_through_the_propagation(chart, N, drop, knew):
     """eqf_add_landmarks_held: the frame's new landmarks appended IN FRONT of the propagation (the reference appends them behind it, VIOFilter.cpp:217 behind :196) and
     passed through it untouched - created by the propagation kernel itself (rows of Sigma, planes, output blocks; no append pass). Against the reference's order
@@ -651,8 +651,9 @@ def test_held_landmarks_pass_through_the_propagation(chart, N, drop, knew):
     lib = load_eqf_lib()
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS[chart], N, seed=7 * N + knew, cap=N + knew + 8, useDiscreteInnovationLift=0)
     cam = default_camera()
-    imus = [random_imu(rng) for _ in range(6)]
-    dts = [0.003] * 6
+    nsteps = 45 if N == 61 else 6  # 45: more IMU samples than one chunk of observer steps holds (a dropped camera frame): the further chunks are launches of their own
+    imus = [random_imu(rng) for _ in range(nsteps)]
+    dts = [0.003] * nsteps
     mean = np.mean(imus, axis=0)
     new_ids = (np.arange(knew) * 13 + int(np.max(ids)) + 5).astype(np.int32)
     new_p = rng.uniform(-1, 1, (knew, 3)) + np.array([0, 0, 5.0])
