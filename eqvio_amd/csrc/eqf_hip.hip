@@ -3218,7 +3218,8 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         // state after the update (an unmeasured landmark can be marginalised before or after it).
         if (N <= SEL_ONE_WG) { // statistics and decision as one launch of one workgroup
             KTimer t(c, KN_STATS);
-            LAUNCH_TS(c, k_stats_select, dim3(1), dim3(256), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam), same_as_staged ? (const double*)c->h_ylm : pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
+            LAUNCH_TS(c, k_stats_select, dim3(1), dim3(256), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam),
+                      same_as_staged ? (const double*)(c->d_meas + 2 * (size_t)c->Ncap) /* the staged copy in HBM: no PCIe round trip in front of the statistics */ : pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
                       (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, thrAbs, thrProb, max_outliers, M, c->h_sel);
             HIPCHK(hipGetLastError());
         } else {
