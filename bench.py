@@ -607,12 +607,17 @@ def frame_mix(N, device, lib, n_frames=1200, n_warm=200):
         lib.eqf_synchronize(core)
         el = time.perf_counter() - t0
         lib.eqf_speculation_stats(core, C.byref(c0), C.byref(q0), C.byref(x0), 0)
+        g0, h0 = C.c_long(), C.c_long()  # propagation launches (warm-up included) that applied a record of removed landmarks / created the frame's new landmarks themselves
+        lib.eqf_gather_stats(core, C.byref(g0), 0)
+        lib.eqf_hold_stats(core, C.byref(h0), 0)
         S = flt.get_sigma()
         ok = bool(np.all(np.isfinite(S)))
         flt.close()
         out.append({"workload": name, "value": n_frames / el, "unit": "updates/s", "frames": n_frames, "features_changed_per_frame": round(turn, 2),
                     "mean_landmarks": (float(np.mean(dims)) - 21.0) / 3.0, "frames_with_tail_queued_speculatively": q0.value / max(c0.value, 1),
-                    "frames_with_tail_cancelled_on_device": x0.value / max(c0.value, 1), "sigma_finite": ok})
+                    "frames_with_tail_cancelled_on_device": x0.value / max(c0.value, 1),
+                    "frames_whose_removed_landmarks_left_inside_the_propagation_kernel": g0.value / (n_warm + n_frames),
+                    "frames_whose_new_landmarks_were_created_by_the_propagation_kernel": h0.value / (n_warm + n_frames), "sigma_finite": ok})
     return out
 
 
