@@ -229,7 +229,7 @@ struct eqf_ctx {
     char* h_rs_ring = nullptr;     // kRing pinned packets: map[Ncap] ints | newp[3 Ncap] | var[Ncap] doubles
     char* d_rs = nullptr;
     size_t rs_bytes = 0;
-    int spec_backoff = 0, spec_backoff_len = 0; // frames left without speculation after cancelled tails (doubling, <= 16), see eqf_stats_then_update
+    int spec_backoff = 0, spec_backoff_len = 0; // frames left without speculation after cancelled tails (doubling, <= 16; <= 256 with the device-side outlier decision), see eqf_stats_then_update
     long spec_calls = 0, spec_queued = 0, spec_cancelled = 0; // eqf_stats_then_update: calls, tails queued speculatively, tails cancelled on the device
     long nees_lu_fallbacks = 0;              // computeNEES calls answered by the partial-pivot elimination (Sigma not numerically SPD)
     int ldzn = 0;
@@ -3305,7 +3305,9 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
     ++c->spec_queued;
     if (c->h_resflags[2]) { // cancelled on the device: nothing was modified, C / residuals of the statistics kernel are still valid
         ++c->spec_cancelled;
-        c->spec_backoff_len = std::min(16, std::max(1, 2 * c->spec_backoff_len));
+        // (up to 256 frames when the caller lets the device take the outlier decision: a frame with candidates then costs one round trip anyway, a cancelled tail two and a wasted
+        //  launch sequence - with candidates in nearly every frame, the shipped thresholds, the cap of 16 wasted a tail every 17th frame)
+        c->spec_backoff_len = std::min(max_outliers >= 0 ? 256 : 16, std::max(1, 2 * c->spec_backoff_len));
         c->spec_backoff = c->spec_backoff_len;
         c->meas_valid = true;
         return 0;
