@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.environ.get("EQVIO_AMD_LIB_DIR") or os.path.join(_HERE, "lib")  # the override: same-box A/B of two builds (scripts/ab_builds.sh)
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_LA_TIMEOUT_US, OPT_Z_IN_LOOKAHEAD, OPT_LA_SPLIT_ROWS, OPT_MEASURE_IN_PROPAGATE, OPT_LIFT_WITH_SYRK, OPT_LA_HOME, OPT_TILES_PER_WORKGROUP, OPT_GATHER_IN_PROPAGATE, OPT_HOLD_NEW_LANDMARKS, OPT_TIMING = 1, 2, 3, 6, 7, 8, 9, 11, 12, 15, 17, 18, 19, 20, 21, 22, 23, 24, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_LA_TIMEOUT_US, OPT_Z_IN_LOOKAHEAD, OPT_LA_SPLIT_ROWS, OPT_MEASURE_IN_PROPAGATE, OPT_LIFT_WITH_SYRK, OPT_LA_HOME, OPT_TILES_PER_WORKGROUP, OPT_GATHER_IN_PROPAGATE, OPT_HOLD_NEW_LANDMARKS, OPT_SELECT_ONE_WORKGROUP, OPT_TIMING = 1, 2, 3, 6, 7, 8, 9, 11, 12, 15, 17, 18, 19, 20, 21, 22, 23, 24, 25, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -408,6 +408,17 @@ class EqfCore:
         self._chk0(self.lib.eqf_stats_then_update(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), thr_abs, thr_prob, meas_var, int(use_equivariant), int(discrete), _dp(a),
                                                   _dp(p), _dp(d), C.byref(upd)))
         return upd.value, a, p, d  # 1 updated, 0 cancelled on the device, -1 not applicable
+
+    def stats_select_update(self, cam, ids, y, thr_abs, thr_prob, max_outliers, meas_var, use_equivariant=True, discrete=False):
+        """eqf_stats_select_update: returns (updated, absErr, probErr, depth2, former state indices of the discarded landmarks)."""
+        ids, y = _i32(ids), _f64(y)
+        n0 = self.N
+        a, p, d = np.zeros(n0), np.zeros(n0), np.zeros(n0)
+        upd, nrm = C.c_int(0), C.c_int(0)
+        rm = np.zeros(max(n0, 1), np.int32)
+        self._chk0(self.lib.eqf_stats_select_update(self.h, C.byref(cam), _ip(ids), _dp(y), len(ids), thr_abs, thr_prob, int(max_outliers), meas_var, int(use_equivariant),
+                                                    int(discrete), _dp(a), _dp(p), _dp(d), C.byref(upd), _ip(rm), C.byref(nrm)))
+        return upd.value, a, p, d, rm[: nrm.value].copy()
 
     def last_gamma(self):
         out = np.zeros(self.n + 64)

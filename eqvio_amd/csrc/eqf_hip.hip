@@ -184,6 +184,7 @@ struct eqf_ctx {
     int opt_prop_tpw = 1;                    // EQF_OPT_TILES_PER_WORKGROUP
     int opt_gather = 1;                      // EQF_OPT_GATHER_IN_PROPAGATE
     int opt_hold = 1;                        // EQF_OPT_HOLD_NEW_LANDMARKS
+    int opt_sel_one = 1;                     // EQF_OPT_SELECT_ONE_WORKGROUP
     // eqf_add_landmarks_held: the last n_held landmarks of the state wait for the next eqf_propagate_fast, which passes them through untouched (GatherArgs)
     int n_held = 0;
     double held_var = 0.0;
@@ -1066,6 +1067,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_TILES_PER_WORKGROUP: *value = c->opt_prop_tpw; return 0;
     case EQF_OPT_GATHER_IN_PROPAGATE: *value = c->opt_gather; return 0;
     case EQF_OPT_HOLD_NEW_LANDMARKS: *value = c->opt_hold; return 0;
+    case EQF_OPT_SELECT_ONE_WORKGROUP: *value = c->opt_sel_one; return 0;
     case EQF_OPT_LA_HOME: *value = c->opt_la_home; return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE: *value = c->opt_measure_prop; return 0;
     case EQF_OPT_LIFT_WITH_SYRK: *value = c->opt_lift_syrk; return 0;
@@ -1120,6 +1122,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_HOLD_NEW_LANDMARKS:
         c->opt_hold = value ? 1 : 0;
+        return 0;
+    case EQF_OPT_SELECT_ONE_WORKGROUP:
+        c->opt_sel_one = value ? 1 : 0;
         return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE:
         c->opt_measure_prop = value ? 1 : 0;
@@ -1388,7 +1393,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_HOLD_NEW_LANDMARKS, c->opt_hold}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_HOLD_NEW_LANDMARKS, c->opt_hold}, {EQF_OPT_SELECT_ONE_WORKGROUP, c->opt_sel_one}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -3216,9 +3221,9 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         // Outlier candidates frame after frame (speculation has backed off): statistics, the outlier decision (k_select_outliers: the discarded
         // landmarks' measurements are masked out of C) and the whole update queued at once, ONE host wait. The discarded landmarks leave the
         // state after the update (an unmeasured landmark can be marginalised before or after it).
-        if (N <= SEL_ONE_WG) { // statistics and decision as one launch of one workgroup
+        if (N <= SEL_ONE_WG && c->opt_sel_one) { // statistics and decision as one launch of one workgroup
             KTimer t(c, KN_STATS);
-            LAUNCH_TS(c, k_stats_select, dim3(1), dim3(256), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam),
+            LAUNCH_TS(c, k_stats_select, dim3(1), dim3(512), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam),
                       same_as_staged ? (const double*)(c->d_meas + 2 * (size_t)c->Ncap) /* the staged copy in HBM: no PCIe round trip in front of the statistics */ : pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
                       (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, thrAbs, thrProb, max_outliers, M, c->h_sel);
             HIPCHK(hipGetLastError());

@@ -766,61 +766,155 @@ __global__ void __launch_bounds__(256) k_select_outliers(int N, int Ncap, int M,
 
 // k_outlier_stats and k_select_outliers as ONE launch of one workgroup (round 5; up to SEL_ONE_WG landmarks): in a frame whose outlier decision is taken on the device the
 // host queues statistics, decision and the whole update back to back, and its launch calls (5 - 6 us each) - not the kernels in front of the factorisation - set the pace
-// of that part of the frame. Same arithmetic per landmark (outlier_stats_body), same ranking: identical results to the two launches.
+// of that part of the frame. Same arithmetic per landmark (outlier_stats_body's), same ranking: identical results to the two launches.
+// A lone workgroup is bound by the latency of its dependent fp64 chains, not by issue, so the work is laid out for latency (first form: 27 us at 200 landmarks):
+//   * 512 lanes: waves 0 - 3 evaluate the statistics of a landmark (output block at the estimate, C0 Sigma_ii C0^T, the two errors), waves 4 - 7 at the same time
+//     what the update needs of it (the equivariant output block, the residual) - two waves per SIMD, the one's stalls are the other's issue slots;
+//   * everything stays in registers until the decision is known: no store to the pinned packet (a PCIe round trip a fence would wait for) and no store of an output block
+//     that the mask would have to zero again in front of the ranking;
+//   * the candidates go into a list as they are found, and the ranking is among the list's entries only, a candidate against 64 entries per instruction
+//     (ballot + population count) - 55 candidates of 200 landmarks with the shipped thresholds - instead of every candidate's lane walking over all landmarks.
 constexpr int SEL_ONE_WG = 512;
+struct alignas(16) SelCand {
+    double val;
+    int kind, idx; // 1: probabilistic, 2: absolute; landmark
+};
+constexpr int SEL_PER_LANE = SEL_ONE_WG / 256;
 template <typename TS>
-__global__ void __launch_bounds__(256) k_stats_select(int N, int Ncap, int ld, int chart, Cam cam, const double* __restrict__ ylm, const double* __restrict__ q0,
+__global__ void __launch_bounds__(512) k_stats_select(int N, int Ncap, int ld, int chart, Cam cam, const double* __restrict__ ylm, const double* __restrict__ q0,
                                                       const double* __restrict__ Qq, const double* __restrict__ Qa, const TS* __restrict__ Sig, double* __restrict__ out, int star,
                                                       double* __restrict__ C, double* __restrict__ ytil, int* __restrict__ lmidx_dev, int* __restrict__ flags, double thrAbs,
                                                       double thrProb, int max_outliers, int M, int* __restrict__ removed_host) {
-    __shared__ double s_val[SEL_ONE_WG];
-    __shared__ signed char s_kind[SEL_ONE_WG]; // 0: no candidate, 1: probabilistic, 2: absolute
+    __shared__ signed char s_kind[SEL_ONE_WG]; // 0: no candidate, 1: probabilistic, 2: absolute, -1: beyond N
     __shared__ unsigned char s_rm[SEL_ONE_WG];
-    __shared__ int s_cnt[2];
-    const int tid = threadIdx.x;
+    __shared__ SelCand s_cand[SEL_ONE_WG]; // the candidates as a list, in no particular order
+    __shared__ int s_cnt[2]; // candidates, discarded
+    const int tid = threadIdx.x, t = tid & 255;
+    const bool stat_half = tid < 256; // wave-uniform
     if (tid < 2)
         s_cnt[tid] = 0;
-    for (int i = tid; i < N; i += 256) {
-        double a = -1.0, p = -1.0; // stay negative for a landmark without a measurement
-        outlier_stats_body<TS>(N, Ncap, ld, chart, cam, ylm, q0, Qq, Qa, Sig, out, star, C, ytil, lmidx_dev, flags, a, p, true, i);
-        const bool measured = a >= 0.0;
-        const bool isabs = measured && a > thrAbs; // the comparisons of VIOFilter.cpp:316, 330 (NaN: false)
-        const bool isprob = measured && !isabs && p > thrProb;
-        s_kind[i] = isabs ? 2 : (isprob ? 1 : 0);
-        s_val[i] = isabs ? a : p;
-    }
-    __threadfence(); // C / yTilde / the index map are in memory before another thread of this workgroup masks or reads them
     __syncthreads();
-    for (int i = tid; i < N; i += 256) {
-        int rank = 0;
-        const int ki = s_kind[i];
-        const double vi = s_val[i];
-        if (ki) {
-            for (int j = 0; j < N; ++j) {
-                const int kj = s_kind[j];
-                rank += (kj > ki) || (kj == ki && (s_val[j] > vi || (s_val[j] == vi && j < i)));
-            }
-            atomicAdd(&s_cnt[0], 1);
+    // registers of a lane: statistics half (abs, prob, depth^2), update half (C block, residual, measurement index)
+    double r_a[SEL_PER_LANE], r_p[SEL_PER_LANE], r_d[SEL_PER_LANE], r_c[SEL_PER_LANE][6], r_y[SEL_PER_LANE][2];
+    int r_j[SEL_PER_LANE];
+#pragma unroll
+    for (int it = 0; it < SEL_PER_LANE; ++it) {
+        const int i = t + 256 * it;
+        r_j[it] = -1;
+        if (i >= N) {
+            if (stat_half && i < SEL_ONE_WG)
+                s_kind[i] = -1;
+            continue;
         }
-        const bool rm = ki && rank < max_outliers;
-        s_rm[i] = rm;
-        removed_host[i] = rm ? 1 : 0;
-        if (rm)
-            atomicAdd(&s_cnt[1], 1);
+        const double yu = ylm[i], yv = ylm[Ncap + i];
+        const int j = (int)ylm[2 * Ncap + i];
+        const V3 p0 = ld3(q0, Ncap, i);
+        const Qt q = ldq(Qq, Ncap, i);
+        const double a = Qa[i];
+        r_j[it] = j;
+        if (j < 0) { // a landmark without a measurement
+            if (stat_half) {
+                const V3 qh = (1.0 / a) * q_rot(q_inv(q), p0);
+                r_a[it] = -1.0, r_p[it] = -1.0, r_d[it] = norm2(qh);
+                s_kind[i] = 0;
+            }
+            continue;
+        }
+        const M3 r0m = chart == EQVIO_COORD_INVDEPTH ? ld_cc(q0, Ncap, i, CC_R0) : M3{};
+        if (!stat_half) {
+            const MeasOut os = measure_one(chart, cam, p0, q, a, yu, yv, star != 0, r0m);
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                r_c[it][e] = os.c[e];
+            r_y[it][0] = os.yt[0], r_y[it][1] = os.yt[1];
+            continue;
+        }
+        const MeasOut o = measure_one(chart, cam, p0, q, a, yu, yv, false, r0m);
+        const int l = 21 + 3 * i;
+        double S[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                S[r][c] = Sig[l + r + (size_t)(l + c) * ld];
+        double CS[2][3]; // cov = C0 S C0^T
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                CS[r][c] = o.c[r * 3 + 0] * S[0][c] + o.c[r * 3 + 1] * S[1][c] + o.c[r * 3 + 2] * S[2][c];
+        const double v00 = CS[0][0] * o.c[0] + CS[0][1] * o.c[1] + CS[0][2] * o.c[2];
+        const double v01 = CS[0][0] * o.c[3] + CS[0][1] * o.c[4] + CS[0][2] * o.c[5];
+        const double v10 = CS[1][0] * o.c[0] + CS[1][1] * o.c[1] + CS[1][2] * o.c[2];
+        const double v11 = CS[1][0] * o.c[3] + CS[1][1] * o.c[4] + CS[1][2] * o.c[5];
+        const double det = v00 * v11 - v01 * v10;
+        const double t0 = (v11 / det) * o.yt[0] + (-v01 / det) * o.yt[1];
+        const double t1 = (-v10 / det) * o.yt[0] + (v00 / det) * o.yt[1];
+        const double ae = sqrt(o.yt[0] * o.yt[0] + o.yt[1] * o.yt[1]);
+        const double pe = o.yt[0] * t0 + o.yt[1] * t1;
+        r_a[it] = ae, r_p[it] = pe, r_d[it] = norm2(o.qh);
+        const bool isabs = ae > thrAbs; // the comparisons of VIOFilter.cpp:316, 330 (NaN: false)
+        const bool isprob = !isabs && pe > thrProb;
+        s_kind[i] = isabs ? 2 : (isprob ? 1 : 0);
+        if (isabs || isprob) {
+            const int c = atomicAdd(&s_cnt[0], 1);
+            s_cand[c] = SelCand{isabs ? ae : pe, isabs ? 2 : 1, i};
+        }
     }
     __syncthreads();
+    // ranking: candidates ordered absolute outliers first (largest absErr first), then probabilistic ones (largest probErr first), ties by index. Among the list's
+    // entries only, by whole waves: wave w takes the candidates c = w, w + 8, ..; its lanes hold 64 entries of the list at a time, and a candidate (one 16-byte
+    // broadcast read from LDS) is compared with all of them in one go (ballot + population count). Lane k of the wave accumulates the rank of the wave's k-th candidate.
+    {
+        const int ncand = s_cnt[0];
+        const int w = tid >> 6, lane = tid & 63;
+        int myrank = 0;
+        for (int r0 = 0; r0 < ncand; r0 += 64) {
+            const int e = r0 + lane;
+            const SelCand en = e < ncand ? s_cand[e] : SelCand{0.0, -1, 0}; // kind -1: never in front of anything
+#pragma unroll 4
+            for (int kk = 0; w + 8 * kk < ncand; ++kk) {
+                const SelCand ci = s_cand[w + 8 * kk];
+                const int part = __popcll(__ballot((en.kind > ci.kind) || (en.kind == ci.kind && (en.val > ci.val || (en.val == ci.val && en.idx < ci.idx)))));
+                myrank += lane == kk ? part : 0;
+            }
+        }
+        const int c = w + 8 * lane;
+        const bool rm = c < ncand && myrank < max_outliers;
+        if (c < ncand)
+            s_rm[s_cand[c].idx] = rm ? 1 : 0;
+        const int nrm = __popcll(__ballot(rm));
+        if (lane == 0 && nrm)
+            atomicAdd(&s_cnt[1], nrm);
+    }
+    __syncthreads();
+    // results: the statistics half writes the host's packet, the update half the output blocks (zero for a discarded landmark: its two columns of Z are (0, R_jj, 0))
     if (tid == 0) {
         removed_host[Ncap] = s_cnt[0];
         removed_host[Ncap + 1] = s_cnt[1];
+        flags[0] = 0;
+        flags[1] = 0;
+        flags[3] = 0;
     }
-    for (int j = tid; j < M; j += 256) {
-        const int li = __hip_atomic_load(lmidx_dev + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s_rm[li]) {
+#pragma unroll
+    for (int it = 0; it < SEL_PER_LANE; ++it) {
+        const int i = t + 256 * it;
+        if (i >= N)
+            continue;
+        const bool rm = r_j[it] >= 0 && s_kind[i] > 0 && s_rm[i];
+        if (stat_half) {
+            out[i] = r_a[it];
+            out[N + i] = r_p[it];
+            out[2 * N + i] = r_d[it];
+            removed_host[i] = rm ? 1 : 0;
+        } else if (r_j[it] >= 0) {
+            const int j = r_j[it];
 #pragma unroll
             for (int e = 0; e < 6; ++e)
-                C[e * Ncap + j] = 0.0;
-            ytil[2 * j] = 0.0;
-            ytil[2 * j + 1] = 0.0;
+                C[e * Ncap + j] = rm ? 0.0 : r_c[it][e];
+            ytil[2 * j] = rm ? 0.0 : r_y[it][0];
+            ytil[2 * j + 1] = rm ? 0.0 : r_y[it][1];
+            lmidx_dev[j] = i;
         }
     }
 }

@@ -106,6 +106,8 @@ enum {
                                   eqf_gather_stats counts. 0: always the pass */
     EQF_OPT_HOLD_NEW_LANDMARKS = 24, /* 1 (default): eqf_add_landmarks_held is available (with EQF_OPT_GATHER_IN_PROPAGATE, fused assembly, fp64 Sigma, not the Normal chart;
                                   eqf_hold_supported says). 0: it returns EQF_E_UNSUPPORTED and the caller appends its new landmarks behind the propagation */
+    EQF_OPT_SELECT_ONE_WORKGROUP = 25, /* 1 (default): up to 512 landmarks, the outlier statistics and the device-side outlier decision of eqf_stats_select_update are one
+                                  launch of one workgroup (k_stats_select); 0: two launches (k_outlier_stats, k_select_outliers), as above 512 landmarks. Same results */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.

@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""frame_mix's shipped-threshold world for a profiler: 200 warm-up frames, then `n` frames, nothing else (no event timing).
+usage: [rocprofv3 --kernel-trace --stats -d out --] python scripts/dbg/shipped_frames.py [shipped|off] [n]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+from eqvio_amd.capi import PreparedFrames, VIOFilter, load_eqf_lib
+from eqvio_amd.simworld import SimWorld
+mode = sys.argv[1] if len(sys.argv) > 1 else "shipped"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+lib = load_eqf_lib()
+N = 200
+s = bench.eurocish_settings()
+if mode == "shipped":
+    s.outlierThresholdAbs, s.outlierThresholdProb, s.featureRetention, s.initialPointVariance = 4.852186665580312, 0.03229809583062128, 0.18594708334486176, 129.90415638150924
+world = SimWorld(seed=321, num_points=2500, max_features=N, trajectory="wave", noise_px=0.5)
+frames = list(world.frames(200 + n))
+sensor, ids, p = world.true_state(0.0, frames[0][2])
+flt = VIOFilter(s, max_landmarks=N + 64, sensor=sensor, ids=ids, p=p, time=0.0)
+pf = PreparedFrames(world.cam, *bench.flatten_frames(frames))
+core = flt.core_handle()
+flt.run_prepared(pf, 0, 200)
+lib.eqf_synchronize(core)
+t0 = time.perf_counter(); flt.run_prepared(pf, 200, n); lib.eqf_synchronize(core); wall = (time.perf_counter() - t0) / n
+print(f"{mode}: {1e6 * wall:.1f} us/frame ({1 / wall:.0f} updates/s); landmarks now {(flt.sigma_dim() - 21) // 3}")

@@ -388,6 +388,57 @@ def test_speculative_tail_equals_stats_plus_update(chart):
     assert np.array_equal(core.get_sigma(), twin.get_sigma())
 
 
+@pytest.mark.parametrize("N,M", [(40, 33), (200, 180), (256, 256), (300, 257), (512, 470)])
+def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M):
+    """eqf_stats_select_update up to 512 landmarks: statistics, VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) and the masking of the discarded measurements
+    are ONE launch of one workgroup (k_stats_select: statistics and output blocks on different waves, whole-wave ranking). Against the two launches
+    (EQF_OPT_SELECT_ONE_WORKGROUP = 0: k_outlier_stats, k_select_outliers): same statistics, same discarded landmarks, same Sigma+ and state, bit for bit; and the
+    discarded set is the reference's: absolute outliers first by absErr, then probabilistic ones by probErr, capped."""
+    from eqvio_amd.capi import OPT_SELECT_ONE_WORKGROUP, OPT_SPECULATIVE
+
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(COORD_INVDEPTH, N, seed=500 + N, cap=N)
+    twin = EqfCore(N, COORD_INVDEPTH)
+    twin.set_state(xi0, Xs, ids, q0, Q)
+    twin.set_sigma(S)
+    twin.set_option(OPT_SELECT_ONE_WORKGROUP, 0)
+    cam = default_camera()
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=rng.permutation(N)[:M])
+    bad = rng.choice(M, 9, replace=False)
+    y.reshape(-1, 2)[bad] += rng.normal(size=(9, 2)) * 30.0  # gross outliers on top of the probabilistic ones
+    y.reshape(-1, 2)[bad[1]] = y.reshape(-1, 2)[bad[0]]
+    var = settings.measurementNoise**2
+    a_ref, p_ref, _ = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N).outlier_stats(cam, mid, y)
+    thr_abs = np.sort(a_ref[a_ref >= 0])[-6]  # five absolute outliers
+    thr_prob = np.median(p_ref[a_ref >= 0])  # half of the rest are probabilistic candidates
+    cap = 11
+    res = []
+    for c in (core, twin):
+        c.set_option(OPT_SPECULATIVE, 0)  # straight to the masked pipeline
+        res.append(c.stats_select_update(cam, mid, y, thr_abs, thr_prob, cap, var, True, False))
+    (u1, a1, p1, d1, r1), (u0, a0, p0, d0, r0) = res
+    assert u1 == 1 and u0 == 1
+    assert np.array_equal(a1, a0) and np.array_equal(p1, p0) and np.array_equal(d1, d0)
+    assert np.array_equal(a1, a_ref) and np.array_equal(p1, p_ref)
+    assert np.array_equal(r1, r0) and len(r1) == cap
+    # the reference's order, restated on the returned statistics
+    meas = a1 >= 0
+    absl = [i for i in np.argsort(-a1, kind="stable") if meas[i] and a1[i] > thr_abs]
+    probl = [i for i in np.argsort(-p1, kind="stable") if meas[i] and not a1[i] > thr_abs and p1[i] > thr_prob]
+    assert len(absl) == 5 and len(absl) + len(probl) > cap
+    assert sorted((absl + probl)[:cap]) == list(r1)
+    assert core.N == N - cap and twin.N == N - cap
+    assert np.array_equal(core.get_sigma(), twin.get_sigma())
+    for u, v in zip(core.get_state(), twin.get_state()):
+        assert np.array_equal(u, v)
+
+
+def EqfCoreStats(xi0, Xs, ids, q0, Q, S, N):
+    c = EqfCore(N, COORD_INVDEPTH)
+    c.set_state(xi0, Xs, ids, q0, Q)
+    c.set_sigma(S)
+    return c
+
+
 @pytest.mark.parametrize("chart", list(CHARTS))
 @pytest.mark.parametrize("k,discrete", [(1, True), (10, True), (30, False), (45, True), (0, True)])
 def test_propagate_fast_equals_riccati_plus_observer(chart, k, discrete):
