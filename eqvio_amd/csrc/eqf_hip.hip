@@ -185,6 +185,10 @@ struct eqf_ctx {
     int opt_gather = 1;                      // EQF_OPT_GATHER_IN_PROPAGATE
     int opt_hold = 1;                        // EQF_OPT_HOLD_NEW_LANDMARKS
     int opt_sel_one = 1;                     // EQF_OPT_SELECT_ONE_WORKGROUP
+    int opt_live_first = 1;                  // EQF_OPT_LIVE_COLUMNS_FIRST
+    bool tail_live_first = false;            // set by eqf_stats_select_update for the tail it is about to queue (consumed by launch_update_tail)
+    const int* la_live_cols = nullptr;       // ... and what launch_lookahead passes on
+    long live_first_launches = 0;
     // eqf_add_landmarks_held: the last n_held landmarks of the state wait for the next eqf_propagate_fast, which passes them through untouched (GatherArgs)
     int n_held = 0;
     double held_var = 0.0;
@@ -1068,6 +1072,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_GATHER_IN_PROPAGATE: *value = c->opt_gather; return 0;
     case EQF_OPT_HOLD_NEW_LANDMARKS: *value = c->opt_hold; return 0;
     case EQF_OPT_SELECT_ONE_WORKGROUP: *value = c->opt_sel_one; return 0;
+    case EQF_OPT_LIVE_COLUMNS_FIRST: *value = c->opt_live_first; return 0;
     case EQF_OPT_LA_HOME: *value = c->opt_la_home; return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE: *value = c->opt_measure_prop; return 0;
     case EQF_OPT_LIFT_WITH_SYRK: *value = c->opt_lift_syrk; return 0;
@@ -1125,6 +1130,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         return 0;
     case EQF_OPT_SELECT_ONE_WORKGROUP:
         c->opt_sel_one = value ? 1 : 0;
+        return 0;
+    case EQF_OPT_LIVE_COLUMNS_FIRST:
+        c->opt_live_first = value ? 1 : 0;
         return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE:
         c->opt_measure_prop = value ? 1 : 0;
@@ -1393,7 +1401,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_HOLD_NEW_LANDMARKS, c->opt_hold}, {EQF_OPT_SELECT_ONE_WORKGROUP, c->opt_sel_one}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_HOLD_NEW_LANDMARKS, c->opt_hold}, {EQF_OPT_SELECT_ONE_WORKGROUP, c->opt_sel_one}, {EQF_OPT_LIVE_COLUMNS_FIRST, c->opt_live_first}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1626,6 +1634,15 @@ int eqf_add_landmarks_held(eqf_ctx* c, const int* ids, const double* p, int k, d
     if (keep_lookup)
         c->lookup_gen = c->lm_gen;
     c->meas_valid = false;
+    return 0;
+}
+int eqf_live_columns_stats(eqf_ctx* c, long* launches, int reset) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    if (launches)
+        *launches = c->live_first_launches;
+    if (reset)
+        c->live_first_launches = 0;
     return 0;
 }
 int eqf_hold_stats(eqf_ctx* c, long* launches, int reset) {
@@ -2479,6 +2496,9 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.flags = c->d_flags;
     a.spec = spec;
     a.spec_seq = spec_seq;
+    a.live_cols = a.NJ <= 16 ? c->la_live_cols : nullptr; // (the instantiations up to 16 panels)
+    if (a.live_cols)
+        ++c->live_first_launches;
     a.tr_steps = trace_slot(c, TR_STEP0);
     a.dbg = c->d_trace ? c->d_ladbg : nullptr;
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
@@ -2835,6 +2855,10 @@ static int launch_update_tail(eqf_ctx* c, const int* ids, int M, double meas_var
     c->tail_la = false, c->tail_zb = false, c->tail_M = M; // retry state of finish_update: reset before anything of this tail is queued
     // "measurement j is landmark j" lets the Z-building prologue skip the index map: true only if the mapping in the pinned packet is the one of THESE ids
     c->tail_ident = c->map_ident && c->map_gen == c->lm_gen && c->map_N == c->N && (int)c->map_ids.size() == M && std::equal(ids, ids + M, c->map_ids.begin());
+    const bool live_first = c->tail_live_first; // k_stats_select in front of this tail puts the measurements of the landmarks that stay first: the index map is not the identity
+    c->tail_live_first = false;
+    if (live_first)
+        c->tail_ident = false;
     // The look-ahead kernel's workgroups are booked against the device's compute units BEFORE anything of the tail depends on that kernel (who builds Z); if they
     // do not come free within the bound (la_book), this update takes k_build_Z + the launch chain
     bool chain_only = false;
@@ -2892,7 +2916,9 @@ static int launch_update_tail(eqf_ctx* c, const int* ids, int M, double meas_var
     }
     host_stamp(c, TH_BUILD_Z_OUT);
     c->tail_M = M; // what a retry of the factorisation on the launch chain needs to know (finish_update)
+    c->la_live_cols = live_first ? c->d_spec + 2 : nullptr;
     rc = launch_factor_tail(c, M, discreteCorr, spec, spec_seq, use_door, door_seq, chain_only, zb, fuse);
+    c->la_live_cols = nullptr;
     booking.keep = rc == 0 && c->tail_la; // released by the doorbell wait (door_wait), sync_ctx or eqf_destroy
     return rc;
 }
@@ -3221,11 +3247,14 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         // Outlier candidates frame after frame (speculation has backed off): statistics, the outlier decision (k_select_outliers: the discarded
         // landmarks' measurements are masked out of C) and the whole update queued at once, ONE host wait. The discarded landmarks leave the
         // state after the update (an unmeasured landmark can be marginalised before or after it).
+        // EQF_OPT_LIVE_COLUMNS_FIRST: up to 16 panels the look-ahead kernel ends with the last panel that holds a column of a landmark that stays (k_stats_select orders them)
+        const bool live_first = N <= SEL_ONE_WG && c->opt_sel_one && c->opt_live_first && blocks(2 * M, 32) <= 16 && blocks(2 * M, 32) > 3;
+        c->tail_live_first = live_first;
         if (N <= SEL_ONE_WG && c->opt_sel_one) { // statistics and decision as one launch of one workgroup
             KTimer t(c, KN_STATS);
             LAUNCH_TS(c, k_stats_select, dim3(1), dim3(512), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam),
                       same_as_staged ? (const double*)(c->d_meas + 2 * (size_t)c->Ncap) /* the staged copy in HBM: no PCIe round trip in front of the statistics */ : pack_by_landmark(c, measof, y), c->q0(), c->Qq(), c->Qa(),
-                      (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, thrAbs, thrProb, max_outliers, M, c->h_sel);
+                      (const TS*)c->sigma(), c->h_res, useEqv ? 1 : 0, c->d_C, c->d_ytil, c->d_lmidx, c->d_flags, thrAbs, thrProb, max_outliers, M, c->h_sel, live_first ? c->d_spec + 2 : (int*)nullptr);
             HIPCHK(hipGetLastError());
         } else {
             KTimer t(c, KN_STATS);

@@ -76,6 +76,9 @@ struct LaArgs {
     // ZB = 3 (round 4): like 2, but the output blocks were evaluated by the observer blocks of the propagation kernel in front (EQF_OPT_MEASURE_IN_PROPAGATE): the
     // half-rows and the owner read zb_C / zb_ytil / zb_lmidx like ZB = 1, workgroup NI computes the statistics like ZB = 2
     MeasFuse zb_mf;
+    // Up to 16 panels, behind k_stats_select (the outlier decision taken on the device): the columns of the measurements that stay are in front, and this word - written by
+    // that kernel - says how many there are. The factorisation ends with the last panel that holds one of them (la_live_panels); W's columns behind it are zero.
+    const int* live_cols;
     trace_t* tr_zb; // EQF_OPT_TRACE: k_build_Z's slot - this kernel's start stands for it (the span to step 0 is the prologue that replaces k_build_Z)
 };
 // tiles: [0, NJ) L_p^-1 | [NJ, NJ + NJ^2) P^(p)_J at p NJ + J (a panel's tiles are neighbours) | then U1, U0 of every S block row
@@ -91,6 +94,13 @@ __device__ __forceinline__ int la_f_p(const LaArgs& a, int p, int h) { return a.
 __device__ __forceinline__ int la_f_u(const LaArgs& a, int I, int s) { return a.NJ + 2 * a.NJ * a.NJ + 2 * I + s; }
 inline size_t la_pub_flags(int NJ) { return (size_t)NJ + 2 * (size_t)NJ * NJ + 2 * (size_t)NJ; }
 __device__ __forceinline__ double* la_tile(const LaArgs& a, int idx) { return a.pub + (size_t)LA_TILE * idx; }
+// panels this launch factorises: all of them, or - LaArgs::live_cols - those up to the last live column (at least three: the owner's roles are laid out for that)
+__device__ __forceinline__ int la_live_panels(const LaArgs& a) {
+    if (!a.live_cols)
+        return a.NJ;
+    const int me = __builtin_amdgcn_readfirstlane(*a.live_cols);
+    return min(a.NJ, max((me + 31) >> 5, 3));
+}
 
 __device__ __forceinline__ void la_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } // global_store_dwordx2 sc1
 __device__ __forceinline__ void la_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -226,7 +236,7 @@ __device__ __forceinline__ void la_owner(const LaArgs& a, double* smem, int* s_a
     // b of a tail, rows 0 .. 15 / 16 .. 31 in operand layout, parked in the unused rows 32 .. 47 of two of the four operand buffers (leading dimension 48);
     // the pairs alternate with the parity of the step: tail k reads what tail k - 1 kept
     auto b_keep = [&](int k, int half) -> double* { return smem + 32 * CH_LDP * ((k & 1) ? 3 * half : 1 + half) + 32; };
-    const int NJ = a.NJ;
+    const int NJ = la_live_panels(a); // (the tiles' and flags' indices are laid out for a.NJ)
     if (ZB) {
         if (a.tr_zb && tid == 0)
             *a.tr_zb = wall_clock64();
@@ -780,13 +790,16 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
     double* sYv = smem + 3 * 32 * CH_LDP;   // yTilde row of the panel (32)
     double* sZp = sYv + 32;                 // z_p as 8 partial sums over 4 columns of L_p^-1 each ([8][32])
     const int NJ = a.NJ, m = a.m, rows = a.rows, ldz = a.ldz, seq = a.seq;
+    const int NJe = la_live_panels(a); // panels that are factorised (LaArgs::live_cols; NJ otherwise)
     const bool srow = hidx < 2 * NJ;
     const bool loc = HOME && srow;                 // this half-row and everybody it exchanges tiles with sit on the home XCD
     const int* const fl = loc ? a.pubfl : a.pubf;  // the flags it polls
     const int I = hidx >> 1, s = hidx & 1;
+    if (srow && I >= NJe) // rows of S behind the last live column: nobody asks for them
+        return;
     const int row0 = srow ? 16 * hidx : m + 16 * (hidx - 2 * NJ);
     const int ilim = srow ? min(m, row0 + 16) : min(rows, row0 + 16);
-    const int Jmax = srow ? I : NJ - 1;
+    const int Jmax = srow ? I : NJe - 1;
     const bool ylast = (!srow) && (rows - 1 >= row0) && (rows - 1 < row0 + 16); // this half-row holds the yTilde row
     const int yloc = rows - 1 - row0;
     const int jh = wave & 1, jr = wave >> 1;
@@ -927,7 +940,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
     // S half-rows: panels 0 .. I-3, then the hand-off of U2 / U1 / U0 to the owner, which forms b = P^(I-2)_I and c = P^(I-1)_I itself. ONE product of the
     // last panel is left to the owner as well: Z(I, I-1) -= P^(I-3)_I (P^(I-3)_(I-1))^T, whose second factor is the owner's own b of the step before -
     // waiting for it here would close a cycle b -> block row -> U -> next b of 5.3 us per step (measured). T half-rows: all panels.
-    const int np = srow ? max(I - 2, 0) : NJ;
+    const int np = srow ? max(I - 2, 0) : NJe;
     auto hand_off = [&]() {
         // to the owner: rows 16 s .. 16 s + 15 of U2 = Z(I, I-2), U1 = Z(I, I-1) and U0 = Z(I, I) with the panels <= I-3 applied (all waves call this)
 #pragma unroll
@@ -1116,6 +1129,12 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
     if (srow)
         hand_off(); // after panel I-3 (block rows 1 and 2 have no panel to wait for: their tiles go to the owner as they are)
     if (!srow) {
+        if (NJe < NJ) { // the columns behind the last factorised panel are those of discarded measurements: W = 0 there (T is zero in them)
+            const int r = tid & 15;
+            if (row0 + r < rows)
+                for (int col = 32 * NJe + (tid >> 4); col < m; col += 32)
+                    a.W[(row0 + r) + (size_t)col * ldz] = 0.0;
+        }
         __syncthreads(); // the last panel's readers of sT / sZp are done
         sT[tid] = gsum;  // [c][r]
         __syncthreads();

@@ -108,6 +108,9 @@ enum {
                                   eqf_hold_supported says). 0: it returns EQF_E_UNSUPPORTED and the caller appends its new landmarks behind the propagation */
     EQF_OPT_SELECT_ONE_WORKGROUP = 25, /* 1 (default): up to 512 landmarks, the outlier statistics and the device-side outlier decision of eqf_stats_select_update are one
                                   launch of one workgroup (k_stats_select); 0: two launches (k_outlier_stats, k_select_outliers), as above 512 landmarks. Same results */
+    EQF_OPT_LIVE_COLUMNS_FIRST = 26, /* 1 (default): in eqf_stats_select_update up to 16 panels (256 measurements), k_stats_select puts the measurements of the landmarks that stay in
+                                  front of the discarded ones and the look-ahead kernel ends with the last panel that holds one of them (the discarded landmarks' columns of Z are
+                                  decoupled, W = 0 there): the same Sigma+ up to the rounding of a different column order. 0: measurement order kept, every panel factorised */
     EQF_OPT_SIGMA_FP32 = 3     /* fp32-Sigma path (BASELINE config 5); all arithmetic stays fp64.
                                   2: Sigma is STORED as float in HBM (4 bytes per element; loads widen, stores round). Fast-Riccati
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.
@@ -272,6 +275,8 @@ int eqf_stats_select_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* id
 /* look-ahead factorisation since the last reset: launches of the persistent kernel; of those, launches whose bounded wait ran out and whose
  * factorisation was redone on the launch chain (same Z: W and Sigma+ bit-identical, Gamma up to rounding; three in a row switch EQF_OPT_LOOKAHEAD off for the context). */
 int eqf_lookahead_stats(eqf_ctx* ctx, long* launches, long* fallbacks, int reset);
+/* EQF_OPT_LIVE_COLUMNS_FIRST: look-ahead launches that took their panel count from the device (the outlier decision in front of them put the live columns first) */
+int eqf_live_columns_stats(eqf_ctx* ctx, long* launches, int reset);
 /* Result of the look-ahead kernel's self-test at eqf_create (the persistent kernel against the launch chain on fixed problems of 3, up to 13 and 17 panels, eight launches each, W compared bit
  * for bit): 1 passed, 0 not run (the kernel is never eligible at this capacity / on this device, or its launch stalled four times because the device was busy -
  * e.g. eight processes creating contexts on one device at once: a stall says nothing about the kernel, and every later launch is bounded and redone on the chain

@@ -388,19 +388,22 @@ def test_speculative_tail_equals_stats_plus_update(chart):
     assert np.array_equal(core.get_sigma(), twin.get_sigma())
 
 
+@pytest.mark.parametrize("cap", [11, 10**6])
 @pytest.mark.parametrize("N,M", [(40, 33), (200, 180), (256, 256), (300, 257), (512, 470)])
-def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M):
+def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap):
     """eqf_stats_select_update up to 512 landmarks: statistics, VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) and the masking of the discarded measurements
     are ONE launch of one workgroup (k_stats_select: statistics and output blocks on different waves, whole-wave ranking). Against the two launches
     (EQF_OPT_SELECT_ONE_WORKGROUP = 0: k_outlier_stats, k_select_outliers): same statistics, same discarded landmarks, same Sigma+ and state, bit for bit; and the
     discarded set is the reference's: absolute outliers first by absErr, then probabilistic ones by probErr, capped."""
-    from eqvio_amd.capi import OPT_SELECT_ONE_WORKGROUP, OPT_SPECULATIVE
+    import ctypes as C
+
+    from eqvio_amd.capi import OPT_LIVE_COLUMNS_FIRST, OPT_SELECT_ONE_WORKGROUP, OPT_SPECULATIVE
 
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(COORD_INVDEPTH, N, seed=500 + N, cap=N)
-    twin = EqfCore(N, COORD_INVDEPTH)
-    twin.set_state(xi0, Xs, ids, q0, Q)
-    twin.set_sigma(S)
+    core.set_option(OPT_LIVE_COLUMNS_FIRST, 0)  # measurement order kept: the same Z as the two launches build
+    twin = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N)
     twin.set_option(OPT_SELECT_ONE_WORKGROUP, 0)
+    third = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N)  # default: the live columns in front, the factorisation ends behind them (up to 16 panels)
     cam = default_camera()
     mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=rng.permutation(N)[:M])
     bad = rng.choice(M, 9, replace=False)
@@ -410,7 +413,6 @@ def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M):
     a_ref, p_ref, _ = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N).outlier_stats(cam, mid, y)
     thr_abs = np.sort(a_ref[a_ref >= 0])[-6]  # five absolute outliers
     thr_prob = np.median(p_ref[a_ref >= 0])  # half of the rest are probabilistic candidates
-    cap = 11
     res = []
     for c in (core, twin):
         c.set_option(OPT_SPECULATIVE, 0)  # straight to the masked pipeline
@@ -419,17 +421,27 @@ def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M):
     assert u1 == 1 and u0 == 1
     assert np.array_equal(a1, a0) and np.array_equal(p1, p0) and np.array_equal(d1, d0)
     assert np.array_equal(a1, a_ref) and np.array_equal(p1, p_ref)
-    assert np.array_equal(r1, r0) and len(r1) == cap
+    assert np.array_equal(r1, r0)
     # the reference's order, restated on the returned statistics
     meas = a1 >= 0
     absl = [i for i in np.argsort(-a1, kind="stable") if meas[i] and a1[i] > thr_abs]
     probl = [i for i in np.argsort(-p1, kind="stable") if meas[i] and not a1[i] > thr_abs and p1[i] > thr_prob]
-    assert len(absl) == 5 and len(absl) + len(probl) > cap
-    assert sorted((absl + probl)[:cap]) == list(r1)
-    assert core.N == N - cap and twin.N == N - cap
+    assert len(absl) == 5 and len(absl) + len(probl) > 11
+    assert sorted((absl + probl)[:cap]) == list(r1)  # (without the cap: about half of the measured landmarks)
+    assert core.N == N - len(r1) and twin.N == N - len(r1)
     assert np.array_equal(core.get_sigma(), twin.get_sigma())
     for u, v in zip(core.get_state(), twin.get_state()):
         assert np.array_equal(u, v)
+    # EQF_OPT_LIVE_COLUMNS_FIRST: another column order of the same Z, the dead columns behind the last factorised panel - the same update up to rounding
+    third.set_option(OPT_SPECULATIVE, 0)
+    u2, a2, p2, d2, r2 = third.stats_select_update(cam, mid, y, thr_abs, thr_prob, cap, var, True, False)
+    assert u2 == 1 and np.array_equal(a2, a1) and np.array_equal(p2, p1) and np.array_equal(r2, r1)
+    used = C.c_long()
+    assert third.lib.eqf_live_columns_stats(third.h, C.byref(used), 0) == 0
+    assert used.value == (1 if 3 < (2 * M + 31) // 32 <= 16 else 0)
+    assert rel_fro(third.get_sigma(), core.get_sigma()) <= 1e-12
+    for u, v in zip(third.get_state(), core.get_state()):
+        np.testing.assert_allclose(u, v, rtol=1e-12, atol=1e-13)
 
 
 def EqfCoreStats(xi0, Xs, ids, q0, Q, S, N):
