@@ -2945,7 +2945,7 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
         KTimer t(c, KN_SYRK);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_lift<double>), dim3(nlift + nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(),
                            c->d_gamma, c->d_flags, trace_slot(c, TR_SYRK), c->d_syrk_order + c->syrk_off[nt], lift_args(c, discreteCorr, spec, spec_seq, use_door, door_seq, la ? nullptr : c->d_gpart, stall_seq),
-                           nlift);
+                           nlift, blocks(m, 32) <= 16 ? c->la_live_cols : (const int*)nullptr);
         HIPCHK(hipGetLastError());
         { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }
         if (c->opt_check) {

@@ -2277,7 +2277,7 @@ template <typename TS, bool WITH_GAMMA>
 // The table (built on the host, eqf_hip.hip: build_syrk_order) gives XCD x a compact square of the tile triangle and walks it column by column, so that an
 // XCD fetches ~2 sqrt(tiles / 8) row panels of W instead of all of them.
 __device__ __forceinline__ void syrk_sub_tile(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec,
-                                              int spec_seq, const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, int stall_seq, int blk) {
+                                              int spec_seq, const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, int stall_seq, int blk, const int* __restrict__ live_cols = nullptr) {
     if (tr && blk == 0 && threadIdx.x == 0)
         *tr = wall_clock64();
     const int failed = flags[0] | (flags[3] == stall_seq ? 1 : 0); // requested together with the cancellation word: one round trip
@@ -2290,13 +2290,15 @@ __device__ __forceinline__ void syrk_sub_tile(int n, int m, int ld, int ldz, con
     const int bi = code & 0xffff, bj = code >> 16;
     const int i0 = bi * 32, j0 = bj * 32;
     const double* W = Wb + m;
+    // live_cols (EQF_OPT_LIVE_COLUMNS_FIRST): W is zero behind the last panel that holds a live column (eqf_lookahead.hpp: la_live_panels) - the sums end there
+    const int mk = live_cols ? min(m, 32 * max((__builtin_amdgcn_readfirstlane(*live_cols) + 31) >> 5, 3)) : m;
     // with_gamma: the diagonal tiles also produce Gamma[i0 : i0+32] = W[rows] z  (Gamma = K yTilde = W L^-1 yTilde, VIO_eqf.cpp:119)
     double gv = 0.0;
     TileRed t;
     if (WITH_GAMMA && bi == bj)
-        t = mfma_tile32_splitk<true, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred, Wb + m + n, ldz, &gv);
+        t = mfma_tile32_splitk<true, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, mk, sred, Wb + m + n, ldz, &gv);
     else
-        t = mfma_tile32_splitk<false, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, m, sred);
+        t = mfma_tile32_splitk<false, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, mk, sred);
     if (WITH_GAMMA && bi == bj && threadIdx.x < 32 && i0 + threadIdx.x < n)
         gamma[i0 + threadIdx.x] = gv;
     if (threadIdx.x >= 256)
@@ -2456,13 +2458,13 @@ __global__ void __launch_bounds__(64) k_lift(const LiftArgs la) { lift_block(la,
 // doorbell rings when it did with two launches; Sigma - which the NEXT frame's first kernel waits for - is complete one lift and one kernel boundary earlier.
 template <typename TS>
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_lift(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, double* __restrict__ gamma,
-                                                            const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, const LiftArgs la, int nlift) {
+                                                            const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, const LiftArgs la, int nlift, const int* __restrict__ live_cols) {
     if ((int)blockIdx.x < nlift) {
         if (threadIdx.x < 64)
             lift_block(la, (int)blockIdx.x, nlift);
         return;
     }
-    syrk_sub_tile<TS, false>(n, m, ld, ldz, Wb, Sig, gamma, la.spec, la.spec_seq, flags, tr, tile_of_block, la.stall_seq, (int)blockIdx.x - nlift);
+    syrk_sub_tile<TS, false>(n, m, ld, ldz, Wb, Sig, gamma, la.spec, la.spec_seq, flags, tr, tile_of_block, la.stall_seq, (int)blockIdx.x - nlift, live_cols);
 }
 // q_hat_i = Q_i^-1 q0_i for all landmarks (stateGroupAction, VIOGroup.cpp:44-52)
 __global__ void __launch_bounds__(64) k_estimate(int N, int Ncap, const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,
