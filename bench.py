@@ -673,7 +673,8 @@ def several_filters_on_one_gpu(settings, N, device, Filter, lib, counts=(1, 2, 4
             out["errors"] = errs
         return out
 
-    sweep = {"N%d" % Nl: [run_config(Nl, R) for R in counts] for Nl in sizes}
+    # (N = 200: three and six filters as well - four look-ahead kernels of 65 workgroups do not fit 256 compute units, and R = 4 is a stable 20 k where R = 3 and R = 6 reach 28 - 29 k)
+    sweep = {"N%d" % Nl: [run_config(Nl, R) for R in (sorted(set(counts) | {3, 6}) if Nl >= 200 else counts) if not (Nl >= 200 and R > 8)] for Nl in sizes}
     # the same with one PROCESS per filter (the reference-compatible mode: its LoopTimer is a global, include/eqvio/LoopTimer.h:95): scripts/multi_process.py
     procs = None
     try:
@@ -691,7 +692,8 @@ def several_filters_on_one_gpu(settings, N, device, Filter, lib, counts=(1, 2, 4
                     "one_process_per_filter = the same as R processes. Three things bound it (DESIGN.md section 7, profiles/r04_multi_*): a stream is one of the runtime's "
                     "GPU_MAX_HW_QUEUES = 4 hardware queues (round 3's second stream per context halved that: saturation at two filters); a look-ahead kernel needs its 66 workgroups "
                     "(N = 200) resident at once, one per compute unit, so three fit a 256-CU device (launches are booked against the CUs inside a process); and in ONE process the "
-                    "launch path of the HIP runtime serialises the host threads (the kernel trace at four threads shows the GPU idle 40 % of the time)"}
+                    "launch path of the HIP runtime serialises the host threads (the kernel trace at four threads shows the GPU idle 40 % of the time). Round 5: in one process R = 3 and R = 6 reach "
+                    "28 - 29 k at N = 200, R = 4 stays at 20 k whatever the booking does (scripts/dbg/r05_variants/booking_released_by_the_kernel.diff)"}
 
 
 def measure_roofline(flt, lib, core, cam, frames, args, n, m):
