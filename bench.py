@@ -675,6 +675,15 @@ def several_filters_on_one_gpu(settings, N, device, Filter, lib, counts=(1, 2, 4
 
     # (N = 200: three and six filters as well - four look-ahead kernels of 65 workgroups do not fit 256 compute units, and R = 4 is a stable 20 k where R = 3 and R = 6 reach 28 - 29 k)
     sweep = {"N%d" % Nl: [run_config(Nl, R) for R in (sorted(set(counts) | {3, 6}) if Nl >= 200 else counts) if not (Nl >= 200 and R > 8)] for Nl in sizes}
+    # N = 200 again with EQF_OWN_HW_QUEUES (eqf_hip.h: eqf_own_hardware_queue): a hardware queue per context instead of the runtime's four shared ones
+    own = None
+    try:
+        os.environ["EQF_OWN_HW_QUEUES"] = "4"
+        own = [run_config(N, R) for R in (2, 3, 4)]
+    except Exception as e:  # noqa: BLE001
+        own = {"error": repr(e)[:200]}
+    finally:
+        os.environ.pop("EQF_OWN_HW_QUEUES", None)
     # the same with one PROCESS per filter (the reference-compatible mode: its LoopTimer is a global, include/eqvio/LoopTimer.h:95): scripts/multi_process.py
     procs = None
     try:
@@ -684,10 +693,10 @@ def several_filters_on_one_gpu(settings, N, device, Filter, lib, counts=(1, 2, 4
         procs = {int(k): v for k, v in json.loads(res.stdout.strip().splitlines()[-1])["aggregate_updates_per_s"].items()}
     except Exception as e:  # noqa: BLE001
         procs = {"error": repr(e)[:200]}
-    threads_best = max(sweep.get("N%d" % N, [{"value": 0.0, "filters": 0}]), key=lambda r: r["value"])
+    threads_best = max(sweep.get("N%d" % N, [{"value": 0.0, "filters": 0}]) + (own if isinstance(own, list) else []), key=lambda r: r["value"])
     best_p = max(((v, k) for k, v in procs.items() if isinstance(k, int)), default=(0.0, 0))
     return {"filters": best_p[1] if best_p[0] > threads_best["value"] else threads_best["filters"], "frames_each": n_frames, "value": max(best_p[0], threads_best["value"]),
-            "unit": "updates/s aggregate on one GPU", "sweep": sweep, "one_process_per_filter_N%d" % N: procs,
+            "unit": "updates/s aggregate on one GPU", "sweep": sweep, "threads_with_own_hardware_queues_N%d" % N: own, "one_process_per_filter_N%d" % N: procs,
             "note": "informational; sweep = aggregate updates/s for R independent filters as R threads of one process (one context + one stream each) at N = 50 / 200; "
                     "one_process_per_filter = the same as R processes. Three things bound it (DESIGN.md section 7, profiles/r04_multi_*): a stream is one of the runtime's "
                     "GPU_MAX_HW_QUEUES = 4 hardware queues (round 3's second stream per context halved that: saturation at two filters); a look-ahead kernel needs its 66 workgroups "

@@ -212,6 +212,8 @@ struct eqf_ctx {
     long zb_launches = 0;
     int cu_count = 256;                      // compute units of the device: the look-ahead kernel needs all its workgroups resident at once
     long la_book_timeouts = 0;               // updates that took the launch chain because the compute units did not come free within la_book's bound
+    bool own_queue = false;                  // the stream was created with a compute-unit mask (all of them): a hardware queue of its own (create_buffers)
+    bool counted_alive = false;
     int la_cus_held = 0;                     // compute units this context has booked for a look-ahead launch in flight (la_book / la_release)
     int la_selftest = 0;                     // look-ahead self-test at creation: 0 not run (never eligible at this capacity), 1 passed, -1 failed (launch chain only)
     long long la_timeout_ticks = LA_TIMEOUT_TICKS; // EQF_OPT_LA_TIMEOUT_US: bound of every device-side wait of the look-ahead kernel (100 MHz ticks)
@@ -397,6 +399,7 @@ int spin_stream(hipStream_t st) {
 // others leave and every kernel involved crawls (measured: 3 filters 22.5 k updates/s aggregate, 4 filters 15 k). The launches are therefore BOOKED against
 // the device's compute units: a context whose launch does not fit waits on the host until an earlier one has rung its doorbell. One filter never waits.
 namespace {
+std::atomic<int> ctx_alive[64]; // contexts of this process per device
 std::mutex la_gate_mutex;
 std::condition_variable la_gate_cv;
 int la_cus_booked[64] = {0}; // per device
@@ -834,7 +837,29 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     c->ld = pick_ld(c->ncap);
     c->mcap = 2 * c->Ncap;
     c->ldz = pick_ld(c->mcap + c->ncap + 1);
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // Round 5: the runtime hands a process' plain streams GPU_MAX_HW_QUEUES = 4 hardware queues, and streams that share one run their kernels one after the other. FOUR
+    // filters in one process ran at 20.4 k updates/s aggregate (N = 200) where three reached 28.5 k - two pairs of streams on two queues, the numbers GPU_MAX_HW_QUEUES = 2
+    // gives. A stream created with a compute-unit mask owns its hardware queue: with EQF_OWN_HW_QUEUES=<n> in the environment the first n contexts of a process on a device
+    // get such a stream (mask: all compute units) - four filters at N = 200: 32.5 - 32.8 k in every run. Not the default: such streams are blocking streams, more than four
+    // of them were slower than the shared queues (N = 50, 8 / 16 filters: 45 / 58 k against 57 / 67 k), and at N = 50 four of them gave 69 k or 23 k depending on what the
+    // process had created before (plain: 44 k). One filter per process (the headline, one rank per GPU) measured the same either way.
+    c->own_queue = false;
+    const int before = ctx_alive[c->device & 63].fetch_add(1);
+    const char* own_env = std::getenv("EQF_OWN_HW_QUEUES");
+    if (own_env && before < atoi(own_env)) {
+        std::vector<uint32_t> mask((size_t)(c->cu_count + 31) / 32, 0u);
+        for (int i = 0; i < c->cu_count; ++i)
+            mask[i >> 5] |= 1u << (i & 31);
+        if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess)
+            c->own_queue = true;
+        else {
+            (void)hipGetLastError();
+            c->stream = nullptr;
+        }
+    }
+    c->counted_alive = true;
+    if (!c->stream)
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // (the second stream is created by the first stand-alone eqf_integrate_observer call: a stream is a hardware queue, the runtime hands out GPU_MAX_HW_QUEUES = 4 of them per
     //  process by default, and streams that share a queue run one after the other - with two streams per context a GPU saturated at TWO filters)
     HIPCHK(hipEventCreateWithFlags(&c->ev_assembled, hipEventDisableTiming));
@@ -922,6 +947,9 @@ void eqf_destroy(eqf_ctx* c) {
     if (c) {
         la_release(c);
         registry_leave(c);
+        if (c->counted_alive)
+            ctx_alive[c->device & 63].fetch_sub(1);
+        c->counted_alive = false;
     }
     if (c && std::getenv("EQF_DEBUG_STATS"))
         std::fprintf(stderr, "[eqf_hip] look-ahead launches %ld (stalled %ld), of them with Z built inside %ld\n", c->la_launches, c->la_fallbacks, c->zb_launches);
@@ -1636,6 +1664,7 @@ int eqf_add_landmarks_held(eqf_ctx* c, const int* ids, const double* p, int k, d
     c->meas_valid = false;
     return 0;
 }
+int eqf_own_hardware_queue(eqf_ctx* c) { return c ? (c->own_queue ? 1 : 0) : EQF_E_BAD_ARG; }
 int eqf_live_columns_stats(eqf_ctx* c, long* launches, int reset) {
     if (!c)
         return EQF_E_BAD_ARG;

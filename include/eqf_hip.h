@@ -275,6 +275,11 @@ int eqf_stats_select_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* id
 /* look-ahead factorisation since the last reset: launches of the persistent kernel; of those, launches whose bounded wait ran out and whose
  * factorisation was redone on the launch chain (same Z: W and Sigma+ bit-identical, Gamma up to rounding; three in a row switch EQF_OPT_LOOKAHEAD off for the context). */
 int eqf_lookahead_stats(eqf_ctx* ctx, long* launches, long* fallbacks, int reset);
+/* 1 when the context's stream owns its hardware queue. The runtime shares GPU_MAX_HW_QUEUES = 4 hardware queues among a process' plain streams, and two filters whose streams
+ * share one take turns kernel by kernel (four filters in one process at N = 200: 20 k updates/s aggregate, three: 28.5 k). With EQF_OWN_HW_QUEUES=<n> in the environment at
+ * eqf_create, the first n contexts of the process on a device get a stream created with a compute-unit mask (all compute units), which has a queue of its own (four filters:
+ * 32.5 k). 0: plain stream (the default; see create_buffers in eqf_hip.hip for why). */
+int eqf_own_hardware_queue(eqf_ctx* ctx);
 /* EQF_OPT_LIVE_COLUMNS_FIRST: look-ahead launches that took their panel count from the device (the outlier decision in front of them put the live columns first) */
 int eqf_live_columns_stats(eqf_ctx* ctx, long* launches, int reset);
 /* Result of the look-ahead kernel's self-test at eqf_create (the persistent kernel against the launch chain on fixed problems of 3, up to 13 and 17 panels, eight launches each, W compared bit

@@ -277,8 +277,8 @@ def test_stalled_lookahead_that_built_z_itself_is_redone_on_the_chain():
         assert np.array_equal(u, v)
 
 
-@pytest.mark.parametrize("N,n_filters", [(200, 4), (200, 8), (500, 4)])
-def test_concurrent_persistent_kernels_stay_on_their_oracles(N, n_filters):
+@pytest.mark.parametrize("N,n_filters,own_queues", [(200, 4, 0), (200, 8, 0), (500, 4, 0), (200, 4, 4)])
+def test_concurrent_persistent_kernels_stay_on_their_oracles(N, n_filters, own_queues, monkeypatch):
     """several filters, one host thread each, whose persistent look-ahead kernels share the GPU. 4 x N = 500 is 4 x 81 workgroups of
     154 KB LDS (one per CU) on 256 CUs: an owner can wait for block rows that are not resident yet. Every filter runs in lockstep with its own
     oracle (3 frames, all filters released together for every frame so that the kernels really overlap); the look-ahead kernel must have been
@@ -289,6 +289,8 @@ def test_concurrent_persistent_kernels_stay_on_their_oracles(N, n_filters):
     settings = bench.eurocish_settings()
     nfr = 3
     jobs = []
+    if own_queues:  # EQF_OWN_HW_QUEUES (eqf_hip.h: eqf_own_hardware_queue): the first contexts of a process get a stream with a hardware queue of its own
+        monkeypatch.setenv("EQF_OWN_HW_QUEUES", str(64))  # (other tests' contexts of this process may still be alive and count)
     for r in range(n_filters):
         world, frames = bench.build_workload(seed=300 + r, n_frames=nfr + 1, N=N)
         flt = bench.make_filter(world, settings, N, 0, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=N, device=0, sensor=se, ids=i, p=p, time=t))
@@ -317,6 +319,10 @@ def test_concurrent_persistent_kernels_stay_on_their_oracles(N, n_filters):
     for t in ths:
         t.join()
     assert not errors, errors
+    from eqvio_amd.capi import load_eqf_lib
+
+    own = [load_eqf_lib().eqf_own_hardware_queue(j[2].core_handle()) for j in jobs]
+    assert own == [1 if own_queues else 0] * n_filters, own
     stats = [_la_stats(j[2]) for j in jobs]
     assert all(la >= 1 for la, _ in stats), stats  # the persistent kernel was selected in every filter
     assert all(la - fb >= 1 for la, fb in stats) or N == 500, stats  # and, where the grids fit the chip together, it also completed
