@@ -15,8 +15,8 @@ def edit(name, pairs):
     open(p, "w").write(s)
 T = "__builtin_amdgcn_s_memrealtime()"
 edit("eqf_kernels.hpp", [
-    ("double thrProb, int max_outliers, int M, int* __restrict__ removed_host) {\n    __shared__ signed char s_kind[SEL_ONE_WG];",
-     "double thrProb, int max_outliers, int M, int* __restrict__ removed_host, unsigned long long* __restrict__ dbg = nullptr) {\n    if (dbg && threadIdx.x == 0) dbg[0] = " + T + ";\n    __shared__ signed char s_kind[SEL_ONE_WG];"),
+    ("double thrProb, int max_outliers, int M, int* __restrict__ removed_host, int* __restrict__ live_cols) {\n    __shared__ signed char s_kind[SEL_ONE_WG];",
+     "double thrProb, int max_outliers, int M, int* __restrict__ removed_host, int* __restrict__ live_cols, unsigned long long* __restrict__ dbg = nullptr) {\n    if (dbg && threadIdx.x == 0) dbg[0] = " + T + ";\n    __shared__ signed char s_kind[SEL_ONE_WG];"),
     ("            s_cand[c] = SelCand{isabs ? ae : pe, isabs ? 2 : 1, i};\n        }\n    }\n    __syncthreads();\n",
      "            s_cand[c] = SelCand{isabs ? ae : pe, isabs ? 2 : 1, i};\n        }\n    }\n    if (dbg && (tid == 0 || tid == 256)) dbg[tid == 0 ? 1 : 2] = " + T + ";\n    __syncthreads();\n    if (dbg && tid == 0) dbg[3] = " + T + ";\n"),
     ("        if (lane == 0 && nrm)\n            atomicAdd(&s_cnt[1], nrm);\n    }\n    __syncthreads();\n",
@@ -26,8 +26,8 @@ edit("eqf_kernels.hpp", [
 ])
 edit("eqf_hip.hip", [
     ("HIPCHK(hipHostMalloc(&c->h_sel, sizeof(int) * ((size_t)c->Ncap + 2)));", "HIPCHK(hipHostMalloc(&c->h_sel, sizeof(int) * ((size_t)c->Ncap + 2 + 64)));"),
-    ("thrAbs, thrProb, max_outliers, M, c->h_sel);\n            HIPCHK(hipGetLastError());\n        } else {",
-     "thrAbs, thrProb, max_outliers, M, c->h_sel, getenv(\"EQF_DBG_SEL\") ? (unsigned long long*)(c->h_sel + ((c->Ncap + 2 + 15) & ~15)) : nullptr);\n            HIPCHK(hipGetLastError());\n        } else {"),
+    ("thrAbs, thrProb, max_outliers, M, c->h_sel, live_first ? c->d_spec + 2 : (int*)nullptr);\n            HIPCHK(hipGetLastError());\n        } else {",
+     "thrAbs, thrProb, max_outliers, M, c->h_sel, live_first ? c->d_spec + 2 : (int*)nullptr, getenv(\"EQF_DBG_SEL\") ? (unsigned long long*)(c->h_sel + ((c->Ncap + 2 + 15) & ~15)) : nullptr);\n            HIPCHK(hipGetLastError());\n        } else {"),
     ("        copy_stats();\n        ++c->sel_frames;", """        copy_stats();
         if (getenv("EQF_DBG_SEL")) {
             static double acc[9]; static long cnt = 0;
