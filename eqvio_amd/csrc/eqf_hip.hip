@@ -212,6 +212,9 @@ struct eqf_ctx {
     long zb_launches = 0;
     int cu_count = 256;                      // compute units of the device: the look-ahead kernel needs all its workgroups resident at once
     long la_book_timeouts = 0;               // updates that took the launch chain because the compute units did not come free within la_book's bound
+    std::vector<char> rm_drop;               // eqf_remove_landmarks' scratch
+    std::vector<int> rm_ids, rm_map;
+    std::vector<double> rm_est;
     bool own_queue = false;                  // the stream was created with a compute-unit mask (all of them): a hardware queue of its own (create_buffers)
     bool counted_alive = false;
     int la_cus_held = 0;                     // compute units this context has booked for a look-ahead launch in flight (la_book / la_release)
@@ -1689,7 +1692,9 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
         return EQF_E_BAD_ARG;
     if (k == 0)
         return 0;
-    std::vector<char> drop(c->N, 0);
+    // (scratch vectors of the context: a frame of the shipped configurations makes two of these calls, and their allocations were 2 of its ~20 us between doorbell and next launch)
+    std::vector<char>& drop = c->rm_drop;
+    drop.assign(c->N, 0);
     for (int t = 0; t < k; ++t) {
         if (indices[t] < 0 || indices[t] >= c->N)
             return EQF_E_BAD_ARG;
@@ -1704,14 +1709,18 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
     }
     pend_begin(c);
     const int N = c->N;
-    std::vector<int> newids, newmap;
+    std::vector<int>&newids = c->rm_ids, &newmap = c->rm_map;
+    newids.clear(), newmap.clear();
+    newids.reserve(N), newmap.reserve(N);
+    bool pending_new = false;
     for (int i = 0; i < N; ++i)
         if (!drop[i]) {
             newids.push_back(c->ids[i]);
             newmap.push_back(c->pend_map[i]);
+            pending_new |= c->pend_map[i] < 0;
         }
     // pending new landmarks that were removed again: renumber the remaining ones
-    {
+    if (pending_new || !c->pend_var.empty()) {
         std::vector<int> renum(c->pend_var.size(), -1);
         std::vector<double> np, nv;
         for (int& mo : newmap)
@@ -1728,7 +1737,8 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
     c->pend_map.swap(newmap);
     const int Nnew = (int)newids.size();
     if (c->est_valid) {
-        std::vector<double> e(4 * (size_t)Nnew);
+        std::vector<double>& e = c->rm_est;
+        e.resize(4 * (size_t)Nnew);
         for (int pl = 0; pl < 4; ++pl) {
             int w = 0;
             for (int i = 0; i < N; ++i)

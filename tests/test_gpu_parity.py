@@ -442,6 +442,22 @@ def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap):
     assert rel_fro(third.get_sigma(), core.get_sigma()) <= 1e-12
     for u, v in zip(third.get_state(), core.get_state()):
         np.testing.assert_allclose(u, v, rtol=1e-12, atol=1e-13)
+    # ... and a look-ahead launch that gives up (time-out 0) is redone on the launch chain from the same live-first output blocks: every column, the dead ones too - the
+    # bits of the launch that ended behind the live ones (W is exactly zero in a dead column either way)
+    from eqvio_amd.capi import OPT_LA_TIMEOUT_US
+
+    fourth = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N)
+    fourth.set_option(OPT_SPECULATIVE, 0)
+    fourth.set_option(OPT_LA_TIMEOUT_US, 0)
+    u3, a3, p3, d3, r3 = fourth.stats_select_update(cam, mid, y, thr_abs, thr_prob, cap, var, True, False)
+    assert u3 == 1 and np.array_equal(r3, r1)
+    la, fb = C.c_long(), C.c_long()
+    assert fourth.lib.eqf_lookahead_stats(fourth.h, C.byref(la), C.byref(fb), 0) == 0
+    if used.value:
+        assert la.value == 1 and fb.value == 1
+        assert np.array_equal(fourth.get_sigma(), third.get_sigma())
+        for u, v in zip(fourth.get_state(), third.get_state()):  # (Gamma is summed in another order on the chain: eqf_hip.h, eqf_lookahead_stats)
+            np.testing.assert_allclose(u, v, rtol=1e-12, atol=1e-13)
 
 
 def EqfCoreStats(xi0, Xs, ids, q0, Q, S, N):
