@@ -186,7 +186,6 @@ struct eqf_ctx {
     int opt_hold = 1;                        // EQF_OPT_HOLD_NEW_LANDMARKS
     int opt_sel_one = 1;                     // EQF_OPT_SELECT_ONE_WORKGROUP
     int opt_live_first = 1;                  // EQF_OPT_LIVE_COLUMNS_FIRST
-    bool tail_live_first = false;            // set by eqf_stats_select_update for the tail it is about to queue (consumed by launch_update_tail)
     const int* la_live_cols = nullptr;       // ... and what launch_lookahead passes on
     long live_first_launches = 0;
     // eqf_add_landmarks_held: the last n_held landmarks of the state wait for the next eqf_propagate_fast, which passes them through untouched (GatherArgs)
@@ -2886,7 +2885,7 @@ static int lookahead_selftest(eqf_ctx* c) {
 static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, int zb = 0,
                               const MeasFuse* zb_mf = nullptr);
 static int launch_update_tail(eqf_ctx* c, const int* ids, int M, double meas_var, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq,
-                              const MeasFuse* fuse = nullptr) {
+                              const MeasFuse* fuse = nullptr, bool live_first = false) {
     HP_SCOPE("abi.launch_update_tail");
     const int n = c->n(), m = 2 * M;
     const int rows = m + n + 1;
@@ -2894,9 +2893,7 @@ static int launch_update_tail(eqf_ctx* c, const int* ids, int M, double meas_var
     c->tail_la = false, c->tail_zb = false, c->tail_M = M; // retry state of finish_update: reset before anything of this tail is queued
     // "measurement j is landmark j" lets the Z-building prologue skip the index map: true only if the mapping in the pinned packet is the one of THESE ids
     c->tail_ident = c->map_ident && c->map_gen == c->lm_gen && c->map_N == c->N && (int)c->map_ids.size() == M && std::equal(ids, ids + M, c->map_ids.begin());
-    const bool live_first = c->tail_live_first; // k_stats_select in front of this tail puts the measurements of the landmarks that stay first: the index map is not the identity
-    c->tail_live_first = false;
-    if (live_first)
+    if (live_first) // k_stats_select in front of this tail puts the measurements of the landmarks that stay first: the index map is not the identity
         c->tail_ident = false;
     // The look-ahead kernel's workgroups are booked against the device's compute units BEFORE anything of the tail depends on that kernel (who builds Z); if they
     // do not come free within the bound (la_book), this update takes k_build_Z + the launch chain
@@ -3288,7 +3285,6 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         // state after the update (an unmeasured landmark can be marginalised before or after it).
         // EQF_OPT_LIVE_COLUMNS_FIRST: up to 16 panels the look-ahead kernel ends with the last panel that holds a column of a landmark that stays (k_stats_select orders them)
         const bool live_first = N <= SEL_ONE_WG && c->opt_sel_one && c->opt_live_first && blocks(2 * M, 32) <= 16 && blocks(2 * M, 32) > 3;
-        c->tail_live_first = live_first;
         if (N <= SEL_ONE_WG && c->opt_sel_one) { // statistics and decision as one launch of one workgroup
             KTimer t(c, KN_STATS);
             LAUNCH_TS(c, k_stats_select, dim3(1), dim3(512), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam),
@@ -3305,7 +3301,7 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
             HIPCHK(hipGetLastError());
         }
         c->meas_valid = false;
-        rc = launch_update_tail(c, ids, M, meas_var, discreteCorr, nullptr, 0, use_door, seq, nullptr);
+        rc = launch_update_tail(c, ids, M, meas_var, discreteCorr, nullptr, 0, use_door, seq, nullptr, live_first);
         if (rc)
             return rc;
         host_stamp(c, TH_TAIL_OUT);
