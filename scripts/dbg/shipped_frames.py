@@ -23,4 +23,10 @@ core = flt.core_handle()
 flt.run_prepared(pf, 0, 200)
 lib.eqf_synchronize(core)
 t0 = time.perf_counter(); flt.run_prepared(pf, 200, n); lib.eqf_synchronize(core); wall = (time.perf_counter() - t0) / n
-print(f"{mode}: {1e6 * wall:.1f} us/frame ({1 / wall:.0f} updates/s); landmarks now {(flt.sigma_dim() - 21) // 3}")
+import ctypes as C
+la, fb, live = C.c_long(), C.c_long(), C.c_long()
+lib.eqf_lookahead_stats(core, C.byref(la), C.byref(fb), 0)
+if hasattr(lib, "eqf_live_columns_stats"):
+    lib.eqf_live_columns_stats(core, C.byref(live), 0)
+print(f"{mode}: {1e6 * wall:.1f} us/frame ({1 / wall:.0f} updates/s); landmarks now {(flt.sigma_dim() - 21) // 3}; look-ahead launches {la.value} (redone on the chain {fb.value}), "
+      f"of them ending behind the last live column {live.value}")
