@@ -4,6 +4,8 @@ usage: [rocprofv3 --kernel-trace --stats -d out --] python scripts/dbg/shipped_f
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+if os.environ.get("WITH_TORCH"):  # torch's wheel brings its own libamdhip64.so.7: imported first, that runtime serves libeqf_hip.so as well (as in bench.py)
+    import torch  # noqa: F401
 import bench
 from eqvio_amd.capi import PreparedFrames, VIOFilter, load_eqf_lib
 from eqvio_amd.simworld import SimWorld
@@ -14,8 +16,11 @@ N = 200
 s = bench.eurocish_settings()
 if mode == "shipped":
     s.outlierThresholdAbs, s.outlierThresholdProb, s.featureRetention, s.initialPointVariance = 4.852186665580312, 0.03229809583062128, 0.18594708334486176, 129.90415638150924
-world = SimWorld(seed=321, num_points=2500, max_features=N, trajectory="wave", noise_px=0.5)
-frames = list(world.frames(200 + n))
+if mode == "hover":  # the headline's quiet world
+    world, frames = bench.build_workload(seed=100, n_frames=200 + n, N=N)
+else:
+    world = SimWorld(seed=321, num_points=2500, max_features=N, trajectory="wave", noise_px=0.5)
+    frames = list(world.frames(200 + n))
 sensor, ids, p = world.true_state(0.0, frames[0][2])
 flt = VIOFilter(s, max_landmarks=N + 64, sensor=sensor, ids=ids, p=p, time=0.0)
 pf = PreparedFrames(world.cam, *bench.flatten_frames(frames))
