@@ -388,9 +388,11 @@ def test_speculative_tail_equals_stats_plus_update(chart):
     assert np.array_equal(core.get_sigma(), twin.get_sigma())
 
 
-@pytest.mark.parametrize("cap", [11, 10**6])
-@pytest.mark.parametrize("N,M", [(40, 33), (200, 180), (256, 256), (300, 257), (512, 470)])
-def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap):
+@pytest.mark.parametrize("N,M,cap,chart,star", [(40, 33, 11, "invdepth", True), (200, 180, 11, "invdepth", True), (256, 256, 11, "invdepth", True), (300, 257, 11, "invdepth", True),
+                                              (512, 470, 11, "invdepth", True), (40, 33, 10**6, "invdepth", True), (200, 180, 10**6, "invdepth", True), (256, 256, 10**6, "invdepth", True),
+                                              (300, 257, 10**6, "invdepth", True), (512, 470, 10**6, "invdepth", True), (200, 180, 10**6, "euclid", True),
+                                              (200, 180, 10**6, "invdepth", False), (200, 180, 10**6, "euclid", False)])
+def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap, chart, star):
     """eqf_stats_select_update up to 512 landmarks: statistics, VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) and the masking of the discarded measurements
     are ONE launch of one workgroup (k_stats_select: statistics and output blocks on different waves, whole-wave ranking). Against the two launches
     (EQF_OPT_SELECT_ONE_WORKGROUP = 0: k_outlier_stats, k_select_outliers): same statistics, same discarded landmarks, same Sigma+ and state, bit for bit; and the
@@ -399,24 +401,25 @@ def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap):
 
     from eqvio_amd.capi import OPT_LIVE_COLUMNS_FIRST, OPT_SELECT_ONE_WORKGROUP, OPT_SPECULATIVE
 
-    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(COORD_INVDEPTH, N, seed=500 + N, cap=N)
+    CH = CHARTS[chart]
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CH, N, seed=500 + N, cap=N)
     core.set_option(OPT_LIVE_COLUMNS_FIRST, 0)  # measurement order kept: the same Z as the two launches build
-    twin = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N)
+    twin = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N, CH)
     twin.set_option(OPT_SELECT_ONE_WORKGROUP, 0)
-    third = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N)  # default: the live columns in front, the factorisation ends behind them (up to 16 panels)
+    third = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N, CH)  # default: the live columns in front, the factorisation ends behind them (up to 16 panels)
     cam = default_camera()
     mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=rng.permutation(N)[:M])
     bad = rng.choice(M, 9, replace=False)
     y.reshape(-1, 2)[bad] += rng.normal(size=(9, 2)) * 30.0  # gross outliers on top of the probabilistic ones
     y.reshape(-1, 2)[bad[1]] = y.reshape(-1, 2)[bad[0]]
     var = settings.measurementNoise**2
-    a_ref, p_ref, _ = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N).outlier_stats(cam, mid, y)
+    a_ref, p_ref, _ = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N, CH).outlier_stats(cam, mid, y)
     thr_abs = np.sort(a_ref[a_ref >= 0])[-6]  # five absolute outliers
     thr_prob = np.median(p_ref[a_ref >= 0])  # half of the rest are probabilistic candidates
     res = []
     for c in (core, twin):
         c.set_option(OPT_SPECULATIVE, 0)  # straight to the masked pipeline
-        res.append(c.stats_select_update(cam, mid, y, thr_abs, thr_prob, cap, var, True, False))
+        res.append(c.stats_select_update(cam, mid, y, thr_abs, thr_prob, cap, var, star, False))
     (u1, a1, p1, d1, r1), (u0, a0, p0, d0, r0) = res
     assert u1 == 1 and u0 == 1
     assert np.array_equal(a1, a0) and np.array_equal(p1, p0) and np.array_equal(d1, d0)
@@ -434,7 +437,7 @@ def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap):
         assert np.array_equal(u, v)
     # EQF_OPT_LIVE_COLUMNS_FIRST: another column order of the same Z, the dead columns behind the last factorised panel - the same update up to rounding
     third.set_option(OPT_SPECULATIVE, 0)
-    u2, a2, p2, d2, r2 = third.stats_select_update(cam, mid, y, thr_abs, thr_prob, cap, var, True, False)
+    u2, a2, p2, d2, r2 = third.stats_select_update(cam, mid, y, thr_abs, thr_prob, cap, var, star, False)
     assert u2 == 1 and np.array_equal(a2, a1) and np.array_equal(p2, p1) and np.array_equal(r2, r1)
     used = C.c_long()
     assert third.lib.eqf_live_columns_stats(third.h, C.byref(used), 0) == 0
@@ -446,10 +449,10 @@ def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap):
     # bits of the launch that ended behind the live ones (W is exactly zero in a dead column either way)
     from eqvio_amd.capi import OPT_LA_TIMEOUT_US
 
-    fourth = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N)
+    fourth = EqfCoreStats(xi0, Xs, ids, q0, Q, S, N, CH)
     fourth.set_option(OPT_SPECULATIVE, 0)
     fourth.set_option(OPT_LA_TIMEOUT_US, 0)
-    u3, a3, p3, d3, r3 = fourth.stats_select_update(cam, mid, y, thr_abs, thr_prob, cap, var, True, False)
+    u3, a3, p3, d3, r3 = fourth.stats_select_update(cam, mid, y, thr_abs, thr_prob, cap, var, star, False)
     assert u3 == 1 and np.array_equal(r3, r1)
     la, fb = C.c_long(), C.c_long()
     assert fourth.lib.eqf_lookahead_stats(fourth.h, C.byref(la), C.byref(fb), 0) == 0
@@ -460,8 +463,8 @@ def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap):
             np.testing.assert_allclose(u, v, rtol=1e-12, atol=1e-13)
 
 
-def EqfCoreStats(xi0, Xs, ids, q0, Q, S, N):
-    c = EqfCore(N, COORD_INVDEPTH)
+def EqfCoreStats(xi0, Xs, ids, q0, Q, S, N, chart=COORD_INVDEPTH):
+    c = EqfCore(N, chart)
     c.set_state(xi0, Xs, ids, q0, Q)
     c.set_sigma(S)
     return c
