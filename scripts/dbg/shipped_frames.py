@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """frame_mix's shipped-threshold world for a profiler: 200 warm-up frames, then `n` frames, nothing else (no event timing).
-usage: [rocprofv3 --kernel-trace --stats -d out --] python scripts/dbg/shipped_frames.py [shipped|off] [n]"""
+usage: [rocprofv3 --kernel-trace --stats -d out --] python scripts/dbg/shipped_frames.py [shipped|off|hover] [n] [landmarks]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -12,7 +12,7 @@ from eqvio_amd.simworld import SimWorld
 mode = sys.argv[1] if len(sys.argv) > 1 else "shipped"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 lib = load_eqf_lib()
-N = 200
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 s = bench.eurocish_settings()
 if mode == "shipped":
     s.outlierThresholdAbs, s.outlierThresholdProb, s.featureRetention, s.initialPointVariance = 4.852186665580312, 0.03229809583062128, 0.18594708334486176, 129.90415638150924
