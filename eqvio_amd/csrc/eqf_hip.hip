@@ -3284,7 +3284,7 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
         // landmarks' measurements are masked out of C) and the whole update queued at once, ONE host wait. The discarded landmarks leave the
         // state after the update (an unmeasured landmark can be marginalised before or after it).
         // EQF_OPT_LIVE_COLUMNS_FIRST: up to 16 panels the look-ahead kernel ends with the last panel that holds a column of a landmark that stays (k_stats_select orders them)
-        const bool live_first = N <= SEL_ONE_WG && c->opt_sel_one && c->opt_live_first && blocks(2 * M, 32) <= 16 && blocks(2 * M, 32) > 3;
+        const bool live_first = N <= SEL_ONE_WG && c->opt_sel_one && c->opt_live_first && blocks(2 * M, 32) <= 16 && blocks(2 * M, 32) >= 3;
         if (N <= SEL_ONE_WG && c->opt_sel_one) { // statistics and decision as one launch of one workgroup
             KTimer t(c, KN_STATS);
             LAUNCH_TS(c, k_stats_select, dim3(1), dim3(512), c->stream, N, c->Ncap, c->ld, c->chart, make_cam(cam),

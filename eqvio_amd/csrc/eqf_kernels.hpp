@@ -2291,7 +2291,7 @@ __device__ __forceinline__ void syrk_sub_tile(int n, int m, int ld, int ldz, con
     const int i0 = bi * 32, j0 = bj * 32;
     const double* W = Wb + m;
     // live_cols (EQF_OPT_LIVE_COLUMNS_FIRST): W is zero behind the last panel that holds a live column (eqf_lookahead.hpp: la_live_panels) - the sums end there
-    const int mk = live_cols ? min(m, 32 * max((__builtin_amdgcn_readfirstlane(*live_cols) + 31) >> 5, 3)) : m;
+    const int mk = live_cols ? min(m, 32 * max((__builtin_amdgcn_readfirstlane(*live_cols) + 31) >> 5, 1)) : m;
     // with_gamma: the diagonal tiles also produce Gamma[i0 : i0+32] = W[rows] z  (Gamma = K yTilde = W L^-1 yTilde, VIO_eqf.cpp:119)
     double gv = 0.0;
     TileRed t;

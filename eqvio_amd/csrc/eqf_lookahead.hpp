@@ -94,12 +94,15 @@ __device__ __forceinline__ int la_f_p(const LaArgs& a, int p, int h) { return a.
 __device__ __forceinline__ int la_f_u(const LaArgs& a, int I, int s) { return a.NJ + 2 * a.NJ * a.NJ + 2 * I + s; }
 inline size_t la_pub_flags(int NJ) { return (size_t)NJ + 2 * (size_t)NJ * NJ + 2 * (size_t)NJ; }
 __device__ __forceinline__ double* la_tile(const LaArgs& a, int idx) { return a.pub + (size_t)LA_TILE * idx; }
-// panels this launch factorises: all of them, or - LaArgs::live_cols - those up to the last live column (at least three: the owner's roles are laid out for that)
+// panels this launch factorises: all of them, or - LaArgs::live_cols - those up to the last live column. One panel is enough: the owner's loops (k + 1 < NJ, k + 2 < NJ) and the
+// half-rows' (np, Jmax) are written for any count - a launch that ends after one or two panels is what three-panel problems with most measurements discarded give
+// (tests/test_gpu_parity.py::test_outlier_decision_in_one_workgroup_equals_the_two_launches[40-33-*]; the host still takes problems below three panels to the launch chain)
+constexpr int LA_MIN_LIVE_PANELS = 1;
 __device__ __forceinline__ int la_live_panels(const LaArgs& a) {
     if (!a.live_cols)
         return a.NJ;
     const int me = __builtin_amdgcn_readfirstlane(*a.live_cols);
-    return min(a.NJ, max((me + 31) >> 5, 3));
+    return min(a.NJ, max((me + 31) >> 5, LA_MIN_LIVE_PANELS));
 }
 
 __device__ __forceinline__ void la_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } // global_store_dwordx2 sc1

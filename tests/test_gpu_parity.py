@@ -441,7 +441,7 @@ def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap, ch
     assert u2 == 1 and np.array_equal(a2, a1) and np.array_equal(p2, p1) and np.array_equal(r2, r1)
     used = C.c_long()
     assert third.lib.eqf_live_columns_stats(third.h, C.byref(used), 0) == 0
-    assert used.value == (1 if 3 < (2 * M + 31) // 32 <= 16 else 0)
+    assert used.value == (1 if 3 <= (2 * M + 31) // 32 <= 16 else 0)
     assert rel_fro(third.get_sigma(), core.get_sigma()) <= 1e-12
     for u, v in zip(third.get_state(), core.get_state()):
         np.testing.assert_allclose(u, v, rtol=1e-12, atol=1e-13)
