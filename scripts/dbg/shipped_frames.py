@@ -33,5 +33,9 @@ la, fb, live = C.c_long(), C.c_long(), C.c_long()
 lib.eqf_lookahead_stats(core, C.byref(la), C.byref(fb), 0)
 if hasattr(lib, "eqf_live_columns_stats"):
     lib.eqf_live_columns_stats(core, C.byref(live), 0)
+sc, sq, scn, sf, sd = C.c_long(), C.c_long(), C.c_long(), C.c_long(), C.c_long()
+lib.eqf_speculation_stats(core, C.byref(sc), C.byref(sq), C.byref(scn), 0)
+lib.eqf_selection_stats(core, C.byref(sf), C.byref(sd), 0)
+print(f"update calls {sc.value}: tail queued speculatively {sq.value} (cancelled on the device {scn.value}), outlier decision on the device {sf.value} (landmarks discarded {sd.value})")
 print(f"{mode}: {1e6 * wall:.1f} us/frame ({1 / wall:.0f} updates/s); landmarks now {(flt.sigma_dim() - 21) // 3}; look-ahead launches {la.value} (redone on the chain {fb.value}), "
       f"of them ending behind the last live column {live.value}")
