@@ -391,7 +391,7 @@ def test_speculative_tail_equals_stats_plus_update(chart):
 @pytest.mark.parametrize("N,M,cap,chart,star", [(40, 33, 11, "invdepth", True), (200, 180, 11, "invdepth", True), (256, 256, 11, "invdepth", True), (300, 257, 11, "invdepth", True),
                                               (512, 470, 11, "invdepth", True), (40, 33, 10**6, "invdepth", True), (200, 180, 10**6, "invdepth", True), (256, 256, 10**6, "invdepth", True),
                                               (300, 257, 10**6, "invdepth", True), (512, 470, 10**6, "invdepth", True), (200, 180, 10**6, "euclid", True),
-                                              (200, 180, 10**6, "invdepth", False), (200, 180, 10**6, "euclid", False)])
+                                              (200, 180, 10**6, "invdepth", False), (200, 180, 10**6, "euclid", False), (300, 200, 10**6, "invdepth", True), (500, 256, 11, "invdepth", True)])
 def test_outlier_decision_in_one_workgroup_equals_the_two_launches(N, M, cap, chart, star):
     """eqf_stats_select_update up to 512 landmarks: statistics, VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) and the masking of the discarded measurements
     are ONE launch of one workgroup (k_stats_select: statistics and output blocks on different waves, whole-wave ranking). Against the two launches
