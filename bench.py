@@ -698,11 +698,14 @@ def several_filters_on_one_gpu(settings, N, device, Filter, lib, counts=(1, 2, 4
     return {"filters": best_p[1] if best_p[0] > threads_best["value"] else threads_best["filters"], "frames_each": n_frames, "value": max(best_p[0], threads_best["value"]),
             "unit": "updates/s aggregate on one GPU", "sweep": sweep, "threads_with_own_hardware_queues_N%d" % N: own, "one_process_per_filter_N%d" % N: procs,
             "note": "informational; sweep = aggregate updates/s for R independent filters as R threads of one process (one context + one stream each) at N = 50 / 200; "
-                    "one_process_per_filter = the same as R processes. Three things bound it (DESIGN.md section 7, profiles/r04_multi_*): a stream is one of the runtime's "
-                    "GPU_MAX_HW_QUEUES = 4 hardware queues (round 3's second stream per context halved that: saturation at two filters); a look-ahead kernel needs its 66 workgroups "
-                    "(N = 200) resident at once, one per compute unit, so three fit a 256-CU device (launches are booked against the CUs inside a process); and in ONE process the "
-                    "launch path of the HIP runtime serialises the host threads (the kernel trace at four threads shows the GPU idle 40 % of the time). Round 5: in one process R = 3 and R = 6 reach "
-                    "28 - 29 k at N = 200, R = 4 stays at 20 k whatever the booking does (scripts/dbg/r05_variants/booking_released_by_the_kernel.diff)"}
+                    "one_process_per_filter = the same as R processes. What bounds it (DESIGN.md section 7): (1) HARDWARE QUEUES - the runtime shares its GPU_MAX_HW_QUEUES = 4 "
+                    "hardware queues among a process' plain streams, its own null stream included, and two filters whose streams share a queue take turns kernel by kernel: four "
+                    "threads on the shared queues are a stable 20 k at N = 200 (exactly what GPU_MAX_HW_QUEUES = 2 gives), three reach 28 k or 16 k depending on which streams share "
+                    "a queue; with a queue per context (EQF_OWN_HW_QUEUES=4: hipExtStreamCreateWithCUMask streams own their queue) R = 2 / 3 / 4 reach 20 / 28 / 32 k in one process "
+                    "(threads_with_own_hardware_queues). (2) COMPUTE UNITS - a look-ahead kernel needs its 66 workgroups (N = 200) resident at once, one per compute unit, so three fit "
+                    "a 256-CU device and a fourth takes turns (launches are booked against the CUs inside a process; across processes the bounded waits and the chain retry keep "
+                    "every filter correct). Round 4's third explanation - the HIP runtime's launch path serialising the host threads - was WRONG (a launch baton that lets one "
+                    "thread into the runtime at a time changed nothing: scripts/dbg/r05_variants/launch_baton.patch)"}
 
 
 def measure_roofline(flt, lib, core, cam, frames, args, n, m):

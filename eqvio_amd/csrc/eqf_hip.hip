@@ -1613,6 +1613,7 @@ int eqf_add_landmarks(eqf_ctx* c, const int* ids, const double* p, int k, double
     if (keep_lookup)
         c->lookup_gen = c->lm_gen;
     c->meas_valid = false;
+    c->ocov_valid = false; // (h_ocov is indexed by the OLD landmark set: eqf_state_estimate -> add / remove -> eqf_output_cov_all must compute afresh)
     return 0;
 }
 
@@ -1664,6 +1665,7 @@ int eqf_add_landmarks_held(eqf_ctx* c, const int* ids, const double* p, int k, d
     if (keep_lookup)
         c->lookup_gen = c->lm_gen;
     c->meas_valid = false;
+    c->ocov_valid = false; // (h_ocov is indexed by the OLD landmark set: eqf_state_estimate -> add / remove -> eqf_output_cov_all must compute afresh)
     return 0;
 }
 int eqf_own_hardware_queue(eqf_ctx* c) { return c ? (c->own_queue ? 1 : 0) : EQF_E_BAD_ARG; }
@@ -1765,6 +1767,7 @@ int eqf_remove_landmarks(eqf_ctx* c, const int* indices, int k) {
     if (keep_lookup)
         c->lookup_gen = c->lm_gen;
     c->meas_valid = false;
+    c->ocov_valid = false; // (h_ocov is indexed by the OLD landmark set: eqf_state_estimate -> add / remove -> eqf_output_cov_all must compute afresh)
     return 0;
 }
 
@@ -2880,6 +2883,7 @@ static int lookahead_selftest(eqf_ctx* c) {
     }
     if (c->la_selftest < 0)
         std::fprintf(stderr, "[eqf_hip] look-ahead self-test failed on device %d: this context factorises on the launch chain\n", c->device);
+    c->la_home_launches = 0; // (the self-test's own launches are not the filter's: eqf_lookahead_home counts what eqf_lookahead_stats counts)
     return 0;
 }
 static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* spec, int spec_seq, bool use_door, int door_seq, bool force_chain, int zb = 0,
@@ -3592,6 +3596,8 @@ int eqf_lookahead_home(const eqf_ctx* c, int* home_xcd, long* home_launches) {
         *home_launches = c->la_home_launches;
     return 0;
 }
+
+int eqf_device_to_itself(eqf_ctx* c) { return c ? (device_to_itself(c) ? 1 : 0) : EQF_E_BAD_ARG; }
 
 int eqf_nees_lu_fallbacks(eqf_ctx* c, long* count) {
     if (!c || !count)

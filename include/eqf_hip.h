@@ -290,6 +290,9 @@ int eqf_lookahead_selftest(const eqf_ctx* ctx);
 /* EQF_OPT_LA_HOME: the XCD this context's look-ahead launches keep their owner and S half-rows on (-1: none was free at creation, or the placement was refused /
  * switched off), and the look-ahead launches that used it. */
 int eqf_lookahead_home(const eqf_ctx* ctx, int* home_xcd, long* home_launches);
+/* 1 when no other context - of this or of any other process of the user - is registered on the device (the condition of the HOME placement from 6 panels on), 0 otherwise.
+ * A test that has the device to itself asserts home_launches == look-ahead launches with it: a silent return to the classic placement (or to the launch chain) turns it red. */
+int eqf_device_to_itself(eqf_ctx* ctx);
 /* frames that took the device-side decision, landmarks it discarded */
 int eqf_selection_stats(eqf_ctx* ctx, long* frames, long* discarded, int reset);
 

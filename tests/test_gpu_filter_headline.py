@@ -60,12 +60,22 @@ def test_headline_path_N200_against_the_oracle():
     """The workload of the bench line itself (seed of rank 0), 6 frames in lockstep. Every frame must have gone through the one-round-trip path: tail
     queued speculatively and never cancelled, factorisation on the look-ahead kernel."""
     N = 200
+    import gc
+
+    gc.collect()  # (filters of earlier tests that are still registered on the device would switch the HOME placement off)
     world, frames = bench.build_workload(seed=100, n_frames=7, N=N)
     flt, orc, _ = run_lockstep(world, frames, bench.eurocish_settings(), N, 6)
     k = counters(flt)
     assert k["calls"] == k["queued"] == 6 and k["cancelled"] == 0, k
     assert k["la_launches"] == 6 and k["la_fallbacks"] == 0, k
     assert flt.sigma_dim() == 21 + 3 * N
+    # VERDICT r5 item 8: the HOME placement leans on an empirically learnt block -> XCD mapping; a driver that deals the blocks differently sends every launch back to the
+    # classic placement (or the chain) silently. With the device to itself - this filter is the only registered context - every look-ahead launch must have been a HOME one.
+    lib = load_eqf_lib()
+    hx, hl = C.c_int(), C.c_long()
+    assert lib.eqf_lookahead_home(flt.core_handle(), C.byref(hx), C.byref(hl)) == 0
+    if lib.eqf_device_to_itself(flt.core_handle()) == 1 and hx.value >= 0:
+        assert hl.value == k["la_launches"], (hx.value, hl.value, k)
 
 
 def test_headline_path_N500_against_the_oracle():

@@ -261,6 +261,41 @@ def test_output_cov_all(chart, N):
     assert np.allclose(g, np.transpose(g, (0, 2, 1)), rtol=0, atol=1e-13 * np.abs(g).max())  # v01 and v10 are separate sums
 
 
+def test_output_cov_all_after_the_landmark_set_changed():
+    """The sequence of the reference-side binding, stateEstimate(); removeLandmarkById() / addNewLandmarks(); getOutputCovById() (VIOFilter.cpp:304-334 around :258-302):
+    the covariances that were computed along with the state estimate belong to the OLD landmark set and must not be served afterwards (they were)."""
+    N = 30
+    rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["invdepth"], N, seed=77)
+    cam = default_camera()
+    imu = random_imu(rng)
+    core.integrate_riccati_fast(imu, 0.02, settings.input_gain_diag12(), settings.state_gain_diag8())
+    orc.integrate_riccati_fast(imu, 0.02)
+    core.output_cov_all(cam)  # (the hint: from here on a state estimate computes the covariances as well)
+    core.integrate_riccati_fast(imu, 0.01, settings.input_gain_diag12(), settings.state_gain_diag8())
+    orc.integrate_riccati_fast(imu, 0.01)
+    for step in range(3):
+        orc.integrate_observer(imu, 0.01, True)  # (the landmark estimates change: the next state estimate asks the device, and computes the covariances along with it)
+        core.integrate_observer(imu[None, :], np.array([0.01]), True)
+        core.state_estimate()  # fills the cache for the current landmark set
+        if step == 0:  # remove two landmarks in the middle
+            for idx in (11, 4):
+                orc.remove_landmark_by_index(idx)
+            core.remove_landmarks(np.array([4, 11], dtype=np.int32))
+        elif step == 1:  # append three
+            nid, npnt = np.arange(500, 503, dtype=np.int32), rng.uniform(-1, 1, (3, 3)) + np.array([0, 0, 4.0])
+            orc.add_landmarks(nid, npnt, 0.6)
+            core.add_landmarks(nid, npnt, 0.6)
+        else:  # remove the last one and append another in one go
+            orc.remove_landmark_by_index(core.N - 1)
+            core.remove_landmarks(np.array([core.N - 1], dtype=np.int32))
+            nid, npnt = np.array([900], dtype=np.int32), np.array([[0.2, -0.1, 3.0]])
+            orc.add_landmarks(nid, npnt, 0.6)
+            core.add_landmarks(nid, npnt, 0.6)
+        g, o = core.output_cov_all(cam), orc.output_cov_all(cam)
+        assert g.shape == o.shape == (core.N, 2, 2)
+        np.testing.assert_allclose(g, o, rtol=1e-10, atol=1e-12 * np.abs(o).max())
+
+
 def test_update_rejects_unknown_and_unsorted_ids():
     rng, settings, orc, core, (xi0, Xs, ids, q0, Q, S) = make_pair(CHARTS["euclid"], 6, seed=3)
     cam = default_camera()
