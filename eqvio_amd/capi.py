@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.environ.get("EQVIO_AMD_LIB_DIR") or os.path.join(_HERE, "lib")  # the override: same-box A/B of two builds (scripts/ab_builds.sh)
 
 COORD_EUCLIDEAN, COORD_INVDEPTH, COORD_NORMAL = 0, 1, 2
-OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_LA_TIMEOUT_US, OPT_Z_IN_LOOKAHEAD, OPT_LA_SPLIT_ROWS, OPT_MEASURE_IN_PROPAGATE, OPT_LIFT_WITH_SYRK, OPT_LA_HOME, OPT_TILES_PER_WORKGROUP, OPT_GATHER_IN_PROPAGATE, OPT_HOLD_NEW_LANDMARKS, OPT_SELECT_ONE_WORKGROUP, OPT_LIVE_COLUMNS_FIRST, OPT_TIMING = 1, 2, 3, 6, 7, 8, 9, 11, 12, 15, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 100
+OPT_RICCATI_DENSE, OPT_CHECK_FINITE, OPT_SIGMA_FP32, OPT_DOORBELL, OPT_SPECULATIVE, OPT_EARLY_LIFT, OPT_TRACE, OPT_FUSED_ASSEMBLY, OPT_LOOKAHEAD, OPT_LA_TIMEOUT_US, OPT_Z_IN_LOOKAHEAD, OPT_LA_SPLIT_ROWS, OPT_MEASURE_IN_PROPAGATE, OPT_LIFT_WITH_SYRK, OPT_LA_HOME, OPT_TILES_PER_WORKGROUP, OPT_GATHER_IN_PROPAGATE, OPT_HOLD_NEW_LANDMARKS, OPT_SELECT_ONE_WORKGROUP, OPT_LIVE_COLUMNS_FIRST, OPT_EARLY_DOORBELL, OPT_TIMING = 1, 2, 3, 6, 7, 8, 9, 11, 12, 15, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 100
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -195,6 +195,8 @@ def load_eqf_lib():
         "eqf_remove_unmeasured_landmarks": (C.c_int, [vp, c_int_p, C.c_int, c_int_p, c_int_p]),
         "eqf_find_unknown_ids": (C.c_int, [vp, c_int_p, C.c_int, c_int_p, c_int_p]),
         "eqf_same_as_mapped": (C.c_int, [vp, c_int_p, C.c_int]),
+        "eqf_update_unsettled": (C.c_int, [vp]),
+        "eqf_remove_invalid_at_update": (C.c_int, [vp]),
         "eqf_add_landmarks_held": (C.c_int, [vp, c_int_p, c_double_p, C.c_int, C.c_double]),
         "eqf_hold_supported": (C.c_int, [vp]),
         "eqf_hold_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.c_int]),
@@ -234,7 +236,7 @@ def load_eqf_lib():
         "eqf_last_kernel_times": (C.c_int, [vp, c_int_p, P(C.c_float), C.c_int]),
     }
     for name, (res, args) in protos.items():
-        if os.environ.get("EQVIO_AMD_LIB_DIR") and name in ("eqf_lookahead_home", "eqf_device_to_itself", "eqf_gather_stats", "eqf_remove_unmeasured_landmarks", "eqf_find_unknown_ids", "eqf_add_landmarks_held", "eqf_hold_supported", "eqf_hold_stats", "eqf_same_as_mapped", "eqf_live_columns_stats", "eqf_own_hardware_queue") and not hasattr(lib, name):
+        if os.environ.get("EQVIO_AMD_LIB_DIR") and name in ("eqf_lookahead_home", "eqf_device_to_itself", "eqf_update_unsettled", "eqf_remove_invalid_at_update", "eqf_gather_stats", "eqf_remove_unmeasured_landmarks", "eqf_find_unknown_ids", "eqf_add_landmarks_held", "eqf_hold_supported", "eqf_hold_stats", "eqf_same_as_mapped", "eqf_live_columns_stats", "eqf_own_hardware_queue") and not hasattr(lib, name):
             continue  # same-box A/B against the libraries of an older commit (scripts/ab_builds.sh): entry points that commit did not have yet
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res

@@ -183,6 +183,18 @@ struct eqf_ctx {
     int opt_la_split = 1;                    // EQF_OPT_LA_SPLIT_ROWS
     int opt_prop_tpw = 1;                    // EQF_OPT_TILES_PER_WORKGROUP
     int opt_gather = 1;                      // EQF_OPT_GATHER_IN_PROPAGATE
+    int opt_early_door = 1;                  // EQF_OPT_EARLY_DOORBELL
+    int early_seq_next = 0, early_armed_seq = 0; // the doorbell sequence the next look-ahead launch carries / the one the launch in flight carries
+    bool early_allowed = false;              // the call in progress can take the early doorbell (eqf_stats_then_update / eqf_stats_select_update)
+    long early_rings = 0;                    // updates the host took from the early doorbell
+    // An update taken from the early doorbell is UNSETTLED until the lift's doorbell has been seen: the sensor lift is applied, the landmark estimates and their
+    // invalid flags (the lift kernel's) are not in yet. settle_update() waits for them; every entry point that needs the device or the estimates settles first,
+    // eqf_propagate_fast settles behind its launch.
+    bool unsettled = false, unsettled_wait = false;
+    int settle_seq = 0, settle_N = 0;
+    unsigned settle_gen = 0, settle_epoch = 0, est_epoch = 0; // est_epoch: bumped wherever the cached estimates are dropped (the state moved on)
+    std::vector<int> settle_ids;             // the landmark ids at the update
+    std::vector<int> invalid_ids;            // ... of which the lift flagged these as invalid (VIO_eqf::removeInvalidLandmarks' test): eqf_remove_invalid_at_update
     int opt_hold = 1;                        // EQF_OPT_HOLD_NEW_LANDMARKS
     int opt_sel_one = 1;                     // EQF_OPT_SELECT_ONE_WORKGROUP
     int opt_live_first = 1;                  // EQF_OPT_LIVE_COLUMNS_FIRST
@@ -535,21 +547,31 @@ int sync_ctx(eqf_ctx* c) {
 // Wait for the doorbell `which` to show `seq` (written by the last workgroup of the kernel launched with it, after every
 // result store has been fenced at system scope). The stream is polled now and then so that a kernel fault is reported
 // instead of spinning forever; if the stream completes without the bell (cannot happen) the call fails loudly.
-int door_wait(eqf_ctx* c, int which, int seq) {
+int door_wait(eqf_ctx* c, int which, int seq, bool* early = nullptr) {
     HP_SCOPE("abi.door_wait");
     volatile int* bell = reinterpret_cast<volatile int*>(c->h_door) + which;
     long spins_after_done = 0;
     const auto t0 = std::chrono::steady_clock::now();
+    // EQF_OPT_EARLY_DOORBELL: a caller that passes `early` also takes the look-ahead kernel's own doorbell (h_door[3]) - the update WILL be applied, Gamma's sensor rows are in
+    // the packet, the lift's results are not - and is told so
+    volatile int* bell_early = (which == 1 && early && c->early_armed_seq == seq) ? reinterpret_cast<volatile int*>(c->h_door) + 3 : nullptr;
+    if (early)
+        *early = false;
     for (long it = 1;; ++it) {
-        if (*bell == seq) {
+        const bool rang_early = bell_early && *bell_early == seq && *bell != seq;
+        if (rang_early)
+            *early = true;
+        if (*bell == seq || rang_early) {
             std::atomic_thread_fence(std::memory_order_acquire);
             c->busy_common = c->busy_steps = c->busy_meas = false;
             c->ring_inflight = 0; // the kernel that rang was queued behind every flush of this context
             c->held_busy = false;
-            ++c->wait_calls;
+            if (!(which == 1 && c->unsettled_wait)) // (eqf_host_wait_stats counts frame boundaries: the second wait of an update taken from the early doorbell is not one)
+                ++c->wait_calls;
             c->wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (which == 1) {
-                host_stamp(c, TH_DOOR);
+                if (!c->unsettled_wait) // (the wait for the lift's doorbell behind an update taken from the early one is not a frame boundary)
+                    host_stamp(c, TH_DOOR);
                 la_release(c); // the lift kernel rang: the look-ahead kernel in front of it has left the compute units
             }
             return 0;
@@ -741,8 +763,14 @@ static int flush_reshape(eqf_ctx* c);
 static int round_sigma(eqf_ctx* c, const int* spec = nullptr, int spec_seq = 0);
 // first statement of every entry point that uses the device state: select the device, apply the recorded landmark bookkeeping
 static void materialise_held(eqf_ctx* c);
-static int enter(eqf_ctx* c) {
+static int settle_update(eqf_ctx* c);
+static int enter(eqf_ctx* c, bool settle = true) {
     HIPCHK(hipSetDevice(c->device));
+    if (settle) { // an update taken from the early doorbell: the lift's results are waited for now (eqf_propagate_fast does that behind its launch)
+        const int r = settle_update(c);
+        if (r)
+            return r;
+    }
     c->ocov_valid = false; // (every call that can change the state or Sigma passes through here)
     materialise_held(c); // held landmarks (eqf_add_landmarks_held) meet an entry point other than eqf_propagate_fast: an ordinary append, still passed through by that propagation
     return flush_reshape(c);
@@ -955,6 +983,8 @@ void eqf_destroy(eqf_ctx* c) {
     }
     if (c && std::getenv("EQF_DEBUG_STATS"))
         std::fprintf(stderr, "[eqf_hip] look-ahead launches %ld (stalled %ld), of them with Z built inside %ld\n", c->la_launches, c->la_fallbacks, c->zb_launches);
+    if (c && std::getenv("EQF_DEBUG_STATS") && c->early_rings)
+        std::fprintf(stderr, "[eqf_hip] updates taken from the early doorbell: %ld\n", c->early_rings);
     if (!c)
         return;
     hipSetDevice(c->device);
@@ -1101,6 +1131,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_TILES_PER_WORKGROUP: *value = c->opt_prop_tpw; return 0;
     case EQF_OPT_GATHER_IN_PROPAGATE: *value = c->opt_gather; return 0;
     case EQF_OPT_HOLD_NEW_LANDMARKS: *value = c->opt_hold; return 0;
+    case EQF_OPT_EARLY_DOORBELL: *value = c->opt_early_door; return 0;
     case EQF_OPT_SELECT_ONE_WORKGROUP: *value = c->opt_sel_one; return 0;
     case EQF_OPT_LIVE_COLUMNS_FIRST: *value = c->opt_live_first; return 0;
     case EQF_OPT_LA_HOME: *value = c->opt_la_home; return 0;
@@ -1164,6 +1195,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case EQF_OPT_LIVE_COLUMNS_FIRST:
         c->opt_live_first = value ? 1 : 0;
         return 0;
+    case EQF_OPT_EARLY_DOORBELL:
+        c->opt_early_door = value ? 1 : 0;
+        return 0;
     case EQF_OPT_MEASURE_IN_PROPAGATE:
         c->opt_measure_prop = value ? 1 : 0;
         c->me_valid = false;
@@ -1215,6 +1249,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     }
 }
 int eqf_synchronize(eqf_ctx* c) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    { int _r = settle_update(c); if (_r) return _r; }
     { int _r = sync_ctx(c); if (_r) return _r; }
     return 0;
 }
@@ -1240,7 +1277,7 @@ int eqf_set_state(eqf_ctx* c, const double* xi0_sensor, const double* X_sensor, 
             return rc;
     }
     { int _r = sync_ctx(c); if (_r) return _r; }
-    c->est_valid = false;
+    c->est_valid = false, ++c->est_epoch;
     c->meas_valid = false;
     c->n_held = 0, c->held_in_memory = false;
     c->xi0 = unpack_sensor(xi0_sensor);
@@ -1349,6 +1386,7 @@ int eqf_get_sigma(eqf_ctx* c, double* sig, int n) {
 }
 
 static int fetch_estimates(eqf_ctx* c) { // d_est -> h_buf (4 planes of stride N)
+    { int _r = settle_update(c); if (_r) return _r; }
     const int N = c->N;
     if (N == 0)
         return 0;
@@ -1431,7 +1469,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_HOLD_NEW_LANDMARKS, c->opt_hold}, {EQF_OPT_SELECT_ONE_WORKGROUP, c->opt_sel_one}, {EQF_OPT_LIVE_COLUMNS_FIRST, c->opt_live_first}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_HOLD_NEW_LANDMARKS, c->opt_hold}, {EQF_OPT_EARLY_DOORBELL, c->opt_early_door}, {EQF_OPT_SELECT_ONE_WORKGROUP, c->opt_sel_one}, {EQF_OPT_LIVE_COLUMNS_FIRST, c->opt_live_first}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -1846,6 +1884,30 @@ int eqf_find_unknown_ids(eqf_ctx* c, const int* ids, int M, int* unknown_j, int*
     }
     *n_unknown = k;
     return 0;
+}
+
+// EQF_OPT_EARLY_DOORBELL: 1 while the last update's lift results (landmark estimates, invalid flags) have not been waited for
+int eqf_update_unsettled(const eqf_ctx* c) { return (c && c->unsettled) ? 1 : 0; }
+// VIO_eqf::removeInvalidLandmarks (VIO_eqf.cpp:213-223) for a caller that deferred it past an unsettled update: the landmarks the UPDATE's lift flagged (Q.a outside
+// (1e-8, 1e8]) leave the state, wherever they sit now. Returns their number (>= 0) or an error (< 0).
+int eqf_remove_invalid_at_update(eqf_ctx* c) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    { int _r = settle_update(c); if (_r) return _r < 0 ? _r : EQF_E_STALLED; }
+    if (c->invalid_ids.empty())
+        return 0;
+    std::vector<int> idx;
+    for (const int id : c->invalid_ids) {
+        const int i = index_of(c, id);
+        if (i >= 0)
+            idx.push_back(i);
+    }
+    c->invalid_ids.clear();
+    std::sort(idx.begin(), idx.end());
+    if (idx.empty())
+        return 0;
+    const int rc = eqf_remove_landmarks(c, idx.data(), (int)idx.size());
+    return rc ? rc : (int)idx.size();
 }
 
 int eqf_remove_invalid_landmarks(eqf_ctx* c) {
@@ -2324,7 +2386,7 @@ int eqf_integrate_observer(eqf_ctx* c, const double* imu13_k, const double* dt_k
     if (k == 0)
         return 0;
     { int _e = enter(c); if (_e) return _e; }
-    c->est_valid = false;
+    c->est_valid = false, ++c->est_epoch;
     c->meas_valid = false;
     c->me_valid = false; // output blocks the propagation kernel evaluated belong to the Q_i from before these steps
     int done = 0;
@@ -2382,7 +2444,7 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
         HIPCHK(hipSetDevice(c->device));
         c->ocov_valid = false;
     } else {
-        int _e = enter(c);
+        int _e = enter(c, false); // (an unsettled update is settled behind this call's launch: nothing it queues or computes needs the lift's results)
         if (_e)
             return _e;
     }
@@ -2422,7 +2484,7 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
         done += chunk;
     }
     if (k > 0) {
-        c->est_valid = false;
+        c->est_valid = false, ++c->est_epoch;
         c->meas_valid = false;
     }
     // 4. Arrow form: the first chunk of observer steps rides along as extra blocks of the Sigma propagation kernel (it does
@@ -2449,7 +2511,7 @@ int eqf_propagate_fast(eqf_ctx* c, const double* imu13_mean, double dt_total, co
         hipLaunchKernelGGL(k_observer, dim3(blocks(Nprop, 64)), dim3(64), 0, c->stream, chunks[q], Nprop, c->Ncap, counts[q], c->q0(), c->Qq(), c->Qa());
         HIPCHK(hipGetLastError());
     }
-    return 0;
+    return settle_update(c); // EQF_OPT_EARLY_DOORBELL: the lift's doorbell of the update in front has rung long since
 }
 
 // Blocked right-looking factorisation of Z (rows x m, leading dimension ldz): one launch per 32-column panel
@@ -2526,6 +2588,12 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     if (++c->la_seq <= 0) // positive: -1 is "no look-ahead launch in front" for k_lift / k_syrk_sub, 0 the initial state of every flag word
         c->la_seq = 1;
     a.seq = c->la_seq;
+    if (c->opt_early_door && c->early_seq_next) { // EQF_OPT_EARLY_DOORBELL: the last T half-row tells the host that the update will be applied (launch_factor_tail set the sequence)
+        a.early_cnt = c->d_door + 3, a.early_door = c->h_door + 3, a.early_gamma_host = c->h_res + 7 * (size_t)c->Ncap;
+        a.early_seq = c->early_seq_next, a.early_spec = spec, a.early_spec_seq = spec_seq;
+        c->early_armed_seq = c->early_seq_next;
+    }
+    c->early_seq_next = 0;
     a.timeout_ticks = c->la_timeout_ticks;
     a.Z = c->d_Z;
     a.W = c->d_W;
@@ -2973,6 +3041,8 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
     LaBookingGuard booking{c}; // (booked by launch_update_tail, before it decided who builds Z; handed over to the doorbell wait when everything is queued)
     if (la)
         ++c->la_launches;
+    c->early_seq_next = (la && use_door && c->early_allowed && c->opt_early && c->opt_lift_syrk && !c->sig32 && !c->opt_timing && !c->opt_check) ? door_seq : 0;
+    c->early_allowed = false;
     rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, zb, zb_mf) : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
     if (rc)
         return rc;
@@ -3026,6 +3096,7 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
 }
 // Host part after the wait: the lift kernel wrote Gamma's sensor part, the new estimates / invalid flags (4N) and the status
 // flags straight into the pinned result packet; the sensor part of Delta is lifted here.
+static int apply_sensor_lift(eqf_ctx* c, int discreteCorr);
 static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
     HP_SCOPE("abi.finish_update");
     const int N = c->N, n = c->n();
@@ -3076,7 +3147,7 @@ static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
         if (std::getenv("EQF_DEBUG_STATS"))
             std::fprintf(stderr, "[eqf_hip] update failed: retried %d tail_la %d tail_zb %d resflags %d %d %d %d la_seq %d\n", (int)retried, (int)c->tail_la, (int)c->tail_zb, c->h_resflags[0],
                          c->h_resflags[1], c->h_resflags[2], c->h_resflags[3], c->la_seq);
-        c->est_valid = false;
+        c->est_valid = false, ++c->est_epoch;
         c->meas_valid = false;
         return c->h_resflags[3] ? EQF_E_STALLED : EQF_E_NOT_SPD;
     }
@@ -3086,6 +3157,52 @@ static int finish_update(eqf_ctx* c, int discreteCorr, bool retried = false) {
     c->n_at_update = n;
     c->est_cache.assign(c->h_res + 3 * (size_t)c->Ncap, c->h_res + 3 * (size_t)c->Ncap + 4 * N);
     c->est_valid = true;
+    return apply_sensor_lift(c, discreteCorr);
+}
+// An update taken from the early doorbell (EQF_OPT_EARLY_DOORBELL): it WILL be applied - every W row is final, no pivot failed, no wait ran out, the tail was not
+// cancelled, and the lift and the covariance update behind the factorisation look at the same words - and Gamma's sensor rows are in the packet: the sensor lift is applied
+// now; the landmark estimates and their invalid flags come with the lift's doorbell (settle_update).
+static int finish_update_early(eqf_ctx* c, int discreteCorr, int seq) {
+    c->h_flags[0] = c->h_flags[1] = 0;
+    if (c->tail_la)
+        c->la_consecutive_stalls = 0;
+    c->gamma_stale = true;
+    c->n_at_update = c->n();
+    c->est_valid = false, ++c->est_epoch;
+    c->unsettled = true;
+    c->settle_seq = seq, c->settle_N = c->N, c->settle_gen = c->lm_gen, c->settle_epoch = c->est_epoch;
+    c->settle_ids = c->ids;
+    ++c->early_rings;
+    return apply_sensor_lift(c, discreteCorr);
+}
+static int settle_update(eqf_ctx* c) {
+    if (!c->unsettled)
+        return 0;
+    HP_SCOPE("abi.settle_update");
+    c->unsettled = false;
+    HIPCHK(hipSetDevice(c->device));
+    c->unsettled_wait = true;
+    const int rc = door_wait(c, 1, c->settle_seq);
+    c->unsettled_wait = false;
+    if (rc)
+        return rc;
+    if (c->h_resflags[0] || c->h_resflags[2] || c->h_resflags[3]) { // (cannot happen: the early doorbell rings only when none of these can be raised any more)
+        std::fprintf(stderr, "[eqf_hip] an update announced by the early doorbell was not applied (flags %d %d %d)\n", c->h_resflags[0], c->h_resflags[2], c->h_resflags[3]);
+        return EQF_E_STALLED;
+    }
+    const int N = c->settle_N;
+    const double* est = c->h_res + 3 * (size_t)c->Ncap;
+    c->invalid_ids.clear();
+    for (int i = 0; i < N; ++i)
+        if (est[3 * (size_t)N + i] != 0.0)
+            c->invalid_ids.push_back(c->settle_ids[i]);
+    if (c->lm_gen == c->settle_gen && c->N == N && c->est_epoch == c->settle_epoch) { // nothing has moved since the update: the estimates are the current ones
+        c->est_cache.assign(est, est + 4 * (size_t)N);
+        c->est_valid = true;
+    }
+    return 0;
+}
+static int apply_sensor_lift(eqf_ctx* c, int discreteCorr) {
     std::memcpy(c->h_buf, c->h_res + 7 * (size_t)c->Ncap, sizeof(double) * 21);
     const double* g = c->h_buf;
     GroupSensor D;
@@ -3305,18 +3422,20 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
             HIPCHK(hipGetLastError());
         }
         c->meas_valid = false;
+        c->early_allowed = c->opt_early_door != 0;
         rc = launch_update_tail(c, ids, M, meas_var, discreteCorr, nullptr, 0, use_door, seq, nullptr, live_first);
         if (rc)
             return rc;
         host_stamp(c, TH_TAIL_OUT);
-        rc = use_door ? door_wait(c, 1, seq) : sync_ctx(c);
+        bool early = false;
+        rc = use_door ? door_wait(c, 1, seq, &early) : sync_ctx(c);
         if (rc)
             return rc;
         copy_stats();
         ++c->sel_frames;
         if (c->h_sel[c->Ncap] == 0) // a frame without an outlier candidate ends the back-off
             c->spec_backoff = c->spec_backoff_len = 0;
-        rc = finish_update(c, discreteCorr);
+        rc = early ? finish_update_early(c, discreteCorr, seq) : finish_update(c, discreteCorr);
         if (rc)
             return rc;
         *updated = 1;
@@ -3367,15 +3486,24 @@ static int stats_then_update(eqf_ctx* c, const eqvio_camera* cam, const int* ids
     mf.thrAbs = thrAbs, mf.thrProb = thrProb;
     mf.spec_w = c->d_spec, mf.spec_seq = seq;
     c->meas_valid = false; // consumed by the tail below (restored if the tail is cancelled)
+    c->early_allowed = c->opt_early_door != 0;
     rc = launch_update_tail(c, ids, M, meas_var, discreteCorr, c->d_spec, seq, use_door, seq, &mf);
     if (rc)
         return rc;
     host_stamp(c, TH_TAIL_OUT);
-    rc = use_door ? door_wait(c, 1, seq) : sync_ctx(c);
+    bool early = false;
+    rc = use_door ? door_wait(c, 1, seq, &early) : sync_ctx(c);
     if (rc)
         return rc;
     copy_stats();
     ++c->spec_queued;
+    if (early) { // (the early doorbell does not ring for a cancelled tail)
+        c->spec_backoff = c->spec_backoff_len = 0;
+        rc = finish_update_early(c, discreteCorr, seq);
+        if (rc == 0)
+            *updated = 1;
+        return rc;
+    }
     if (c->h_resflags[2]) { // cancelled on the device: nothing was modified, C / residuals of the statistics kernel are still valid
         ++c->spec_cancelled;
         // (up to 256 frames when the caller lets the device take the outlier decision: a frame with candidates then costs one round trip anyway, a cancelled tail two and a wasted

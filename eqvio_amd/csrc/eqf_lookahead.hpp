@@ -80,6 +80,15 @@ struct LaArgs {
     // that kernel - says how many there are. The factorisation ends with the last panel that holds one of them (la_live_panels); W's columns behind it are zero.
     const int* live_cols;
     trace_t* tr_zb; // EQF_OPT_TRACE: k_build_Z's slot - this kernel's start stands for it (the span to step 0 is the prologue that replaces k_build_Z)
+    // EQF_OPT_EARLY_DOORBELL (round 5): the T half-row that finishes last - every W row final, no wait ran out, no pivot failed, the tail not cancelled - hands the host Gamma's
+    // sensor rows and rings a doorbell of its own: the host hears that the update WILL be applied (lift and covariance update behind this kernel only look at the same words) a
+    // kernel boundary and a lift earlier than from k_syrk_lift's doorbell, and starts the next frame's propagation on it
+    int* early_cnt;           // device counter of finished T half-rows (low 16 bits) and of those that gave up (high bits); left at 0
+    int* early_door;          // pinned
+    double* early_gamma_host; // pinned: Gamma[0 .. 20]
+    int early_seq;
+    const int* early_spec;    // the tail's cancellation word (or nullptr)
+    int early_spec_seq;
 };
 // tiles: [0, NJ) L_p^-1 | [NJ, NJ + NJ^2) P^(p)_J at p NJ + J (a panel's tiles are neighbours) | then U1, U0 of every S block row
 // flags: the same indices (one int per tile; U1 / U0 share the flag of U1)
@@ -1148,6 +1157,10 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
             for (int c = 0; c < 32; ++c)
                 g += sT[tid + 16 * c];
             la_st(a.gamma + (row - m), g);
+            if (a.early_door && row - m < 21) { // EQF_OPT_EARLY_DOORBELL: Gamma's sensor rows go to the host's packet from here (fenced at system scope before this half-row counts itself in)
+                a.early_gamma_host[row - m] = g;
+                __threadfence_system();
+            }
         }
     }
 }
@@ -1587,6 +1600,10 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             for (int c = 0; c < 32; ++c)
                 g += sT[tid + 16 * c];
             la_st(a.gamma + (row - m), g);
+            if (a.early_door && row - m < 21) { // EQF_OPT_EARLY_DOORBELL: Gamma's sensor rows go to the host's packet from here (fenced at system scope before this half-row counts itself in)
+                a.early_gamma_host[row - m] = g;
+                __threadfence_system();
+            }
         }
     }
 }
@@ -1615,6 +1632,30 @@ __device__ __forceinline__ void la_stats(const LaArgs& a) {
         mf.ytil[2 * j] = o.yt[0];
         mf.ytil[2 * j + 1] = o.yt[1];
         mf.lmidx_dev[j] = lidx;
+    }
+}
+
+// A T half-row counts itself in (all threads call this); the last one rings the early doorbell if nobody gave up (LaArgs::early_door). EXTRA: the statistics workgroup of the
+// ZB >= 2 forms counts as well (what it wrote to the host's packet is fenced at system scope before it does). The two T half-rows that hold Gamma's sensor rows have written
+// them to the host's packet and fenced before they counted in, so the last one's acquire on the counter orders its doorbell store behind them.
+// Round 6: no barrier, no store acknowledgement and no release in front of the count (they cost the factorisation 2 us at N = 50: chain 17.6 -> 19.6 us, half of what the earlier
+// doorbell gave). The doorbell promises that the update WILL be applied, not that W is in memory (the kernels behind this one wait for the kernel's end as before); what has to be
+// visible when it rings - Gamma's sensor rows, the statistics - was written by the counting thread's own wave and fenced at system scope before it got here; `gave_up` is final
+// (every wave of a T half-row has passed its last barrier).
+template <bool EXTRA>
+__device__ __forceinline__ void la_early_count(const LaArgs& a, const bool gave_up) {
+    if (threadIdx.x == 0) {
+        const int nT = a.NI - (2 * a.NJ - 1) + (EXTRA ? 1 : 0);
+        const int add = 1 + (gave_up ? 0x10000 : 0);
+        const int tot = __hip_atomic_fetch_add(a.early_cnt, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        if ((tot & 0xffff) == nT) {
+            __hip_atomic_store(a.early_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int f0 = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int f3 = __hip_atomic_load(a.flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int sp = a.early_spec ? __hip_atomic_load(a.early_spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            if ((tot >> 16) == 0 && f0 == 0 && f3 != a.seq && !(a.early_spec && sp == a.early_spec_seq)) // (nothing of this thread's to release: what the host reads behind
+                *reinterpret_cast<volatile int*>(a.early_door) = a.early_seq;                               //  the bell was fenced at system scope by its writers before they counted in)
+        }
     }
 }
 
@@ -1647,6 +1688,8 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
                 __hip_atomic_store(a.flags + 4, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(a.flags + 3, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (a.early_door && x != 0 && 7 * slot + (x - 1) < nT + (ZB >= 2 ? 1 : 0)) // (a T half-row or the statistics workgroup: counted as one that gave up, so that the counter comes back to 0)
+                la_early_count<(ZB >= 2)>(a, true);
             return;
         }
         if (x == 0) {
@@ -1661,6 +1704,10 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
                 hidx = 2 * a.NJ + r;
             else if (ZB >= 2 && r == nT) {
                 la_stats<ZB>(a);
+                if (a.early_door) {
+                    __threadfence_system();
+                    la_early_count<true>(a, false);
+                }
                 return;
             } else
                 return;
@@ -1668,6 +1715,10 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     } else if constexpr (ZB >= 2) {
         if ((int)blockIdx.x >= a.NI) { // the statistics workgroup
             la_stats<ZB>(a);
+            if (a.early_door) {
+                __threadfence_system();
+                la_early_count<true>(a, false);
+            }
             return;
         }
     }
@@ -1689,6 +1740,8 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     // clear it, so no clear can race with a workgroup that reports early, and a stale word of an earlier launch never matches
     if ((threadIdx.x & 63) == 0 && (s_abort[0] | s_abort[1]))
         __hip_atomic_store(a.flags + 3, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.early_door && !owner && hidx >= 2 * a.NJ && (HOME || (int)blockIdx.x < a.NI)) // a T half-row (not a part A of a split S half-row: those blocks follow the T half-rows)
+        la_early_count<(ZB >= 2)>(a, (s_abort[0] | s_abort[1]) != 0);
 }
 
 } // namespace eqf

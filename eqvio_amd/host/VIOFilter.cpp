@@ -149,6 +149,7 @@ void VIO_eqf::create(int device, int maxLandmarks, CoordinateChoice cc) {
     ids_.clear();
 }
 void VIO_eqf::set(const VIOState& xi0, const VIOGroup& X) {
+    settleInvalid();
     const int N = (int)xi0.cameraLandmarks.size();
     if ((int)X.Q.size() != N || (int)X.id.size() != N)
         throw std::invalid_argument("VIO_eqf::set: xi0 and X landmark counts differ");
@@ -193,6 +194,7 @@ VIOState VIO_eqf::xi0() const {
     return xi;
 }
 VIOGroup VIO_eqf::X() const {
+    settleInvalid();
     const int N = numLandmarks();
     double s[23], g[23];
     std::vector<int> ids(N + 1);
@@ -212,16 +214,19 @@ VIOGroup VIO_eqf::X() const {
     return X;
 }
 MatrixXd VIO_eqf::Sigma() const {
+    settleInvalid();
     MatrixXd S;
     S.r = S.c = 21 + 3 * numLandmarks();
     S.d.resize((size_t)S.r * S.c);
     check(eqf_get_sigma(ctx, S.d.data(), S.r), "eqf_get_sigma");
     return S;
 }
-void VIO_eqf::setSigma(const MatrixXd& S) { check(eqf_set_sigma(ctx, S.d.data(), S.r), "eqf_set_sigma"); }
-void VIO_eqf::setSigmaDiag(const std::vector<double>& diag) { check(eqf_set_sigma_diag(ctx, diag.data(), (int)diag.size()), "eqf_set_sigma_diag"); }
+void VIO_eqf::setSigma(const MatrixXd& S) { settleInvalid(); check(eqf_set_sigma(ctx, S.d.data(), S.r), "eqf_set_sigma"); }
+void VIO_eqf::setSigmaDiag(const std::vector<double>& diag) { settleInvalid(); check(eqf_set_sigma_diag(ctx, diag.data(), (int)diag.size()), "eqf_set_sigma_diag"); }
 
 bool VIO_eqf::addNewLandmarks(std::vector<Landmark>& newLandmarks, double var, bool held) { // VIO_eqf.cpp:225-245
+    if (!held)
+        settleInvalid();
     const int k = (int)newLandmarks.size();
     if (k == 0)
         return true;
@@ -244,6 +249,7 @@ bool VIO_eqf::addNewLandmarks(std::vector<Landmark>& newLandmarks, double var, b
     return true;
 }
 void VIO_eqf::removeLandmarksByIndex(const std::vector<int>& idx) {
+    settleInvalid();
     if (idx.empty())
         return;
     check(eqf_remove_landmarks(ctx, idx.data(), (int)idx.size()), "eqf_remove_landmarks");
@@ -294,7 +300,27 @@ void VIO_eqf::removeLandmarkById(const int& id) {                               
         throw std::out_of_range("VIO_eqf::removeLandmarkById: unknown id");
     removeLandmarkByIndex((int)std::distance(ids_.begin(), it));
 }
+// EQF_OPT_EARLY_DOORBELL: behind an update whose lift results are not in yet the removal is deferred (settleInvalid: behind the next propagation's launch, or in front of
+// whatever else looks at the landmarks first) - a landmark can be marginalised before or after the propagation, bit for bit the same for everybody else
+int VIO_eqf::settleInvalid() const {
+    if (!invalidPending_)
+        return 0;
+    invalidPending_ = false;
+    const int rc = eqf_remove_invalid_at_update(ctx);
+    if (rc < 0)
+        check(rc, "eqf_remove_invalid_at_update");
+    if (rc > 0) {
+        ids_.resize(eqf_num_landmarks(ctx));
+        eqf_get_ids(ctx, ids_.data(), (int)ids_.size());
+    }
+    return rc;
+}
 void VIO_eqf::removeInvalidLandmarks() { // VIO_eqf.cpp:213-223
+    if (eqf_update_unsettled(ctx) == 1) {
+        invalidPending_ = true;
+        return;
+    }
+    settleInvalid();
     const int rc = eqf_remove_invalid_landmarks(ctx);
     if (rc < 0)
         check(rc, "eqf_remove_invalid_landmarks");
@@ -304,6 +330,7 @@ void VIO_eqf::removeInvalidLandmarks() { // VIO_eqf.cpp:213-223
     }
 }
 std::array<double, 9> VIO_eqf::getLandmarkCovById(const int& id) const { // VIO_eqf.cpp:188-194 (column-major 3x3)
+    settleInvalid();
     const auto it = std::find(ids_.begin(), ids_.end(), id);
     if (it == ids_.end())
         throw std::out_of_range("VIO_eqf::getLandmarkCovById: unknown id");
@@ -313,6 +340,7 @@ std::array<double, 9> VIO_eqf::getLandmarkCovById(const int& id) const { // VIO_
     return blk;
 }
 void VIO_eqf::integrateObserverStates(const std::vector<IMUVelocity>& imus, const std::vector<double>& dts, bool discreteLift) {
+    settleInvalid();
     const int k = (int)imus.size();
     if (k == 0)
         return;
@@ -322,14 +350,17 @@ void VIO_eqf::integrateObserverStates(const std::vector<IMUVelocity>& imus, cons
     check(eqf_integrate_observer(ctx, flat.data(), dts.data(), k, discreteLift ? 1 : 0), "eqf_integrate_observer");
 }
 void VIO_eqf::integrateObserverState(const IMUVelocity& imu, const double& dt, const bool& discreteLift) { // VIO_eqf.cpp:47-60
+    settleInvalid();
     integrateObserverStates({imu}, {dt}, discreteLift);
 }
 void VIO_eqf::integrateRiccatiStateAccurate(const IMUVelocity& v, const double& dt, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8) {
+    settleInvalid();
     double imu[13];
     v.pack(imu);
     check(eqf_integrate_riccati_accurate(ctx, imu, dt, Qd.data(), Pd8.data()), "integrateRiccatiStateAccurate");
 }
 void VIO_eqf::integrateRiccatiStateDiscrete(const IMUVelocity& v, const double& dt, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8) { // VIO_eqf.cpp:93-103
+    settleInvalid();
     double imu[13];
     v.pack(imu);
     check(eqf_integrate_riccati_discrete(ctx, imu, dt, Qd.data(), Pd8.data()), "integrateRiccatiStateDiscrete");
@@ -344,11 +375,13 @@ void VIO_eqf::propagateFast(const IMUVelocity& mean, const double& dtTotal, cons
     check(eqf_propagate_fast(ctx, m13, dtTotal, Qd.data(), Pd8.data(), all.data(), dts.data(), (int)imus.size(), discreteLift ? 1 : 0), "eqf_propagate_fast");
 }
 void VIO_eqf::integrateRiccatiStateFast(const IMUVelocity& imu, const double& dt, const std::array<double, 12>& Qd, const std::array<double, 8>& Pd8) { // :62-72
+    settleInvalid();
     double v[13];
     imu.pack(v);
     check(eqf_integrate_riccati_fast(ctx, v, dt, Qd.data(), Pd8.data()), "eqf_integrate_riccati_fast");
 }
 void VIO_eqf::performVisionUpdate(const VisionMeasurement& m, double var, const bool& useEqv, const bool& discreteCorrection) { // :105-135
+    settleInvalid();
     if (m.camCoordinates.empty())
         return;
     const FlatMeas fm(m);
@@ -357,6 +390,7 @@ void VIO_eqf::performVisionUpdate(const VisionMeasurement& m, double var, const 
     check(eqf_vision_update(ctx, &m.cameraPtr->c, ids.data(), y.data(), (int)ids.size(), var, useEqv ? 1 : 0, discreteCorrection ? 1 : 0), "eqf_vision_update");
 }
 VIOState VIO_eqf::stateEstimate() const { // :137
+    settleInvalid();
     const int N = numLandmarks();
     double s[23];
     std::vector<int> ids(N + 1);
@@ -372,6 +406,7 @@ VIOState VIO_eqf::stateEstimate() const { // :137
     return xi;
 }
 double VIO_eqf::computeNEES(const VIOState& trueState) const { // VIO_eqf.cpp:153-170
+    settleInvalid();
     double s[23];
     packSensor(trueState.sensor, s);
     const int Nt = (int)trueState.cameraLandmarks.size();
@@ -388,6 +423,7 @@ double VIO_eqf::computeNEES(const VIOState& trueState) const { // VIO_eqf.cpp:15
     return nees;
 }
 void VIO_eqf::outlierStats(const VisionMeasurement& m, std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2) const {
+    settleInvalid();
     const int N = numLandmarks();
     absErr.assign(N, -1.0);
     probErr.assign(N, -1.0);
@@ -409,6 +445,7 @@ void VIO_eqf::stageMeasurement(const VisionMeasurement& m) {
 }
 int VIO_eqf::statsThenUpdate(const VisionMeasurement& m, double thrAbs, double thrProb, double var, bool useEqv, bool discreteCorrection, std::vector<double>& absErr,
                               std::vector<double>& probErr, std::vector<double>& depth2, long maxOutliers) {
+    settleInvalid();
     const int N = numLandmarks();
     absErr.assign(N, -1.0);
     probErr.assign(N, -1.0);
@@ -686,6 +723,10 @@ void VIOFilter::processVisionData(const VisionMeasurement& measurement) { // :19
         if (measurement.flatRebuilds() != before) // the map had been edited behind the cache: lost and new landmarks are looked for now, behind the propagation
             removedEarly = false, heldAdd = false;
     }
+    // (EQF_OPT_EARLY_DOORBELL) the invalid landmarks of the previous update leave now, beside the propagation kernel; if there were any, the measurement may hold their ids
+    // again - new landmarks, as for the reference, whose removal ran before this call: they are looked for below
+    if (filterState.settleInvalid() > 0)
+        heldAdd = false;
     if (!integrationFlag || !initialisedFlag)
         return;
     loopTimer.endTiming("propagation");

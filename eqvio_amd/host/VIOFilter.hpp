@@ -195,6 +195,7 @@ struct VIO_eqf {
     void removeLandmarkById(const int& id);
     void removeLandmarksByIndex(const std::vector<int>& idx); // batched form of the above
     void removeInvalidLandmarks();
+    int settleInvalid() const; // a removal of invalid landmarks deferred past an unsettled update (EQF_OPT_EARLY_DOORBELL) happens now; returns how many left
     bool removeUnmeasured(const std::vector<int>& measurementIds); // false: ids not ascending, nothing done
     bool sameAsMapped(const std::vector<int>& measurementIds) const; // exactly the ids the last update mapped, one per landmark
     bool findUnknownIds(const std::vector<int>& measurementIds, std::vector<int>& unknownJ, int& n) const; // false: ids not ascending
@@ -221,7 +222,8 @@ struct VIO_eqf {
                          std::vector<double>& absErr, std::vector<double>& probErr, std::vector<double>& depth2, long maxOutliers = -1);
 
   private:
-    std::vector<int> ids_;
+    mutable std::vector<int> ids_;
+    mutable bool invalidPending_ = false;
     std::vector<int> scratchIdx_;
     void check(int rc, const char* what) const;
 };

@@ -106,6 +106,16 @@ enum {
                                   eqf_gather_stats counts. 0: always the pass */
     EQF_OPT_HOLD_NEW_LANDMARKS = 24, /* 1 (default): eqf_add_landmarks_held is available (with EQF_OPT_GATHER_IN_PROPAGATE, fused assembly, fp64 Sigma, not the Normal chart;
                                   eqf_hold_supported says). 0: it returns EQF_E_UNSUPPORTED and the caller appends its new landmarks behind the propagation */
+    EQF_OPT_EARLY_DOORBELL = 27, /* 1 (default): eqf_stats_then_update / eqf_stats_select_update return on a doorbell rung by the look-ahead factorisation kernel itself - by its
+                                  last T half-row, when every W row is final, no pivot failed, no wait ran out and the tail was not cancelled: the update WILL be applied, and Gamma's
+                                  sensor rows are in the result packet - a kernel boundary and the landmark lift earlier than on the lift's doorbell (6 us at 200 landmarks). The
+                                  sensor lift is applied on the host at once; the landmark estimates and their invalid flags arrive with the lift's doorbell, which the next entry
+                                  point that needs them waits for (eqf_propagate_fast behind its launch; eqf_update_unsettled says whether that is still to come). A caller that
+                                  removes invalid landmarks after every update (VIO_eqf::removeInvalidLandmarks) defers that past the next propagation - a landmark can be
+                                  marginalised before or after it, bit for bit the same for everybody else - with eqf_remove_invalid_at_update. 0: the lift's doorbell only.
+                                  Built in round 5 and not taken (level at 200 landmarks, where the next propagation waits for the covariance update anyway; the counting cost the
+                                  factorisation 2 us); taken in round 6 with a count that needs no barrier, acknowledgement or release: +3 .. 4.5 % at 50, +2.8 % at 100 landmarks -
+                                  the sizes the reference's own configurations run at, where the GPU idled 10 us per frame behind the host -, level at 200 */
     EQF_OPT_SELECT_ONE_WORKGROUP = 25, /* 1 (default): up to 512 landmarks, the outlier statistics and the device-side outlier decision of eqf_stats_select_update are one
                                   launch of one workgroup (k_stats_select); 0: two launches (k_outlier_stats, k_select_outliers), as above 512 landmarks. Same results */
     EQF_OPT_LIVE_COLUMNS_FIRST = 26, /* 1 (default): in eqf_stats_select_update up to 16 panels (256 measurements), k_stats_select puts the measurements of the landmarks that stay in
@@ -189,6 +199,10 @@ int eqf_find_unknown_ids(eqf_ctx* ctx, const int* ids, int M, int* unknown_j, in
 int eqf_same_as_mapped(const eqf_ctx* ctx, const int* ids, int M);
 /* VIO_eqf::removeInvalidLandmarks (VIO_eqf.cpp:213-223). Returns the number removed (>=0) or <0. */
 int eqf_remove_invalid_landmarks(eqf_ctx* ctx);
+/* EQF_OPT_EARLY_DOORBELL: 1 while the lift results of the last update (estimates, invalid flags) have not been waited for yet; and removeInvalidLandmarks for a caller that
+ * deferred it past such an update: the landmarks the UPDATE's lift flagged as invalid leave the state, wherever they sit now. Returns their number (>= 0) or < 0. */
+int eqf_update_unsettled(const eqf_ctx* ctx);
+int eqf_remove_invalid_at_update(eqf_ctx* ctx);
 
 /* VIO_eqf::integrateRiccatiStateFast (VIO_eqf.cpp:62-72). Q = diag(Qdiag12) (constructInputGainMatrix,
  * VIOFilterSettings.h:192-201), P = diag: Pdiag8 = the 7 sensor 3-blocks + the per-landmark value
