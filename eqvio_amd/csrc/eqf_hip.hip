@@ -414,6 +414,7 @@ int spin_stream(hipStream_t st) {
 // the device's compute units: a context whose launch does not fit waits on the host until an earlier one has rung its doorbell. One filter never waits.
 namespace {
 std::atomic<int> ctx_alive[64]; // contexts of this process per device
+thread_local bool replaces_own_queue = false; // set by grow_capacity around eqf_create
 std::mutex la_gate_mutex;
 std::condition_variable la_gate_cv;
 int la_cus_booked[64] = {0}; // per device
@@ -876,7 +877,8 @@ static int create_buffers(eqf_ctx* c, int max_landmarks) {
     c->own_queue = false;
     const int before = ctx_alive[c->device & 63].fetch_add(1);
     const char* own_env = std::getenv("EQF_OWN_HW_QUEUES");
-    if (own_env && before < atoi(own_env)) {
+    // (replaces_own_queue: grow_capacity builds the replacement of a context that HAS a queue of its own while that context is still counted - it keeps one)
+    if ((own_env && before < atoi(own_env)) || replaces_own_queue) {
         std::vector<uint32_t> mask((size_t)(c->cu_count + 31) / 32, 0u);
         for (int i = 0; i < c->cu_count; ++i)
             mask[i >> 5] |= 1u << (i & 31);
@@ -1463,7 +1465,9 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     if (rc)
         return rc;
     eqf_ctx* t = nullptr;
+    replaces_own_queue = c->own_queue;
     rc = eqf_create(&t, c->device, new_cap, c->chart);
+    replaces_own_queue = false;
     if (rc)
         return rc == EQF_E_NO_DEVICE ? rc : EQF_E_CAPACITY; // allocation failure at the new size
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
@@ -2879,7 +2883,7 @@ static int lookahead_selftest_pass(eqf_ctx* c, bool& placement_refused) {
                     if (hipGetLastError() != hipSuccess)
                         return fail(EQF_E_NO_DEVICE);
                     const int base = (2 * blocks(m, 32) - 1) + blocks(rows - m, 16);
-                    la_book(c, base + 1 + la_split_extra(c, blocks(m, 32), base)); // (a timeout books nothing: the launch is bounded and a stall repeats the attempt)
+                    (void)la_book(c, base + 1 + la_split_extra(c, blocks(m, 32), base)); // (result ignored on purpose: a timeout books nothing, the launch is bounded and a stall repeats the attempt)
                     rc = launch_lookahead(c, rows, m, c->ldz, nullptr, 0);
                 }
                 if (rc)

@@ -2154,6 +2154,9 @@ __global__ void __launch_bounds__(PROP_T) k_propagate_main(int N, int Ncap, int 
 // k4-steps congruent to w mod 4) and the partial tiles are reduced through LDS in a fixed order (deterministic).
 // Out-of-range operand rows / k are clamped for the load and zeroed by a multiplier so every load is unconditional.
 
+#ifndef EQF_SYRK_UNROLL
+#define EQF_SYRK_UNROLL 4 // k-steps of a wave whose operand loads are in flight at once (mfma_tile32_splitk)
+#endif
 struct TileRed {
     double v[4]; // element e of lane t: (i = t & 31, j = (t >> 5) + 8 e)
 };
@@ -2173,7 +2176,7 @@ __device__ __forceinline__ TileRed mfma_tile32_splitk(const double* __restrict__
     d4 acc00 = {0, 0, 0, 0}, acc10 = acc00, acc01 = acc00, acc11 = acc00;
     double ga = 0.0, gb = 0.0;
     const int nsteps = (K + 3) >> 2;
-#pragma unroll 4
+#pragma unroll EQF_SYRK_UNROLL
     for (int st = wave; st < nsteps; st += NW) {
         const int kk = 4 * st + lk;
         const int kc = min(kk, K - 1);
@@ -2292,6 +2295,15 @@ __device__ __forceinline__ void syrk_sub_tile(int n, int m, int ld, int ldz, con
     const double* W = Wb + m;
     // live_cols (EQF_OPT_LIVE_COLUMNS_FIRST): W is zero behind the last panel that holds a live column (eqf_lookahead.hpp: la_live_panels) - the sums end there
     const int mk = live_cols ? min(m, 32 * max((__builtin_amdgcn_readfirstlane(*live_cols) + 31) >> 5, 1)) : m;
+    // Round 6: this tile's entries of Sigma are requested NOW, in front of the products, instead of behind their reduction (one memory round trip, ~1 us, off the end of the
+    // kernel that stands between the factorisation and the next frame's propagation)
+    const int i = i0 + (threadIdx.x & 31);
+    TS sig_pre[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + (threadIdx.x >> 5) + 8 * e;
+        sig_pre[e] = (threadIdx.x < 256 && i < n && j < n && (bi != bj || i >= j)) ? Sig[i + (size_t)j * ld] : TS(0);
+    }
     // with_gamma: the diagonal tiles also produce Gamma[i0 : i0+32] = W[rows] z  (Gamma = K yTilde = W L^-1 yTilde, VIO_eqf.cpp:119)
     double gv = 0.0;
     TileRed t;
@@ -2303,12 +2315,11 @@ __device__ __forceinline__ void syrk_sub_tile(int n, int m, int ld, int ldz, con
         gamma[i0 + threadIdx.x] = gv;
     if (threadIdx.x >= 256)
         return;
-    const int i = i0 + (threadIdx.x & 31);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int j = j0 + (threadIdx.x >> 5) + 8 * e;
         if (i < n && j < n && (bi != bj || i >= j)) {
-            const double v = Sig[i + (size_t)j * ld] - t.v[e];
+            const double v = sig_pre[e] - t.v[e];
             Sig[i + (size_t)j * ld] = v;
             if (i != j)
                 Sig[j + (size_t)i * ld] = v;

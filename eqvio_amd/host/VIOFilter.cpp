@@ -44,7 +44,7 @@ void VisionMeasurement::refreshFlat() const {
     // noticing. The cache is therefore trusted only after ONE walk over the map that compares every id and both pixel values (O(M), no allocation;
     // about as long as the two allocations a rebuild would cost); the first difference rebuilds it.
     const size_t n = camCoordinates.size();
-    if (flatTrusted_ && flatN_ == n && flatIds_.size() == n)
+    if (flatTrusted_.on && flatN_ == n && flatIds_.size() == n)
         return; // validated at the start of the call that holds this measurement (Validated)
     if (flatN_ == n && flatIds_.size() == n) {
         size_t j = 0;

@@ -137,16 +137,27 @@ struct VisionMeasurement {
         const VisionMeasurement& m;
         explicit Validated(const VisionMeasurement& meas) : m(meas) {
             m.refreshFlat();
-            m.flatTrusted_ = true;
+            m.flatTrusted_.on = true;
         }
-        ~Validated() { m.flatTrusted_ = false; }
+        ~Validated() { m.flatTrusted_.on = false; }
         Validated(const Validated&) = delete;
         Validated& operator=(const Validated&) = delete;
     };
 
   private:
     void refreshFlat() const;
-    mutable bool flatTrusted_ = false;
+    // The trust a Validated guard lends is the guarded OBJECT's for the guard's lifetime: a copy made meanwhile (processVisionData's matchedMeasurement) starts untrusted -
+    // nothing would reset a copied flag, and its refreshFlat() would skip the validating walk for good
+    struct Trust {
+        bool on = false;
+        Trust() = default;
+        Trust(const Trust&) {}
+        Trust& operator=(const Trust&) {
+            on = false;
+            return *this;
+        }
+    };
+    mutable Trust flatTrusted_;
     mutable std::vector<int> flatIds_;
     mutable std::vector<double> flatY_;
     mutable size_t flatN_ = (size_t)-1;

@@ -108,8 +108,24 @@ def pin_rank(local_rank, world_size, devices=None, cores_per_rank=4, sysfs="/sys
         return {"rank": local_rank, "bus_id": None, "numa_node": -1, "cpus": sorted(os.sched_getaffinity(0)), "pinned": False, "why": repr(e)}
     entry = dict(plan(bus, os.sched_getaffinity(0), cores_per_rank, sysfs)[local_rank])
     try:
-        os.sched_setaffinity(0, set(entry["cpus"]))
-        entry["pinned"] = True
+        # Every thread the process has by now, not only the caller: the bus-id query above may have started the HIP runtime (it does on builds that do not cache the
+        # property), and the runtime's helper threads were created with the old mask - sched_setaffinity(0, ...) alone pins the calling thread only.
+        # Threads created from here on inherit the caller's mask.
+        cpus = set(entry["cpus"])
+        tids = []
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")]
+        except OSError:
+            pass
+        moved = 0
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, cpus)
+                moved += 1
+            except OSError:  # a thread that has just exited
+                pass
+        os.sched_setaffinity(0, cpus)
+        entry["pinned"], entry["threads_pinned"] = True, max(moved, 1)
     except OSError as e:
         entry["pinned"], entry["why"] = False, repr(e)
     return entry

@@ -95,7 +95,12 @@ enum {
                                   XCD (the context's "home", claimed at eqf_create) and their hand-offs inside that XCD's L2 (plain stores, a second flag array): 1.1 instead of
                                   2.0 us per hop. What the T half-rows on the other XCDs read is written through a second time. Same arithmetic: bit-identical to 0 and to the
                                   launch chain. Checked at eqf_create (self-test; every home workgroup compares HW_REG_XCC_ID with the XCD it expects) and switched off for the
-                                  context if the device deals its blocks differently. eqf_lookahead_home reports the home and the launches that used it. 0: classic placement */
+                                  context if the device deals its blocks differently. eqf_lookahead_home reports the home and the launches that used it. 0: classic placement.
+                                  Only for a filter that has the device to itself (eqf_device_to_itself): contexts register their pid in a shared-memory table per user and
+                                  device (/dev/shm/eqf_hip_contexts_u<uid>_d<device>). What that table cannot see - another user's processes, a container with its own pid
+                                  namespace sharing /dev/shm (its pids look dead and its slots are reclaimed), a process that crashed (its slots stay until the 1-in-4096
+                                  liveness sweep) - costs PERFORMANCE only, never correctness: two filters that both take the placement put their home workgroups on the same
+                                  XCD (measured: 26.3 k against 31.3 k updates/s for four filters). Set 0 where filters of several users or containers share a GPU */
     EQF_OPT_TILES_PER_WORKGROUP = 22, /* 1 (default): above 256 landmarks (lower-triangle form of the propagation kernel) a workgroup takes as many consecutive tiles of one block
                                   row as it needs for ALL tile workgroups of the launch to be resident at once (N = 500: 3, 187 workgroups instead of 528 in three rounds) and forms
                                   the i side of its tiles once. Same sums per entry: bit-identical. 0: one tile per workgroup; k > 1: k tiles (tests, A/B) */
@@ -126,7 +131,7 @@ enum {
                                      path only: dense / accurate Riccati return EQF_E_UNSUPPORTED.
                                   1: numerical model of the same thing on the fp64 store: Sigma rounded to the nearest float after
                                      every store - bit-identical results to mode 2 (tests/test_gpu_fp32_sigma.py), any mode.
-                                  3: numerical model of a MIXED store (round 5): the 21 x 21 sensor block, the sensor-landmark strips and the 3 x 3 landmark
+                                  3: a ROUNDING MODEL, NOT A STORE (round 5; it saves neither time nor memory - Sigma stays an fp64 buffer): what a MIXED store would do to the numbers: the 21 x 21 sensor block, the sensor-landmark strips and the 3 x 3 landmark
                                      diagonal blocks keep their doubles (4.6 % of Sigma at 200 landmarks), only the landmark-landmark off-diagonal blocks are
                                      rounded to float after every store. Against the fp64 oracle at <= 200 features: Sigma 1.2e-7, pose 1.0e-8, worst landmark
                                      2.6e-6 (all-float store: 1.3e-5 / 2.4e-6 / 2.0e-4) - SURVEY's 1e-5 landmark bound holds. A model on the fp64 store only: the

@@ -34,6 +34,19 @@ int main() {
     auto v = c.flat();
     CHECK((*v.second)[6] == -1.0 && (*v.second)[7] == -2.0);
     CHECK(m.flatY()[6] == 190.0);
+    // a copy made while a Validated guard trusts the original (processVisionData's matchedMeasurement) must not inherit the trust - nothing would ever reset it,
+    // and an edit of the copy that keeps its size (a pixel replaced in place) would be served from the stale cache
+    {
+        VisionMeasurement::Validated guard(m);
+        VisionMeasurement d = m; // copied under the guard
+        d.camCoordinates[13] = {77.0, 88.0};
+        CHECK(d.flatY()[4] == 77.0 && d.flatY()[5] == 88.0);
+        VisionMeasurement e2;
+        e2 = m; // assigned under the guard
+        e2.camCoordinates[3] = {-5.0, -6.0};
+        CHECK(e2.flatY()[0] == -5.0 && e2.flatY()[1] == -6.0);
+        CHECK(m.flatY()[4] == 5.0); // the guarded original is served from its (validated) cache
+    }
     // shrink and grow
     c.camCoordinates.clear();
     CHECK(c.flatIds().empty() && c.flatY().empty());

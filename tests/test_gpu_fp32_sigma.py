@@ -151,7 +151,8 @@ def test_fp32_sigma_against_the_oracle(max_features):
 
 
 def test_mixed_store_against_the_oracle():
-    """which part of Sigma loses the landmark bound when it is rounded to float? EQF_OPT_SIGMA_FP32 = 3 is the numerical model of a MIXED store: the
+    """which part of Sigma loses the landmark bound when it is rounded to float? EQF_OPT_SIGMA_FP32 = 3 is a ROUNDING MODEL of a mixed store, not a store
+    (Sigma stays an fp64 buffer, rounded after every store: the mode saves neither time nor memory; the only real float store is mode 2, which misses the landmark bound): the
     21 x 21 sensor block, the sensor-landmark strips and the 3 x 3 landmark diagonal blocks stay fp64 (4.6 % of Sigma at 200 landmarks), only the landmark-landmark
     off-diagonal blocks are rounded to float after every store. Same UZH-FPV-like run at <= 200 features as above, against the fp64 oracle, next to the all-float model
     (= 1). Measured (printed): see DESIGN.md section 5."""

@@ -90,3 +90,40 @@ def test_pin_rank_pins_this_process(tmp_path, monkeypatch):
         assert sorted(os.sched_getaffinity(0)) == [allowed[1]]
     finally:
         os.sched_setaffinity(0, allowed)
+
+
+def test_pin_rank_pins_the_threads_that_exist_already(tmp_path, monkeypatch):
+    """the bus-id query may start the HIP runtime, whose helper threads keep the old mask under sched_setaffinity(0, ...) alone: every thread of
+    the process is moved (a thread started before the call stands in for the runtime's)."""
+    import threading
+
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip("needs two CPUs")
+    n = max(allowed) + 1
+    sysfs = fake_sysfs(tmp_path, {0: n}, smt=1, gpus={"0000:03:00.0": 0})
+    monkeypatch.setenv("EQVIO_GPU_BUS_IDS", "0000:03:00.0")
+    stop, tid, seen = threading.Event(), [], []
+
+    def helper():
+        tid.append(threading.get_native_id())
+        stop.wait(10)
+        seen.append(sorted(os.sched_getaffinity(0)))  # (0 = the calling thread)
+
+    t = threading.Thread(target=helper)
+    t.start()
+    while not tid:
+        pass
+    try:
+        e = pin_rank(0, 1, cores_per_rank=1, sysfs=sysfs)
+        assert e["pinned"] and e["threads_pinned"] >= 2
+        assert sorted(os.sched_getaffinity(tid[0])) == e["cpus"]
+    finally:
+        stop.set()
+        t.join()
+        for x in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(x), allowed)
+            except OSError:
+                pass
+    assert seen == [e["cpus"]]
