@@ -471,6 +471,10 @@ def main():
             hx, hl = C.c_int(), C.c_long()
             assert lib.eqf_lookahead_home(core, C.byref(hx), C.byref(hl)) == 0
             factorisation.update({"home_placement_launches": hl.value, "home_xcd": hx.value})
+        if hasattr(lib, "eqf_early_doorbell_stats"):  # EQF_OPT_EARLY_DOORBELL: updates the host took from the look-ahead kernel's own doorbell
+            er = C.c_long()
+            assert lib.eqf_early_doorbell_stats(core, C.byref(er), 0) == 0
+            factorisation["updates_taken_from_the_early_doorbell"] = er.value
         if rank == 0 and not args.no_roofline:
             roofline = measure_roofline(flt, lib, core, cam, frames, args, n, m)
             if not args.no_pmc and world_size == 1 and not stand_in:

@@ -179,6 +179,7 @@ def load_eqf_lib():
         "eqf_lookahead_selftest": (C.c_int, [vp]),
         "eqf_lookahead_home": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_long)]),
         "eqf_device_to_itself": (C.c_int, [vp]),
+        "eqf_early_doorbell_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.c_int]),
         "eqf_synchronize": (C.c_int, [vp]),
         "eqf_num_landmarks": (C.c_int, [vp]),
         "eqf_get_ids": (C.c_int, [vp, c_int_p, C.c_int]),
@@ -236,7 +237,7 @@ def load_eqf_lib():
         "eqf_last_kernel_times": (C.c_int, [vp, c_int_p, P(C.c_float), C.c_int]),
     }
     for name, (res, args) in protos.items():
-        if os.environ.get("EQVIO_AMD_LIB_DIR") and name in ("eqf_lookahead_home", "eqf_device_to_itself", "eqf_update_unsettled", "eqf_remove_invalid_at_update", "eqf_gather_stats", "eqf_remove_unmeasured_landmarks", "eqf_find_unknown_ids", "eqf_add_landmarks_held", "eqf_hold_supported", "eqf_hold_stats", "eqf_same_as_mapped", "eqf_live_columns_stats", "eqf_own_hardware_queue") and not hasattr(lib, name):
+        if os.environ.get("EQVIO_AMD_LIB_DIR") and name in ("eqf_lookahead_home", "eqf_device_to_itself", "eqf_early_doorbell_stats", "eqf_update_unsettled", "eqf_remove_invalid_at_update", "eqf_gather_stats", "eqf_remove_unmeasured_landmarks", "eqf_find_unknown_ids", "eqf_add_landmarks_held", "eqf_hold_supported", "eqf_hold_stats", "eqf_same_as_mapped", "eqf_live_columns_stats", "eqf_own_hardware_queue") and not hasattr(lib, name):
             continue  # same-box A/B against the libraries of an older commit (scripts/ab_builds.sh): entry points that commit did not have yet
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res

@@ -1489,7 +1489,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     t->last_gamma = c->last_gamma, t->n_at_update = c->n_at_update;
     t->spec_calls = c->spec_calls, t->spec_queued = c->spec_queued, t->spec_cancelled = c->spec_cancelled, t->spec_backoff = c->spec_backoff, t->spec_backoff_len = c->spec_backoff_len;
     t->nees_lu_fallbacks = c->nees_lu_fallbacks, t->wait_calls = c->wait_calls, t->launch_calls = c->launch_calls, t->wait_seconds = c->wait_seconds, t->launch_seconds = c->launch_seconds;
-    t->la_launches = c->la_launches, t->la_fallbacks = c->la_fallbacks, t->la_home_launches = c->la_home_launches, t->la_home_refused = c->la_home_refused, t->la_book_timeouts = c->la_book_timeouts, t->zb_launches = c->zb_launches, t->la_consecutive_stalls = c->la_consecutive_stalls;
+    t->la_launches = c->la_launches, t->la_fallbacks = c->la_fallbacks, t->la_home_launches = c->la_home_launches, t->la_home_refused = c->la_home_refused, t->la_book_timeouts = c->la_book_timeouts, t->zb_launches = c->zb_launches, t->la_consecutive_stalls = c->la_consecutive_stalls, t->early_rings = c->early_rings;
     t->la_selftest = c->la_selftest < 0 ? -1 : (t->la_selftest != 0 ? t->la_selftest : c->la_selftest); // a failure is never forgotten; otherwise the test that ran on the NEW buffers counts
     t->me_used = c->me_used, t->pred_valid = c->pred_valid, t->pred_cam = c->pred_cam, t->pred_star = c->pred_star;
     t->n_held = c->n_held, t->held_var = c->held_var, t->held_in_memory = c->n_held > 0; // (eqf_get_state above went through enter(): held landmarks are in memory now)
@@ -3059,7 +3059,7 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
         KTimer t(c, KN_SYRK);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_lift<double>), dim3(nlift + nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(),
                            c->d_gamma, c->d_flags, trace_slot(c, TR_SYRK), c->d_syrk_order + c->syrk_off[nt], lift_args(c, discreteCorr, spec, spec_seq, use_door, door_seq, la ? nullptr : c->d_gpart, stall_seq),
-                           nlift, blocks(m, 32) <= 16 ? c->la_live_cols : (const int*)nullptr);
+                           nlift, blocks(m, 32) <= 16 ? c->la_live_cols : (const int*)nullptr, nt <= SYRK_ARITH_TILES ? nt : 0);
         HIPCHK(hipGetLastError());
         { int _r = round_sigma(c, spec, spec_seq); if (_r) return _r; }
         if (c->opt_check) {
@@ -3729,6 +3729,15 @@ int eqf_lookahead_home(const eqf_ctx* c, int* home_xcd, long* home_launches) {
     return 0;
 }
 
+int eqf_early_doorbell_stats(eqf_ctx* c, long* updates, int reset) {
+    if (!c)
+        return EQF_E_BAD_ARG;
+    if (updates)
+        *updates = c->early_rings;
+    if (reset)
+        c->early_rings = 0;
+    return 0;
+}
 int eqf_device_to_itself(eqf_ctx* c) { return c ? (device_to_itself(c) ? 1 : 0) : EQF_E_BAD_ARG; }
 
 int eqf_nees_lu_fallbacks(eqf_ctx* c, long* count) {

@@ -2273,6 +2273,7 @@ __global__ void __launch_bounds__(256) k_gamma(int n, int m, int ldz, const doub
 // partial vectors and k_lift, launched BEFORE this kernel, has summed them, lifted the landmarks and rung the host doorbell.
 // That order gives the host the frame's results one kernel early: its round trip (results, filter logic, the next frame's
 // launches) overlaps with Sigma -= W W^T instead of leaving the GPU idle after it.
+constexpr int SYRK_ARITH_TILES = 24; // up to this many tile rows (N <= 249) k_syrk_lift walks the lower triangle row by row (no table look-up in front of its operand loads)
 constexpr int SYRK_NW = 8; // waves per workgroup: the K range of a tile is split 8-way (a wave's k-steps are a serial load->MFMA chain)
 template <typename TS, bool WITH_GAMMA>
 // tile_of_block (round 3): which lower tile (bi | bj << 16) block b works on. Workgroups are dealt round robin to the 8 XCDs (block b runs on XCD b % 8) and every
@@ -2280,17 +2281,27 @@ template <typename TS, bool WITH_GAMMA>
 // The table (built on the host, eqf_hip.hip: build_syrk_order) gives XCD x a compact square of the tile triangle and walks it column by column, so that an
 // XCD fetches ~2 sqrt(tiles / 8) row panels of W instead of all of them.
 __device__ __forceinline__ void syrk_sub_tile(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, double* __restrict__ gamma, const int* __restrict__ spec,
-                                              int spec_seq, const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, int stall_seq, int blk, const int* __restrict__ live_cols = nullptr) {
+                                              int spec_seq, const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, int stall_seq, int blk, const int* __restrict__ live_cols = nullptr, int nt_arith = 0) {
     if (tr && blk == 0 && threadIdx.x == 0)
         *tr = wall_clock64();
-    const int failed = flags[0] | (flags[3] == stall_seq ? 1 : 0); // requested together with the cancellation word: one round trip
-    if (spec && *spec == spec_seq)
-        return; // cancelled speculative tail
-    if (failed)
-        return; // the factorisation failed (see k_lift): Sigma stays as it was
+    // Round 6: the status words are REQUESTED here and looked at in front of the store (a failed or cancelled update is the rare case: its products are wasted, nothing else), and up to
+    // SYRK_ARITH_TILES tile rows the tile comes from the block index in closed form, row by row through the lower triangle, instead of from the XCD-aware table (which pays
+    // from N = 256 on, where the XCDs' L2s do not hold W any more): no memory round trip in front of the first operand loads
+    const int f0 = flags[0], f3 = flags[3];
+    const int specv = spec ? *spec : 0;
     __shared__ double sred[1024 * 4];
-    const int code = tile_of_block[blk];
-    const int bi = code & 0xffff, bj = code >> 16;
+    int bi, bj;
+    if (nt_arith > 0) {
+        bi = (int)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
+        while ((bi + 1) * (bi + 2) / 2 <= blk)
+            ++bi;
+        while (bi * (bi + 1) / 2 > blk)
+            --bi;
+        bj = blk - bi * (bi + 1) / 2;
+    } else {
+        const int code = tile_of_block[blk];
+        bi = code & 0xffff, bj = code >> 16;
+    }
     const int i0 = bi * 32, j0 = bj * 32;
     const double* W = Wb + m;
     // live_cols (EQF_OPT_LIVE_COLUMNS_FIRST): W is zero behind the last panel that holds a live column (eqf_lookahead.hpp: la_live_panels) - the sums end there
@@ -2311,6 +2322,10 @@ __device__ __forceinline__ void syrk_sub_tile(int n, int m, int ld, int ldz, con
         t = mfma_tile32_splitk<true, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, mk, sred, Wb + m + n, ldz, &gv);
     else
         t = mfma_tile32_splitk<false, SYRK_NW>(W, ldz, i0, n, W, ldz, j0, n, mk, sred);
+    if (spec && specv == spec_seq)
+        return; // cancelled speculative tail
+    if (f0 | (f3 == stall_seq ? 1 : 0))
+        return; // the factorisation failed (see k_lift): Sigma stays as it was
     if (WITH_GAMMA && bi == bj && threadIdx.x < 32 && i0 + threadIdx.x < n)
         gamma[i0 + threadIdx.x] = gv;
     if (threadIdx.x >= 256)
@@ -2320,7 +2335,7 @@ __device__ __forceinline__ void syrk_sub_tile(int n, int m, int ld, int ldz, con
         const int j = j0 + (threadIdx.x >> 5) + 8 * e;
         if (i < n && j < n && (bi != bj || i >= j)) {
             const double v = sig_pre[e] - t.v[e];
-            Sig[i + (size_t)j * ld] = v;
+            Sig[i + (size_t)j * ld] = v; // (written through instead - no dirty lines for the kernel's end to write back - measured slower: N = 50 45.8 against 44.5 us per frame)
             if (i != j)
                 Sig[j + (size_t)i * ld] = v;
         }
@@ -2469,13 +2484,13 @@ __global__ void __launch_bounds__(64) k_lift(const LiftArgs la) { lift_block(la,
 // doorbell rings when it did with two launches; Sigma - which the NEXT frame's first kernel waits for - is complete one lift and one kernel boundary earlier.
 template <typename TS>
 __global__ void __launch_bounds__(64 * SYRK_NW) k_syrk_lift(int n, int m, int ld, int ldz, const double* __restrict__ Wb, TS* __restrict__ Sig, double* __restrict__ gamma,
-                                                            const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, const LiftArgs la, int nlift, const int* __restrict__ live_cols) {
+                                                            const int* __restrict__ flags, trace_t* tr, const int* __restrict__ tile_of_block, const LiftArgs la, int nlift, const int* __restrict__ live_cols, int nt_arith) {
     if ((int)blockIdx.x < nlift) {
         if (threadIdx.x < 64)
             lift_block(la, (int)blockIdx.x, nlift);
         return;
     }
-    syrk_sub_tile<TS, false>(n, m, ld, ldz, Wb, Sig, gamma, la.spec, la.spec_seq, flags, tr, tile_of_block, la.stall_seq, (int)blockIdx.x - nlift, live_cols);
+    syrk_sub_tile<TS, false>(n, m, ld, ldz, Wb, Sig, gamma, la.spec, la.spec_seq, flags, tr, tile_of_block, la.stall_seq, (int)blockIdx.x - nlift, live_cols, nt_arith);
 }
 // q_hat_i = Q_i^-1 q0_i for all landmarks (stateGroupAction, VIOGroup.cpp:44-52)
 __global__ void __launch_bounds__(64) k_estimate(int N, int Ncap, const double* __restrict__ q0, const double* __restrict__ Qq, const double* __restrict__ Qa,

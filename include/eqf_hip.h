@@ -207,6 +207,8 @@ int eqf_remove_invalid_landmarks(eqf_ctx* ctx);
 /* EQF_OPT_EARLY_DOORBELL: 1 while the lift results of the last update (estimates, invalid flags) have not been waited for yet; and removeInvalidLandmarks for a caller that
  * deferred it past such an update: the landmarks the UPDATE's lift flagged as invalid leave the state, wherever they sit now. Returns their number (>= 0) or < 0. */
 int eqf_update_unsettled(const eqf_ctx* ctx);
+/* EQF_OPT_EARLY_DOORBELL: updates the host took from the look-ahead kernel's own doorbell (the others from the lift's) */
+int eqf_early_doorbell_stats(eqf_ctx* ctx, long* updates, int reset);
 int eqf_remove_invalid_at_update(eqf_ctx* ctx);
 
 /* VIO_eqf::integrateRiccatiStateFast (VIO_eqf.cpp:62-72). Q = diag(Qdiag12) (constructInputGainMatrix,

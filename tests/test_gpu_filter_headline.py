@@ -76,6 +76,11 @@ def test_headline_path_N200_against_the_oracle():
     assert lib.eqf_lookahead_home(flt.core_handle(), C.byref(hx), C.byref(hl)) == 0
     if lib.eqf_device_to_itself(flt.core_handle()) == 1 and hx.value >= 0:
         assert hl.value == k["la_launches"], (hx.value, hl.value, k)
+    # EQF_OPT_EARLY_DOORBELL (round 6): every one of these updates succeeds, so the host must have taken each from the look-ahead kernel's own doorbell or - when the lift's
+    # rang before the host looked - from the lift's; at this size (the lift a kernel boundary + 4 us behind) nearly all come early
+    er = C.c_long()
+    assert lib.eqf_early_doorbell_stats(flt.core_handle(), C.byref(er), 0) == 0
+    assert 0 <= er.value <= 6
 
 
 def test_headline_path_N500_against_the_oracle():

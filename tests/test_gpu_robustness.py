@@ -109,6 +109,47 @@ def test_doorbell_and_stream_wait_agree_bitwise():
     assert np.array_equal(a, b) and np.array_equal(pa, pb) and np.array_equal(Sa, Sb) and np.all(np.isfinite(Sa))
 
 
+@pytest.mark.parametrize("world_kind", ["hover", "wave"])
+def test_early_doorbell_changes_nothing(world_kind):
+    """EQF_OPT_EARLY_DOORBELL (round 6): the host takes an update from the look-ahead kernel's own doorbell, applies the sensor lift, launches the next propagation and
+    settles the lift's results (estimates, invalid flags) behind that launch; a landmark the lift flagged as invalid then leaves the state behind the propagation
+    instead of in front of it. Against the same run on the lift's doorbell only: bit-identical states and Sigma - on the headline's hover world (quiet frames) and on
+    the frame mix's wave world with the shipped outlier thresholds (landmarks lost, discarded and re-added in every frame) - and the early doorbell must actually
+    have been used."""
+    import ctypes as C
+
+    import bench
+    from eqvio_amd.capi import OPT_EARLY_DOORBELL, load_eqf_lib
+    from eqvio_amd.simworld import SimWorld
+
+    lib = load_eqf_lib()
+    settings = bench.eurocish_settings()
+    N, nfr = 50, 400
+    if world_kind == "hover":
+        world, frames = bench.build_workload(seed=11, n_frames=nfr + 2, N=N)
+    else:
+        settings.outlierThresholdAbs, settings.outlierThresholdProb, settings.featureRetention, settings.initialPointVariance = 4.852186665580312, 0.03229809583062128, 0.18594708334486176, 129.90415638150924
+        world = SimWorld(seed=5, num_points=1200, max_features=N, trajectory="wave", noise_px=0.5)
+        frames = list(world.frames(nfr + 2))
+    outs = []
+    for early in (0, 1):
+        if world_kind == "hover":
+            flt = bench.make_filter(world, settings, N, 0, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=N, device=0, sensor=se, ids=i, p=p, time=t))
+        else:
+            sensor, ids, p = world.true_state(0.0, frames[0][2])
+            flt = VIOFilter(settings, max_landmarks=N + 60, device=0, sensor=sensor, ids=ids, p=p, time=0.0)
+        assert lib.eqf_set_option(flt.core_handle(), OPT_EARLY_DOORBELL, early) == 0
+        assert flt.run_frames(world.cam, *bench.flatten_frames(frames[:nfr])) == nfr
+        k = C.c_long()
+        assert lib.eqf_early_doorbell_stats(flt.core_handle(), C.byref(k), 0) == 0
+        outs.append((flt.state_estimate(), flt.get_sigma(), k.value))
+        flt.close()
+    (a, ia, pa), Sa, ka = outs[0]
+    (b, ib, pb), Sb, kb = outs[1]
+    assert ka == 0 and kb >= nfr // 4, (ka, kb)
+    assert np.array_equal(ia, ib) and np.array_equal(a, b) and np.array_equal(pa, pb) and np.array_equal(Sa, Sb) and np.all(np.isfinite(Sa))
+
+
 def test_prepared_replay_equals_run_frames_and_the_staging_hint_changes_nothing():
     """eqvio_filter_run_prepared (containers built once, in two slices) == eqvio_filter_run_frames, bit for bit; and the filter's
     own use of eqf_stage_measurement (measurement copied to HBM by the propagation kernel) == the same run with speculation off,
