@@ -368,15 +368,18 @@ struct KTimer {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::chrono::steady_clock::time_point h0;
     int nlaunch; // launches inside the span: reported as that many entries of span / nlaunch each (no events BETWEEN them)
+    // option 100 = 2 (round 6): only the factorisation's launches are bracketed and the frame is otherwise the one of the timed region (lift and covariance update one launch,
+    // early doorbell): the dominant kernel's span with the GPU as busy around it as it is there
+    bool on() const { return c->opt_timing == 1 || (c->opt_timing == 2 && (which == KN_CHOL_LOOKAHEAD || which == KN_CHOL_PANEL || which == KN_CHOL_UPDATE)); }
     KTimer(eqf_ctx* ctx, int w, int n = 1) : c(ctx), which(w), h0(std::chrono::steady_clock::now()), nlaunch(n) {
-        if (c->opt_timing) {
+        if (on()) {
             e0 = get_event(c);
             e1 = get_event(c);
             hipEventRecord(e0, c->stream);
         }
     }
     ~KTimer() {
-        if (c->opt_timing) {
+        if (on()) {
             hipEventRecord(e1, c->stream);
             c->tev.push_back({which, {e0, e1}});
             c->tev_n.push_back(nlaunch);
@@ -3045,7 +3048,7 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
     LaBookingGuard booking{c}; // (booked by launch_update_tail, before it decided who builds Z; handed over to the doorbell wait when everything is queued)
     if (la)
         ++c->la_launches;
-    c->early_seq_next = (la && use_door && c->early_allowed && c->opt_early && c->opt_lift_syrk && !c->sig32 && !c->opt_timing && !c->opt_check) ? door_seq : 0;
+    c->early_seq_next = (la && use_door && c->early_allowed && c->opt_early && c->opt_lift_syrk && !c->sig32 && c->opt_timing != 1 && !c->opt_check) ? door_seq : 0;
     c->early_allowed = false;
     rc = la ? launch_lookahead(c, rows, m, c->ldz, spec, spec_seq, zb, zb_mf) : launch_chain(c, rows, m, c->ldz, c->d_Z, c->d_W, true, spec, spec_seq, c->opt_early ? c->d_gpart : nullptr);
     if (rc)
@@ -3054,7 +3057,7 @@ static int launch_factor_tail(eqf_ctx* c, int M, int discreteCorr, const int* sp
     const int stall_seq = la ? c->la_seq : -1; // the stall word the kernels behind the factorisation compare (sequence valued: eqf_lookahead.hpp)
     // EQF_OPT_LIFT_WITH_SYRK: lift and covariance update wait for the same kernel and touch different data - one launch, the lift's workgroups in front
     // (not with per-kernel timing, which wants the two spans apart, and not with fp32 storage, whose rounding pass follows the covariance update)
-    if (c->opt_early && c->opt_lift_syrk && !c->sig32 && !c->opt_timing && c->N > 0) {
+    if (c->opt_early && c->opt_lift_syrk && !c->sig32 && c->opt_timing != 1 && c->N > 0) {
         const int nt = blocks(n, 32), nlift = blocks(c->N, 64);
         KTimer t(c, KN_SYRK);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_lift<double>), dim3(nlift + nt * (nt + 1) / 2), dim3(64 * SYRK_NW), 0, c->stream, n, m, c->ld, c->ldz, c->d_W, (double*)c->sigma(),

@@ -254,51 +254,51 @@ struct Cam {
     int model = 0;
     double d[5] = {0, 0, 0, 0, 0};
 };
-// distortion of normalised image coordinates (x, y) -> (xd, yd) and its 2x2 Jacobian (row-major j[4])
-HD void cam_distort(const Cam& c, double x, double y, double& xd, double& yd, double* j) {
+// distortion of normalised image coordinates (x, y) -> (xd, yd) and its 2x2 Jacobian, row-major (j0 j1; j2 j3), returned by value.
+// Round 6: named scalars in a struct returned by value, not an array - through the three camera branches the compiler kept the off-diagonal entries of `double j[4]` in SCRATCH, stored at a run-time
+// selected offset (24 bytes per lane and a store -> load round trip in every kernel that projects a point: the propagation kernel's observer blocks, k_measure,
+// k_outlier_stats, k_output_cov, k_stats_select, the look-ahead kernel's statistics workgroup - profiles/r05 resource usage). Same expressions, same values.
+struct CamD {
+    double xd, yd, j0, j1, j2, j3;
+};
+HD CamD cam_distort(const Cam& c, double x, double y) {
+    CamD o;
     if (c.model == 1) {
         const double k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3], k3 = c.d[4];
         const double r2 = x * x + y * y;
         const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
         const double dr = k1 + r2 * (2.0 * k2 + r2 * 3.0 * k3); // d rad / d r2
-        xd = x * rad + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
-        yd = y * rad + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
-        j[0] = rad + 2.0 * x * x * dr + 2.0 * p1 * y + 6.0 * p2 * x;
-        j[1] = 2.0 * x * y * dr + 2.0 * p1 * x + 2.0 * p2 * y;
-        j[2] = j[1];
-        j[3] = rad + 2.0 * y * y * dr + 6.0 * p1 * y + 2.0 * p2 * x;
+        o.xd = x * rad + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+        o.yd = y * rad + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+        o.j0 = rad + 2.0 * x * x * dr + 2.0 * p1 * y + 6.0 * p2 * x;
+        o.j1 = 2.0 * x * y * dr + 2.0 * p1 * x + 2.0 * p2 * y;
+        o.j2 = o.j1;
+        o.j3 = rad + 2.0 * y * y * dr + 6.0 * p1 * y + 2.0 * p2 * x;
     } else if (c.model == 2) {
         const double r = sqrt(x * x + y * y);
         const double th = atan(r), t2 = th * th;
         const double thd = th * (1.0 + t2 * (c.d[0] + t2 * (c.d[1] + t2 * (c.d[2] + t2 * c.d[3]))));
         const double dthd = 1.0 + t2 * (3.0 * c.d[0] + t2 * (5.0 * c.d[1] + t2 * (7.0 * c.d[2] + t2 * 9.0 * c.d[3])));
         if (r < 1e-8) {
-            xd = x;
-            yd = y;
-            j[0] = j[3] = 1.0;
-            j[1] = j[2] = 0.0;
+            o = CamD{x, y, 1.0, 0.0, 0.0, 1.0};
         } else {
             const double sc = thd / r;
             const double dsc = (dthd / (1.0 + r * r) - sc) / r; // d sc / d r
-            xd = sc * x;
-            yd = sc * y;
-            j[0] = sc + dsc * x * x / r;
-            j[1] = dsc * x * y / r;
-            j[2] = j[1];
-            j[3] = sc + dsc * y * y / r;
+            o.xd = sc * x;
+            o.yd = sc * y;
+            o.j0 = sc + dsc * x * x / r;
+            o.j1 = dsc * x * y / r;
+            o.j2 = o.j1;
+            o.j3 = sc + dsc * y * y / r;
         }
-    } else {
-        xd = x;
-        yd = y;
-        j[0] = j[3] = 1.0;
-        j[1] = j[2] = 0.0;
-    }
+    } else
+        o = CamD{x, y, 1.0, 0.0, 0.0, 1.0};
+    return o;
 }
 HD void cam_project(const Cam& c, V3 p, double& u, double& v) {
-    double xd, yd, j[4];
-    cam_distort(c, p.x / p.z, p.y / p.z, xd, yd, j);
-    u = c.fx * xd + c.cx;
-    v = c.fy * yd + c.cy;
+    const CamD o = cam_distort(c, p.x / p.z, p.y / p.z);
+    u = c.fx * o.xd + c.cx;
+    v = c.fy * o.yd + c.cy;
 }
 // pixel -> unit bearing: inverse of the distortion by Newton's method from the distorted coordinates (the map is a small
 // perturbation of the identity on the image), equidistant: the scalar equation theta_d(theta) = |(xd, yd)| instead
@@ -307,12 +307,11 @@ HD V3 cam_undistort(const Cam& c, double u, double v) {
     if (c.model == 1) {
         double x = xd, y = yd;
         for (int it = 0; it < 12; ++it) {
-            double fx, fy, j[4];
-            cam_distort(c, x, y, fx, fy, j);
-            const double ex = fx - xd, ey = fy - yd;
-            const double idet = 1.0 / (j[0] * j[3] - j[1] * j[2]);
-            x -= (j[3] * ex - j[1] * ey) * idet;
-            y -= (j[0] * ey - j[2] * ex) * idet;
+            const CamD o = cam_distort(c, x, y);
+            const double ex = o.xd - xd, ey = o.yd - yd;
+            const double idet = 1.0 / (o.j0 * o.j3 - o.j1 * o.j2);
+            x -= (o.j3 * ex - o.j1 * ey) * idet;
+            y -= (o.j0 * ey - o.j2 * ex) * idet;
         }
         return normalized(V3{x, y, 1.0});
     }
@@ -336,11 +335,10 @@ HD V3 cam_undistort(const Cam& c, double u, double v) {
 HD void cam_jac(const Cam& c, V3 p, V3& j0, V3& j1) {
     const double iz = 1.0 / p.z;
     const double x = p.x * iz, y = p.y * iz;
-    double xd, yd, j[4];
-    cam_distort(c, x, y, xd, yd, j);
+    const CamD o = cam_distort(c, x, y);
     // d(x, y)/dp = [[iz, 0, -x iz], [0, iz, -y iz]]
-    j0 = V3{c.fx * j[0] * iz, c.fx * j[1] * iz, -c.fx * (j[0] * x + j[1] * y) * iz};
-    j1 = V3{c.fy * j[2] * iz, c.fy * j[3] * iz, -c.fy * (j[2] * x + j[3] * y) * iz};
+    j0 = V3{c.fx * o.j0 * iz, c.fx * o.j1 * iz, -c.fx * (o.j0 * x + o.j1 * y) * iz};
+    j1 = V3{c.fy * o.j2 * iz, c.fy * o.j3 * iz, -c.fy * (o.j2 * x + o.j3 * y) * iz};
 }
 // projection Jacobian J(p) (2x3) times skew(p): rows returned as two V3  (DRho of euclid.cpp:173-178)
 HD void cam_jac_skew(const Cam& c, V3 p, V3& r0, V3& r1) {
