@@ -223,6 +223,7 @@ def load_eqf_lib():
         "eqf_nees_lu_fallbacks": (C.c_int, [vp, C.POINTER(C.c_long)]),
         "eqf_speculation_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
         "eqf_measure_in_propagate_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.c_int]),
+        "eqf_z_in_lookahead_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.c_int]),
         "eqf_gather_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.c_int]),
         "eqf_selection_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]),
         "eqf_output_cov_all": (C.c_int, [vp, P(Camera), c_double_p]),

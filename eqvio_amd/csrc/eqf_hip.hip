@@ -180,6 +180,7 @@ struct eqf_ctx {
     unsigned long long* d_ladbg = nullptr; // EQF_OPT_TRACE: stamps inside the look-ahead kernel (96 x 8)
     int opt_lookahead = 1;                   // EQF_OPT_LOOKAHEAD
     int opt_zb = 1;                          // EQF_OPT_Z_IN_LOOKAHEAD
+    int opt_zb_large = 1;                    // ... also with 17 .. 32 panels (round 6); option value 2 = up to 16 panels only (round 5's behaviour, for A/B runs)
     int opt_la_split = 1;                    // EQF_OPT_LA_SPLIT_ROWS
     int opt_prop_tpw = 1;                    // EQF_OPT_TILES_PER_WORKGROUP
     int opt_gather = 1;                      // EQF_OPT_GATHER_IN_PROPAGATE
@@ -1131,7 +1132,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_DOORBELL: *value = c->opt_door; return 0;
     case EQF_OPT_EARLY_LIFT: *value = c->opt_early; return 0;
     case EQF_OPT_FUSED_ASSEMBLY: *value = c->opt_fuse_asm; return 0;
-    case EQF_OPT_Z_IN_LOOKAHEAD: *value = c->opt_zb; return 0;
+    case EQF_OPT_Z_IN_LOOKAHEAD: *value = c->opt_zb ? (c->opt_zb_large ? 1 : 2) : 0; return 0;
     case EQF_OPT_LA_SPLIT_ROWS: *value = c->opt_la_split; return 0;
     case EQF_OPT_TILES_PER_WORKGROUP: *value = c->opt_prop_tpw; return 0;
     case EQF_OPT_GATHER_IN_PROPAGATE: *value = c->opt_gather; return 0;
@@ -1175,7 +1176,7 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
         c->opt_fuse_asm = value;
         return 0;
     case EQF_OPT_Z_IN_LOOKAHEAD:
-        c->opt_zb = value ? 1 : 0;
+        c->opt_zb = value ? 1 : 0, c->opt_zb_large = value == 2 ? 0 : 1;
         return 0;
     case EQF_OPT_LA_SPLIT_ROWS:
         c->opt_la_split = value ? 1 : 0;
@@ -1476,7 +1477,7 @@ static int grow_capacity(eqf_ctx* c, int new_cap) {
     // EVERY option of eqf_set_option (tests/test_gpu_edge_cases.py: test_options_and_counters_survive_capacity_growth walks the enum)
     const int opts[][2] = {{EQF_OPT_SIGMA_FP32, c->opt_f32}, {EQF_OPT_RICCATI_DENSE, c->opt_dense}, {EQF_OPT_CHECK_FINITE, c->opt_check}, {EQF_OPT_SPECULATIVE, c->opt_spec},
                            {EQF_OPT_DOORBELL, c->opt_door}, {EQF_OPT_EARLY_LIFT, c->opt_early}, {EQF_OPT_FUSED_ASSEMBLY, c->opt_fuse_asm}, {EQF_OPT_LOOKAHEAD, c->opt_lookahead},
-                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_HOLD_NEW_LANDMARKS, c->opt_hold}, {EQF_OPT_EARLY_DOORBELL, c->opt_early_door}, {EQF_OPT_SELECT_ONE_WORKGROUP, c->opt_sel_one}, {EQF_OPT_LIVE_COLUMNS_FIRST, c->opt_live_first}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
+                           {EQF_OPT_LA_TIMEOUT_US, (int)(c->la_timeout_ticks / 100)}, {EQF_OPT_Z_IN_LOOKAHEAD, c->opt_zb ? (c->opt_zb_large ? 1 : 2) : 0}, {EQF_OPT_LA_SPLIT_ROWS, c->opt_la_split}, {EQF_OPT_LA_HOME, c->opt_la_home}, {EQF_OPT_TILES_PER_WORKGROUP, c->opt_prop_tpw}, {EQF_OPT_GATHER_IN_PROPAGATE, c->opt_gather}, {EQF_OPT_HOLD_NEW_LANDMARKS, c->opt_hold}, {EQF_OPT_EARLY_DOORBELL, c->opt_early_door}, {EQF_OPT_SELECT_ONE_WORKGROUP, c->opt_sel_one}, {EQF_OPT_LIVE_COLUMNS_FIRST, c->opt_live_first}, {EQF_OPT_MEASURE_IN_PROPAGATE, c->opt_measure_prop}, {EQF_OPT_LIFT_WITH_SYRK, c->opt_lift_syrk}, {EQF_OPT_TRACE, c->d_trace ? 1 : 0}, {100, c->opt_timing}};
     for (const auto& o : opts)
         if ((rc = eqf_set_option(t, o[0], o[1])) != 0)
             break;
@@ -2579,7 +2580,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.ldz = ldz;
     a.NJ = blocks(m, 32);
     a.NI = (2 * a.NJ - 1) + blocks(rows - m, 16); // the owner + the S half-rows 2 .. 2 NJ - 1 + the T half-rows (16 rows each)
-    const int extra = zb ? 0 : la_split_extra(c, a.NJ, a.NI);
+    const int extra = la_split_extra(c, a.NJ, a.NI); // (0 up to 17 panels)
     a.split_from = extra ? LA_SPLIT_FROM : a.NJ;
     // EQF_OPT_LA_HOME (up to 16 panels, a device of 8 XCDs x 32 compute units): the owner and the 2 NJ - 2 S half-rows are the blocks of ONE XCD (b & 7 == home), the T
     // half-rows (+ the statistics workgroup) are dealt to the other seven; the rest of the 8 x slots grid returns at once (eqf_lookahead.hpp: la_st_l)
@@ -2620,6 +2621,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     KTimer t(c, KN_CHOL_LOOKAHEAD); // ONE launch: the whole factorisation
     // MAXT = tiles a wave keeps in registers = ceil(NJ / 4)
     if (zb) { // EQF_OPT_Z_IN_LOOKAHEAD: the half-rows build their rows of Z themselves
+        const bool large = a.NJ > 16; // round 6: the 17 .. 32-panel form (la_row2 + la_build_rows2; output blocks from memory: zb = 1 or 3)
         a.zb_sig = (const double*)c->sigma(), a.zb_ld = c->ld, a.zb_M = m / 2, a.zb_Mcap = c->Ncap, a.zb_var = c->tail_var;
         a.zb_C = c->d_C, a.zb_ytil = c->d_ytil, a.zb_lmidx = c->d_lmidx, a.zb_linv0 = c->d_Linv;
         // (the pinned packet's mapping is the one this update was mapped with - map_measurement ran in this call or, for a staged measurement, in stage_prepare)
@@ -2636,11 +2638,15 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
         } else if (zb == 3) { // C, yTilde, index map from the propagation kernel's observer blocks; the statistics workgroup as above
             a.zb_mf = *zb_mf;
             a.spec = nullptr;
-            if (home)
+            if (large)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8, 3>), dim3(a.NI + extra + 1), dim3(LA_T), 0, c->stream, a);
+            else if (home)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 3, true>), dim3(home_grid), dim3(LA_T), 0, c->stream, a);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 3>), dim3(a.NI + 1), dim3(LA_T), 0, c->stream, a);
-        } else if (home) // C, yTilde, index map from the measurement kernel
+        } else if (large)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<8, 1>), dim3(a.NI + extra), dim3(LA_T), 0, c->stream, a);
+        else if (home) // C, yTilde, index map from the measurement kernel
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 1, true>), dim3(home_grid), dim3(LA_T), 0, c->stream, a);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_lookahead<4, 1>), dim3(a.NI), dim3(LA_T), 0, c->stream, a);
@@ -2986,7 +2992,7 @@ static int launch_update_tail(eqf_ctx* c, const int* ids, int M, double meas_var
     }
     // EQF_OPT_Z_IN_LOOKAHEAD: with the C blocks in memory (k_measure / k_outlier_stats ran), fp64 Sigma and 3 .. 16 panels, the look-ahead kernel builds Z itself
     // (with measurement fusion - the speculative frame tail - it evaluates the C blocks as well, if the measurement has been staged to HBM: ZB = 2)
-    const bool zb_ok = c->opt_zb && !c->sig32 && !chain_only && lookahead_eligible(c, m) && blocks(m, 32) <= 16;
+    const bool zb_ok = c->opt_zb && !c->sig32 && !chain_only && lookahead_eligible(c, m) && (blocks(m, 32) <= 16 || c->opt_zb_large); // (round 6: 17 .. 32 panels too, la_build_rows2)
     // ZB = 2 up to 8 panels (N <= 128) only: measured +2.8 % at N = 50, +1.8 % at N = 100 and neutral at N = 200, where the tail's first launch then reaches
     // the GPU late
     // ZB = 3 (round 4, up to 16 panels): the propagation kernel's observer blocks have evaluated the output blocks of THIS measurement (staged, same landmark set) with
@@ -3682,6 +3688,14 @@ int eqf_measure_in_propagate_stats(eqf_ctx* c, long* used, int reset) {
     *used = c->me_used;
     if (reset)
         c->me_used = 0;
+    return 0;
+}
+int eqf_z_in_lookahead_stats(eqf_ctx* c, long* launches, int reset) {
+    if (!c || !launches)
+        return EQF_E_BAD_ARG;
+    *launches = c->zb_launches;
+    if (reset)
+        c->zb_launches = 0;
     return 0;
 }
 int eqf_gather_stats(eqf_ctx* c, long* launches, int reset) {

@@ -1289,9 +1289,12 @@ __global__ void __launch_bounds__(256) k_chol_first(int w, int ldz, const double
 // The entries of Z = [S ; T ; yTilde^T], written once: k_build_Z stores them, the look-ahead kernel's half-rows can build their own rows from the same
 // expressions (EQF_OPT_Z_IN_LOOKAHEAD), and the results must not differ by a bit.
 // T[t, 2j + a] = Sigma[t, l_j : l_j + 3] C_j[a, :]^T
+// (Round 6: the fused multiply-adds are written out. Left to the compiler, the contraction of a0 b0 + a1 b1 + a2 b2 depended on the code around the inlined copy - the
+//  17 .. 32-panel prologue la_build_rows2 came out one bit away from k_build_Z in a third of W's entries.)
+__device__ __forceinline__ double bz_dot3(double a0, double b0, double a1, double b1, double a2, double b2) { return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0)); }
 __device__ __forceinline__ void bz_T_pair(double s0, double s1, double s2, const double (&cj)[6], double& o0, double& o1) {
-    o0 = s0 * cj[0] + s1 * cj[1] + s2 * cj[2];
-    o1 = s0 * cj[3] + s1 * cj[4] + s2 * cj[5];
+    o0 = bz_dot3(s0, cj[0], s1, cj[1], s2, cj[2]);
+    o1 = bz_dot3(s0, cj[3], s1, cj[4], s2, cj[5]);
 }
 // S[2i + a, 2j + b] = (C_i Sigma[l_i, l_j] C_j^T)[a, b] (+ the measurement variance on the diagonal); sv[3 c + r] = Sigma[l_i + r, l_j + c]
 __device__ __forceinline__ void bz_S_block(const double (&ci)[6], const double (&cj)[6], const double (&sv)[9], bool same_measurement, double meas_var, double (&out)[2][2]) {
@@ -1299,14 +1302,14 @@ __device__ __forceinline__ void bz_S_block(const double (&ci)[6], const double (
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const double s0 = sv[3 * c], s1 = sv[3 * c + 1], s2 = sv[3 * c + 2];
-        CS[0][c] = ci[0] * s0 + ci[1] * s1 + ci[2] * s2;
-        CS[1][c] = ci[3] * s0 + ci[4] * s1 + ci[5] * s2;
+        CS[0][c] = bz_dot3(ci[0], s0, ci[1], s1, ci[2], s2);
+        CS[1][c] = bz_dot3(ci[3], s0, ci[4], s1, ci[5], s2);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-            double v = CS[a][0] * cj[3 * bb] + CS[a][1] * cj[3 * bb + 1] + CS[a][2] * cj[3 * bb + 2];
+            double v = bz_dot3(CS[a][0], cj[3 * bb], CS[a][1], cj[3 * bb + 1], CS[a][2], cj[3 * bb + 2]);
             if (same_measurement && a == bb)
                 v += meas_var;
             out[a][bb] = v;

@@ -1165,6 +1165,170 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
     }
 }
 
+// ---- the rows of Z built by a half-row of the 17 .. 32-panel form (round 6: EQF_OPT_Z_IN_LOOKAHEAD above 16 panels) -----------------------------------
+// What la_row's ZB prologue does up to 256 measurements, for up to 512 and for the tile ranges of split half-rows (part A: tiles 0 .. Jlo - 1, part B: Jlo .. I): the
+// columns [32 Jfirst, 32 (Jmax + 1)) of this half-row's 16 rows of Z = [S ; T ; yTilde^T], with k_build_Z's expressions (bz_T_pair / bz_S_block: not a bit may differ),
+// the output blocks C_j / yTilde from memory (ZB = 1: the measurement kernel, ZB = 3: the propagation kernel's observer blocks).
+// * A T half-row - these end the kernel at 25 .. 32 panels, so what their prologue takes the frame pays - requests every Sigma entry it needs up front (thread = (row,
+//   measurement), 16 x 3 entries per thread at 512 measurements: one memory round trip) and stages chunks of 256 columns through LDS into the accumulator layout.
+//   (Measured at N = 500, kernel span against the k_build_Z route's 197 us: the next chunk's entries requested under the evaluation of the current one, 4 round trips,
+//   +9.6 us; every entry evaluated by the lane that keeps it - 24 loads per tile and lane, no LDS, no barrier - +18.6 us: at 256 registers the loads go out a few at a time.)
+// * An S half-row evaluates 3 x 3 blocks of Sigma, one per 2 x 2 block of S (thread = (measurement of the row pair, measurement of the column pair)), into LDS in chunks
+//   of 256 columns, the next chunk's Sigma entries requested in front of the evaluation of the current one, and reads them in the accumulator layout.
+template <int MAXT, bool srow>
+__device__ __forceinline__ void la_build_rows2(const LaArgs& a, const int hidx, double* smem, const int row0, const int ilim, const int Jfirst, const int Jmax, double (&acc)[MAXT][4]) {
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jh = wave & 1, jr = wave >> 1;
+    const int m = a.m, rows = a.rows;
+    const int M = a.zb_M, Mcap = a.zb_Mcap, ldS = a.zb_ld, nS = rows - 1 - m;
+    const int* lmg = a.zb_lmidx;
+    const bool ident = a.zb_ident != 0;
+    if constexpr (!srow) {
+        // thread = (row r16, measurement (tid >> 4) + 32 k): every Sigma entry of the prologue requested up front (KT x 3 per thread: one memory round trip), then chunks of
+        // 256 columns through LDS into the accumulator layout
+        constexpr int CW = 256, KT = 16; // M <= 512
+        double* sZ = smem;               // [r + 16 c], r < 16, c < CW
+        const int ncols = min(m, 32 * (Jmax + 1));
+        const int r16 = tid & 15, tt = (row0 - m) + r16; // row of Sigma / of T; tt == nS: the yTilde row
+        const int jmax = min(M, (ncols + 1) / 2);
+        double preT[KT][3];
+        if (tt < nS) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int jj = (tid >> 4) + 32 * k;
+                if (jj < jmax) {
+                    const int lj = 21 + 3 * (ident ? jj : lmg[jj]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        preT[k][c] = a.zb_sig[tt + (size_t)(lj + c) * ldS];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[t][q] = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < KT / 4; ++ch) {
+            const int c0 = CW * ch;
+            if (c0 < ncols) { // (uniform)
+                if (tt <= nS) {
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const int k = 4 * ch + k4;
+                        const int jj = (tid >> 4) + 32 * k;
+                        if (jj < jmax) {
+                            double o0, o1;
+                            if (tt < nS) {
+                                double cj[6];
+#pragma unroll
+                                for (int e = 0; e < 6; ++e)
+                                    cj[e] = a.zb_C[e * Mcap + jj];
+                                bz_T_pair(preT[k][0], preT[k][1], preT[k][2], cj, o0, o1);
+                            } else {
+                                o0 = a.zb_ytil[2 * jj];
+                                o1 = a.zb_ytil[2 * jj + 1];
+                            }
+                            sZ[r16 + 16 * (2 * jj - c0)] = o0;
+                            sZ[r16 + 16 * (2 * jj + 1 - c0)] = o1;
+                        }
+                    }
+                }
+                __syncthreads();
+                const int rl = min(lr, ilim - 1 - row0);
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    const int J = 4 * t + jr;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int jc = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
+                        if (J <= Jmax && J >= Jfirst && jc >= c0 && jc < c0 + CW)
+                            acc[t][q] = sZ[rl + 16 * (jc - c0)];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        constexpr int CW = 256;
+        double* sZ = smem; // [r + 16 c], r < 16, c < CW
+        const int ncols = min(m, 32 * (Jmax + 1)); // columns this half-row ever reads
+        const int cbeg = ((32 * Jfirst) / CW) * CW; // first chunk that holds one of them
+        auto c_of = [&](int jj, double (&cj)[6]) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                cj[e] = a.zb_C[e * Mcap + jj];
+        };
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[t][q] = 0.0;
+        constexpr int KS = 2; // column measurements per thread and chunk of 128 measurements (8 row measurements x 64 lanes of column measurements)
+        const int i8 = tid & 7, iS = 8 * hidx + i8; // measurement of the row pair (2 i, 2 i + 1)
+        double preS[KS][9];
+        double ci[6];
+        if (iS < M)
+            c_of(iS, ci);
+        auto request = [&](int c0) {
+            const int jbeg = c0 / 2, jend = min(M, (min(ncols, c0 + CW) + 1) / 2);
+            if (iS < M) {
+                const int li = 21 + 3 * (ident ? iS : lmg[iS]);
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    const int jj = jbeg + (tid >> 3) + 64 * k;
+                    if (jj < jend) {
+                        const int lj = 21 + 3 * (ident ? jj : lmg[jj]);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+                                preS[k][3 * c + r] = a.zb_sig[li + r + (size_t)(lj + c) * ldS];
+                    }
+                }
+            }
+        };
+        if (cbeg < ncols)
+            request(cbeg);
+        for (int c0 = cbeg; c0 < ncols; c0 += CW) {
+            const int jbeg = c0 / 2, jend = min(M, (min(ncols, c0 + CW) + 1) / 2);
+            if (iS < M) {
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    const int jj = jbeg + (tid >> 3) + 64 * k;
+                    if (jj < jend) {
+                        double cj[6], blk[2][2];
+                        c_of(jj, cj);
+                        bz_S_block(ci, cj, preS[k], iS == jj, a.zb_var, blk);
+#pragma unroll
+                        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                            for (int bb = 0; bb < 2; ++bb)
+                                sZ[(2 * i8 + aa) + 16 * (2 * jj + bb - c0)] = blk[aa][bb];
+                    }
+                }
+            }
+            if (c0 + CW < ncols)
+                request(c0 + CW); // in flight across the barrier and the read-out below
+            __syncthreads();
+            const int rl = min(lr, ilim - 1 - row0);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int J = 4 * t + jr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int jc = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
+                    if (J <= Jmax && J >= Jfirst && jc >= c0 && jc < c0 + CW)
+                        acc[t][q] = sZ[rl + 16 * (jc - c0)];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- a half block row with a look-ahead of its own (17 .. 32 panels) ----------------------------------------------------------------------
 // la_row above walks a panel as wait L_p -> barrier -> P_h -> barrier -> wait P_J -> trailing update, one after the other. With 17 .. 32 panels
 // the trailing update of the early panels is MFMA bound per CU (31 tiles x 16 MFMAs of ~100 cycles on 4 SIMDs = 5.3 us against an owner step of 4.7 us)
@@ -1173,7 +1337,7 @@ __device__ __forceinline__ void la_row(const LaArgs& a, const int hidx, double* 
 // to it before anything else, form P_h(p+1) = Z(h, p+1) L_(p+1)^-T with the L_(p+1)^-1 they fetched on the way (the owner is ahead), publish it
 // (S half-rows) and only then turn to their other tiles - while the other six waves are in the trailing update of panel p. One workgroup barrier per
 // panel; P_h, L^-1 and z in LDS are double buffered by panel parity. Same products in the same order per tile: bit-identical to la_row and to the chain.
-template <int MAXT, bool srow>
+template <int MAXT, bool srow, int ZB = 0>
 // Round 4, N > 256: an S half-row of a LATE block row (I >= a.split_from) holds up to 32 tiles, and the trailing update of the early panels is MFMA-issue bound on its
 // compute unit (8 tiles per wave: 5.3 us per panel against an owner step of 4.4): those rows handed their tiles over late and the owner's steps were 4.3 - 8.7 us
 // (profiles/r04_v2_N500_lookahead_trace.txt). Their tile columns are split over TWO workgroups: part A (partA) holds the tiles 0 .. Jlo - 1, forms and publishes the factor
@@ -1205,17 +1369,24 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
     const int ri = row0 + lr;
     const int ric = min(ri, ilim - 1);
     double acc[MAXT][4];
+    if constexpr (ZB == 0) {
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int J = 4 * t + jr;
+        for (int t = 0; t < MAXT; ++t) {
+            const int J = 4 * t + jr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
-            acc[t][q] = (J <= Jmax && J >= Jfirst) ? a.Z[ric + (size_t)j * ldz] : 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const int j = min(32 * J + 16 * jh + lk + 4 * q, m - 1);
+                acc[t][q] = (J <= Jmax && J >= Jfirst) ? a.Z[ric + (size_t)j * ldz] : 0.0;
+            }
         }
+        if (ylast && tid < 32)
+            la_put16(a.puby + 16 * (size_t)tid, a.Z[(rows - 1) + (size_t)min(tid, m - 1) * ldz], seq);
+    } else {
+        // round 6: no k_build_Z launch in front of the 17 .. 32-panel form either - this half-row's tiles are built here (an S half-row's la_build_rows2 ends with a barrier: smem is free again)
+        la_build_rows2<MAXT, srow>(a, hidx, smem, row0, ilim, Jfirst, Jmax, acc);
+        if (ylast && tid < 32)
+            la_put16(a.puby + 16 * (size_t)tid, a.zb_ytil[min(tid, m - 1)], seq);
     }
-    if (ylast && tid < 32)
-        la_put16(a.puby + 16 * (size_t)tid, a.Z[(rows - 1) + (size_t)min(tid, m - 1) * ldz], seq);
     double gsum = 0.0;
     const int np = srow ? (partA ? Jlo : max(I - 2, 0)) : NJ; // see la_row
     auto hand_off = [&]() {
@@ -1713,7 +1884,8 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
                 return;
         }
     } else if constexpr (ZB >= 2) {
-        if ((int)blockIdx.x >= a.NI) { // the statistics workgroup
+        // (17 .. 32 panels: the parts A of the split half-rows sit between the T half-rows and the statistics workgroup)
+        if ((int)blockIdx.x >= a.NI + (MAXT > 4 && a.split_from < a.NJ ? 2 * (a.NJ - a.split_from) : 0)) { // the statistics workgroup
             la_stats<ZB>(a);
             if (a.early_door) {
                 __threadfence_system();
@@ -1724,16 +1896,16 @@ __global__ void __launch_bounds__(LA_T) k_chol_lookahead(const LaArgs a) {
     }
     if (owner)
         la_owner<ZB, HOME>(a, smem, s_abort, s_cnt, pl);
-    else if (MAXT > 4) { // 17 .. 32 panels: the half-rows with a look-ahead of their own
+    else if constexpr (MAXT > 4) { // 17 .. 32 panels: the half-rows with a look-ahead of their own
         const int nbase = a.NI; // owner + S half-rows + T half-rows; behind them the parts A of the split half-rows (block rows >= split_from, two halves each)
         if ((int)blockIdx.x >= nbase) {
             const int e = (int)blockIdx.x - nbase, I = a.split_from + (e >> 1);
-            la_row2<MAXT, true>(a, 2 * I + (e & 1), smem, s_abort, s_cnt, pl, 4 * ((I + 5) >> 3), true);
+            la_row2<MAXT, true, ZB>(a, 2 * I + (e & 1), smem, s_abort, s_cnt, pl, 4 * ((I + 5) >> 3), true);
         } else if (hidx < 2 * a.NJ) {
             const int I = hidx >> 1;
-            la_row2<MAXT, true>(a, hidx, smem, s_abort, s_cnt, pl, I >= a.split_from ? 4 * ((I + 5) >> 3) : 0, false);
+            la_row2<MAXT, true, ZB>(a, hidx, smem, s_abort, s_cnt, pl, I >= a.split_from ? 4 * ((I + 5) >> 3) : 0, false);
         } else
-            la_row2<MAXT, false>(a, hidx, smem, s_abort, s_cnt, pl);
+            la_row2<MAXT, false, ZB>(a, hidx, smem, s_abort, s_cnt, pl);
     } else
         la_row<MAXT, ZB, HOME>(a, hidx, smem, s_abort, s_cnt, pl);
     // any wave that saw a timeout reports it (the owner's waves return at different times). The stall word carries the launch's sequence number: nobody has to

@@ -65,7 +65,7 @@ enum {
                                   When it runs out the launch is abandoned and the factorisation redone on the launch chain (same Z: W and Sigma+
                                   bit-identical, Gamma up to rounding). 0 makes every look-ahead
                                   launch stall at its first wait: the test hook for that path */
-    EQF_OPT_Z_IN_LOOKAHEAD = 17, /* 1 (default): where it applies (fp64 Sigma, 3 .. 16 panels) there is no k_build_Z launch: the look-ahead kernel's half-rows build their
+    EQF_OPT_Z_IN_LOOKAHEAD = 17, /* 1 (default): where it applies (fp64 Sigma, 3 .. 32 panels; 2: 3 .. 16 panels only, round 5's behaviour) there is no k_build_Z launch: the look-ahead kernel's half-rows build their
                                   own 16 rows of Z = [S ; T ; yTilde^T] and its owner the first tile, from k_build_Z's expressions (bit-identical W / Sigma). In the
                                   speculative frame tail (eqf_stats_then_update with the measurement staged by the propagation call) its workgroups evaluate the
                                   output blocks C_j themselves as well and one more workgroup computes the outlier statistics and the speculation word; after
@@ -81,8 +81,8 @@ enum {
     EQF_OPT_MEASURE_IN_PROPAGATE = 19, /* 1 (default): when a measurement has been staged (eqf_stage_measurement) the observer blocks of eqf_propagate_fast's kernel - which have a
                                   landmark's propagated group element in registers when their chain of steps ends - evaluate its output block C_i / C*_i and residual
                                   there and leave them in memory, with the camera and output choice of the LAST eqf_stats_then_update call. If the next such call asks for
-                                  the same (and the staged measurement and landmark set still stand) there is no k_build_Z launch up to 16 panels: the look-ahead kernel
-                                  builds Z from those blocks and one more workgroup of it computes the outlier statistics (above 16 panels, or on the launch chain, k_build_Z runs
+                                  the same (and the staged measurement and landmark set still stand) there is no k_build_Z launch (up to 32 panels since round 6): the look-ahead kernel
+                                  builds Z from those blocks and one more workgroup of it computes the outlier statistics (on the launch chain k_build_Z runs
                                   but reads the blocks instead of evaluating them again: 25 -> 15 us at N = 500); otherwise the call takes its ordinary route.
                                   Same function and inputs as the update's own evaluation, compiled in another kernel: the compiler contracts the expressions into
                                   fused multiply-adds differently there, so the results agree to rounding (1e-14 on Sigma), not bit for bit (the other routes do
@@ -280,8 +280,10 @@ int eqf_stats_then_update(eqf_ctx* ctx, const eqvio_camera* cam, const int* ids,
  * statistics kernel (every measured id already a landmark); of those, tails the device cancelled because a landmark exceeded an outlier
  * threshold (the caller then takes the two-round-trip path: removeOutliers / addNewLandmarks / eqf_vision_update). */
 int eqf_speculation_stats(eqf_ctx* ctx, long* calls, long* queued, long* cancelled, int reset);
-/* EQF_OPT_MEASURE_IN_PROPAGATE: update calls that used the output blocks evaluated by the propagation kernel in front (up to 16 panels: no k_build_Z launch). */
+/* EQF_OPT_MEASURE_IN_PROPAGATE: update calls that used the output blocks evaluated by the propagation kernel in front (no k_build_Z launch where the look-ahead kernel runs). */
 int eqf_measure_in_propagate_stats(eqf_ctx* ctx, long* used, int reset);
+/* EQF_OPT_Z_IN_LOOKAHEAD: look-ahead launches whose half-rows built Z themselves (no k_build_Z launch in front; 3 .. 32 panels since round 6). */
+int eqf_z_in_lookahead_stats(eqf_ctx* ctx, long* launches, int reset);
 /* EQF_OPT_GATHER_IN_PROPAGATE: propagation launches that applied a record of removed landmarks themselves */
 int eqf_gather_stats(eqf_ctx* ctx, long* launches, int reset);
 /* eqf_stats_then_update with VIOFilter::removeOutliers' decision (VIOFilter.cpp:304-364) made on the device where that saves the frame a host round trip:

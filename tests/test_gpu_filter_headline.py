@@ -373,6 +373,57 @@ def test_output_blocks_wait_for_the_last_observer_step():
     flt.close()
 
 
+@pytest.mark.parametrize("N,Mmeas,shuffled", [(272, 272, False), (300, 289, True), (500, 500, False), (512, 497, True)])
+def test_z_inside_the_lookahead_kernel_above_16_panels(N, Mmeas, shuffled):
+    """Round 6: EQF_OPT_Z_IN_LOOKAHEAD also with 17 .. 32 panels (la_build_rows2: the half-rows of the la_row2 form - split ones included - build their tile ranges of Z
+    themselves, no k_build_Z launch). Option value 2 keeps round 5's behaviour (k_build_Z above 16 panels). Through eqf_vision_update (output blocks from the
+    measurement kernel: the same expressions entry by entry, Sigma+ and the state must be identical BIT FOR BIT) and through the staged eqf_stats_then_update (output
+    blocks from the propagation kernel, statistics from the kernel's own workgroup: rounding level, test_output_blocks_from_the_propagation_kernel says why). Ragged last
+    panels, fewer measurements than landmarks, identity and loaded index maps; every launch must have built Z inside (counter) and none may have stalled."""
+    from eqvio_amd.capi import COORD_INVDEPTH, OPT_Z_IN_LOOKAHEAD, EqfCore
+    from util import default_camera, random_imu, random_spd, reasonable_state, settings_for, synth_measurement
+
+    rng = np.random.default_rng(1000 + N)
+    s = settings_for(COORD_INVDEPTH, fastRiccati=1)
+    xi0, Xs, ids, q0, Q = reasonable_state(rng, N, shuffle_ids=shuffled)
+    S0 = random_spd(rng, 21 + 3 * N)
+    cam = default_camera()
+    Qd, Pd = s.input_gain_diag12(), s.state_gain_diag8()
+    imus = np.stack([random_imu(rng, stamp=0.005 * i) for i in range(4)])
+    mean = random_imu(rng)
+    sub = None if Mmeas == N else np.sort(rng.permutation(N)[:Mmeas])
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=0.5, subset=sub)
+    outs = {}
+    for route in ("update", "staged"):
+        for zb in (2, 1):
+            core = EqfCore(N, COORD_INVDEPTH)
+            core.set_option(OPT_Z_IN_LOOKAHEAD, zb)
+            core.set_state(xi0, Xs, ids, q0, Q)
+            core.set_sigma(S0)
+            stats = None
+            if route == "update":
+                core.vision_update(cam, mid, y, 4.0, True, True)
+            else:
+                for rep in range(2):  # the second frame finds the camera of the first: output blocks from the propagation kernel
+                    core.stage_measurement(mid, y)
+                    core.propagate_fast(mean, 0.02, Qd, Pd, imus, np.full(4, 0.005), True)
+                    upd, *stats = core.stats_then_update(cam, mid, y, 1e9, 1e9, 4.0, True, True)
+                    assert upd == 1
+            la, fb, zbl = C.c_long(), C.c_long(), C.c_long()
+            assert core.lib.eqf_lookahead_stats(core.h, C.byref(la), C.byref(fb), 0) == 0
+            assert la.value == (1 if route == "update" else 2) and fb.value == 0
+            assert core.lib.eqf_z_in_lookahead_stats(core.h, C.byref(zbl), 0) == 0
+            assert zbl.value == (1 if zb == 1 else 0), (route, zb, zbl.value)  # (staged: the first frame has no camera yet and takes k_build_Z)
+            outs[route, zb] = (core.get_state(), core.get_sigma(), stats)
+            core.close()
+    (sa, Sa, _), (sb, Sb, _) = outs["update", 2], outs["update", 1]
+    assert all(np.array_equal(x, z) for x, z in zip(sa, sb)) and np.array_equal(Sa, Sb)
+    (sa, Sa, ta), (sb, Sb, tb) = outs["staged", 2], outs["staged", 1]
+    assert all(np.allclose(x, z, rtol=1e-11, atol=1e-13) for x, z in zip(sa, sb)) and np.allclose(Sa, Sb, rtol=1e-10, atol=1e-12 * np.abs(Sa).max())
+    for u, v in zip(ta, tb):
+        assert np.allclose(u, v, rtol=1e-10, atol=1e-12)
+
+
 @pytest.mark.parametrize("shuffled", [False, True])
 def test_index_map_of_the_z_building_prologue(shuffled):
     """The look-ahead kernel's prologue builds Z from Sigma's landmark blocks; since round 4 it does not load the measurement -> landmark index map when the host

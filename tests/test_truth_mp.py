@@ -107,7 +107,11 @@ def test_device_is_closer_to_truth_than_the_as_written_fp64_reference():
     e_dev = np.array(e_dev)
     print("device err vs truth", e_dev, "\nas-written fp64 err vs truth", e_asw, "\ndevice Gamma err", np.array(e_g))
     assert e_dev.max() < 5e-9
-    assert np.all(e_dev[1:] <= e_asw[1:])  # frame 0 is well conditioned: both at rounding level
+    # frame 0 is well conditioned: both at rounding level; frame 1 (cond(S) ~ 1e13 for the first time) leaves every fp64 evaluation ~2.2e-9 from the truth, whichever
+    # way the last bits fall (round 6, fused multiply-adds of the S / T entries written out: device 2.24e-9, as written 2.22e-9) - from then on the as-written arithmetic
+    # drifts to 1e-7 and the device does not
+    assert np.all(e_dev[1:] <= np.maximum(e_asw[1:], 3e-9))
+    assert e_asw[2:].min() > 3 * e_dev[2:].max()
     assert e_dev[0] < 1e-13
     _, Xs, _, _, Q = core.get_state()
     assert np.max(np.abs(Xs - d["truth_Xs"][-1])) < 1e-6  # the state follows Gamma (errors 1e-8..1e-7 relative in every fp64 evaluation)
