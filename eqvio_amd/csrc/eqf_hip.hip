@@ -185,6 +185,7 @@ struct eqf_ctx {
     int opt_prop_tpw = 1;                    // EQF_OPT_TILES_PER_WORKGROUP
     int opt_gather = 1;                      // EQF_OPT_GATHER_IN_PROPAGATE
     int opt_early_door = 1;                  // EQF_OPT_EARLY_DOORBELL
+    int opt_la_watch_ahead = 1;              // (debug knob, option 102) LaArgs::watch_ahead
     int early_seq_next = 0, early_armed_seq = 0; // the doorbell sequence the next look-ahead launch carries / the one the launch in flight carries
     bool early_allowed = false;              // the call in progress can take the early doorbell (eqf_stats_then_update / eqf_stats_select_update)
     long early_rings = 0;                    // updates the host took from the early doorbell
@@ -1148,6 +1149,7 @@ int eqf_get_option(const eqf_ctx* c, int option, int* value) {
     case EQF_OPT_TRACE: *value = c->d_trace ? 1 : 0; return 0;
     case EQF_OPT_SIGMA_FP32: *value = c->opt_f32; return 0;
     case 100: *value = c->opt_timing; return 0;
+    case 102: *value = c->opt_la_watch_ahead; return 0;
     default: return EQF_E_BAD_ARG;
     }
 }
@@ -1249,6 +1251,9 @@ int eqf_set_option(eqf_ctx* c, int option, int value) {
     case 100:
         c->opt_timing = value;
         timing_reset(c);
+        return 0;
+    case 102: // (debug knob, not in the header: same-process A/B of LaArgs::watch_ahead)
+        c->opt_la_watch_ahead = value ? 1 : 0;
         return 0;
     default:
         return EQF_E_BAD_ARG;
@@ -2582,6 +2587,7 @@ static int launch_lookahead(eqf_ctx* c, int rows, int m, int ldz, const int* spe
     a.NI = (2 * a.NJ - 1) + blocks(rows - m, 16); // the owner + the S half-rows 2 .. 2 NJ - 1 + the T half-rows (16 rows each)
     const int extra = la_split_extra(c, a.NJ, a.NI); // (0 up to 17 panels)
     a.split_from = extra ? LA_SPLIT_FROM : a.NJ;
+    a.watch_ahead = c->opt_la_watch_ahead;
     // EQF_OPT_LA_HOME (up to 16 panels, a device of 8 XCDs x 32 compute units): the owner and the 2 NJ - 2 S half-rows are the blocks of ONE XCD (b & 7 == home), the T
     // half-rows (+ the statistics workgroup) are dealt to the other seven; the rest of the 8 x slots grid returns at once (eqf_lookahead.hpp: la_st_l)
     const int nT = a.NI - (2 * a.NJ - 1);

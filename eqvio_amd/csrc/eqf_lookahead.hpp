@@ -43,6 +43,7 @@ constexpr long long LA_TIMEOUT_TICKS = 2000000; // 20 ms at 100 MHz
 
 struct LaArgs {
     int rows, m, ldz, NJ, NI, seq;
+    int watch_ahead;         // round 6 (la_row2): a lane's flag word of the coming panel is requested a panel ahead (debug knob 102: 0 = every panel polls, as before)
     int split_from;          // S block rows I >= split_from are held by TWO workgroups per half-row (la_row2: Jlo, partA); >= NJ: none
     int home;                // HOME instantiations (round 5): the XCD block 0 of this stream's grids runs on (block b runs on XCD (home + b) & 7); -1 otherwise
     int* pubfl;              // HOME: the flags of the hand-offs that stay inside the home XCD's L2 (same indices as pubf)
@@ -1210,6 +1211,14 @@ __device__ __forceinline__ void la_build_rows2(const LaArgs& a, const int hidx, 
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 acc[t][q] = 0.0;
+        // the output blocks into LDS, once, behind Sigma's requests ([6 j + e]; read from memory inside the chunk loop they were one more round trip in front of every chunk:
+        // the first T half-row's panel 0 began 14.5 us after the kernel, profiles/r06_watch_ahead_N500_lookahead_trace.txt)
+        double* sC = smem + 16 * CW;
+        for (int jj = tid; jj < jmax; jj += LA_T)
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                sC[6 * jj + e] = a.zb_C[e * Mcap + jj];
+        __syncthreads();
 #pragma unroll
         for (int ch = 0; ch < KT / 4; ++ch) {
             const int c0 = CW * ch;
@@ -1225,7 +1234,7 @@ __device__ __forceinline__ void la_build_rows2(const LaArgs& a, const int hidx, 
                                 double cj[6];
 #pragma unroll
                                 for (int e = 0; e < 6; ++e)
-                                    cj[e] = a.zb_C[e * Mcap + jj];
+                                    cj[e] = sC[6 * jj + e];
                                 bz_T_pair(preT[k][0], preT[k][1], preT[k][2], cj, o0, o1);
                             } else {
                                 o0 = a.zb_ytil[2 * jj];
@@ -1292,6 +1301,16 @@ __device__ __forceinline__ void la_build_rows2(const LaArgs& a, const int hidx, 
         };
         if (cbeg < ncols)
             request(cbeg);
+        // the column measurements' output blocks into LDS, once, behind the first requests (see the T half-rows above)
+        double* sC = smem + 16 * CW;
+        {
+            const int jlo = cbeg / 2, jhi = min(M, (ncols + 1) / 2);
+            for (int jj = jlo + tid; jj < jhi; jj += LA_T)
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+                    sC[6 * jj + e] = a.zb_C[e * Mcap + jj];
+            __syncthreads();
+        }
         for (int c0 = cbeg; c0 < ncols; c0 += CW) {
             const int jbeg = c0 / 2, jend = min(M, (min(ncols, c0 + CW) + 1) / 2);
             if (iS < M) {
@@ -1300,7 +1319,9 @@ __device__ __forceinline__ void la_build_rows2(const LaArgs& a, const int hidx, 
                     const int jj = jbeg + (tid >> 3) + 64 * k;
                     if (jj < jend) {
                         double cj[6], blk[2][2];
-                        c_of(jj, cj);
+#pragma unroll
+                        for (int e = 0; e < 6; ++e)
+                            cj[e] = sC[6 * jj + e];
                         bz_S_block(ci, cj, preS[k], iS == jj, a.zb_var, blk);
 #pragma unroll
                         for (int aa = 0; aa < 2; ++aa)
@@ -1452,15 +1473,29 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         }
         sZpB(q)[32 * h + c] = z;
     };
+    // Round 6: the waves 0 .. 3 store the W rows (thread (r, c): the columns c and c + 16, a Gamma share for each - the same sums as one column per thread), and they do it at the
+    // END of a panel, in front of the barrier they reach first. The store used to stand at the top of the panel in every wave, and the waves 4 .. 7 - the panel's longest:
+    // their yTilde word comes back behind an `s_waitcnt vmcnt(0)` - waited for its acknowledgement there: 2.5 us from the panel's top to their first operand request
+    // where the waves 0 .. 3 took 0.8 (profiles/r06_watch_ahead_N500_lookahead_trace.txt), in every panel of every T half-row, which are the ones that end the kernel.
+    double gsum2 = 0.0;
     auto store_w = [&](int q) {
-        const int wq = min(32, m - 32 * q);
-        const int r = tid & 15, c = tid >> 4;
-        const double pv = sPIB(q)[r + c * CH_LDP];
-        if (row0 + r < rows && c < wq)
-            a.W[(row0 + r) + (size_t)(32 * q + c) * ldz] = pv;
-        const double* sZp = sZpB(q);
-        const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
-        gsum = fma(pv, c < wq ? zc : 0.0, gsum);
+        if (tid < 256) {
+            const int wq = min(32, m - 32 * q);
+            const int r = tid & 15;
+            const double* sZp = sZpB(q);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = (tid >> 4) + 16 * u;
+                const double pv = sPIB(q)[r + c * CH_LDP];
+                if (row0 + r < rows && c < wq)
+                    a.W[(row0 + r) + (size_t)(32 * q + c) * ldz] = pv;
+                const double zc = ((sZp[c] + sZp[32 + c]) + (sZp[64 + c] + sZp[96 + c])) + ((sZp[128 + c] + sZp[160 + c]) + (sZp[192 + c] + sZp[224 + c]));
+                if (u == 0)
+                    gsum = fma(pv, c < wq ? zc : 0.0, gsum);
+                else
+                    gsum2 = fma(pv, c < wq ? zc : 0.0, gsum2);
+            }
+        }
     };
     if (partB) {
         // part B of a split half-row: the panels 0 .. Jlo - 2 on its own tiles, every wave by itself
@@ -1559,6 +1594,7 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         if (srow && tid == 0)
             la_raise_f(a, la_f_p(a, 0, hidx));
     }
+    int pre_flag = 0; // (lane-private) the word this lane watches at the top of the coming panel, as it read a panel before
     for (int p = partB ? Jlo - 1 : 0; p < np; ++p) {
         int lrv = lr, lkv = lk;
         asm volatile("" : "+v"(lrv), "+v"(lkv));
@@ -1568,39 +1604,55 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
         unsigned long long* dbr = a.dbg + 8 * ((hidx == 2 * NJ ? 32 : 64) + p);
         if (dbg_row)
             dbr[0] = wall_clock64();
-        // (c) final W rows (+ Gamma) of a T half-row - of the panel BEFORE this one: z_(p-1) was completed by the barrier that ended panel p - 1, and nothing
-        // waits for W until the very end, so the store costs the critical path of a panel nothing here
-        if (!srow && p > 0)
-            store_w(p - 1);
         if (dbg_row)
             dbr[1] = wall_clock64();
         // (d) the trailing update Z(h, J) -= P_h(p) P_J(p)^T; the look-ahead pair first brings the next panel tile forward
         const bool ahead = p + 1 < np && jr == ((p + 1) & 3); // this wave owns half of Z(h, p + 1)
-        auto tile_used = [&](int t, int& J) -> bool {
+        auto tile_used_at = [&](int q, int t, int& J) -> bool { // tile t of this wave takes part in the trailing update of panel q
             J = 4 * t + jr;
-            return t < MAXT && J > p && J <= Jmax && !(srow && J == I && jh > s) && !(srow && p == I - 3 && J == I - 1) && !(srow && p == I - 3 && J == I && jh < s);
+            return t < MAXT && J > q && J <= Jmax && !(srow && J == I && jh > s) && !(srow && q == I - 3 && J == I - 1) && !(srow && q == I - 3 && J == I && jh < s);
         };
+        auto tile_used = [&](int t, int& J) -> bool { return tile_used_at(p, t, J); };
         // this wave's operands: rows 16 jh .. of P^(p)_J = what half-row 2 J + jh published; lane t watches the flag of tile t, lane 63 of a look-ahead
         // wave the flag of L_(p+1)^-1
-        {
+        // Round 6: every lane asks for the word it will watch at panel p + 1 NOW (no wait) and looks at the answer at the top of that panel. A half-row that runs behind
+        // the owner and its peers - all of them from panel ~12 on at 25 .. 32 panels, ~30 us behind - finds it raised and goes straight to its operand loads: one memory round
+        // trip less per panel, which is what such a half-row needs to catch up (its panel was flag poll -> L^-1 / operands -> products -> barrier at the owner's pace).
+        auto watch = [&](int q, bool& want) -> const int* {
             int J;
-            const bool need = tile_used(lane, J) && !(srow && J == I && jh == s);
-            const bool look = ahead && lane == 63;
-            const int* f = a.pubf + (look ? la_f_linv(a, p + 1) : la_f_p(a, p, 2 * (need ? J : 0) + jh));
-            if (!srow && wave >= 4 && p > 0) {
-                // waves 4 .. 7 of a T half-row: the yTilde row of THIS panel (published a panel ago) on the same round trip as the flags, then z_p
+            const bool need = tile_used_at(q, lane, J) && !(srow && J == I && jh == s);
+            const bool look = q + 1 < np && jr == ((q + 1) & 3) && lane == 63;
+            want = need || look;
+            return a.pubf + (look ? la_f_linv(a, q + 1) : la_f_p(a, q, 2 * (need ? J : 0) + jh));
+        };
+        {
+            bool want;
+            const int* f = watch(p, want);
+            const bool need = want, look = false; // (one condition below: this lane watches a word)
+            const bool seen = want && a.watch_ahead && pre_flag == pl.seq; // raised a panel ago already
+            if (p + 1 < np) {
+                bool wantn;
+                const int* fn = watch(p + 1, wantn);
+                pre_flag = wantn ? __hip_atomic_load(fn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            }
+            // Round 6: z_p is the work of the four waves that do NOT hold the look-ahead pair of this panel (the pair brings tile p + 1 forward first: ~1.5 us more than the
+            // others; yTilde + z_p are ~1 us) - waves 4 .. 7 if the pair sits in 0 .. 3 (jr = (p + 1) & 3 < 2), waves 0 .. 3 otherwise. It was always 4 .. 7, which then
+            // ended every second panel 2 us behind the waves 0 .. 3
+            const bool zwave = (wave >= 4) == (((p + 1) & 3) < 2 || !a.watch_ahead);
+            if (!srow && zwave && p > 0) {
+                // four waves of a T half-row: the yTilde row of THIS panel (published a panel ago) on the same round trip as the flags, then z_p
                 const char* yp = a.puby + 512 * (size_t)p + 16 * (size_t)(tid & 31);
                 v4i r;
                 for (;;) {
                     int v = pl.seq;
-                    if (need || look)
+                    if ((need || look) && !seen)
                         v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(yp) : "memory");
                     if ((v == pl.seq && r.z == pl.seq && r.w == ~pl.seq) || !la_retry(pl))
                         break;
                 }
                 z_partials(p, __hiloint2double(r.y, r.x));
-            } else if (need || look) {
+            } else if ((need || look) && !seen) {
                 for (;;) {
                     const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (v == pl.seq || !la_retry(pl))
@@ -1746,6 +1798,10 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             if (wave == 3)
                 dbr[6] = wall_clock64();
         }
+        // (c) final W rows (+ Gamma) of a T half-row - of the panel BEFORE this one (z_(p-1) was completed by the barrier that ended panel p - 1; its buffers are not
+        // written again before panel p + 1; nothing waits for W until the very end): see store_w
+        if (!srow && p > 0)
+            store_w(p - 1);
         if (p + 1 < np) {
             if (tid == 0 && s_abort[1])
                 s_abort[0] = 1;
@@ -1762,7 +1818,10 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
             store_w(np - 1);
         }
         __syncthreads(); // the Gamma partial sums below overwrite the third P_h buffer
-        sT[tid] = gsum; // [c][r]
+        if (tid < 256) {
+            sT[tid] = gsum; // [c][r]
+            sT[tid + 256] = gsum2;
+        }
         __syncthreads();
         const int row = row0 + tid;
         if (tid < 16 && row >= m && row < rows - 1) {

@@ -38,6 +38,12 @@ for p in range(NJ):
         r = a[32 + p] - t0
         lp = (a[p, 4] - t0) if p >= 1 else float("nan")
         print(f"  p={p:2d}  {r[0]:8.2f} {r[1]:8.2f} {r[2]:8.2f}   ({r[0] - lp:5.2f} {r[1] - lp:5.2f} {r[2] - lp:5.2f})")
+if NJ > 16:  # la_row2 stamps every wave: where does a panel of the first T half-row go? (microseconds after its own panel top)
+    print("first T block row (17 .. 32 panels), microseconds after the panel's top: W rows stored | flags seen: wave 0, last wave | trailing update done: wave 0, wave 3, wave 7, last wave | next panel's top")
+    for p in range(NJ - 1):
+        if a[32 + p, 0] > 0 and a[32 + p + 1, 0] > 0:
+            r = a[32 + p] - a[32 + p, 0]
+            print(f"  p={p:2d}  {r[1]:6.2f} | {r[7]:6.2f} {r[3]:6.2f} | {r[2]:6.2f} {r[6]:6.2f} {r[5]:6.2f} {r[4]:6.2f} | {a[32 + p + 1, 0] - a[32 + p, 0]:6.2f}")
 print("S block row I (top half) at its last panel p = I - 3, microseconds after L_p was ready in the owner: waiting for it | L+tile in LDS | P_h flag | updates done | hand-off flag | seen by the owner's wave 3   (the tail of step I - 2 uses it)")
 for I in range(3, NJ):
     if a[64 + I, 0] > 0:
