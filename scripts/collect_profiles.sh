@@ -25,7 +25,8 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_G
 python $R/scripts/rocpd_pmc.py $(find /tmp/p_m -name "*.db" | head -1) > $OUT/${V}_pmc_mfma.csv
 cd $R
 python scripts/frame_trace.py $NL 2000 > $OUT/${V}_frame_trace.txt 2>&1
-python bench.py --landmarks $NL --steps 2000 --warmup 200 --no-multi-filter --no-binding > $OUT/${V}_bench.json 2> $OUT/bench.err
+LST=2000; LWU=200; if [ "$NL" -ge 400 ]; then LST=600; LWU=100; fi
+python bench.py --landmarks $NL --steps $LST --warmup $LWU --no-multi-filter --no-binding > $OUT/${V}_bench.json 2> $OUT/bench.err
 if [ "$FULL" = "full" ]; then
   python scripts/host_share.py $NL 6000 > $OUT/${V}_host_share.txt 2>&1
   python scripts/propagate_vs_steps.py > $OUT/${V}_propagate_vs_steps.txt 2>&1
