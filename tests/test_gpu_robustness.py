@@ -276,22 +276,23 @@ def test_stalled_lookahead_is_redone_on_the_chain_bit_identically():
     stall.close()
 
 
-def test_stalled_lookahead_that_built_z_itself_is_redone_on_the_chain():
+@pytest.mark.parametrize("N,Mmeas", [(72, 66), (300, 283)])
+def test_stalled_lookahead_that_built_z_itself_is_redone_on_the_chain(N, Mmeas):
     """EQF_OPT_Z_IN_LOOKAHEAD (default, stand-alone update path): the look-ahead kernel builds Z in its registers and there is no k_build_Z launch. A launch
     that stalls (EQF_OPT_LA_TIMEOUT_US = 0) has left no Z in memory: the retry must build it (k_build_Z from the C blocks of the measurement kernel) before the
-    launch chain runs. Result: bit-identical to a context that never used the look-ahead kernel, with and without the option."""
+    launch chain runs. Result: bit-identical to a context that never used the look-ahead kernel, with and without the option. (N = 300: the 17 .. 32-panel form, which
+    builds Z itself since round 6.)"""
     import ctypes as C
 
     from eqvio_amd.capi import OPT_LA_TIMEOUT_US, OPT_LOOKAHEAD, OPT_Z_IN_LOOKAHEAD, EqfCore
     from util import CHARTS, default_camera, random_imu, random_spd, reasonable_state, settings_for, synth_measurement
 
     rng = np.random.default_rng(12)
-    N = 72
     xi0, Xs, ids, q0, Q = reasonable_state(rng, N)
     S = random_spd(rng, 21 + 3 * N)
     settings = settings_for(CHARTS["invdepth"])
     cam = default_camera()
-    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=np.sort(rng.permutation(N)[:66]))
+    mid, y = synth_measurement(rng, cam, ids, q0, Q, noise_px=1.0, subset=np.sort(rng.permutation(N)[:Mmeas]))
     imu = random_imu(rng)
     out = {}
     for name, la, zb, timeout in (("chain", 0, 1, None), ("inside", 1, 1, None), ("build_z", 1, 0, None), ("stalled", 1, 1, 0)):
