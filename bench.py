@@ -404,6 +404,7 @@ def main():
     ap.add_argument("--no-multi-filter", action="store_true")
     ap.add_argument("--no-frame-mix", action="store_true")
     ap.add_argument("--no-binding", action="store_true")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the other state sizes (BASELINE configs 2 / 3: 40 and 500 landmarks)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes of the roofline object (three short runs of this script under the profiler)")
     ap.add_argument("--config", default="headline", choices=["headline", "batch8"],
                     help="batch8: BASELINE.json configs[3] - a batch of 8 sequences (trajectories wave / square / sine / line x maxFeatures 40 / 200, seeds 0-7, 60 s each) "
@@ -452,7 +453,7 @@ def main():
     n, m = 21 + 3 * N, 2 * N
     ms_per_step = 1e3 * elapsed / args.steps
     frame_flops = flops_propagate(n) + flops_update(n, m)
-    roofline = cpu = multi = mix = binding = factorisation = None
+    roofline = cpu = multi = mix = binding = factorisation = sizes = None
     if not stand_in:
         lib = backend.lib
         cam = world.cam
@@ -489,6 +490,8 @@ def main():
             mix = frame_mix(N, local_rank, lib)
         if rank == 0 and world_size == 1 and not args.no_binding:
             binding = reference_side_binding(N)
+        if rank == 0 and world_size == 1 and not args.no_sizes and not stand_in:
+            sizes = other_state_sizes(local_rank, lib)
 
     if rank == 0:
         out = {
@@ -530,9 +533,43 @@ def main():
             out["frame_mix"] = mix
         if binding is not None:
             out["reference_side_binding"] = binding
+        if sizes is not None:
+            out["other_state_sizes"] = sizes
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def other_state_sizes(device, lib, sizes=(40, 500), n_frames=300, n_warm=60):
+    """The same hover workload at the sizes of BASELINE's other configurations - 40 landmarks (`maxFeatures` of the reference's shipped configurations, config 2's range) and 500
+    (config 3) - through the same calls as the headline line: updates/s, the look-ahead kernel's launches (stalled ones are redone on the launch chain and counted) and how many of them
+    built Z themselves (no k_build_Z launch: 3 launches per frame)."""
+    import ctypes as C
+
+    from eqvio_amd.capi import PreparedFrames, VIOFilter
+
+    out = []
+    for Nl in sizes:
+        world, frames = build_workload(seed=500 + Nl, n_frames=n_warm + n_frames + 2, N=Nl)
+        flt = make_filter(world, eurocish_settings(), Nl, device, frames, lambda s, se, i, p, t: VIOFilter(s, max_landmarks=Nl, device=device, sensor=se, ids=i, p=p, time=t))
+        core = flt.core_handle()
+        warm = PreparedFrames(world.cam, *flatten_frames(frames[:n_warm]))
+        timed = PreparedFrames(world.cam, *flatten_frames(frames[n_warm:n_warm + n_frames]))
+        assert flt.run_prepared(warm) == n_warm
+        lib.eqf_synchronize(core)
+        a, b, z = C.c_long(), C.c_long(), C.c_long()
+        lib.eqf_lookahead_stats(core, C.byref(a), C.byref(b), 1)
+        lib.eqf_z_in_lookahead_stats(core, C.byref(z), 1)
+        t0 = time.perf_counter()
+        assert flt.run_prepared(timed) == n_frames
+        lib.eqf_synchronize(core)
+        el = time.perf_counter() - t0
+        lib.eqf_lookahead_stats(core, C.byref(a), C.byref(b), 0)
+        lib.eqf_z_in_lookahead_stats(core, C.byref(z), 0)
+        out.append({"landmarks": Nl, "state_dim": 21 + 3 * Nl, "value": n_frames / el, "unit": "updates/s", "us_per_frame": 1e6 * el / n_frames, "frames": n_frames,
+                    "lookahead_launches": a.value, "stalled_and_redone_on_the_chain": b.value, "launches_that_built_Z_themselves": z.value})
+        flt.close()
+    return out
 
 
 def reference_side_binding(N, n_frames=400):
@@ -832,7 +869,7 @@ def _pmc_pass(N, counters, steps=40, warmup=10):
     tmp = tempfile.mkdtemp(prefix="eqvio_pmc_", dir="/tmp")
     try:
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", tmp, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--landmarks", str(N), "--steps", str(steps),
-               "--warmup", str(warmup), "--no-cpu-baseline", "--no-roofline", "--no-multi-filter", "--no-frame-mix", "--no-binding", "--no-pmc"]
+               "--warmup", str(warmup), "--no-cpu-baseline", "--no-roofline", "--no-multi-filter", "--no-frame-mix", "--no-binding", "--no-sizes", "--no-pmc"]
         subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, timeout=600, check=True)
         dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
         if not dbs:

@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/$V
 mkdir -p $OUT
 ST=50; WU=10
 if [ "$NL" -ge 400 ]; then ST=30; WU=5; fi
-BCMD="python $R/bench.py --landmarks $NL --steps $ST --warmup $WU --no-cpu-baseline --no-roofline --no-multi-filter --no-frame-mix --no-binding"
+BCMD="python $R/bench.py --landmarks $NL --steps $ST --warmup $WU --no-cpu-baseline --no-roofline --no-multi-filter --no-frame-mix --no-binding --no-sizes"
 rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w /tmp/p_m
 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- $BCMD > /tmp/kt.log 2>&1
 DB=$(find /tmp/p_kt -name "*.db" | head -1)
@@ -26,7 +26,7 @@ python $R/scripts/rocpd_pmc.py $(find /tmp/p_m -name "*.db" | head -1) > $OUT/${
 cd $R
 python scripts/frame_trace.py $NL 2000 > $OUT/${V}_frame_trace.txt 2>&1
 LST=2000; LWU=200; if [ "$NL" -ge 400 ]; then LST=600; LWU=100; fi
-python bench.py --landmarks $NL --steps $LST --warmup $LWU --no-multi-filter --no-binding > $OUT/${V}_bench.json 2> $OUT/bench.err
+python bench.py --landmarks $NL --steps $LST --warmup $LWU --no-multi-filter --no-binding --no-sizes > $OUT/${V}_bench.json 2> $OUT/bench.err
 if [ "$FULL" = "full" ]; then
   python scripts/host_share.py $NL 6000 > $OUT/${V}_host_share.txt 2>&1
   python scripts/propagate_vs_steps.py > $OUT/${V}_propagate_vs_steps.txt 2>&1
