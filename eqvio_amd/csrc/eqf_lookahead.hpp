@@ -1212,7 +1212,7 @@ __device__ __forceinline__ void la_build_rows2(const LaArgs& a, const int hidx, 
             for (int q = 0; q < 4; ++q)
                 acc[t][q] = 0.0;
         // the output blocks into LDS, once, behind Sigma's requests ([6 j + e]; read from memory inside the chunk loop they were one more round trip in front of every chunk:
-        // the first T half-row's panel 0 began 14.5 us after the kernel, profiles/r06_watch_ahead_N500_lookahead_trace.txt)
+        // the first T half-row's panel 0 began 15.4 us after the kernel and 10.6 with the blocks in LDS, profiles/r06_la_row2_N500_lookahead_trace_{before,after}.txt)
         double* sC = smem + 16 * CW;
         for (int jj = tid; jj < jmax; jj += LA_T)
 #pragma unroll
@@ -1476,7 +1476,7 @@ __device__ __forceinline__ void la_row2(const LaArgs& a, const int hidx, double*
     // Round 6: the waves 0 .. 3 store the W rows (thread (r, c): the columns c and c + 16, a Gamma share for each - the same sums as one column per thread), and they do it at the
     // END of a panel, in front of the barrier they reach first. The store used to stand at the top of the panel in every wave, and the waves 4 .. 7 - the panel's longest:
     // their yTilde word comes back behind an `s_waitcnt vmcnt(0)` - waited for its acknowledgement there: 2.5 us from the panel's top to their first operand request
-    // where the waves 0 .. 3 took 0.8 (profiles/r06_watch_ahead_N500_lookahead_trace.txt), in every panel of every T half-row, which are the ones that end the kernel.
+    // where the waves 0 .. 3 took 0.8 (profiles/r06_la_row2_N500_lookahead_trace_before.txt), in every panel of every T half-row, which are the ones that end the kernel.
     double gsum2 = 0.0;
     auto store_w = [&](int q) {
         if (tid < 256) {
